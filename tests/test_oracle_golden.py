@@ -1,0 +1,123 @@
+"""CPU: the oracle (oracle/mpifft_oracle.py) against the fixtures that the REAL
+reference produced (tests/golden/*, written by oracle/refharness/make_golden.py).
+This is what pins the oracle; the GPU parity tests then compare the HIP path
+with the oracle and with the same fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mpifft_oracle as orc
+
+N = [8, 16, 32]
+TOL = {"double": 1e-13, "single": 2e-5}
+
+
+@pytest.fixture(scope="module", params=["double", "single"])
+def gold(request, golden_dir):
+    return request.param, np.load(os.path.join(golden_dir, "ref_8x16x32_%s.npz" % request.param))
+
+
+def test_layout_tables(golden_dir):
+    table = json.load(open(os.path.join(golden_dir, "layouts.json")))
+    assert len(table) > 200
+    for row in table:
+        Nn, P, r = row["N"], row["P"], row["rank"]
+        if row["decomp"] == "slab":
+            lay = orc.SlabLayout(Nn, P)
+            cshape = lay.complex_shape()
+            rs, cs = lay.real_local_slice(r), lay.complex_local_slice(r)
+            rsp = lay.real_local_slice(r, 1.5)
+        else:
+            lay = orc.PencilLayout(Nn, P, row["P1_arg"], row["decomp"][-1])
+            assert (lay.P1, lay.P2) == (row["P1"], row["P2"])
+            assert lay.ranks(r) == (row["c0"], row["c1"])
+            cshape = lay.complex_shape(r)
+            rs, cs = lay.real_local_slice(r), lay.complex_local_slice(r)
+            rsp = lay.real_local_slice(r, 1.5)
+        assert list(lay.real_shape()) == row["real_shape"]
+        assert list(cshape) == row["complex_shape"]
+        assert list(lay.real_shape_padded()) == row["real_shape_padded"]
+        sl = lambda s: [[int(x.start or 0), int(x.stop)] for x in s]
+        assert sl(rs) == row["real_slice"]
+        assert sl(cs) == row["complex_slice"]
+        assert sl(rsp) == row["real_slice_padded"]
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_slab_r2c(gold, P):
+    prec, g = gold
+    lay = orc.SlabLayout(N, P)
+    fus = orc.slab_r2c_forward(orc.scatter_real(g["A"], lay), N, prec)
+    C = orc.gather_complex(fus, lay, fus[0].dtype)
+    for mode in ("Alltoall", "Alltoallw"):
+        assert orc.rel_l2(C, g["slab_P%d_%s_fwd" % (P, mode)]) < TOL[prec]
+    back = orc.slab_r2c_backward(fus, N, prec)
+    B = orc.gather_real(back, lay, back[0].dtype)
+    assert orc.rel_l2(B, g["slab_P%d_Alltoallw_bwd" % P]) < TOL[prec]
+    assert orc.rel_l2(B, g["A"]) < 10 * TOL[prec]
+
+
+@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2)])
+@pytest.mark.parametrize("align", ["X", "Y"])
+def test_pencil_r2c(gold, P, P1, align):
+    prec, g = gold
+    lay = orc.PencilLayout(N, P, P1, align)
+    fus = orc.pencil_r2c_forward(orc.scatter_real(g["A"], lay), N, P1, align, prec)
+    C = orc.gather_complex(fus, lay, fus[0].dtype)
+    assert orc.rel_l2(C, g["pencil%s_P%d_P1%s_fwd" % (align, P, P1)]) < TOL[prec]
+    back = orc.pencil_r2c_backward(fus, N, P1, align, prec)
+    B = orc.gather_real(back, lay, back[0].dtype)
+    assert orc.rel_l2(B, g["pencil%s_P%d_P1%s_bwd" % (align, P, P1)]) < TOL[prec]
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_slab_padded(gold, P):
+    prec, g = gold
+    lay = orc.SlabLayout(N, P)
+    ap = orc.slab_r2c_backward_padded(orc.scatter_complex(g["C0"], lay), N, prec)
+    AP = orc.gather_real(ap, lay, ap[0].dtype, 1.5)
+    assert orc.rel_l2(AP, g["slab_P%d_pad_bwd" % P]) < TOL[prec]
+    cp = orc.slab_r2c_forward_padded(ap, N, prec)
+    CP = orc.gather_complex(cp, lay, cp[0].dtype)
+    assert orc.rel_l2(CP, g["slab_P%d_pad_fwd" % P]) < TOL[prec]
+    assert orc.rel_l2(CP, g["C0"]) < 10 * TOL[prec]
+
+
+@pytest.mark.parametrize("align", ["X", "Y"])
+def test_pencil_padded(gold, align):
+    prec, g = gold
+    lay = orc.PencilLayout(N, 4, None, align)
+    ap = orc.pencil_r2c_backward_padded(orc.scatter_complex(g["C0"], lay), N, None, align, prec)
+    AP = orc.gather_real(ap, lay, ap[0].dtype, 1.5)
+    assert orc.rel_l2(AP, g["pencil%s_P4_pad_bwd" % align]) < TOL[prec]
+    cp = orc.pencil_r2c_forward_padded(ap, N, None, align, prec)
+    CP = orc.gather_complex(cp, lay, cp[0].dtype)
+    assert orc.rel_l2(CP, g["pencil%s_P4_pad_fwd" % align]) < TOL[prec]
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_slab_c2c(gold, P):
+    prec, g = gold
+    lay = orc.SlabLayout(N, P, kind="C2C")
+    fus = orc.slab_c2c_forward(orc.scatter_real(g["Ac"], lay), N, prec)
+    C = np.zeros(lay.global_complex_shape(), dtype=fus[0].dtype)
+    for r, p in enumerate(fus):
+        C[lay.complex_local_slice(r)] = p
+    assert orc.rel_l2(C, g["slabc2c_P%d_fwd" % P]) < TOL[prec]
+    back = orc.slab_c2c_backward(fus, N, prec)
+    B = orc.gather_real(back, lay, back[0].dtype)
+    assert orc.rel_l2(B, g["slabc2c_P%d_bwd" % P]) < TOL[prec]
+
+
+def test_forward_is_rfftn(gold):
+    """The reference's own oracle (tests/test_FFT.py:66-85): distributed result ==
+    serial rfftn on the same data, also with the reference's max-norm criterion."""
+    prec, g = gold
+    A = g["A"]
+    B2 = np.fft.rfftn(A.astype(np.float64))
+    for key in ("slab_P4_Alltoallw_fwd", "pencilX_P8_P1None_fwd", "pencilY_P4_P1None_fwd"):
+        c = g[key]
+        rtol = 1e-8 if prec == "double" else 1e-4
+        assert np.all(np.abs((c - B2) / c.max()) < rtol)
