@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- 3-D R2C+C2R pairs/s of the slab transform on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one fftn + one ifftn of a 1024^3 fp64 cube (BASELINE.json metric),
+inputs and outputs resident in HBM.  N ranks share ONE cube (strong scaling,
+slab decomposition, RCCL all-to-all over xGMI).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# the product library is loaded before anything that could drag in another HIP runtime
+from mpifft4py_amd import _lib, comm as mcomm  # noqa: E402
+from mpifft4py_amd import DeviceArray, Pencil_R2C, Slab_R2C  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def make_comm(world):
+    if world == 1:
+        return mcomm.SelfComm(int(os.environ.get("LOCAL_RANK", "0")) % max(_lib.device_count(), 1)), None
+    bcast, dist = None, None
+    try:
+        import torch.distributed as dist       # plumbing only: rendezvous for the RCCL id
+        dist.init_process_group("gloo")
+
+        def bcast(obj):
+            box = [obj]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+    except Exception as e:                      # noqa: BLE001
+        sys.stderr.write("torch.distributed unavailable (%s): file rendezvous\n" % e)
+        bcast, dist = None, None
+    return mcomm.from_env(bcast), dist
+
+
+def cpu_baseline(n_full, seconds_budget=30.0):
+    """The oracle's path for P = 1 (numpy.fft semantics: rfftn + irfftn, slab.py:369/249)
+    timed on the host cores with scipy.fft's pocketfft and all cores, on a bounded
+    sample: a smaller cube, scaled to the full cube by the N^3 log2 N^3 work ratio."""
+    import scipy.fft as sfft
+    cores = os.cpu_count() or 1
+    n = min(n_full, 512)
+    rng = np.random.default_rng(1234)
+    a = rng.random((n, n, n))
+    t0 = time.perf_counter()
+    c = sfft.rfftn(a, workers=cores)
+    b = sfft.irfftn(c, s=a.shape, workers=cores)
+    first = time.perf_counter() - t0
+    reps = int(max(1, min(5, (seconds_budget - first) // max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c = sfft.rfftn(a, workers=cores)
+        b = sfft.irfftn(c, s=a.shape, workers=cores)
+    dt = (time.perf_counter() - t0) / reps
+    err = float(np.linalg.norm((b - a).ravel()) / np.linalg.norm(a.ravel()))
+    work = lambda m: m ** 3 * 3 * np.log2(m)
+    scale = work(n) / work(n_full)
+    return {"value": (1.0 / dt) * scale, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d^3 fp64 rfftn+irfftn pair via scipy.fft(pocketfft, workers=%d): %.3f s/pair "
+                      "(round-trip rel-L2 %.1e); scaled to %d^3 by N^3*log2(N^3) (x%.4f)"
+                      % (n, cores, dt, err, n_full, scale)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1024)
+    ap.add_argument("--decomp", default="slab", choices=["slab", "pencil"])
+    ap.add_argument("--precision", default="double", choices=["double", "single"])
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--pipeline", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.stderr.write("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "(one process per GPU)\n" % args.gpus)
+            sys.exit(2)
+    comm, dist = make_comm(world)
+    n = args.n
+    N = np.array([n, n, n])
+    L = np.array([2 * np.pi] * 3)
+    if args.decomp == "slab":
+        F = Slab_R2C(N, L, comm, args.precision, pipeline=args.pipeline)
+    else:
+        F = Pencil_R2C(N, L, comm, args.precision, communication="Alltoallw", alignment="X",
+                       allow_single=True, pipeline=args.pipeline)
+    u = DeviceArray.random(F.real_shape(), F.float, seed=1234 + rank)
+    fu = DeviceArray.empty(F.complex_shape(), F.complex)
+    u2 = DeviceArray.empty(F.real_shape(), F.float)
+
+    def sync_all():
+        F.sync()
+        _lib.call("mfft_device_sync")
+        comm.barrier()
+
+    for _ in range(args.warmup):
+        F.fftn(u, fu)
+        F.ifftn(fu, u2)
+    sync_all()
+    # correctness gate on the data the timed loop uses: round trip of the first x-plane(s)
+    k = max(1, min(F.real_shape()[0], 2))
+    a0 = u.leading(0, k).get()
+    b0 = u2.leading(0, k).get()
+    rt_err = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
+
+    F.enable_timing(True)
+    F.reset_timing()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        F.fftn(u, fu)
+        F.ifftn(fu, u2)
+    F.sync()
+    _lib.call("mfft_device_sync")
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    dt = comm.allreduce(dt, op=mcomm.MAX) if world > 1 else dt
+    stages = F.stage_times()
+
+    if rank == 0:
+        esz = 8 if args.precision == "double" else 4
+        R = esz * n ** 3
+        C = 2 * esz * n * n * (n // 2 + 1)
+        alg_pair = 2.0 * (R + 5.0 * C)
+        ms = 1e3 * dt / args.steps
+        # dominant kernel family: the strided-axis c2c (stages *_x, *_y)
+        col = [(k_, v) for k_, v in stages.items() if k_.endswith("_x") or k_.endswith("_y")]
+        col_ms = sum(v[0] for _, v in col)
+        col_calls = sum(v[1] for _, v in col)
+        col_bytes = col[0][1][2] if col else 0.0
+        avg_ms = col_ms / max(col_calls, 1)
+        achieved = (col_bytes / (avg_ms * 1e-3)) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "3D R2C+C2R pairs/sec, %d^3 fp64 %s" % (n, args.decomp),
+            "value": args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64" if args.precision == "double" else "f32",
+            "data": "synthetic",
+            "config": {"workload": "%d^3 %s %s R2C forward+inverse, device-resident, %d rank(s)"
+                                   % (n, "fp64" if args.precision == "double" else "fp32", args.decomp, world),
+                       "roundtrip_rel_l2": rt_err,
+                       "alg_bytes_per_pair": alg_pair,
+                       "whole_path_hbm_GBs_per_gpu": alg_pair / world / (ms * 1e-3) / 1e9,
+                       "whole_path_frac_of_8TBs": alg_pair / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "stage_ms": {k_: v[0] / max(v[1], 1) for k_, v in sorted(stages.items())}},
+            "roofline": {"bound": "hbm", "kernel": "col_fft (strided-axis c2c, stages *_x/*_y)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": col_bytes, "avg_launch_ms": avg_ms},
+        }
+        if world == 1 and args.cpu_baseline == "auto":
+            out["cpu_baseline"] = cpu_baseline(n)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+if __name__ == "__main__":
+    main()

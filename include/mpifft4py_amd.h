@@ -1,0 +1,152 @@
+/* mpifft4py_amd.h -- C ABI of libmpifft4py_amd.so
+ *
+ * MI355X-native (gfx950) distributed 3-D FFT: the drop-in boundary for the hot
+ * path of spectralDNS/mpiFFT4py (slab / pencil R2C.fftn / ifftn).  The
+ * reference has no C ABI of its own; its backend seam is the Python module
+ * `mpiFFT4py/serialFFT` (serialFFT/__init__.py:1-6) plus the mpi4py
+ * communicator handed to the constructors.  Every entry point below names the
+ * reference interface it replaces.  The Python package `mpifft4py_amd` binds
+ * this file with ctypes (mpifft4py_amd/_lib.py); INTEGRATION.md shows the stub
+ * a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, ints.  No C++/torch types cross the boundary.
+ *   - every function returns 0 on success or a negative mfft_status; the text of
+ *     the last failure on the calling thread is mfft_last_error().
+ *   - all data pointers are DEVICE pointers (HBM) unless named *_host.
+ *   - arrays are C-order; complex = interleaved (re, im).
+ *   - a plan is bound to the device current at creation and to one comm.
+ */
+#ifndef MPIFFT4PY_AMD_H
+#define MPIFFT4PY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFFT_API __attribute__((visibility("default")))
+
+typedef enum {
+  MFFT_OK = 0,
+  MFFT_ERR_INVALID = -1,      /* bad argument */
+  MFFT_ERR_UNSUPPORTED = -2,  /* e.g. transform length that is not 2^a*{1,3,5} */
+  MFFT_ERR_HIP = -3,          /* HIP runtime failure */
+  MFFT_ERR_RCCL = -4,         /* RCCL failure / library not loadable */
+  MFFT_ERR_NOMEM = -5,
+  MFFT_ERR_INTERNAL = -6
+} mfft_status;
+
+typedef enum { MFFT_SINGLE = 0, MFFT_DOUBLE = 1 } mfft_precision;     /* mpibase.py:133-137 */
+typedef enum { MFFT_R2C = 0, MFFT_C2C = 1 } mfft_kind;                 /* slab.R2C / slab.C2C */
+typedef enum { MFFT_SLAB = 0, MFFT_PENCIL_X = 1, MFFT_PENCIL_Y = 2 } mfft_decomp;
+typedef enum { MFFT_DEALIAS_NONE = 0, MFFT_DEALIAS_2_3 = 1, MFFT_DEALIAS_3_2 = 2 } mfft_dealias;
+
+typedef struct mfft_comm_s* mfft_comm_t;
+typedef struct mfft_plan_s* mfft_plan_t;
+
+/* ---- library / device ------------------------------------------------- */
+MFFT_API int mfft_version(void);
+MFFT_API const char* mfft_last_error(void);
+MFFT_API int mfft_device_count(int* count);
+MFFT_API int mfft_set_device(int device);
+MFFT_API int mfft_get_device(int* device);
+MFFT_API int mfft_device_name(char* buf, size_t buflen);
+MFFT_API int mfft_device_sync(void);
+
+/* ---- device memory (replaces mpibase.py:38-51 empty/zeros and the
+ *      work_arrays cache, mpibase.py:53-131, for device-resident buffers) --- */
+MFFT_API int mfft_malloc(void** dptr, size_t bytes);
+MFFT_API int mfft_free(void* dptr);
+MFFT_API int mfft_memset(void* dptr, int value, size_t bytes);
+MFFT_API int mfft_memcpy_h2d(void* dst, const void* src_host, size_t bytes);
+MFFT_API int mfft_memcpy_d2h(void* dst_host, const void* src, size_t bytes);
+MFFT_API int mfft_memcpy_d2d(void* dst, const void* src, size_t bytes);
+MFFT_API int mfft_fill_uniform(void* dptr, size_t count, int precision, uint64_t seed); /* U[0,1) synthetic input */
+
+/* ---- communicators (replace the mpi4py Comm injected at slab.py:77-81,
+ *      pencil.py:173-195: Get_size/Get_rank/Split + Alltoall(w)) ----------- */
+#define MFFT_UNIQUE_ID_BYTES 128
+MFFT_API int mfft_comm_create_self(mfft_comm_t* comm);                 /* P = 1, no RCCL */
+MFFT_API int mfft_get_unique_id(void* id128);                           /* rank 0; ncclGetUniqueId */
+MFFT_API int mfft_comm_create_rccl(int nranks, int rank, const void* id128, mfft_comm_t* comm);
+/* in-process group: nranks virtual ranks, each driven by its own host thread,
+ * rank r living on devices[r] (NULL = all on the current device); exchange is
+ * peer-to-peer device copies. */
+MFFT_API int mfft_comm_create_local(int nranks, const int* devices, mfft_comm_t* comms_out);
+MFFT_API int mfft_comm_size(mfft_comm_t comm, int* size);
+MFFT_API int mfft_comm_rank(mfft_comm_t comm, int* rank);
+MFFT_API int mfft_comm_barrier(mfft_comm_t comm);
+/* host-buffer helpers for tests/demos (tests/test_FFT.py:77-78 Bcast; demo:103 reduce) */
+MFFT_API int mfft_comm_bcast_host(mfft_comm_t comm, void* buf_host, size_t bytes, int root);
+MFFT_API int mfft_comm_allreduce_sum_host(mfft_comm_t comm, double* vals_host, int count);
+MFFT_API int mfft_comm_allreduce_max_host(mfft_comm_t comm, double* vals_host, int count);
+MFFT_API int mfft_comm_destroy(mfft_comm_t comm);
+
+/* ---- plans: slab.R2C / slab.C2C / pencil.R2CX / pencil.R2CY --------------
+ * (constructors slab.py:67-96, 556-574; pencil.py:167-216, 903-913) */
+typedef struct {
+  int64_t n[3];       /* global real mesh N0,N1,N2 */
+  int precision;      /* mfft_precision */
+  int kind;           /* mfft_kind */
+  int decomp;         /* mfft_decomp */
+  int p1;             /* pencil: ranks along the first axis, 0 = Compute_dims default */
+  double padsize;     /* 3/2-rule pad factor (1.5) */
+  int pipeline;       /* >1: split exchanges into this many overlapped sub-steps */
+  int reserved[7];
+} mfft_plan_desc;
+
+MFFT_API int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* plan);
+MFFT_API int mfft_plan_destroy(mfft_plan_t plan);
+/* local shapes and global start offsets (slab.py:98-144, pencil.py:248-287, 915-943) */
+MFFT_API int mfft_plan_layout(mfft_plan_t plan, int64_t real_shape[3], int64_t complex_shape[3],
+                              int64_t real_start[3], int64_t complex_start[3],
+                              int64_t real_shape_padded[3], int64_t grid[2], int64_t subranks[2]);
+MFFT_API int mfft_plan_workspace_bytes(mfft_plan_t plan, size_t* bytes);
+
+/* fftn: slab.py:349-485 / pencil.py:634-883, 1228-1475.  `u` is never written. */
+MFFT_API int mfft_forward(mfft_plan_t plan, const void* u, void* fu, int dealias);
+/* ifftn: slab.py:214-346 / pencil.py:386-632, 1001-1224.  `fu` is never written. */
+MFFT_API int mfft_backward(mfft_plan_t plan, const void* fu, void* u, int dealias);
+/* block the host until everything the plan enqueued has finished */
+MFFT_API int mfft_plan_sync(mfft_plan_t plan);
+
+/* 2/3-rule mask (slab.py:191-197; applied by cython/maths.pyx:9-19): uint8 per
+ * local complex element, device-resident */
+MFFT_API int mfft_plan_set_dealias_mask(mfft_plan_t plan, const uint8_t* mask_host, size_t count);
+
+/* per-stage timing with HIP events on the plan's own streams (bench roofline) */
+MFFT_API int mfft_plan_timing(mfft_plan_t plan, int enable);
+MFFT_API int mfft_plan_timing_reset(mfft_plan_t plan);
+/* returns number of stages; arrays may be NULL to query the count */
+MFFT_API int mfft_plan_timing_get(mfft_plan_t plan, int max_stages, char names[][32],
+                                  double* total_ms, int64_t* calls, double* alg_bytes_per_call);
+
+/* ---- stage level: the serialFFT seam (numpy_fft.py:25-107 / pyfftw_fft.py:26-203)
+ * batched transforms of one axis of a contiguous C-order 3-D array on the
+ * current device, default stream; synchronous w.r.t. the host on return. */
+MFFT_API int mfft_c2c_axis(const void* in, void* out, const int64_t shape[3], int axis,
+                           int inverse, int precision);                 /* fft / ifft  (ifft scaled 1/n) */
+MFFT_API int mfft_r2c_last(const void* in, void* out, const int64_t real_shape[3], int precision);    /* rfft axis=2 */
+MFFT_API int mfft_c2r_last(const void* in, void* out, const int64_t real_shape[3], int precision);    /* irfft axis=2, scaled 1/n */
+/* slab pack / unpack (slab.py:403; cython/maths.pyx:21-31 transpose_Uc) */
+MFFT_API int mfft_slab_pack(const void* uc_hatT, void* u_mpi, int P, int64_t np0, int64_t np1, int64_t nf, int precision);
+MFFT_API int mfft_slab_unpack(const void* u_mpi, void* uc_hatT, int P, int64_t np0, int64_t np1, int64_t nf, int precision);
+/* fu[i] *= mask[i] (cython/maths.pyx:9-19 dealias_filter) */
+MFFT_API int mfft_dealias_filter(void* fu, const uint8_t* mask_dev, size_t count, int precision);
+/* 1 if a transform of length n along an axis is supported */
+MFFT_API int mfft_length_supported(int64_t n, int real_transform);
+
+/* ---- HIP-event timers on the default stream (bench.py) ------------------ */
+typedef struct mfft_timer_s* mfft_timer_t;
+MFFT_API int mfft_timer_create(mfft_timer_t* t);
+MFFT_API int mfft_timer_start(mfft_timer_t t);
+MFFT_API int mfft_timer_stop(mfft_timer_t t, float* elapsed_ms);   /* synchronises on the stop event */
+MFFT_API int mfft_timer_destroy(mfft_timer_t t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPIFFT4PY_AMD_H */

@@ -1,0 +1,140 @@
+"""ctypes binding of libmpifft4py_amd.so (the C ABI in include/mpifft4py_amd.h).
+
+The product path has NO fallback: if the shared library is missing or a HIP
+call fails, an exception is raised.  Nothing in this package imports numpy.fft,
+the oracle, or torch.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t,
+                    c_uint64, c_uint8, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpifft4py_amd.so")
+
+SINGLE, DOUBLE = 0, 1
+R2C, C2C = 0, 1
+SLAB, PENCIL_X, PENCIL_Y = 0, 1, 2
+DEALIAS_NONE, DEALIAS_2_3, DEALIAS_3_2 = 0, 1, 2
+UNIQUE_ID_BYTES = 128
+
+
+class PlanDesc(ctypes.Structure):
+    _fields_ = [("n", c_int64 * 3), ("precision", c_int), ("kind", c_int), ("decomp", c_int),
+                ("p1", c_int), ("padsize", c_double), ("pipeline", c_int), ("reserved", c_int * 7)]
+
+
+class MfftError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "mfft_version": ([], c_int),
+    "mfft_last_error": ([], c_char_p),
+    "mfft_device_count": ([POINTER(c_int)], c_int),
+    "mfft_set_device": ([c_int], c_int),
+    "mfft_get_device": ([POINTER(c_int)], c_int),
+    "mfft_device_name": ([c_char_p, c_size_t], c_int),
+    "mfft_device_sync": ([], c_int),
+    "mfft_malloc": ([POINTER(c_void_p), c_size_t], c_int),
+    "mfft_free": ([c_void_p], c_int),
+    "mfft_memset": ([c_void_p, c_int, c_size_t], c_int),
+    "mfft_memcpy_h2d": ([c_void_p, c_void_p, c_size_t], c_int),
+    "mfft_memcpy_d2h": ([c_void_p, c_void_p, c_size_t], c_int),
+    "mfft_memcpy_d2d": ([c_void_p, c_void_p, c_size_t], c_int),
+    "mfft_fill_uniform": ([c_void_p, c_size_t, c_int, c_uint64], c_int),
+    "mfft_comm_create_self": ([POINTER(c_void_p)], c_int),
+    "mfft_get_unique_id": ([c_void_p], c_int),
+    "mfft_comm_create_rccl": ([c_int, c_int, c_void_p, POINTER(c_void_p)], c_int),
+    "mfft_comm_create_local": ([c_int, POINTER(c_int), POINTER(c_void_p)], c_int),
+    "mfft_comm_size": ([c_void_p, POINTER(c_int)], c_int),
+    "mfft_comm_rank": ([c_void_p, POINTER(c_int)], c_int),
+    "mfft_comm_barrier": ([c_void_p], c_int),
+    "mfft_comm_bcast_host": ([c_void_p, c_void_p, c_size_t, c_int], c_int),
+    "mfft_comm_allreduce_sum_host": ([c_void_p, POINTER(c_double), c_int], c_int),
+    "mfft_comm_allreduce_max_host": ([c_void_p, POINTER(c_double), c_int], c_int),
+    "mfft_comm_destroy": ([c_void_p], c_int),
+    "mfft_plan_create": ([c_void_p, POINTER(PlanDesc), POINTER(c_void_p)], c_int),
+    "mfft_plan_destroy": ([c_void_p], c_int),
+    "mfft_plan_layout": ([c_void_p] + [POINTER(c_int64)] * 7, c_int),
+    "mfft_plan_workspace_bytes": ([c_void_p, POINTER(c_size_t)], c_int),
+    "mfft_forward": ([c_void_p, c_void_p, c_void_p, c_int], c_int),
+    "mfft_backward": ([c_void_p, c_void_p, c_void_p, c_int], c_int),
+    "mfft_plan_sync": ([c_void_p], c_int),
+    "mfft_plan_set_dealias_mask": ([c_void_p, c_void_p, c_size_t], c_int),
+    "mfft_plan_timing": ([c_void_p, c_int], c_int),
+    "mfft_plan_timing_reset": ([c_void_p], c_int),
+    "mfft_plan_timing_get": ([c_void_p, c_int, c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)], c_int),
+    "mfft_c2c_axis": ([c_void_p, c_void_p, POINTER(c_int64), c_int, c_int, c_int], c_int),
+    "mfft_r2c_last": ([c_void_p, c_void_p, POINTER(c_int64), c_int], c_int),
+    "mfft_c2r_last": ([c_void_p, c_void_p, POINTER(c_int64), c_int], c_int),
+    "mfft_slab_pack": ([c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int], c_int),
+    "mfft_slab_unpack": ([c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int], c_int),
+    "mfft_dealias_filter": ([c_void_p, c_void_p, c_size_t, c_int], c_int),
+    "mfft_length_supported": ([c_int64, c_int], c_int),
+    "mfft_timer_create": ([POINTER(c_void_p)], c_int),
+    "mfft_timer_start": ([c_void_p], c_int),
+    "mfft_timer_stop": ([c_void_p, POINTER(c_float)], c_int),
+    "mfft_timer_destroy": ([c_void_p], c_int),
+}
+
+# functions whose int result is a count, not a status
+_COUNT_RESULT = {"mfft_version", "mfft_length_supported", "mfft_plan_timing_get"}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MfftError(
+            "%s not found: build it with `make -C mpifft4py_amd/csrc` (or python -c "
+            "'import __graft_entry__ as g; g.build()').  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here means header and library disagree
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc):
+    if rc < 0:
+        msg = load().mfft_last_error()
+        raise MfftError("libmpifft4py_amd error %d: %s" % (rc, msg.decode() if msg else "?"))
+    return rc
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if name in _COUNT_RESULT:
+        if rc < 0:
+            check(rc)
+        return rc
+    return check(rc)
+
+
+def device_count():
+    n = c_int(0)
+    rc = load().mfft_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def precision_code(dtype_or_name):
+    import numpy as np
+    if dtype_or_name in ("single", "double"):
+        return SINGLE if dtype_or_name == "single" else DOUBLE
+    dt = np.dtype(dtype_or_name)
+    if dt in (np.dtype(np.float32), np.dtype(np.complex64)):
+        return SINGLE
+    if dt in (np.dtype(np.float64), np.dtype(np.complex128)):
+        return DOUBLE
+    raise TypeError("unsupported dtype %s" % dt)

@@ -1,0 +1,36 @@
+// comm.h -- communicator abstraction behind mfft_comm_t.
+//
+// Replaces the mpi4py communicator the reference receives in its constructors
+// (slab.py:77-81, pencil.py:173-195).  Three transports:
+//   SelfComm  : P = 1.
+//   RcclComm  : one process per GPU, RCCL (loaded with dlopen at first use) over
+//               xGMI; the exchange is a grouped ncclSend/ncclRecv all-to-all-v.
+//   LocalComm : P virtual ranks inside ONE process, each driven by its own host
+//               thread, exchanging with peer-to-peer device copies.  Used for
+//               single-process multi-GPU runs and to exercise the full
+//               distributed algorithm on a single GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <vector>
+
+struct mfft_comm_s {
+  int size = 1, rank = 0;
+  virtual ~mfft_comm_s() {}
+  // All-to-all-v inside a sub-group.  `peers` lists the comm ranks of the group
+  // (every member passes the same list); chunk i is sent to / received from
+  // peers[i].  Counts and displacements are in BYTES.  Enqueued on stream s.
+  virtual int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv,
+                        const size_t* rcount, const size_t* rdisp, const int* peers, int npeers,
+                        hipStream_t s) = 0;
+  virtual int barrier() = 0;
+  virtual int bcast_host(void* buf, size_t bytes, int root) = 0;
+  virtual int allreduce_host(double* vals, int count, int op /*0 sum, 1 max*/) = 0;
+};
+
+namespace mfft {
+int comm_create_self(mfft_comm_s** out);
+int comm_get_unique_id(void* id128);
+int comm_create_rccl(int nranks, int rank, const void* id128, mfft_comm_s** out);
+int comm_create_local(int nranks, const int* devices, mfft_comm_s** out);
+}  // namespace mfft

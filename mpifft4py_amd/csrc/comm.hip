@@ -1,0 +1,319 @@
+// comm.hip -- Self / RCCL / in-process transports (see comm.h)
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include "comm.h"
+#include "mfft_internal.h"
+
+namespace mfft {
+
+// ===========================================================================
+// Self
+// ===========================================================================
+struct SelfComm : mfft_comm_s {
+  int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
+                const size_t* rdisp, const int*, int npeers, hipStream_t s) override {
+    if (npeers != 1) return set_error(MFFT_ERR_INVALID, "self comm: group of %d", npeers);
+    if (scount[0] != rcount[0]) return set_error(MFFT_ERR_INVALID, "self comm: count mismatch");
+    if (scount[0])
+      MFFT_HIP(hipMemcpyAsync(static_cast<char*>(recv) + rdisp[0], static_cast<const char*>(send) + sdisp[0],
+                              scount[0], hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
+  int barrier() override { return 0; }
+  int bcast_host(void*, size_t, int) override { return 0; }
+  int allreduce_host(double*, int, int) override { return 0; }
+};
+
+int comm_create_self(mfft_comm_s** out) {
+  *out = new SelfComm();
+  return 0;
+}
+
+// ===========================================================================
+// RCCL (dlopen'ed so that single-GPU use never touches the library and so that
+// whichever librccl.so.1 the process already holds is the one that is used)
+// ===========================================================================
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  static bool ok = false;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.handle) break;
+    }
+    if (!api.handle) return;
+#define MFFT_SYM(f) api.f = reinterpret_cast<decltype(api.f)>(dlsym(api.handle, "nccl" #f))
+    MFFT_SYM(GetUniqueId);
+    MFFT_SYM(CommInitRank);
+    MFFT_SYM(CommDestroy);
+    MFFT_SYM(Send);
+    MFFT_SYM(Recv);
+    MFFT_SYM(GroupStart);
+    MFFT_SYM(GroupEnd);
+    MFFT_SYM(Broadcast);
+    MFFT_SYM(AllReduce);
+    MFFT_SYM(GetErrorString);
+#undef MFFT_SYM
+    ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.Send && api.Recv && api.GroupStart &&
+         api.GroupEnd && api.Broadcast && api.AllReduce && api.GetErrorString;
+  });
+  return ok ? &api : nullptr;
+}
+
+#define MFFT_NCCL(api, call)                                                                        \
+  do {                                                                                              \
+    ncclResult_t r_ = (call);                                                                       \
+    if (r_ != ncclSuccess)                                                                          \
+      return set_error(MFFT_ERR_RCCL, "%s failed: %s (%s:%d)", #call, (api)->GetErrorString(r_),    \
+                       __FILE__, __LINE__);                                                         \
+  } while (0)
+
+struct RcclComm : mfft_comm_s {
+  RcclApi* api = nullptr;
+  ncclComm_t comm = nullptr;
+  hipStream_t hstream = nullptr;     // for the host-buffer helpers
+  ~RcclComm() override {
+    if (comm) api->CommDestroy(comm);
+    if (hstream) (void)hipStreamDestroy(hstream);
+  }
+  int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
+                const size_t* rdisp, const int* peers, int npeers, hipStream_t s) override {
+    const char* sp = static_cast<const char*>(send);
+    char* rp = static_cast<char*>(recv);
+    // the self chunk never enters RCCL
+    for (int i = 0; i < npeers; ++i)
+      if (peers[i] == rank && scount[i])
+        MFFT_HIP(hipMemcpyAsync(rp + rdisp[i], sp + sdisp[i], scount[i], hipMemcpyDeviceToDevice, s));
+    if (npeers > 1) {
+      MFFT_NCCL(api, api->GroupStart());
+      for (int i = 0; i < npeers; ++i) {
+        if (peers[i] == rank) continue;
+        if (scount[i]) MFFT_NCCL(api, api->Send(sp + sdisp[i], scount[i], ncclUint8, peers[i], comm, s));
+        if (rcount[i]) MFFT_NCCL(api, api->Recv(rp + rdisp[i], rcount[i], ncclUint8, peers[i], comm, s));
+      }
+      MFFT_NCCL(api, api->GroupEnd());
+    }
+    return 0;
+  }
+  int barrier() override {
+    double v = 0;
+    return allreduce_host(&v, 1, 0);
+  }
+  int bcast_host(void* buf, size_t bytes, int root) override {
+    if (bytes == 0) return 0;
+    void* d = nullptr;
+    MFFT_HIP(hipMalloc(&d, bytes));
+    if (rank == root) MFFT_HIP(hipMemcpyAsync(d, buf, bytes, hipMemcpyHostToDevice, hstream));
+    ncclResult_t r = api->Broadcast(d, d, bytes, ncclUint8, root, comm, hstream);
+    if (r != ncclSuccess) {
+      (void)hipFree(d);
+      return set_error(MFFT_ERR_RCCL, "ncclBroadcast failed: %s", api->GetErrorString(r));
+    }
+    MFFT_HIP(hipMemcpyAsync(buf, d, bytes, hipMemcpyDeviceToHost, hstream));
+    MFFT_HIP(hipStreamSynchronize(hstream));
+    MFFT_HIP(hipFree(d));
+    return 0;
+  }
+  int allreduce_host(double* vals, int count, int op) override {
+    if (count <= 0) return 0;
+    void* d = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)count;
+    MFFT_HIP(hipMalloc(&d, bytes));
+    MFFT_HIP(hipMemcpyAsync(d, vals, bytes, hipMemcpyHostToDevice, hstream));
+    ncclResult_t r = api->AllReduce(d, d, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, comm, hstream);
+    if (r != ncclSuccess) {
+      (void)hipFree(d);
+      return set_error(MFFT_ERR_RCCL, "ncclAllReduce failed: %s", api->GetErrorString(r));
+    }
+    MFFT_HIP(hipMemcpyAsync(vals, d, bytes, hipMemcpyDeviceToHost, hstream));
+    MFFT_HIP(hipStreamSynchronize(hstream));
+    MFFT_HIP(hipFree(d));
+    return 0;
+  }
+};
+
+int comm_get_unique_id(void* id128) {
+  RcclApi* api = rccl_api();
+  if (!api) return set_error(MFFT_ERR_RCCL, "librccl.so.1 could not be loaded: %s", dlerror());
+  ncclUniqueId id;
+  MFFT_NCCL(api, api->GetUniqueId(&id));
+  static_assert(sizeof(id) == MFFT_UNIQUE_ID_BYTES, "unique id size");
+  memcpy(id128, &id, sizeof id);
+  return 0;
+}
+
+int comm_create_rccl(int nranks, int rank, const void* id128, mfft_comm_s** out) {
+  RcclApi* api = rccl_api();
+  if (!api) return set_error(MFFT_ERR_RCCL, "librccl.so.1 could not be loaded: %s", dlerror());
+  if (nranks < 1 || rank < 0 || rank >= nranks) return set_error(MFFT_ERR_INVALID, "bad rank %d of %d", rank, nranks);
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  std::unique_ptr<RcclComm> c(new RcclComm());
+  c->api = api;
+  c->size = nranks;
+  c->rank = rank;
+  MFFT_NCCL(api, api->CommInitRank(&c->comm, nranks, id, rank));
+  MFFT_HIP(hipStreamCreateWithFlags(&c->hstream, hipStreamNonBlocking));
+  *out = c.release();
+  return 0;
+}
+
+// ===========================================================================
+// in-process group of virtual ranks (host thread per rank)
+// ===========================================================================
+struct LocalShared {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  long generation = 0;
+  int refs = 0;
+  struct Post {
+    const char* send = nullptr;
+    std::vector<size_t> sdisp, scount;
+    hipEvent_t ready = nullptr, done = nullptr;
+    int device = 0;
+    void* host_ptr = nullptr;
+  };
+  std::vector<Post> posts;
+
+  void wait_all() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long gen = generation;
+    if (++arrived == n) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
+struct LocalComm : mfft_comm_s {
+  std::shared_ptr<LocalShared> sh;
+  ~LocalComm() override {
+    LocalShared::Post& p = sh->posts[rank];
+    if (p.ready) (void)hipEventDestroy(p.ready);
+    if (p.done) (void)hipEventDestroy(p.done);
+    p.ready = p.done = nullptr;
+  }
+  int ensure_events() {
+    LocalShared::Post& p = sh->posts[rank];
+    if (!p.ready) {
+      MFFT_HIP(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming));
+      MFFT_HIP(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+    }
+    return 0;
+  }
+  int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
+                const size_t* rdisp, const int* peers, int npeers, hipStream_t s) override {
+    MFFT_TRY(ensure_events());
+    LocalShared::Post& me = sh->posts[rank];
+    int myidx = -1;
+    for (int i = 0; i < npeers; ++i)
+      if (peers[i] == rank) myidx = i;
+    if (myidx < 0) return set_error(MFFT_ERR_INVALID, "local comm: rank %d not in its own group", rank);
+    me.send = static_cast<const char*>(send);
+    me.sdisp.assign(sdisp, sdisp + npeers);
+    me.scount.assign(scount, scount + npeers);
+    MFFT_HIP(hipEventRecord(me.ready, s));
+    sh->wait_all();                                   // every member has posted
+    char* rp = static_cast<char*>(recv);
+    for (int i = 0; i < npeers; ++i) {
+      LocalShared::Post& pe = sh->posts[peers[i]];
+      if (pe.scount[myidx] != rcount[i])
+        return set_error(MFFT_ERR_INTERNAL, "local comm: rank %d expects %zu bytes from %d, peer sends %zu", rank,
+                         rcount[i], peers[i], pe.scount[myidx]);
+      if (!rcount[i]) continue;
+      if (peers[i] != rank) MFFT_HIP(hipStreamWaitEvent(s, pe.ready, 0));
+      MFFT_HIP(hipMemcpyAsync(rp + rdisp[i], pe.send + pe.sdisp[myidx], rcount[i], hipMemcpyDeviceToDevice, s));
+    }
+    MFFT_HIP(hipEventRecord(me.done, s));
+    sh->wait_all();                                   // every member has enqueued its pulls
+    // nobody may overwrite its send buffer before all peers have pulled from it
+    for (int i = 0; i < npeers; ++i)
+      if (peers[i] != rank) MFFT_HIP(hipStreamWaitEvent(s, sh->posts[peers[i]].done, 0));
+    sh->wait_all();                                   // events may be re-recorded only after everyone waited on them
+    return 0;
+  }
+  int barrier() override {
+    sh->wait_all();
+    return 0;
+  }
+  int bcast_host(void* buf, size_t bytes, int root) override {
+    sh->posts[rank].host_ptr = buf;
+    sh->wait_all();
+    if (rank != root && bytes) memcpy(buf, sh->posts[root].host_ptr, bytes);
+    sh->wait_all();
+    return 0;
+  }
+  int allreduce_host(double* vals, int count, int op) override {
+    sh->posts[rank].host_ptr = vals;
+    sh->wait_all();
+    std::vector<double> acc(vals, vals + count);
+    for (int r = 0; r < size; ++r) {
+      if (r == rank) continue;
+      const double* o = static_cast<const double*>(sh->posts[r].host_ptr);
+      for (int i = 0; i < count; ++i) acc[i] = op == 1 ? (o[i] > acc[i] ? o[i] : acc[i]) : acc[i] + o[i];
+    }
+    sh->wait_all();
+    for (int i = 0; i < count; ++i) vals[i] = acc[i];
+    sh->wait_all();
+    return 0;
+  }
+};
+
+int comm_create_local(int nranks, const int* devices, mfft_comm_s** out) {
+  if (nranks < 1) return set_error(MFFT_ERR_INVALID, "nranks must be >= 1");
+  int cur = 0;
+  MFFT_HIP(hipGetDevice(&cur));
+  auto sh = std::make_shared<LocalShared>();
+  sh->n = nranks;
+  sh->posts.resize(nranks);
+  for (int r = 0; r < nranks; ++r) sh->posts[r].device = devices ? devices[r] : cur;
+  // peer access between distinct devices (ignore "already enabled")
+  for (int a = 0; a < nranks; ++a)
+    for (int b = 0; b < nranks; ++b) {
+      const int da = sh->posts[a].device, db = sh->posts[b].device;
+      if (da == db) continue;
+      int can = 0;
+      (void)hipDeviceCanAccessPeer(&can, da, db);
+      if (can) {
+        (void)hipSetDevice(da);
+        hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+        if (e != hipSuccess) (void)hipGetLastError();
+      }
+    }
+  (void)hipSetDevice(cur);
+  for (int r = 0; r < nranks; ++r) {
+    LocalComm* c = new LocalComm();
+    c->size = nranks;
+    c->rank = r;
+    c->sh = sh;
+    out[r] = c;
+  }
+  return 0;
+}
+
+}  // namespace mfft

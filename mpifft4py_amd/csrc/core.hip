@@ -1,0 +1,351 @@
+// core.hip -- kernel registry, twiddle cache, launch layer and the small
+// data-movement kernels (box copy / mask / scale / synthetic fill).
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include "mfft_internal.h"
+
+namespace mfft {
+
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+int set_error(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+const char* last_error() { return g_err.c_str(); }
+
+std::vector<KernelEntry>& kernel_registry() {
+  static std::vector<KernelEntry> reg;
+  return reg;
+}
+
+const KernelEntry* find_kernel(int family, int n, int prec, int inv) {
+  for (const KernelEntry& e : kernel_registry())
+    if (e.family == family && e.n == n && e.prec == prec && e.inv == inv) return &e;
+  return nullptr;
+}
+
+bool length_supported(int64_t n, bool real_transform) {
+  if (n <= 0 || n > (1 << 20)) return false;
+  if (real_transform) return find_kernel(FAM_R2C, (int)n, MFFT_DOUBLE, 0) != nullptr;
+  return n == 1 || find_kernel(FAM_COL, (int)n, MFFT_DOUBLE, 0) != nullptr;
+}
+
+// ---------------------------------------------------------------------------
+// per-device caches: inter-pass twiddles per kernel entry, real twiddles per
+// (n, prec); kernels with > 64 KiB dynamic LDS get the opt-in attribute once.
+// ---------------------------------------------------------------------------
+struct DevCache {
+  std::map<const KernelEntry*, void*> tw;
+  std::map<std::pair<int, int>, void*> rtw;
+  std::map<const void*, bool> attr_done;
+};
+static std::mutex g_cache_mu;
+static std::map<int, DevCache> g_cache;
+
+static int prepare_kernel(const KernelEntry* e, void** tw_out) {
+  int dev = 0;
+  MFFT_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  DevCache& c = g_cache[dev];
+  if (!c.attr_done[e->func]) {
+    if (e->lds_bytes > 65536)
+      MFFT_HIP(hipFuncSetAttribute(e->func, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+    c.attr_done[e->func] = true;
+  }
+  auto it = c.tw.find(e);
+  if (it == c.tw.end()) {
+    const size_t bytes = (size_t)e->tw_count * elem_bytes(e->prec, true);
+    std::vector<char> host(bytes);
+    e->build_tw(host.data());
+    void* d = nullptr;
+    MFFT_HIP(hipMalloc(&d, bytes));
+    MFFT_HIP(hipMemcpy(d, host.data(), bytes, hipMemcpyHostToDevice));
+    it = c.tw.emplace(e, d).first;
+  }
+  *tw_out = it->second;
+  return 0;
+}
+
+static int real_twiddles(int n, int prec, void** out) {
+  int dev = 0;
+  MFFT_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  DevCache& c = g_cache[dev];
+  auto key = std::make_pair(n, prec);
+  auto it = c.rtw.find(key);
+  if (it == c.rtw.end()) {
+    void* d = nullptr;
+    if (prec == MFFT_DOUBLE) {
+      auto v = build_real_twiddles<double>(n);
+      MFFT_HIP(hipMalloc(&d, v.size() * sizeof(v[0])));
+      MFFT_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+    } else {
+      auto v = build_real_twiddles<float>(n);
+      MFFT_HIP(hipMalloc(&d, v.size() * sizeof(v[0])));
+      MFFT_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+    }
+    it = c.rtw.emplace(key, d).first;
+  }
+  *out = it->second;
+  return 0;
+}
+
+static RowMap to_map(const RowSpec& r, int n) { return make_rowmap(r.hi, r.lo, r.split, n); }
+
+// ---------------------------------------------------------------------------
+template <typename T>
+static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStream_t s) {
+  ColParams<T> P;
+  P.in = static_cast<const cx<T>*>(a.in);
+  P.out = static_cast<cx<T>*>(a.out);
+  P.tw = static_cast<const cx<T>*>(tw);
+  P.in_outer = a.in_outer;
+  P.out_outer = a.out_outer;
+  P.in_map = to_map(a.in_rows, a.n);
+  P.out_map = to_map(a.out_rows, a.n);
+  P.ncols = (int)a.ncols;
+  P.ntile_c = (int)((a.ncols + e->tile - 1) / e->tile);
+  P.nouter = (int)a.nouter;
+  P.scale = (T)a.scale;
+  const int64_t grid = (int64_t)P.ntile_c * a.nouter;
+  if (grid <= 0) return 0;
+  if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large (%lld tiles)", (long long)grid);
+  e->launch(&P, (int)grid, s);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_col(const ColArgs& a, hipStream_t s) {
+  if (a.n == 1) return set_error(MFFT_ERR_UNSUPPORTED, "length-1 transform along a strided axis");
+  if (a.n >= 65536) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %d too large", a.n);
+  if (a.ncols >= (1ll << 31)) return set_error(MFFT_ERR_UNSUPPORTED, "too many columns");
+  const KernelEntry* e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0);
+  if (!e)
+    return set_error(MFFT_ERR_UNSUPPORTED,
+                     "no kernel for a complex transform of length %d (supported: 2^a, 3*2^a, 5*2^a up to 4096)", a.n);
+  void* tw = nullptr;
+  MFFT_TRY(prepare_kernel(e, &tw));
+  return a.prec == MFFT_DOUBLE ? launch_col_t<double>(e, a, tw, s) : launch_col_t<float>(e, a, tw, s);
+}
+
+template <typename T>
+static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStream_t s) {
+  RowParams<T> P;
+  P.in = static_cast<const cx<T>*>(a.in);
+  P.out = static_cast<cx<T>*>(a.out);
+  P.tw = static_cast<const cx<T>*>(tw);
+  P.in_stride = a.in_stride;
+  P.out_stride = a.out_stride;
+  P.nrows = a.nrows;
+  P.scale = (T)a.scale;
+  const int64_t grid = (a.nrows + e->tile - 1) / e->tile;
+  if (grid <= 0) return 0;
+  if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large");
+  e->launch(&P, (int)grid, s);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_row(const RowArgs& a, hipStream_t s) {
+  const KernelEntry* e = find_kernel(FAM_ROW, a.n, a.prec, a.inverse ? 1 : 0);
+  if (!e)
+    return set_error(MFFT_ERR_UNSUPPORTED,
+                     "no kernel for a complex transform of length %d (supported: 2^a, 3*2^a, 5*2^a up to 4096)", a.n);
+  void* tw = nullptr;
+  MFFT_TRY(prepare_kernel(e, &tw));
+  return a.prec == MFFT_DOUBLE ? launch_row_t<double>(e, a, tw, s) : launch_row_t<float>(e, a, tw, s);
+}
+
+template <typename T>
+static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void* rtw, hipStream_t s) {
+  RealParams<T> P;
+  P.in = a.in;
+  P.out = a.out;
+  P.tw = static_cast<const cx<T>*>(tw);
+  P.rtw = static_cast<const cx<T>*>(rtw);
+  P.in_stride = a.in_stride;
+  P.out_stride = a.out_stride;
+  P.nrows = a.nrows;
+  P.scale = (T)a.scale;
+  const int64_t grid = (a.nrows + e->tile - 1) / e->tile;
+  if (grid <= 0) return 0;
+  if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large");
+  e->launch(&P, (int)grid, s);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
+  const KernelEntry* e = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0);
+  if (!e)
+    return set_error(MFFT_ERR_UNSUPPORTED,
+                     "no kernel for a real transform of length %d (supported: even 2^a, 3*2^a, 5*2^a up to 8192)", a.n);
+  // a real row is read as (n/2) complex values: rows must stay 2-element aligned
+  const int64_t real_stride = fam == FAM_R2C ? a.in_stride : a.out_stride;
+  if (real_stride % 2 != 0)
+    return set_error(MFFT_ERR_UNSUPPORTED, "real row stride %lld must be even", (long long)real_stride);
+  void *tw = nullptr, *rtw = nullptr;
+  MFFT_TRY(prepare_kernel(e, &tw));
+  MFFT_TRY(real_twiddles(a.n, a.prec, &rtw));
+  return a.prec == MFFT_DOUBLE ? launch_real_t<double>(e, a, tw, rtw, s) : launch_real_t<float>(e, a, tw, rtw, s);
+}
+
+int launch_r2c(const RealArgs& a, hipStream_t s) { return launch_real(FAM_R2C, a, s); }
+int launch_c2r(const RealArgs& a, hipStream_t s) { return launch_real(FAM_C2R, a, s); }
+
+// ---------------------------------------------------------------------------
+// data-movement kernels
+// ---------------------------------------------------------------------------
+// One workgroup row-chunk per (i, j): threads stride over the contiguous k run
+// in 16-byte units when alignment allows (VEC elements of the scalar type R).
+template <typename R, int MODE>
+__global__ __launch_bounds__(256) void box_copy_kernel(const R* __restrict__ src, R* __restrict__ dst,
+                                                       int64_t e1, int64_t e2, int64_t s0, int64_t s1,
+                                                       int64_t d0, int64_t d1, R scale, int64_t nrows) {
+  // e2, strides in units of R; grid-stride over rows (i*e1 + j), blockDim.y rows per block
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; row < nrows;
+       row += (int64_t)gridDim.x * blockDim.y) {
+    const int64_t i = row / e1, j = row - i * e1;
+    const R* sp = src + i * s0 + j * s1;
+    R* dp = dst + i * d0 + j * d1;
+    for (int64_t k = threadIdx.x; k < e2; k += blockDim.x) {
+      R v = sp[k] * scale;
+      if (MODE == 1) v += dp[k];
+      dp[k] = v;
+    }
+  }
+}
+
+struct alignas(16) vec16 { double a, b; };
+template <int MODE>
+__global__ __launch_bounds__(256) void box_copy16_kernel(const vec16* __restrict__ src, vec16* __restrict__ dst,
+                                                         int64_t e1, int64_t e2, int64_t s0, int64_t s1,
+                                                         int64_t d0, int64_t d1, int64_t nrows) {
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; row < nrows;
+       row += (int64_t)gridDim.x * blockDim.y) {
+    const int64_t i = row / e1, j = row - i * e1;
+    const vec16* sp = src + i * s0 + j * s1;
+    vec16* dp = dst + i * d0 + j * d1;
+    for (int64_t k = threadIdx.x; k < e2; k += blockDim.x) dp[k] = sp[k];
+  }
+}
+
+int launch_box_copy(const BoxArgs& a, hipStream_t s) {
+  const int64_t nrows = a.e0 * a.e1;
+  if (nrows <= 0 || a.e2 <= 0) return 0;
+  // pick block shape: x covers the contiguous run, y packs several short rows
+  const int unit = a.elem;    // bytes per element
+  const bool plain = (a.mode == 0 && a.scale == 1.0);
+  if (plain && unit == 16) {
+    int bx = 64;
+    while (bx < 256 && bx < a.e2) bx *= 2;
+    const int by = 256 / bx;
+    int64_t grid = (nrows + by - 1) / by;
+    if (grid > 65536 * 4) grid = 65536 * 4;
+    hipLaunchKernelGGL(box_copy16_kernel<0>, dim3((unsigned)grid), dim3(bx, by), 0, s,
+                       static_cast<const vec16*>(a.src), static_cast<vec16*>(a.dst), a.e1, a.e2, a.s0, a.s1,
+                       a.d0, a.d1, nrows);
+    MFFT_HIP(hipGetLastError());
+    return 0;
+  }
+  // scalar path in units of the real type
+  const int rbytes = a.prec == MFFT_DOUBLE ? 8 : 4;
+  const int per = unit / rbytes;            // reals per element
+  const int64_t e2 = a.e2 * per;
+  int bx = 64;
+  while (bx < 256 && bx < e2) bx *= 2;
+  const int by = 256 / bx;
+  int64_t grid = (nrows + by - 1) / by;
+  if (grid > 65536 * 4) grid = 65536 * 4;
+#define MFFT_BOX(R, MODE)                                                                                   \
+  hipLaunchKernelGGL((box_copy_kernel<R, MODE>), dim3((unsigned)grid), dim3(bx, by), 0, s,                  \
+                     static_cast<const R*>(a.src), static_cast<R*>(a.dst), a.e1, e2, a.s0 * per, a.s1 * per, \
+                     a.d0 * per, a.d1 * per, (R)a.scale, nrows)
+  if (a.prec == MFFT_DOUBLE) {
+    if (a.mode == 1) MFFT_BOX(double, 1); else MFFT_BOX(double, 0);
+  } else {
+    if (a.mode == 1) MFFT_BOX(float, 1); else MFFT_BOX(float, 0);
+  }
+#undef MFFT_BOX
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mask_kernel(cx<T>* fu, const uint8_t* mask, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const T m = (T)mask[i];
+    cx<T> v = fu[i];
+    v.x *= m;
+    v.y *= m;
+    fu[i] = v;
+  }
+}
+
+int launch_mask(void* fu, const uint8_t* mask, size_t count, int prec, hipStream_t s) {
+  if (count == 0) return 0;
+  size_t grid = (count + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  if (prec == MFFT_DOUBLE)
+    hipLaunchKernelGGL(mask_kernel<double>, dim3((unsigned)grid), dim3(256), 0, s, static_cast<cx<double>*>(fu), mask, count);
+  else
+    hipLaunchKernelGGL(mask_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, static_cast<cx<float>*>(fu), mask, count);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(T* d, size_t count, T sc) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    d[i] *= sc;
+}
+
+int launch_scale(void* data, size_t count, double scale, int prec, hipStream_t s) {
+  if (count == 0) return 0;
+  size_t grid = (count + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  if (prec == MFFT_DOUBLE)
+    hipLaunchKernelGGL(scale_kernel<double>, dim3((unsigned)grid), dim3(256), 0, s, static_cast<double*>(data), count, scale);
+  else
+    hipLaunchKernelGGL(scale_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, static_cast<float*>(data), count, (float)scale);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+// counter-based uniform [0,1) generator (splitmix64 of the element index)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fill_kernel(T* d, size_t count, uint64_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t r = splitmix64(seed * 0xD1B54A32D192ED03ull + i);
+    d[i] = (T)((double)(r >> 11) * (1.0 / 9007199254740992.0));
+  }
+}
+
+int launch_fill_uniform(void* data, size_t count, int prec, uint64_t seed, hipStream_t s) {
+  if (count == 0) return 0;
+  size_t grid = (count + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  if (prec == MFFT_DOUBLE)
+    hipLaunchKernelGGL(fill_kernel<double>, dim3((unsigned)grid), dim3(256), 0, s, static_cast<double*>(data), count, seed);
+  else
+    hipLaunchKernelGGL(fill_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, static_cast<float*>(data), count, seed);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mfft

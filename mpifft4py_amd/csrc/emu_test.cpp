@@ -1,0 +1,336 @@
+// emu_test.cpp -- host-side workgroup emulator for the kernel bodies in
+// fft_kernels.h (TEST INFRASTRUCTURE, built with g++, never part of the product
+// library).  Each GPU thread of a workgroup is a ucontext fibre; MFFT_BARRIER()
+// yields to a round-robin scheduler, so the very same body code that hipcc
+// compiles for gfx950 runs here with real barrier semantics and a real shared
+// "LDS" buffer.  It checks every kernel family and radix plan against an
+// O(N^2) long-double DFT, so index/twiddle mistakes are found without a GPU.
+//
+//   make emu && ./emu_test
+#include <ucontext.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <functional>
+#include <random>
+#include <vector>
+
+#include "fft_kernels.h"
+#include "twiddle.h"
+#include "plans.h"
+
+namespace mfft {
+
+struct EmuState {
+  std::vector<ucontext_t> ctx;
+  std::vector<char> done;
+  std::vector<int> nbar;
+  ucontext_t sched;
+  int cur = -1;
+  std::function<void(int)> fn;
+};
+static EmuState* g_emu = nullptr;
+
+void emu_barrier() {
+  EmuState* e = g_emu;
+  e->nbar[e->cur]++;
+  swapcontext(&e->ctx[e->cur], &e->sched);
+}
+
+static void fibre_entry() {
+  EmuState* e = g_emu;
+  int tid = e->cur;
+  e->fn(tid);
+  e->done[tid] = 1;
+  swapcontext(&e->ctx[tid], &e->sched);
+}
+
+// run one workgroup of `block` threads
+static void emu_run_block(int block, const std::function<void(int)>& fn) {
+  static std::vector<char> stacks;
+  const size_t STK = 256 * 1024;
+  if (stacks.size() < STK * block) stacks.resize(STK * block);
+  EmuState e;
+  e.ctx.resize(block);
+  e.done.assign(block, 0);
+  e.nbar.assign(block, 0);
+  e.fn = fn;
+  g_emu = &e;
+  for (int t = 0; t < block; ++t) {
+    getcontext(&e.ctx[t]);
+    e.ctx[t].uc_stack.ss_sp = stacks.data() + STK * t;
+    e.ctx[t].uc_stack.ss_size = STK;
+    e.ctx[t].uc_link = nullptr;
+    makecontext(&e.ctx[t], fibre_entry, 0);
+  }
+  bool all_done = false;
+  while (!all_done) {
+    all_done = true;
+    for (int t = 0; t < block; ++t) {
+      if (e.done[t]) continue;
+      e.cur = t;
+      swapcontext(&e.sched, &e.ctx[t]);
+      if (!e.done[t]) all_done = false;
+    }
+    // every thread must have passed the same number of barriers
+    for (int t = 1; t < block; ++t)
+      if (e.nbar[t] != e.nbar[0]) {
+        fprintf(stderr, "EMU: divergent barrier count (thread %d: %d vs %d)\n", t, e.nbar[t], e.nbar[0]);
+        abort();
+      }
+  }
+  g_emu = nullptr;
+}
+
+template <class Body>
+static void emu_launch(int grid, int block, size_t lds_bytes, Body body) {
+  std::vector<char> lds(lds_bytes + 64);
+  for (int b = 0; b < grid; ++b) {
+    memset(lds.data(), 0xCD, lds.size());
+    emu_run_block(block, [&](int tid) { body(b, tid, lds.data()); });
+  }
+}
+
+}  // namespace mfft
+
+using namespace mfft;
+
+typedef std::vector<cx<long double>> lvec;
+
+static lvec naive_dft_slow(const lvec& x, int sign) {
+  int n = (int)x.size();
+  lvec X(n);
+  const long double two_pi = 6.283185307179586476925286766559L;
+  for (int k = 0; k < n; ++k) {
+    long double sr = 0, si = 0;
+    for (int t = 0; t < n; ++t) {
+      long long m = ((long long)k * t) % n;
+      long double a = sign * two_pi * (long double)m / n;
+      long double c = cosl(a), s = sinl(a);
+      sr += x[t].x * c - x[t].y * s;
+      si += x[t].x * s + x[t].y * c;
+    }
+    X[k].x = sr;
+    X[k].y = si;
+  }
+  return X;
+}
+
+// O(N log N) long-double reference (recursive decimation in time over the
+// smallest prime factor), validated against the O(N^2) sum in main().
+static lvec naive_dft(const lvec& x, int sign) {
+  int n = (int)x.size();
+  int p = 0;
+  for (int q : {2, 3, 5}) if (n % q == 0) { p = q; break; }
+  if (n <= 5 || p == 0) return naive_dft_slow(x, sign);
+  int m = n / p;
+  std::vector<lvec> sub(p);
+  for (int q = 0; q < p; ++q) {
+    lvec s(m);
+    for (int t = 0; t < m; ++t) s[t] = x[(size_t)t * p + q];
+    sub[q] = naive_dft(s, sign);
+  }
+  lvec X(n);
+  const long double two_pi = 6.283185307179586476925286766559L;
+  for (int k = 0; k < n; ++k) {
+    long double sr = 0, si = 0;
+    for (int q = 0; q < p; ++q) {
+      long long mm = ((long long)k * q) % n;
+      long double a = sign * two_pi * (long double)mm / n;
+      long double c = cosl(a), s = sinl(a);
+      const cx<long double>& z = sub[q][k % m];
+      sr += z.x * c - z.y * s;
+      si += z.x * s + z.y * c;
+    }
+    X[k].x = sr;
+    X[k].y = si;
+  }
+  return X;
+}
+
+static int g_fail = 0;
+static void report(const char* what, int n, const char* prec, double err, double tol) {
+  bool ok = err < tol && err == err;
+  printf("%-28s N=%-5d %-6s rel-L2 err %.3e  %s\n", what, n, prec, err, ok ? "ok" : "FAIL");
+  if (!ok) g_fail++;
+}
+
+template <typename T> static double tol_of() { return sizeof(T) == 8 ? 1e-14 : 5e-6; }
+template <typename T> static const char* pname() { return sizeof(T) == 8 ? "double" : "single"; }
+
+// ---------------------------------------------------------------------------
+template <class S, typename T, int COLS, bool INV, bool TWLDS>
+static void test_col(bool two_level) {
+  typedef ColFft<S, T, COLS, INV, TWLDS> K;
+  const int N = S::N;
+  const int ncols = COLS * 2 + 3;          // ragged last tile
+  const int nouter = 2;
+  std::mt19937_64 rng(1234 + N);
+  std::uniform_real_distribution<double> U(-1, 1);
+  // input layout [outer][row][col] with row pitch pin; output pitch pout
+  const int pin = ncols + 2, pout = ncols + 5;
+  const int split = two_level ? (N % 4 == 0 ? N / 4 : N) : N;
+  // two-level output: row r -> (r/split)*hi + (r%split)*lo with hi = "chunk" stride
+  const i64 out_lo = pout, out_hi = (i64)split * pout * nouter;   // chunks interleave the outer index
+  std::vector<cx<T>> in((size_t)nouter * N * pin), out((size_t)nouter * N * pout * 2, mk<T>((T)777, (T)777));
+  for (auto& z : in) z = mk<T>((T)U(rng), (T)U(rng));
+  auto tw = build_pass_twiddles<S, T>();
+  ColParams<T> P;
+  P.in = in.data();
+  P.out = out.data();
+  P.tw = tw.data();
+  P.in_outer = (i64)N * pin;
+  P.in_map = make_rowmap(0, pin, N, N);
+  if (two_level) {
+    P.out_outer = (i64)split * pout;
+    P.out_map = make_rowmap(out_hi, out_lo, split, N);
+  } else {
+    P.out_outer = (i64)N * pout;
+    P.out_map = make_rowmap(0, pout, N, N);
+  }
+  P.ncols = ncols;
+  P.ntile_c = (ncols + COLS - 1) / COLS;
+  P.nouter = nouter;
+  P.scale = INV ? (T)(1.0 / N) : (T)1;
+  emu_launch(P.ntile_c * nouter, K::THREADS, K::LDS_BYTES,
+             [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  long double num = 0, den = 0;
+  for (int o = 0; o < nouter; ++o)
+    for (int c = 0; c < ncols; ++c) {
+      lvec x(N);
+      for (int r = 0; r < N; ++r) {
+        cx<T> z = in[(size_t)o * N * pin + (size_t)r * pin + c];
+        x[r].x = z.x;
+        x[r].y = z.y;
+      }
+      lvec X = naive_dft(x, INV ? +1 : -1);
+      for (int r = 0; r < N; ++r) {
+        i64 off = (i64)o * P.out_outer + row_off(P.out_map, r) + c;
+        cx<T> g = out[off];
+        long double ex = X[r].x * (INV ? 1.0L / N : 1.0L), ey = X[r].y * (INV ? 1.0L / N : 1.0L);
+        num += (g.x - ex) * (g.x - ex) + (g.y - ey) * (g.y - ey);
+        den += ex * ex + ey * ey;
+      }
+    }
+  char name[64];
+  snprintf(name, sizeof name, "col c%d %s%s%s", COLS, INV ? "inv" : "fwd", TWLDS ? " twlds" : "", two_level ? " 2lvl" : "");
+  report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
+}
+
+template <class S, typename T, int ROWS, bool INV, bool TWLDS>
+static void test_row() {
+  typedef RowFft<S, T, ROWS, INV, TWLDS> K;
+  const int N = S::N;
+  const int nrows = ROWS * 2 + 1;
+  std::mt19937_64 rng(99 + N);
+  std::uniform_real_distribution<double> U(-1, 1);
+  const int pin = N + 3, pout = N + 1;
+  std::vector<cx<T>> in((size_t)nrows * pin), out((size_t)nrows * pout);
+  for (auto& z : in) z = mk<T>((T)U(rng), (T)U(rng));
+  auto tw = build_pass_twiddles<S, T>();
+  RowParams<T> P{in.data(), out.data(), tw.data(), pin, pout, nrows, INV ? (T)(1.0 / N) : (T)1};
+  emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
+             [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  long double num = 0, den = 0;
+  for (int r = 0; r < nrows; ++r) {
+    lvec x(N);
+    for (int i = 0; i < N; ++i) { x[i].x = in[(size_t)r * pin + i].x; x[i].y = in[(size_t)r * pin + i].y; }
+    lvec X = naive_dft(x, INV ? +1 : -1);
+    for (int i = 0; i < N; ++i) {
+      long double s = INV ? 1.0L / N : 1.0L;
+      cx<T> g = out[(size_t)r * pout + i];
+      num += (g.x - X[i].x * s) * (g.x - X[i].x * s) + (g.y - X[i].y * s) * (g.y - X[i].y * s);
+      den += X[i].x * s * X[i].x * s + X[i].y * s * X[i].y * s;
+    }
+  }
+  char name[64];
+  snprintf(name, sizeof name, "row r%d %s%s", ROWS, INV ? "inv" : "fwd", TWLDS ? " twlds" : "");
+  report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
+}
+
+template <class S, typename T, int ROWS, bool TWLDS>
+static void test_real() {
+  const int M = S::N, N = 2 * M;
+  const int nrows = ROWS + 2;
+  std::mt19937_64 rng(7 + N);
+  std::uniform_real_distribution<double> U(-1, 1);
+  const int pin = N + 2, pout = M + 1 + 2;
+  std::vector<T> in((size_t)nrows * pin);
+  std::vector<cx<T>> out((size_t)nrows * pout);
+  for (auto& z : in) z = (T)U(rng);
+  auto tw = build_pass_twiddles<S, T>();
+  auto rtw = build_real_twiddles<T>(N);
+  {
+    typedef R2CFft<S, T, ROWS, TWLDS> K;
+    RealParams<T> P{in.data(), out.data(), tw.data(), rtw.data(), pin, pout, nrows, (T)1};
+    emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
+               [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  }
+  long double num = 0, den = 0;
+  for (int r = 0; r < nrows; ++r) {
+    lvec x(N);
+    for (int i = 0; i < N; ++i) { x[i].x = in[(size_t)r * pin + i]; x[i].y = 0; }
+    lvec X = naive_dft(x, -1);
+    for (int k = 0; k <= M; ++k) {
+      cx<T> g = out[(size_t)r * pout + k];
+      num += (g.x - X[k].x) * (g.x - X[k].x) + (g.y - X[k].y) * (g.y - X[k].y);
+      den += X[k].x * X[k].x + X[k].y * X[k].y;
+    }
+  }
+  char name[64];
+  snprintf(name, sizeof name, "r2c r%d%s", ROWS, TWLDS ? " twlds" : "");
+  report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
+  // c2r of (the r2c result with garbage imaginary parts in bins 0 and M) must return the input
+  std::vector<T> back((size_t)nrows * pin, (T)0);
+  for (int r = 0; r < nrows; ++r) {
+    out[(size_t)r * pout + 0].y = (T)3.5;
+    out[(size_t)r * pout + M].y = (T)-2.25;
+  }
+  {
+    typedef C2RFft<S, T, ROWS, TWLDS> K;
+    RealParams<T> P{out.data(), back.data(), tw.data(), rtw.data(), pout, pin, nrows, (T)(1.0 / N)};
+    emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
+               [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  }
+  num = den = 0;
+  for (int r = 0; r < nrows; ++r)
+    for (int i = 0; i < N; ++i) {
+      long double d = (long double)back[(size_t)r * pin + i] - in[(size_t)r * pin + i];
+      num += d * d;
+      den += (long double)in[(size_t)r * pin + i] * in[(size_t)r * pin + i];
+    }
+  snprintf(name, sizeof name, "c2r(r2c) r%d%s", ROWS, TWLDS ? " twlds" : "");
+  report(name, N, pname<T>(), (double)sqrtl(num / den), 4 * tol_of<T>());
+}
+
+template <class S> static void test_spec_all() {
+  test_col<S, double, 4, false, true>(false);
+  test_col<S, double, 4, true, false>(true);
+  test_col<S, float, 8, false, false>(true);
+  test_col<S, float, 8, true, true>(false);
+  test_row<S, double, 2, false, true>();
+  test_row<S, double, 2, true, false>();
+  test_row<S, float, 3, false, false>();
+  test_real<S, double, 2, true>();
+  test_real<S, float, 3, false>();
+}
+
+int main() {
+  {  // validate the fast reference against the plain O(N^2) sum
+    for (int n : {12, 40, 96, 250}) {
+      lvec x(n);
+      for (int i = 0; i < n; ++i) { x[i].x = sinl(1.0L + i * i); x[i].y = cosl(3.0L * i + 0.5L); }
+      lvec a = naive_dft(x, -1), b = naive_dft_slow(x, -1);
+      long double d = 0, r = 0;
+      for (int i = 0; i < n; ++i) { d += (a[i].x - b[i].x) * (a[i].x - b[i].x) + (a[i].y - b[i].y) * (a[i].y - b[i].y); r += b[i].x * b[i].x + b[i].y * b[i].y; }
+      report("reference self-check", n, "ldbl", (double)sqrtl(d / r), 1e-17);
+    }
+  }
+  // every plan in plans.h is exercised
+#define MFFT_PLAN(N, ...) test_spec_all<Spec<N, __VA_ARGS__>>();
+  MFFT_FOR_EACH_PLAN(MFFT_PLAN)
+#undef MFFT_PLAN
+  printf("%s (%d failures)\n", g_fail ? "EMU TESTS FAILED" : "EMU TESTS PASSED", g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -1,0 +1,294 @@
+// fft_core.h -- register-resident Stockham FFT building blocks for gfx950.
+//
+// Everything here is plain C++17 that compiles both as HIP device code (hipcc,
+// --offload-arch=gfx950) and as host code (g++), so that the exact same index
+// math can be exercised by the workgroup emulator in emu_test.cpp before a
+// kernel ever reaches the GPU.  No CUDA-compat headers, no library FFT.
+//
+// Replaces (reference): the third-party per-rank FFT backends reached through
+// mpiFFT4py/serialFFT/pyfftw_fft.py:26-203 and numpy_fft.py:25-107.
+//
+// Design (MI355X-first):
+//  * A length-N transform is owned by TPT = N/E threads, each holding E complex
+//    values in VGPRs.  A pass of radix R performs E/R butterflies per thread on
+//    the registers v[m + r*E/R].  With that register layout EVERY pass reads the
+//    positions  j + k*TPT (k = 0..E-1), so the first pass can be fed straight
+//    from global memory, the last pass leaves the natural-order result in the
+//    same registers (=> same global addresses: in-place safe), and LDS is only
+//    used for the autosort exchange between passes.
+//  * Inverse transforms reuse the forward butterflies through the re<->im swap
+//    identity  ifft(x) = swap(fft(swap(x))), so there is one code path.
+//  * Inter-pass twiddles come from a small per-(N,radix-sequence) table
+//    (sum over passes of Ns*(R-1) entries, < N) that the kernels stage in LDS.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MFFT_HD __host__ __device__ __forceinline__
+#define MFFT_HDC __host__ __device__ constexpr
+#else
+#define MFFT_HD inline __attribute__((always_inline))
+#define MFFT_HDC constexpr
+#endif
+
+namespace mfft {
+
+template <typename T>
+struct cx {
+  T x, y;
+};
+
+template <typename T> MFFT_HD cx<T> mk(T x, T y) { cx<T> r; r.x = x; r.y = y; return r; }
+template <typename T> MFFT_HD cx<T> operator+(cx<T> a, cx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <typename T> MFFT_HD cx<T> operator-(cx<T> a, cx<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
+template <typename T> MFFT_HD cx<T> operator*(cx<T> a, cx<T> b) {
+  return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+template <typename T> MFFT_HD cx<T> scale(cx<T> a, T s) { return mk<T>(a.x * s, a.y * s); }
+template <typename T> MFFT_HD cx<T> conj(cx<T> a) { return mk<T>(a.x, -a.y); }
+template <typename T> MFFT_HD cx<T> mul_mi(cx<T> a) { return mk<T>(a.y, -a.x); }   // a * (-i)
+template <typename T> MFFT_HD cx<T> mul_pi(cx<T> a) { return mk<T>(-a.y, a.x); }   // a * (+i)
+template <typename T> MFFT_HD cx<T> swapri(cx<T> a) { return mk<T>(a.y, a.x); }
+
+// ---------------------------------------------------------------------------
+// compile-time constants: cos/sin(2*pi*k/32), k = 0..8 (first octant+), the
+// rest by symmetry.  Literals carry 21 significant digits.
+// ---------------------------------------------------------------------------
+MFFT_HDC long double c32_oct(int k) {
+  return k == 0 ? 1.0L
+       : k == 1 ? 0.980785280403230449126L
+       : k == 2 ? 0.923879532511286756128L
+       : k == 3 ? 0.831469612302545237079L
+       : k == 4 ? 0.707106781186547524401L
+       : k == 5 ? 0.555570233019602224743L
+       : k == 6 ? 0.382683432365089771728L
+       : k == 7 ? 0.195090322016128267848L
+       : 0.0L;
+}
+// cos(2 pi k / 32), any k
+MFFT_HDC long double cos32(int k) {
+  k = ((k % 32) + 32) % 32;
+  return k <= 8 ? c32_oct(k) : k <= 16 ? -c32_oct(16 - k) : k <= 24 ? -c32_oct(k - 16) : c32_oct(32 - k);
+}
+MFFT_HDC long double sin32(int k) { return cos32(k - 8); }
+
+MFFT_HDC int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+MFFT_HDC int clcm(int a, int b) { return a / cgcd(a, b) * b; }
+
+// ---------------------------------------------------------------------------
+// In-register forward DFTs (sign -), natural order in / natural order out.
+// ---------------------------------------------------------------------------
+template <int R> struct Bfly;
+
+template <> struct Bfly<1> {
+  template <typename T> static MFFT_HD void run(cx<T> (&)[1]) {}
+};
+
+template <> struct Bfly<2> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[2]) {
+    cx<T> a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  }
+};
+
+template <> struct Bfly<3> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[3]) {
+    const T s = (T)0.866025403784438646764L;   // sqrt(3)/2
+    cx<T> t1 = v[1] + v[2];
+    cx<T> t2 = mk<T>(v[0].x - (T)0.5 * t1.x, v[0].y - (T)0.5 * t1.y);
+    cx<T> t3 = scale(v[1] - v[2], s);
+    v[0] = v[0] + t1;
+    v[1] = t2 + mul_mi(t3);
+    v[2] = t2 + mul_pi(t3);
+  }
+};
+
+template <> struct Bfly<4> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[4]) {
+    cx<T> t0 = v[0] + v[2], t1 = v[0] - v[2];
+    cx<T> t2 = v[1] + v[3], t3 = mul_mi(v[1] - v[3]);
+    v[0] = t0 + t2;
+    v[1] = t1 + t3;
+    v[2] = t0 - t2;
+    v[3] = t1 - t3;
+  }
+};
+
+template <> struct Bfly<5> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[5]) {
+    const T c1 = (T)0.309016994374947424102L;    // cos(2pi/5)
+    const T c2 = (T)-0.809016994374947424102L;   // cos(4pi/5)
+    const T s1 = (T)0.951056516295153572116L;    // sin(2pi/5)
+    const T s2 = (T)0.587785252292473129169L;    // sin(4pi/5)
+    cx<T> a1 = v[1] + v[4], a2 = v[2] + v[3];
+    cx<T> b1 = v[1] - v[4], b2 = v[2] - v[3];
+    cx<T> p1 = mk<T>(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+    cx<T> p2 = mk<T>(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+    cx<T> q1 = mk<T>(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    cx<T> q2 = mk<T>(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    v[0] = v[0] + a1 + a2;
+    v[1] = p1 + mul_mi(q1);
+    v[4] = p1 + mul_pi(q1);
+    v[2] = p2 + mul_mi(q2);
+    v[3] = p2 + mul_pi(q2);
+  }
+};
+
+// multiply by W_32^K = exp(-2 pi i K / 32), K compile-time
+template <int K, typename T> MFFT_HD cx<T> mul_w32(cx<T> a) {
+  constexpr int k = ((K % 32) + 32) % 32;
+  if constexpr (k == 0) {
+    return a;
+  } else if constexpr (k == 8) {
+    return mul_mi(a);
+  } else if constexpr (k == 16) {
+    return mk<T>(-a.x, -a.y);
+  } else if constexpr (k == 24) {
+    return mul_pi(a);
+  } else if constexpr (k == 4) {
+    const T h = (T)0.707106781186547524401L;
+    return mk<T>((a.x + a.y) * h, (a.y - a.x) * h);
+  } else if constexpr (k == 12) {
+    const T h = (T)0.707106781186547524401L;
+    return mk<T>((a.y - a.x) * h, -(a.x + a.y) * h);
+  } else if constexpr (k == 20) {
+    const T h = (T)0.707106781186547524401L;
+    return mk<T>(-(a.x + a.y) * h, (a.x - a.y) * h);
+  } else if constexpr (k == 28) {
+    const T h = (T)0.707106781186547524401L;
+    return mk<T>((a.x - a.y) * h, (a.x + a.y) * h);
+  } else {
+    constexpr T c = (T)cos32(k);
+    constexpr T s = (T)(-sin32(k));
+    return mk<T>(a.x * c - a.y * s, a.x * s + a.y * c);
+  }
+}
+
+// Cooley-Tukey composition R = RA * RB for the power-of-two radices 8/16/32:
+//   X[a' + RA*b'] = sum_b W_RB^{b b'} W_R^{b a'} sum_a x[RB*a + b] W_RA^{a a'}
+template <int R, int RA> struct BflyCT {
+  static constexpr int RB = R / RA;
+  template <int B, typename T> static MFFT_HD void stage1(cx<T> (&v)[R], cx<T> (&s)[R]) {
+    if constexpr (B < RB) {
+      cx<T> t[RA];
+#pragma unroll
+      for (int a = 0; a < RA; ++a) t[a] = v[RB * a + B];
+      Bfly<RA>::run(t);
+      tw_row<B, 0>(t, s);
+      stage1<B + 1>(v, s);
+    }
+  }
+  template <int B, int A, typename T> static MFFT_HD void tw_row(cx<T> (&t)[RA], cx<T> (&s)[R]) {
+    if constexpr (A < RA) {
+      s[B * RA + A] = mul_w32<(B * A) * (32 / R)>(t[A]);
+      tw_row<B, A + 1>(t, s);
+    }
+  }
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[R]) {
+    cx<T> s[R];
+    stage1<0>(v, s);
+#pragma unroll
+    for (int a = 0; a < RA; ++a) {
+      cx<T> t[RB];
+#pragma unroll
+      for (int b = 0; b < RB; ++b) t[b] = s[b * RA + a];
+      Bfly<RB>::run(t);
+#pragma unroll
+      for (int b = 0; b < RB; ++b) v[a + RA * b] = t[b];
+    }
+  }
+};
+
+template <> struct Bfly<8> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[8]) { BflyCT<8, 4>::run(v); }
+};
+template <> struct Bfly<16> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[16]) { BflyCT<16, 4>::run(v); }
+};
+template <> struct Bfly<32> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[32]) { BflyCT<32, 4>::run(v); }
+};
+
+// ---------------------------------------------------------------------------
+// Transform specification: length N and its radix sequence (first pass first).
+// ---------------------------------------------------------------------------
+template <int... Rs> MFFT_HDC int rs_get(int p) {
+  constexpr int r[sizeof...(Rs)] = {Rs...};
+  return r[p];
+}
+template <int... Rs> MFFT_HDC int rs_lcm() {
+  int e = 1;
+  for (int p = 0; p < (int)sizeof...(Rs); ++p) e = clcm(e, rs_get<Rs...>(p));
+  return e;
+}
+template <int... Rs> MFFT_HDC int rs_ns(int p) {   // product of the radices before pass p
+  int s = 1;
+  for (int q = 0; q < p; ++q) s *= rs_get<Rs...>(q);
+  return s;
+}
+template <int... Rs> MFFT_HDC int rs_twoff(int p) {   // offset of pass p's twiddles (p >= 1)
+  int o = 0;
+  for (int q = 1; q < p; ++q) o += rs_ns<Rs...>(q) * (rs_get<Rs...>(q) - 1);
+  return o;
+}
+
+template <int N_, int... Rs>
+struct Spec {
+  static constexpr int N = N_;
+  static constexpr int NP = sizeof...(Rs);
+  static constexpr int E = rs_lcm<Rs...>();   // complex values per thread
+  static constexpr int TPT = N / E;           // threads per transform
+  static constexpr int TW = rs_twoff<Rs...>(NP) > 0 ? rs_twoff<Rs...>(NP) : 1;   // table entries
+  static MFFT_HDC int R(int p) { return rs_get<Rs...>(p); }
+  static MFFT_HDC int Ns(int p) { return rs_ns<Rs...>(p); }
+  static MFFT_HDC int tw_off(int p) { return rs_twoff<Rs...>(p); }
+  static_assert(rs_ns<Rs...>(NP) == N, "radices must multiply to N");
+  static_assert(E * TPT == N, "E must divide N");
+};
+
+// ---------------------------------------------------------------------------
+// One pass on the registers of thread j (0 <= j < TPT).
+//   tw  : pointer to the twiddle table (LDS or global), layout see Spec::tw_off
+// ---------------------------------------------------------------------------
+template <class S, int P, typename T, class TwPtr>
+MFFT_HD void pass_compute(cx<T> (&v)[S::E], int j, TwPtr tw) {
+  constexpr int R = S::R(P), Ns = S::Ns(P), G = S::E / R, OFF = S::tw_off(P);
+#pragma unroll
+  for (int m = 0; m < G; ++m) {
+    cx<T> t[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) t[r] = v[m + r * G];
+    if constexpr (P > 0) {
+      const int w = (j + m * S::TPT) % Ns;
+#pragma unroll
+      for (int r = 1; r < R; ++r) t[r] = t[r] * tw[OFF + (r - 1) * Ns + w];
+    }
+    Bfly<R>::run(t);
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[m + r * G] = t[r];
+  }
+}
+
+// Autosort scatter of pass P's outputs: value r of butterfly jb goes to
+// position (jb/Ns)*Ns*R + jb%Ns + r*Ns.  `put(pos, value)`.
+template <class S, int P, typename T, class Put>
+MFFT_HD void pass_scatter(const cx<T> (&v)[S::E], int j, Put put) {
+  constexpr int R = S::R(P), Ns = S::Ns(P), G = S::E / R;
+#pragma unroll
+  for (int m = 0; m < G; ++m) {
+    const int jb = j + m * S::TPT;
+    const int base = (jb / Ns) * (Ns * R) + (jb % Ns);
+#pragma unroll
+    for (int r = 0; r < R; ++r) put(base + r * Ns, v[m + r * G]);
+  }
+}
+
+// Gather for the next pass: v[k] = get(j + k*TPT).
+template <class S, typename T, class Get>
+MFFT_HD void pass_gather(cx<T> (&v)[S::E], int j, Get get) {
+#pragma unroll
+  for (int k = 0; k < S::E; ++k) v[k] = get(j + k * S::TPT);
+}
+
+}  // namespace mfft

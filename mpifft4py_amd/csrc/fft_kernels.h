@@ -1,0 +1,371 @@
+// fft_kernels.h -- workgroup-level FFT kernel bodies (HIP, gfx950).
+//
+// Four kernel families, all built on fft_core.h:
+//   col_fft_body : batched c2c along a STRIDED axis.  A workgroup owns a tile of
+//                  COLS adjacent (contiguous-in-memory) columns x N rows; lanes
+//                  run fastest over the columns so every global access is a
+//                  COLS*sizeof(complex) contiguous segment (128 B for fp64/COLS=8).
+//                  Input and output rows use two-level addressing
+//                  row r -> (r / split) * hi + (r % split) * lo, which is what lets
+//                  the slab/pencil pack and unpack steps (reference slab.py:403,
+//                  cython/maths.pyx:21-31, the Alltoallw sub-array types of
+//                  slab.py:199-211 / pencil.py:218-246) be fused into the FFT's own
+//                  loads/stores instead of being separate full-volume copies.
+//   row_fft_body : batched c2c along the CONTIGUOUS axis (lanes along the row).
+//   r2c_body     : real -> half-complex along the contiguous axis: length-N real
+//                  row = length-N/2 complex FFT + split post-pass (reference:
+//                  rfft / rfft2 / rfftn last-axis stage, numpy_fft.py:39-44,67-72).
+//   c2r_body     : inverse of r2c (irfft; Im of the k=0 and k=N/2 bins ignored,
+//                  as pocketfft/FFTW c2r do).
+//
+// The bodies are written once and compiled (a) by hipcc as __device__ code that
+// the __global__ wrappers in kernels.hip call, and (b) by g++ for the fibre-based
+// workgroup emulator (emu_test.cpp), where MFFT_BARRIER() yields to a scheduler.
+#pragma once
+#include "fft_core.h"
+
+#if defined(__HIPCC__)
+#define MFFT_D __device__ __forceinline__
+#define MFFT_BARRIER() __syncthreads()
+#else
+#define MFFT_D inline
+namespace mfft { void emu_barrier(); }
+#define MFFT_BARRIER() ::mfft::emu_barrier()
+#endif
+
+namespace mfft {
+
+typedef long long i64;
+
+// exact r / d for 0 <= r < 2^16, 1 <= d < 2^16 with m = floor(2^32 / d) + 1
+MFFT_HD unsigned fastdiv(unsigned r, unsigned m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(r, m);
+#else
+  return (unsigned)(((unsigned long long)r * m) >> 32);
+#endif
+}
+
+// two-level row addressing
+struct RowMap {
+  i64 hi, lo;        // element strides
+  unsigned split;    // rows per group (>= n means "no split": offset = r*lo)
+  unsigned magic;    // floor(2^32/split)+1
+};
+// rows 0..n-1; split >= n (or 0) means plain stride `lo`
+inline RowMap make_rowmap(i64 hi, i64 lo, i64 split, i64 n) {
+  RowMap m;
+  if (split <= 0 || split >= n) {          // single group
+    m.hi = 0; m.lo = lo; m.split = 0x7FFFFFFFu; m.magic = 1u;   // q = 0 for r < 2^31
+  } else if (split == 1) {                 // every row its own group
+    m.hi = 0; m.lo = hi; m.split = 0x7FFFFFFFu; m.magic = 1u;
+  } else {
+    m.hi = hi; m.lo = lo; m.split = (unsigned)split;
+    m.magic = (unsigned)(0x100000000ull / (unsigned long long)split + 1ull);
+  }
+  return m;
+}
+MFFT_HD i64 row_off(const RowMap& m, unsigned r) {
+  unsigned q = fastdiv(r, m.magic);
+  unsigned rem = r - q * m.split;
+  return (i64)q * m.hi + (i64)rem * m.lo;
+}
+
+template <typename T>
+struct ColParams {
+  const cx<T>* in;
+  cx<T>* out;
+  const cx<T>* tw;       // Spec::TW inter-pass twiddles (device memory)
+  i64 in_outer, out_outer;
+  RowMap in_map, out_map;
+  int ncols;             // contiguous columns per outer batch
+  int ntile_c;           // ceil(ncols / COLS)
+  int nouter;
+  T scale;
+};
+
+template <typename T>
+struct RowParams {
+  const cx<T>* in;
+  cx<T>* out;
+  const cx<T>* tw;
+  i64 in_stride, out_stride;   // row strides in complex elements
+  i64 nrows;
+  T scale;
+};
+
+template <typename T>
+struct RealParams {            // r2c: in = real rows, out = complex rows; c2r the reverse
+  const void* in;
+  void* out;
+  const cx<T>* tw;             // twiddles of the length-N/2 complex transform
+  const cx<T>* rtw;            // exp(-2 pi i k / N), k = 0..N/2-1
+  i64 in_stride, out_stride;   // row strides in elements of the respective type
+  i64 nrows;
+  T scale;
+};
+
+// position -> padded LDS slot for row-major (lane-along-row) exchange buffers:
+// one pad element every PD positions breaks the stride-R0 bank aliasing of the
+// first autosort scatter.
+template <int PD> MFFT_HD int padpos(int pos) {
+  if constexpr (PD > 0) return pos + pos / PD;
+  else return pos;
+}
+template <int N, int PD> constexpr int padded_len() { return PD > 0 ? N + N / PD + 1 : N; }
+
+// ---------------------------------------------------------------------------
+// generic pass driver: runs passes P..NP-1 with LDS exchanges in between.
+//   put(pos, cx), get(pos) access this transform's exchange region.
+// On entry v holds the inputs of pass 0 (positions j + k*TPT).
+// ---------------------------------------------------------------------------
+template <class S, int P, typename T, class TwPtr, class Put, class Get>
+MFFT_D void run_passes(cx<T> (&v)[S::E], int j, TwPtr tw, Put put, Get get) {
+  pass_compute<S, P, T>(v, j, tw);
+  if constexpr (P + 1 < S::NP) {
+    if constexpr (P > 0) MFFT_BARRIER();          // everyone finished the previous gather
+    pass_scatter<S, P, T>(v, j, put);
+    MFFT_BARRIER();
+    pass_gather<S, T>(v, j, get);
+    run_passes<S, P + 1, T>(v, j, tw, put, get);
+  }
+}
+
+// stage the twiddle table into LDS (cooperatively), returns pointer to it
+template <class S, typename T>
+MFFT_D void stage_twiddles(cx<T>* lds_tw, const cx<T>* gtw, int tid, int nthreads) {
+  for (int i = tid; i < S::TW; i += nthreads) lds_tw[i] = gtw[i];
+}
+
+// ---------------------------------------------------------------------------
+// strided-axis c2c
+// ---------------------------------------------------------------------------
+template <class S, typename T, int COLS, bool INV, bool TWLDS>
+struct ColFft {
+  static constexpr int THREADS = S::TPT * COLS;
+  static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
+  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(S::N * COLS * sizeof(cx<T>)) : 0;
+  static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
+
+  static MFFT_D void body(const ColParams<T>& P, int bid, int tid, char* lds) {
+    cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
+    cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES);
+    const int outer = bid / P.ntile_c;
+    const int tc = bid - outer * P.ntile_c;
+    const int c = tid % COLS;
+    const int j = tid / COLS;
+    const int col = tc * COLS + c;
+    const bool active = col < P.ncols;
+    const cx<T>* ip = P.in + (i64)outer * P.in_outer + col;
+    cx<T>* op = P.out + (i64)outer * P.out_outer + col;
+
+    cx<T> v[S::E];
+#pragma unroll
+    for (int k = 0; k < S::E; ++k) {
+      const unsigned r = (unsigned)(j + k * S::TPT);
+      cx<T> x = mk<T>((T)0, (T)0);
+      if (active) x = ip[row_off(P.in_map, r)];
+      v[k] = INV ? swapri(x) : x;
+    }
+    if constexpr (TWLDS && S::NP > 1) {
+      stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
+      MFFT_BARRIER();
+    }
+    auto put = [&](int pos, cx<T> val) { xch[pos * COLS + c] = val; };
+    auto get = [&](int pos) { return xch[pos * COLS + c]; };
+    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, put, get);
+    else run_passes<S, 0, T>(v, j, P.tw, put, get);
+
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const unsigned r = (unsigned)(j + k * S::TPT);
+        cx<T> x = scale(v[k], P.scale);
+        op[row_off(P.out_map, r)] = INV ? swapri(x) : x;
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// contiguous-axis c2c
+// ---------------------------------------------------------------------------
+template <class S, typename T, int ROWS, bool INV, bool TWLDS>
+struct RowFft {
+  static constexpr int THREADS = S::TPT * ROWS;
+  static constexpr int PD = S::R(0);
+  static constexpr int PLEN = padded_len<S::N, PD>();
+  static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
+  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(PLEN * ROWS * sizeof(cx<T>)) : 0;
+  static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
+
+  static MFFT_D void body(const RowParams<T>& P, int bid, int tid, char* lds) {
+    cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
+    const int rl = tid / S::TPT;
+    const int j = tid % S::TPT;
+    cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES) + rl * PLEN;
+    const i64 row = (i64)bid * ROWS + rl;
+    const bool active = row < P.nrows;
+    const cx<T>* ip = P.in + row * P.in_stride;
+    cx<T>* op = P.out + row * P.out_stride;
+
+    cx<T> v[S::E];
+#pragma unroll
+    for (int k = 0; k < S::E; ++k) {
+      cx<T> x = mk<T>((T)0, (T)0);
+      if (active) x = ip[j + k * S::TPT];
+      v[k] = INV ? swapri(x) : x;
+    }
+    if constexpr (TWLDS && S::NP > 1) {
+      stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
+      MFFT_BARRIER();
+    }
+    auto put = [&](int pos, cx<T> val) { xch[padpos<PD>(pos)] = val; };
+    auto get = [&](int pos) { return xch[padpos<PD>(pos)]; };
+    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, put, get);
+    else run_passes<S, 0, T>(v, j, P.tw, put, get);
+
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        cx<T> x = scale(v[k], P.scale);
+        op[j + k * S::TPT] = INV ? swapri(x) : x;
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// real -> half-complex along the contiguous axis.  S describes M = N/2.
+// ---------------------------------------------------------------------------
+template <class S, typename T, int ROWS, bool TWLDS>
+struct R2CFft {
+  static constexpr int M = S::N;
+  static constexpr int THREADS = S::TPT * ROWS;
+  static constexpr int PD = S::R(0);
+  static constexpr int PLEN = padded_len<M, PD>();
+  static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
+  static constexpr int XCH_BYTES = (int)(PLEN * ROWS * sizeof(cx<T>));
+  static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
+
+  static MFFT_D void body(const RealParams<T>& P, int bid, int tid, char* lds) {
+    cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
+    const int rl = tid / S::TPT;
+    const int j = tid % S::TPT;
+    cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES) + rl * PLEN;
+    const i64 row = (i64)bid * ROWS + rl;
+    const bool active = row < P.nrows;
+    // a row of N reals read as N/2 complex (x[2n], x[2n+1])
+    const cx<T>* ip = reinterpret_cast<const cx<T>*>(static_cast<const T*>(P.in) + row * P.in_stride);
+    cx<T>* op = static_cast<cx<T>*>(P.out) + row * P.out_stride;
+
+    cx<T> v[S::E];
+#pragma unroll
+    for (int k = 0; k < S::E; ++k) {
+      cx<T> x = mk<T>((T)0, (T)0);
+      if (active) x = ip[j + k * S::TPT];
+      v[k] = x;
+    }
+    if constexpr (TWLDS && S::NP > 1) {
+      stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
+      MFFT_BARRIER();
+    }
+    auto put = [&](int pos, cx<T> val) { xch[padpos<PD>(pos)] = val; };
+    auto get = [&](int pos) { return xch[padpos<PD>(pos)]; };
+    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, put, get);
+    else run_passes<S, 0, T>(v, j, P.tw, put, get);
+
+    // split post-pass: X[k] = E[k] + w_k O[k],  E = (Z[k] + conj Z[M-k])/2,
+    // O = -i (Z[k] - conj Z[M-k])/2,  w_k = exp(-2 pi i k / N)
+    if constexpr (S::NP > 1) MFFT_BARRIER();
+#pragma unroll
+    for (int k = 0; k < S::E; ++k) put(j + k * S::TPT, v[k]);
+    MFFT_BARRIER();
+    if (active) {
+      const T half = (T)0.5;
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const int pos = j + k * S::TPT;
+        const int mp = pos == 0 ? 0 : M - pos;
+        const cx<T> zk = v[k];
+        const cx<T> zm = conj(get(mp));
+        const cx<T> e = scale(zk + zm, half);
+        const cx<T> o = mul_mi(scale(zk - zm, half));
+        const cx<T> w = P.rtw[pos];
+        if (pos == 0) {
+          op[0] = mk<T>((zk.x + zk.y) * P.scale, (T)0);
+          op[M] = mk<T>((zk.x - zk.y) * P.scale, (T)0);
+        } else {
+          op[pos] = scale(e + w * o, P.scale);
+        }
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// half-complex -> real along the contiguous axis.  S describes M = N/2.
+// out = irfft(in) * N * scale   (scale = 1/N gives numpy's irfft)
+// ---------------------------------------------------------------------------
+template <class S, typename T, int ROWS, bool TWLDS>
+struct C2RFft {
+  static constexpr int M = S::N;
+  static constexpr int THREADS = S::TPT * ROWS;
+  static constexpr int PD = S::R(0);
+  static constexpr int PLEN = padded_len<M, PD>();
+  static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
+  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(PLEN * ROWS * sizeof(cx<T>)) : 0;
+  static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
+
+  static MFFT_D void body(const RealParams<T>& P, int bid, int tid, char* lds) {
+    cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
+    const int rl = tid / S::TPT;
+    const int j = tid % S::TPT;
+    cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES) + rl * PLEN;
+    const i64 row = (i64)bid * ROWS + rl;
+    const bool active = row < P.nrows;
+    const cx<T>* ip = static_cast<const cx<T>*>(P.in) + row * P.in_stride;
+    cx<T>* op = reinterpret_cast<cx<T>*>(static_cast<T*>(P.out) + row * P.out_stride);
+
+    // pre-pass: Z[k] = (X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])
+    // (twice the textbook value; the factor is folded into the normalisation)
+    cx<T> v[S::E];
+#pragma unroll
+    for (int k = 0; k < S::E; ++k) {
+      const int pos = j + k * S::TPT;
+      cx<T> z = mk<T>((T)0, (T)0);
+      if (active) {
+        cx<T> xk = ip[pos];
+        cx<T> xm = conj(ip[M - pos]);
+        if (pos == 0) {            // imaginary parts of the k=0 and k=N/2 bins are ignored
+          xk.y = (T)0;
+          xm.y = (T)0;
+        }
+        const cx<T> e = xk + xm;
+        const cx<T> d = xk - xm;
+        const cx<T> o = d * conj(P.rtw[pos]);
+        z = e + mul_pi(o);
+      }
+      v[k] = swapri(z);            // inverse transform through the swap identity
+    }
+    if constexpr (TWLDS && S::NP > 1) {
+      stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
+      MFFT_BARRIER();
+    }
+    auto put = [&](int pos, cx<T> val) { xch[padpos<PD>(pos)] = val; };
+    auto get = [&](int pos) { return xch[padpos<PD>(pos)]; };
+    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, put, get);
+    else run_passes<S, 0, T>(v, j, P.tw, put, get);
+
+    if (active) {
+      const T s = P.scale;
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        cx<T> x = swapri(v[k]);
+        op[j + k * S::TPT] = scale(x, s);
+      }
+    }
+  }
+};
+
+}  // namespace mfft

@@ -1,0 +1,4 @@
+// gfx950 instantiations: plan group C, float precision
+#define MFFT_TU_PLANS MFFT_PLANS_C
+#define MFFT_TU_REAL float
+#include "kernels_tu.inc"

@@ -1,0 +1,4 @@
+// gfx950 instantiations: plan group E, float precision
+#define MFFT_TU_PLANS MFFT_PLANS_E
+#define MFFT_TU_REAL float
+#include "kernels_tu.inc"

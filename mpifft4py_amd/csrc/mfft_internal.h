@@ -1,0 +1,93 @@
+// mfft_internal.h -- internal C++ interfaces of libmpifft4py_amd.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/mpifft4py_amd.h"
+#include "registry.h"
+
+namespace mfft {
+
+// ---- errors ------------------------------------------------------------------
+int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+const char* last_error();
+
+#define MFFT_HIP(call)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return ::mfft::set_error(MFFT_ERR_HIP, "%s failed: %s (%s:%d)", #call,             \
+                               hipGetErrorString(e_), __FILE__, __LINE__);               \
+  } while (0)
+
+#define MFFT_TRY(call)                  \
+  do {                                  \
+    int rc_ = (call);                   \
+    if (rc_ != 0) return rc_;           \
+  } while (0)
+
+inline size_t elem_bytes(int prec, bool complex_) { return (prec == MFFT_DOUBLE ? 8 : 4) * (complex_ ? 2 : 1); }
+
+// ---- kernel launch layer -------------------------------------------------------
+struct RowSpec {       // row r -> (r / split) * hi + (r % split) * lo   (elements)
+  int64_t hi = 0, lo = 0, split = 0;   // split <= 0: single group
+};
+
+struct ColArgs {
+  const void* in = nullptr;
+  void* out = nullptr;
+  int n = 0;             // transform length
+  int prec = MFFT_DOUBLE;
+  bool inverse = false;
+  int64_t in_outer = 0, out_outer = 0;
+  RowSpec in_rows, out_rows;
+  int64_t ncols = 0;     // contiguous columns per outer batch
+  int64_t nouter = 1;
+  double scale = 1.0;
+};
+int launch_col(const ColArgs& a, hipStream_t s);
+
+struct RowArgs {
+  const void* in = nullptr;
+  void* out = nullptr;
+  int n = 0;
+  int prec = MFFT_DOUBLE;
+  bool inverse = false;
+  int64_t in_stride = 0, out_stride = 0, nrows = 0;
+  double scale = 1.0;
+};
+int launch_row(const RowArgs& a, hipStream_t s);
+
+struct RealArgs {
+  const void* in = nullptr;
+  void* out = nullptr;
+  int n = 0;             // REAL length
+  int prec = MFFT_DOUBLE;
+  int64_t in_stride = 0, out_stride = 0, nrows = 0;   // in elements of the respective types
+  double scale = 1.0;
+};
+int launch_r2c(const RealArgs& a, hipStream_t s);
+int launch_c2r(const RealArgs& a, hipStream_t s);
+
+// strided 3-D box copy: dst[i][j][k] = src[i][j][k] over extents e0,e1,e2 with
+// element strides (k contiguous); elem = bytes per element (8 or 16)
+struct BoxArgs {
+  const void* src = nullptr;
+  void* dst = nullptr;
+  int64_t e0 = 1, e1 = 1, e2 = 1;
+  int64_t s0 = 0, s1 = 0;     // src strides of dims 0,1 (dim 2 contiguous)
+  int64_t d0 = 0, d1 = 0;     // dst strides
+  int elem = 16;
+  int mode = 0;               // 0 copy, 1 accumulate (dst += src)
+  double scale = 1.0;         // applied to src (complex/real agnostic)
+  int prec = MFFT_DOUBLE;
+};
+int launch_box_copy(const BoxArgs& a, hipStream_t s);
+int launch_mask(void* fu, const uint8_t* mask, size_t count, int prec, hipStream_t s);
+int launch_scale(void* data, size_t count_real, double scale, int prec, hipStream_t s);
+int launch_fill_uniform(void* data, size_t count, int prec, uint64_t seed, hipStream_t s);
+
+bool length_supported(int64_t n, bool real_transform);
+
+}  // namespace mfft

@@ -1,0 +1,801 @@
+// plan.hip -- slab / pencil 3-D transform executor behind mfft_plan_t.
+//
+// Restates, for device-resident data and HIP kernels, the stage ordering of
+//   slab  R2C/C2C : mpiFFT4py/slab.py:349-443 (fftn), 214-308 (ifftn), 743-772, 638-669
+//   pencil R2CY   : mpiFFT4py/pencil.py:730-754 (fftn), 483-507 (ifftn)
+//   pencil R2CX   : mpiFFT4py/pencil.py:1312-1337 (fftn), 1082-1105 (ifftn)
+//   3/2-rule      : slab.py:250-268, 310-344, 372-386, 445-483; pencil.py:604-632,
+//                   858-883, 1196-1224, 1440-1475
+// with the pack / unpack copies (slab.py:403, cython/maths.pyx:21-31 and the
+// Alltoallw sub-array types) folded into the strided FFT kernels' two-level row
+// addressing wherever the split axis is not the contiguous one.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <cstring>
+#include <string>
+#include "comm.h"
+#include "mfft_internal.h"
+
+using namespace mfft;
+
+namespace {
+
+struct StageTimer {
+  std::string name;
+  double alg_bytes = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  double total_ms = 0;
+  int64_t calls = 0;
+};
+
+struct Chunk {
+  int64_t len, start;
+};
+
+std::vector<Chunk> pencil_chunks(int64_t n, int size) {   // pencil.py:80-90
+  std::vector<Chunk> c(size);
+  const int64_t q = n / size, r = n % size;
+  for (int i = 0; i < size; ++i) c[i] = Chunk{q + ((r == 1 && i == size - 1) ? 1 : 0), q * i};
+  return c;
+}
+
+void compute_dims(int n, int* p1, int* p2) {   // MPI.Compute_dims(n, 2): balanced, non-increasing
+  int best1 = n, best2 = 1;
+  for (int a = 1; a * a <= n; ++a)
+    if (n % a == 0) {
+      best1 = n / a;
+      best2 = a;
+    }
+  *p1 = best1;
+  *p2 = best2;
+}
+
+}  // namespace
+
+struct mfft_plan_s {
+  mfft_comm_s* comm = nullptr;
+  mfft_plan_desc d;
+  int P = 1, rank = 0, dev = 0;
+  hipStream_t stream = nullptr;
+  int prec = MFFT_DOUBLE;
+  bool r2c = true;
+  int64_t N0 = 0, N1 = 0, N2 = 0, Nf = 0;
+  size_t es = 16, rs = 8;       // bytes per complex / per "real-space" element
+  // slab
+  int64_t Np0 = 0, Np1 = 0;
+  // pencil
+  int P1 = 1, P2 = 1, c0 = 0, c1 = 0;
+  int64_t N1_0 = 0, N1_1 = 0, N2_0 = 0, N2_1 = 0;   // N0/P1, N1/P1, N0/P2, N1/P2
+  std::vector<int> group0, group1, world;
+  std::vector<Chunk> zc;        // z chunks of the first exchange
+  int64_t q = 0, zstart = 0;    // my z extent in spectral space
+  // 3/2-rule
+  int64_t M0 = 0, M1 = 0, M2 = 0, Mf = 0;
+  void* work[3] = {nullptr, nullptr, nullptr};
+  size_t work_bytes[3] = {0, 0, 0};
+  uint8_t* mask = nullptr;
+  size_t mask_count = 0;
+  bool timing = false;
+  std::vector<StageTimer> timers;
+
+  ~mfft_plan_s() {
+    for (void* w : work)
+      if (w) (void)hipFree(w);
+    if (mask) (void)hipFree(mask);
+    for (auto& t : timers) {
+      for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+      for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  int ensure_work(int i, size_t bytes) {
+    if (work_bytes[i] >= bytes) return 0;
+    if (work[i]) MFFT_HIP(hipFree(work[i]));
+    work[i] = nullptr;
+    work_bytes[i] = 0;
+    hipError_t e = hipMalloc(&work[i], bytes);
+    if (e != hipSuccess) return set_error(MFFT_ERR_NOMEM, "hipMalloc(%zu) for work buffer %d failed: %s", bytes, i, hipGetErrorString(e));
+    work_bytes[i] = bytes;
+    return 0;
+  }
+
+  StageTimer* timer(const char* name, double alg_bytes) {
+    for (auto& t : timers)
+      if (t.name == name) return &t;
+    timers.emplace_back();
+    timers.back().name = name;
+    timers.back().alg_bytes = alg_bytes;
+    return &timers.back();
+  }
+
+  template <class F>
+  int stage(const char* name, double alg_bytes, F f) {
+    if (!timing) return f();
+    // NOTE: pointers into `timers` are not kept across calls (vector may grow)
+    StageTimer* t = timer(name, alg_bytes);
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!t->pool.empty()) {
+      ev = t->pool.back();
+      t->pool.pop_back();
+    } else {
+      MFFT_HIP(hipEventCreate(&ev.first));
+      MFFT_HIP(hipEventCreate(&ev.second));
+    }
+    MFFT_HIP(hipEventRecord(ev.first, stream));
+    int rc = f();
+    MFFT_HIP(hipEventRecord(ev.second, stream));
+    t = timer(name, alg_bytes);
+    t->pending.push_back(ev);
+    return rc;
+  }
+
+  int collect_timing() {
+    for (auto& t : timers) {
+      for (auto& e : t.pending) {
+        MFFT_HIP(hipEventSynchronize(e.second));
+        float ms = 0;
+        MFFT_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        t.total_ms += ms;
+        t.calls += 1;
+        t.pool.push_back(e);
+      }
+      t.pending.clear();
+    }
+    return 0;
+  }
+
+  // ---- kernel helpers (all on this->stream) -----------------------------------
+  int r2c_rows(const void* in, void* out, int64_t nrows, int64_t n, int64_t in_stride, int64_t out_stride, double scale = 1.0) {
+    RealArgs a;
+    a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.in_stride = in_stride; a.out_stride = out_stride;
+    a.nrows = nrows; a.scale = scale;
+    return launch_r2c(a, stream);
+  }
+  int c2r_rows(const void* in, void* out, int64_t nrows, int64_t n, int64_t in_stride, int64_t out_stride, double scale) {
+    RealArgs a;
+    a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.in_stride = in_stride; a.out_stride = out_stride;
+    a.nrows = nrows; a.scale = scale;
+    return launch_c2r(a, stream);
+  }
+  int c2c_rows(const void* in, void* out, int64_t nrows, int64_t n, int64_t in_stride, int64_t out_stride, bool inv, double scale) {
+    RowArgs a;
+    a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.inverse = inv; a.in_stride = in_stride;
+    a.out_stride = out_stride; a.nrows = nrows; a.scale = scale;
+    return launch_row(a, stream);
+  }
+  // z-axis stage of the forward / backward transform (real or complex flavour)
+  int z_forward(const void* in, void* out, int64_t nrows, int64_t nz, int64_t nzf) {
+    if (r2c) return r2c_rows(in, out, nrows, nz, nz, nzf);
+    return c2c_rows(in, out, nrows, nz, nz, nzf, false, 1.0);
+  }
+  int z_backward(const void* in, void* out, int64_t nrows, int64_t nz, int64_t nzf) {
+    if (r2c) return c2r_rows(in, out, nrows, nz, nzf, nz, 1.0 / (double)nz);
+    return c2c_rows(in, out, nrows, nz, nzf, nz, true, 1.0 / (double)nz);
+  }
+  int col(const void* in, void* out, int64_t n, bool inv, int64_t nouter, int64_t ncols, int64_t in_outer, RowSpec in_rows,
+          int64_t out_outer, RowSpec out_rows, double scale = 0.0) {
+    ColArgs a;
+    a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.inverse = inv; a.nouter = nouter; a.ncols = ncols;
+    a.in_outer = in_outer; a.out_outer = out_outer; a.in_rows = in_rows; a.out_rows = out_rows;
+    a.scale = scale != 0.0 ? scale : (inv ? 1.0 / (double)n : 1.0);
+    return launch_col(a, stream);
+  }
+  static RowSpec plain(int64_t stride) { RowSpec r; r.lo = stride; r.hi = 0; r.split = 0; return r; }
+  static RowSpec two_level(int64_t split, int64_t hi, int64_t lo) { RowSpec r; r.split = split; r.hi = hi; r.lo = lo; return r; }
+
+  int exchange(const std::vector<int>& grp, const void* send, const std::vector<size_t>& sc, const std::vector<size_t>& sd,
+               void* recv, const std::vector<size_t>& rc, const std::vector<size_t>& rd) {
+    return comm->alltoallv(send, sc.data(), sd.data(), recv, rc.data(), rd.data(), grp.data(), (int)grp.size(), stream);
+  }
+  int exchange_equal(const std::vector<int>& grp, const void* send, void* recv, size_t chunk_bytes) {
+    const int n = (int)grp.size();
+    std::vector<size_t> c(n, chunk_bytes), dsp(n);
+    for (int i = 0; i < n; ++i) dsp[i] = (size_t)i * chunk_bytes;
+    return exchange(grp, send, c, dsp, recv, c, dsp);
+  }
+  int box(const void* src, void* dst, int64_t e0, int64_t e1, int64_t e2, int64_t s0, int64_t s1, int64_t d0, int64_t d1,
+          int mode = 0, double scale = 1.0) {
+    BoxArgs b;
+    b.src = src; b.dst = dst; b.e0 = e0; b.e1 = e1; b.e2 = e2; b.s0 = s0; b.s1 = s1; b.d0 = d0; b.d1 = d1;
+    b.elem = (int)es; b.mode = mode; b.scale = scale; b.prec = prec;
+    return launch_box_copy(b, stream);
+  }
+  int zero(void* p, size_t bytes) {
+    MFFT_HIP(hipMemsetAsync(p, 0, bytes, stream));
+    return 0;
+  }
+
+  // copy src (n along `axis`) into the zero-initialised padded dst (npad along
+  // axis): low half to the front, high half to the back (slab.py:518-523).
+  // shapes: src (a0, n, a2) -> dst (a0, npad, a2) viewed with the axis in the middle.
+  int pad_axis(const void* src, void* dst, int64_t a0, int64_t n, int64_t npad, int64_t a2, double scale) {
+    const char* s = static_cast<const char*>(src);
+    char* dd = static_cast<char*>(dst);
+    MFFT_TRY(zero(dst, (size_t)(a0 * npad * a2) * es));
+    const int64_t h = n / 2;
+    MFFT_TRY(box(s, dd, a0, 1, h * a2, n * a2, 0, npad * a2, 0, 0, scale));
+    MFFT_TRY(box(s + (size_t)(h * a2) * es, dd + (size_t)((npad - h) * a2) * es, a0, 1, (n - h) * a2, n * a2, 0,
+                 npad * a2, 0, 0, scale));
+    return 0;
+  }
+  // truncation with Nyquist fold (slab.py:529-533): dst[:n/2+1] = src[:n/2+1]; dst[n/2:] += src[-n/2:]
+  // src may have a longer contiguous run (a2s >= a2): only the first a2 are taken.
+  int trunc_axis(const void* src, void* dst, int64_t a0, int64_t n, int64_t npad, int64_t a2, int64_t a2s, double scale) {
+    const char* s = static_cast<const char*>(src);
+    char* dd = static_cast<char*>(dst);
+    MFFT_TRY(zero(dst, (size_t)(a0 * n * a2) * es));
+    const int64_t h = n / 2;
+    MFFT_TRY(box(s, dd, a0, h + 1, a2, npad * a2s, a2s, n * a2, a2, 0, scale));
+    MFFT_TRY(box(s + (size_t)((npad - h) * a2s) * es, dd + (size_t)(h * a2) * es, a0, h, a2, npad * a2s, a2s, n * a2, a2, 1, scale));
+    return 0;
+  }
+
+  int slab_forward(const void* u, void* fu);
+  int slab_backward(const void* fu, void* u, bool masked);
+  int slab_forward_padded(const void* u, void* fu);
+  int slab_backward_padded(const void* fu, void* u);
+  int pencil_forward(const void* u, void* fu);
+  int pencil_backward(const void* fu, void* u, bool masked);
+  int pencil_forward_padded(const void* u, void* fu);
+  int pencil_backward_padded(const void* fu, void* u);
+  int apply_mask_copy(const void* fu, void** masked_out);
+  int64_t local_complex_count() const {
+    if (d.decomp == MFFT_SLAB) return N0 * Np1 * Nf;
+    if (d.decomp == MFFT_PENCIL_X) return N0 * N1_1 * q;
+    return N2_0 * N1 * q;
+  }
+};
+
+// ===========================================================================
+// slab
+// ===========================================================================
+int mfft_plan_s::slab_forward(const void* u, void* fu) {
+  const double Cb = (double)(N0 * Np1 * Nf) * es;            // local complex bytes
+  const double Rb = (double)(Np0 * N1 * N2) * rs;            // local real-space bytes
+  if (P == 1) {
+    MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Nf); }));
+    MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(fu, fu, N1, false, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
+    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
+    return 0;
+  }
+  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  MFFT_TRY(ensure_work(0, cb));
+  MFFT_TRY(ensure_work(1, cb));
+  void *A = work[0], *B = work[1];
+  MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, A, Np0 * N1, N2, Nf); }));
+  // y transform writes straight into the packed (P, Np0, Np1, Nf) send layout (slab.py:403)
+  MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
+    return col(A, B, N1, false, Np0, Nf, N1 * Nf, plain(Nf), Np1 * Nf, two_level(Np1, Np0 * Np1 * Nf, Nf));
+  }));
+  MFFT_TRY(stage("fwd_a2a", 0, [&] { return exchange_equal(world, B, fu, (size_t)(Np0 * Np1 * Nf) * es); }));
+  MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
+  return 0;
+}
+
+int mfft_plan_s::apply_mask_copy(const void* fu, void** masked_out) {
+  const size_t cnt = (size_t)local_complex_count();
+  if (!mask || mask_count != cnt) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask of %zu entries was set", cnt);
+  MFFT_TRY(ensure_work(2, cnt * es));
+  MFFT_HIP(hipMemcpyAsync(work[2], fu, cnt * es, hipMemcpyDeviceToDevice, stream));
+  MFFT_TRY(launch_mask(work[2], mask, cnt, prec, stream));
+  *masked_out = work[2];
+  return 0;
+}
+
+int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
+  const double Cb = (double)(N0 * Np1 * Nf) * es;
+  const double Rb = (double)(Np0 * N1 * N2) * rs;
+  const void* src = fu;
+  if (masked) {
+    void* m = nullptr;
+    MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &m); }));
+    src = m;
+  }
+  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  MFFT_TRY(ensure_work(0, cb));
+  void* A = work[0];
+  if (P == 1) {
+    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
+    MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(A, A, N1, true, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
+    MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A, u, N0 * N1, N2, Nf); }));
+    return 0;
+  }
+  MFFT_TRY(ensure_work(1, cb));
+  void* B = work[1];
+  MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
+  MFFT_TRY(stage("bwd_a2a", 0, [&] { return exchange_equal(world, A, B, (size_t)(Np0 * Np1 * Nf) * es); }));
+  // y transform reads the (P, Np0, Np1, Nf) receive layout directly (transpose_Uc fused, maths.pyx:21-31)
+  MFFT_TRY(stage("bwd_y", 2 * Cb, [&] {
+    return col(B, A, N1, true, Np0, Nf, Np1 * Nf, two_level(Np1, Np0 * Np1 * Nf, Nf), N1 * Nf, plain(Nf));
+  }));
+  MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A, u, Np0 * N1, N2, Nf); }));
+  return 0;
+}
+
+// ---- 3/2-rule, slab (R2C: slab.py:310-344, 445-483; P == 1: 250-268, 372-386) ----
+int mfft_plan_s::slab_backward_padded(const void* fu, void* u) {
+  if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
+  if (P > 1 && P > N0 / 2) return set_error(MFFT_ERR_INVALID, "number of ranks cannot exceed N[0]/2 for the 3/2-rule");
+  const double ps = d.padsize, sc3 = ps * ps * ps;
+  const int64_t Mp0 = M0 / P;
+  // W0: (M0, Np1, Nf) padded in x; W1: (Mp0, N1, Nf) after the exchange; then (Mp0, M1, Nf), (Mp0, M1, Mf)
+  MFFT_TRY(ensure_work(0, (size_t)std::max(M0 * Np1 * Nf, Mp0 * M1 * Mf) * es));
+  MFFT_TRY(ensure_work(1, (size_t)std::max(Mp0 * N1 * Nf, Mp0 * M1 * Nf) * es));
+  MFFT_TRY(ensure_work(2, (size_t)(Mp0 * M1 * Nf) * es));
+  void *W0 = work[0], *W1 = work[1], *W2 = work[2];
+  MFFT_TRY(stage("pad_x", 0, [&] { return pad_axis(fu, W0, 1, N0, M0, Np1 * Nf, sc3); }));
+  MFFT_TRY(stage("bwd_x", 0, [&] { return col(W0, W0, M0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
+  const void* yin = W0;
+  if (P > 1) {
+    MFFT_TRY(stage("bwd_a2a", 0, [&] { return exchange_equal(world, W0, W1, (size_t)(Mp0 * Np1 * Nf) * es); }));
+    // unpack (P, Mp0, Np1, Nf) -> (Mp0, N1, Nf)
+    MFFT_TRY(stage("unpack", 0, [&] {
+      for (int p = 0; p < P; ++p)
+        MFFT_TRY(box(static_cast<char*>(W1) + (size_t)p * (Mp0 * Np1 * Nf) * es,
+                     static_cast<char*>(W2) + (size_t)(p * Np1 * Nf) * es, Mp0, 1, Np1 * Nf, Np1 * Nf, 0, N1 * Nf, 0));
+      return 0;
+    }));
+    yin = W2;
+  }
+  // pad y: (Mp0, N1, Nf) -> (Mp0, M1, Nf)
+  void* ypad = (yin == W2) ? W1 : W2;
+  MFFT_TRY(stage("pad_y", 0, [&] { return pad_axis(yin, ypad, Mp0, N1, M1, Nf, 1.0); }));
+  MFFT_TRY(stage("bwd_y", 0, [&] { return col(ypad, ypad, M1, true, Mp0, Nf, M1 * Nf, plain(Nf), M1 * Nf, plain(Nf)); }));
+  // pad z: (Mp0*M1, Nf) -> (Mp0*M1, Mf)
+  MFFT_TRY(stage("pad_z", 0, [&] {
+    MFFT_TRY(zero(W0, (size_t)(Mp0 * M1 * Mf) * es));
+    return box(ypad, W0, 1, Mp0 * M1, Nf, 0, Nf, 0, Mf);
+  }));
+  MFFT_TRY(stage("bwd_z", 0, [&] { return c2r_rows(W0, u, Mp0 * M1, M2, Mf, M2, 1.0 / (double)M2); }));
+  return 0;
+}
+
+int mfft_plan_s::slab_forward_padded(const void* u, void* fu) {
+  if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
+  if (P > 1 && P > N0 / 2) return set_error(MFFT_ERR_INVALID, "number of ranks cannot exceed N[0]/2 for the 3/2-rule");
+  const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
+  const int64_t Mp0 = M0 / P;
+  MFFT_TRY(ensure_work(0, (size_t)std::max(Mp0 * M1 * Mf, M0 * Np1 * Nf) * es));
+  MFFT_TRY(ensure_work(1, (size_t)std::max(Mp0 * N1 * Nf, M0 * Np1 * Nf) * es));
+  MFFT_TRY(ensure_work(2, (size_t)(M0 * Np1 * Nf) * es));
+  void *W0 = work[0], *W1 = work[1], *W2 = work[2];
+  MFFT_TRY(stage("fwd_z", 0, [&] { return r2c_rows(u, W0, Mp0 * M1, M2, M2, Mf); }));
+  MFFT_TRY(stage("fwd_y", 0, [&] { return col(W0, W0, M1, false, Mp0, Mf, M1 * Mf, plain(Mf), M1 * Mf, plain(Mf)); }));
+  // truncate y and z: (Mp0, M1, Mf) -> (Mp0, N1, Nf)   (slab.py:459 copy_from_padded axis 1)
+  MFFT_TRY(stage("trunc_y", 0, [&] { return trunc_axis(W0, W1, Mp0, N1, M1, Nf, Mf, 1.0); }));
+  void* xin = W1;
+  if (P > 1) {
+    // pack (Mp0, P, Np1, Nf) -> (P, Mp0, Np1, Nf) and exchange
+    MFFT_TRY(stage("pack", 0, [&] {
+      for (int p = 0; p < P; ++p)
+        MFFT_TRY(box(static_cast<char*>(W1) + (size_t)(p * Np1 * Nf) * es,
+                     static_cast<char*>(W0) + (size_t)p * (Mp0 * Np1 * Nf) * es, Mp0, 1, Np1 * Nf, N1 * Nf, 0, Np1 * Nf, 0));
+      return 0;
+    }));
+    MFFT_TRY(stage("fwd_a2a", 0, [&] { return exchange_equal(world, W0, W2, (size_t)(Mp0 * Np1 * Nf) * es); }));
+    xin = W2;
+  }
+  MFFT_TRY(stage("fwd_x", 0, [&] { return col(xin, xin, M0, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
+  MFFT_TRY(stage("trunc_x", 0, [&] { return trunc_axis(xin, fu, 1, N0, M0, Np1 * Nf, Np1 * Nf, isc3); }));
+  return 0;
+}
+
+// ===========================================================================
+// pencil
+// ===========================================================================
+// pack the z chunks of Z (rows, Nf) into consecutive (rows, len_l) blocks / the reverse
+static int pack_z(mfft_plan_s* p, const void* Z, void* S, int64_t rows, int64_t nf, const std::vector<Chunk>& zc, bool unpack) {
+  size_t off = 0;
+  for (const Chunk& c : zc) {
+    const char* zp = static_cast<const char*>(Z) + (size_t)c.start * p->es;
+    char* sp = static_cast<char*>(S) + off;
+    if (!unpack) MFFT_TRY(p->box(zp, sp, 1, rows, c.len, 0, nf, 0, c.len));
+    else MFFT_TRY(p->box(sp, const_cast<char*>(zp), 1, rows, c.len, 0, c.len, 0, nf));
+    off += (size_t)(rows * c.len) * p->es;
+  }
+  return 0;
+}
+
+int mfft_plan_s::pencil_forward(const void* u, void* fu) {
+  const int64_t m = N1_0, n = N2_1;                 // local real rows in x, y
+  const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
+  const bool X = d.decomp == MFFT_PENCIL_X;
+  const std::vector<int>& gz = X ? group1 : group0;  // group of the z-splitting exchange
+  const int Pz = (int)gz.size();
+  const size_t wb = (size_t)std::max(m * n * Nf, std::max(m * N1 * q, N0 * n * q)) * es;
+  MFFT_TRY(ensure_work(0, wb));
+  MFFT_TRY(ensure_work(1, wb));
+  void *W0 = work[0], *W1 = work[1];
+  MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, W0, m * n, N2, Nf); }));
+  MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, m * n, Nf, zc, false); }));
+  std::vector<size_t> sc(Pz), sd(Pz), rc(Pz), rd(Pz);
+  size_t off = 0;
+  for (int l = 0; l < Pz; ++l) {
+    sc[l] = (size_t)(m * n * zc[l].len) * es;
+    sd[l] = off;
+    off += sc[l];
+    rc[l] = (size_t)(m * n * q) * es;
+    rd[l] = (size_t)l * rc[l];
+  }
+  MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return exchange(gz, W1, sc, sd, W0, rc, rd); }));
+  if (X) {
+    // W0 = P2 blocks (m, n, q) -> y transform (gathers y through two-level rows) -> P1 blocks (m, N1_1, q)
+    MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
+      return col(W0, W1, N1, false, m, q, n * q, two_level(n, m * n * q, q), N1_1 * q, two_level(N1_1, m * N1_1 * q, q));
+    }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return exchange_equal(group0, W1, fu, (size_t)(m * N1_1 * q) * es); }));
+    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
+  } else {
+    // W0 = (N0, n, q): x transform in place, x chunks are contiguous -> exchange -> y transform gathers
+    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, W0, N0, false, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return exchange_equal(group1, W0, W1, (size_t)(N2_0 * n * q) * es); }));
+    MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
+      return col(W1, fu, N1, false, N2_0, q, n * q, two_level(n, N2_0 * n * q, q), N1 * q, plain(q));
+    }));
+  }
+  return 0;
+}
+
+int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
+  const int64_t m = N1_0, n = N2_1;
+  const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
+  const bool X = d.decomp == MFFT_PENCIL_X;
+  const std::vector<int>& gz = X ? group1 : group0;
+  const int Pz = (int)gz.size();
+  const void* src = fu;
+  if (masked) {
+    void* mm = nullptr;
+    MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &mm); }));
+    src = mm;
+  }
+  const size_t wb = (size_t)std::max(m * n * Nf, std::max(m * N1 * q, N0 * n * q)) * es;
+  MFFT_TRY(ensure_work(0, wb));
+  MFFT_TRY(ensure_work(1, wb));
+  void *W0 = work[0], *W1 = work[1];
+  if (X) {
+    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, W0, N0, true, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return exchange_equal(group0, W0, W1, (size_t)(m * N1_1 * q) * es); }));
+    MFFT_TRY(stage("bwd_y", 2 * Cb, [&] {
+      return col(W1, W0, N1, true, m, q, N1_1 * q, two_level(N1_1, m * N1_1 * q, q), n * q, two_level(n, m * n * q, q));
+    }));
+  } else {
+    MFFT_TRY(stage("bwd_y", 2 * Cb, [&] {
+      return col(src, W0, N1, true, N2_0, q, N1 * q, plain(q), n * q, two_level(n, N2_0 * n * q, q));
+    }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return exchange_equal(group1, W0, W1, (size_t)(N2_0 * n * q) * es); }));
+    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(W1, W0, N0, true, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+  }
+  // W0 holds Pz blocks (m, n, q) (for Y: x chunks of (N0, n, q), also contiguous)
+  std::vector<size_t> sc(Pz), sd(Pz), rc(Pz), rd(Pz);
+  size_t off = 0;
+  for (int l = 0; l < Pz; ++l) {
+    sc[l] = (size_t)(m * n * q) * es;
+    sd[l] = (size_t)l * sc[l];
+    rc[l] = (size_t)(m * n * zc[l].len) * es;
+    rd[l] = off;
+    off += rc[l];
+  }
+  MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return exchange(gz, W0, sc, sd, W1, rc, rd); }));
+  MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z(this, W0, W1, m * n, Nf, zc, true); }));
+  MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(W0, u, m * n, N2, Nf); }));
+  return 0;
+}
+
+// ---- 3/2-rule, pencil (Alltoallw branches; padding of an axis happens right
+// before the transform along it, when the axis is locally complete) -------------
+int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
+  const double ps = d.padsize, sc3 = ps * ps * ps;
+  const bool X = d.decomp == MFFT_PENCIL_X;
+  const std::vector<int>& gz = X ? group1 : group0;
+  const int Pz = (int)gz.size();
+  const int64_t mp = M0 / P1, np = M1 / P2;          // padded local real rows in x, y
+  const size_t wb = (size_t)std::max(std::max(M0 * N1_1 * q, mp * M1 * q), std::max(std::max(N2_0 * M1 * q, M0 * np * q), mp * np * Mf)) * es;
+  for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
+  void *W0 = work[0], *W1 = work[1], *W2 = work[2];
+  if (X) {
+    // fu (N0, N1_1, q): pad x -> (M0, N1_1, q), ifft x
+    MFFT_TRY(stage("pad_x", 0, [&] { return pad_axis(fu, W0, 1, N0, M0, N1_1 * q, sc3); }));
+    MFFT_TRY(stage("bwd_x", 0, [&] { return col(W0, W0, M0, true, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return exchange_equal(group0, W0, W1, (size_t)(mp * N1_1 * q) * es); }));
+    // W1 = P1 blocks (mp, N1_1, q) -> gather to (mp, N1, q)
+    MFFT_TRY(stage("unpack", 0, [&] {
+      for (int g = 0; g < P1; ++g)
+        MFFT_TRY(box(static_cast<char*>(W1) + (size_t)g * (mp * N1_1 * q) * es, static_cast<char*>(W2) + (size_t)(g * N1_1 * q) * es,
+                     mp, 1, N1_1 * q, N1_1 * q, 0, N1 * q, 0));
+      return 0;
+    }));
+    MFFT_TRY(stage("pad_y", 0, [&] { return pad_axis(W2, W0, mp, N1, M1, q, 1.0); }));
+    // ifft y on (mp, M1, q), writing P2 blocks (mp, np, q)
+    MFFT_TRY(stage("bwd_y", 0, [&] {
+      return col(W0, W1, M1, true, mp, q, M1 * q, plain(q), np * q, two_level(np, mp * np * q, q));
+    }));
+  } else {
+    // fu (N2_0, N1, q): pad y -> (N2_0, M1, q), ifft y writing P2 blocks (N2_0, np, q)
+    MFFT_TRY(stage("pad_y", 0, [&] { return pad_axis(fu, W0, N2_0, N1, M1, q, sc3); }));
+    MFFT_TRY(stage("bwd_y", 0, [&] {
+      return col(W0, W1, M1, true, N2_0, q, M1 * q, plain(q), np * q, two_level(np, N2_0 * np * q, q));
+    }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return exchange_equal(group1, W1, W0, (size_t)(N2_0 * np * q) * es); }));
+    // W0 = (N0, np, q): pad x -> (M0, np, q), ifft x
+    MFFT_TRY(stage("pad_x", 0, [&] { return pad_axis(W0, W1, 1, N0, M0, np * q, 1.0); }));
+    MFFT_TRY(stage("bwd_x", 0, [&] { return col(W1, W1, M0, true, 1, np * q, 0, plain(np * q), 0, plain(np * q)); }));
+  }
+  // W1 holds Pz blocks (mp, np, q) (X: y chunks; Y: contiguous x chunks)
+  std::vector<size_t> sc(Pz), sd(Pz), rc(Pz), rd(Pz);
+  size_t off = 0;
+  for (int l = 0; l < Pz; ++l) {
+    sc[l] = (size_t)(mp * np * q) * es;
+    sd[l] = (size_t)l * sc[l];
+    rc[l] = (size_t)(mp * np * zc[l].len) * es;
+    rd[l] = off;
+    off += rc[l];
+  }
+  MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return exchange(gz, W1, sc, sd, W0, rc, rd); }));
+  // unpack z into the zero-padded (mp*np, Mf) rows
+  MFFT_TRY(stage("bwd_unpackz", 0, [&] {
+    MFFT_TRY(zero(W2, (size_t)(mp * np * Mf) * es));
+    return pack_z(this, W2, W0, mp * np, Mf, zc, true);
+  }));
+  MFFT_TRY(stage("bwd_z", 0, [&] { return c2r_rows(W2, u, mp * np, M2, Mf, M2, 1.0 / (double)M2); }));
+  return 0;
+}
+
+int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
+  const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
+  const bool X = d.decomp == MFFT_PENCIL_X;
+  const std::vector<int>& gz = X ? group1 : group0;
+  const int Pz = (int)gz.size();
+  const int64_t mp = M0 / P1, np = M1 / P2;
+  const size_t wb = (size_t)std::max(std::max(M0 * N1_1 * q, mp * M1 * q), std::max(std::max(N2_0 * M1 * q, M0 * np * q), mp * np * Mf)) * es;
+  for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
+  void *W0 = work[0], *W1 = work[1], *W2 = work[2];
+  MFFT_TRY(stage("fwd_z", 0, [&] { return r2c_rows(u, W0, mp * np, M2, M2, Mf); }));
+  // only the first Nf modes travel (truncation in z); pack z chunks
+  MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, mp * np, Mf, zc, false); }));
+  std::vector<size_t> sc(Pz), sd(Pz), rc(Pz), rd(Pz);
+  size_t off = 0;
+  for (int l = 0; l < Pz; ++l) {
+    sc[l] = (size_t)(mp * np * zc[l].len) * es;
+    sd[l] = off;
+    off += sc[l];
+    rc[l] = (size_t)(mp * np * q) * es;
+    rd[l] = (size_t)l * rc[l];
+  }
+  MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return exchange(gz, W1, sc, sd, W0, rc, rd); }));
+  if (X) {
+    // W0 = P2 blocks (mp, np, q): fft y over M1 = P2*np (gather), out (mp, M1, q)
+    MFFT_TRY(stage("fwd_y", 0, [&] {
+      return col(W0, W1, M1, false, mp, q, np * q, two_level(np, mp * np * q, q), M1 * q, plain(q));
+    }));
+    MFFT_TRY(stage("trunc_y", 0, [&] { return trunc_axis(W1, W0, mp, N1, M1, q, q, 1.0); }));
+    // pack y chunks (mp, P1, N1_1, q) -> (P1, mp, N1_1, q)
+    MFFT_TRY(stage("pack", 0, [&] {
+      for (int g = 0; g < P1; ++g)
+        MFFT_TRY(box(static_cast<char*>(W0) + (size_t)(g * N1_1 * q) * es, static_cast<char*>(W1) + (size_t)g * (mp * N1_1 * q) * es,
+                     mp, 1, N1_1 * q, N1 * q, 0, N1_1 * q, 0));
+      return 0;
+    }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return exchange_equal(group0, W1, W2, (size_t)(mp * N1_1 * q) * es); }));
+    MFFT_TRY(stage("fwd_x", 0, [&] { return col(W2, W2, M0, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
+    MFFT_TRY(stage("trunc_x", 0, [&] { return trunc_axis(W2, fu, 1, N0, M0, N1_1 * q, N1_1 * q, isc3); }));
+  } else {
+    // W0 = (M0, np, q): fft x, truncate to (N0, np, q)
+    MFFT_TRY(stage("fwd_x", 0, [&] { return col(W0, W0, M0, false, 1, np * q, 0, plain(np * q), 0, plain(np * q)); }));
+    MFFT_TRY(stage("trunc_x", 0, [&] { return trunc_axis(W0, W1, 1, N0, M0, np * q, np * q, 1.0); }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return exchange_equal(group1, W1, W0, (size_t)(N2_0 * np * q) * es); }));
+    // W0 = P2 blocks (N2_0, np, q): fft y over M1 gathering, out (N2_0, M1, q)
+    MFFT_TRY(stage("fwd_y", 0, [&] {
+      return col(W0, W1, M1, false, N2_0, q, np * q, two_level(np, N2_0 * np * q, q), M1 * q, plain(q));
+    }));
+    MFFT_TRY(stage("trunc_y", 0, [&] { return trunc_axis(W1, fu, N2_0, N1, M1, q, q, isc3); }));
+  }
+  return 0;
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* out) {
+  if (!comm || !desc || !out) return set_error(MFFT_ERR_INVALID, "null argument");
+  std::unique_ptr<mfft_plan_s> p(new mfft_plan_s());
+  p->comm = comm;
+  p->d = *desc;
+  p->P = comm->size;
+  p->rank = comm->rank;
+  p->prec = desc->precision;
+  p->r2c = desc->kind == MFFT_R2C;
+  p->N0 = desc->n[0];
+  p->N1 = desc->n[1];
+  p->N2 = desc->n[2];
+  if (p->N0 < 1 || p->N1 < 1 || p->N2 < 1) return set_error(MFFT_ERR_INVALID, "bad mesh");
+  if (desc->precision != MFFT_SINGLE && desc->precision != MFFT_DOUBLE) return set_error(MFFT_ERR_INVALID, "bad precision");
+  p->Nf = p->r2c ? p->N2 / 2 + 1 : p->N2;
+  p->es = elem_bytes(p->prec, true);
+  p->rs = p->r2c ? elem_bytes(p->prec, false) : p->es;
+  const double ps = desc->padsize > 0 ? desc->padsize : 1.5;
+  p->d.padsize = ps;
+  p->M0 = (int64_t)(ps * p->N0);
+  p->M1 = (int64_t)(ps * p->N1);
+  p->M2 = (int64_t)(ps * p->N2);
+  p->Mf = p->r2c ? (int64_t)(ps * p->N2) / 2 + 1 : p->M2;
+  MFFT_HIP(hipGetDevice(&p->dev));
+  p->world.resize(p->P);
+  for (int i = 0; i < p->P; ++i) p->world[i] = i;
+  const int P = p->P;
+  if (p->r2c && p->N2 % 2) return set_error(MFFT_ERR_UNSUPPORTED, "odd N[2]=%lld is not supported for R2C", (long long)p->N2);
+  if (desc->decomp == MFFT_SLAB) {
+    if (p->N0 % P || p->N1 % P) return set_error(MFFT_ERR_INVALID, "N[0]=%lld and N[1]=%lld must be divisible by the number of ranks %d", (long long)p->N0, (long long)p->N1, P);
+    p->Np0 = p->N0 / P;
+    p->Np1 = p->N1 / P;
+  } else if (desc->decomp == MFFT_PENCIL_X || desc->decomp == MFFT_PENCIL_Y) {
+    if (!p->r2c) return set_error(MFFT_ERR_UNSUPPORTED, "pencil plans are R2C (the reference has no pencil C2C)");
+    int P1 = desc->p1, P2;
+    if (P1 <= 0) compute_dims(P, &P1, &P2);
+    else {
+      if (P % P1) return set_error(MFFT_ERR_INVALID, "P1=%d does not divide %d ranks", P1, P);
+      P2 = P / P1;
+    }
+    p->P1 = P1;
+    p->P2 = P2;
+    p->c0 = p->rank % P1;       // comm0 = consecutive ranks (pencil.py:192-195)
+    p->c1 = p->rank / P1;
+    if (p->N0 % P1 || p->N1 % P1 || p->N0 % P2 || p->N1 % P2 || p->N2 % P1 || p->N2 % P2)
+      return set_error(MFFT_ERR_INVALID, "mesh not divisible by the %dx%d process grid", P1, P2);
+    p->N1_0 = p->N0 / P1;
+    p->N1_1 = p->N1 / P1;
+    p->N2_0 = p->N0 / P2;
+    p->N2_1 = p->N1 / P2;
+    for (int i = 0; i < P1; ++i) p->group0.push_back(p->c1 * P1 + i);
+    for (int i = 0; i < P2; ++i) p->group1.push_back(p->c0 + i * P1);
+    const int Pz = desc->decomp == MFFT_PENCIL_X ? P2 : P1;
+    const int cz = desc->decomp == MFFT_PENCIL_X ? p->c1 : p->c0;
+    if (Pz > 1 && ((p->N2 / Pz) % 2)) return set_error(MFFT_ERR_UNSUPPORTED, "N[2]/%d must be even for the pencil z split", Pz);
+    if (p->Nf % Pz > 1) return set_error(MFFT_ERR_UNSUPPORTED, "Nf=%lld cannot be split over %d ranks", (long long)p->Nf, Pz);
+    p->zc = pencil_chunks(p->Nf, Pz);
+    p->q = p->zc[cz].len;
+    p->zstart = p->zc[cz].start;
+  } else {
+    return set_error(MFFT_ERR_INVALID, "bad decomposition %d", desc->decomp);
+  }
+  // every transform length must have a kernel
+  auto need = [&](int64_t n, bool real) -> int {
+    if (n == 1 && !real) return 0;
+    if (!length_supported(n, real)) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %lld%s has no kernel (supported: 2^a, 3*2^a, 5*2^a)", (long long)n, real ? " (real)" : "");
+    return 0;
+  };
+  MFFT_TRY(need(p->N0, false));
+  MFFT_TRY(need(p->N1, false));
+  MFFT_TRY(need(p->N2, p->r2c));
+  MFFT_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  *out = p.release();
+  return 0;
+}
+
+int mfft_plan_destroy(mfft_plan_t plan) {
+  if (!plan) return 0;
+  (void)hipStreamSynchronize(plan->stream);
+  delete plan;
+  return 0;
+}
+
+int mfft_plan_layout(mfft_plan_t p, int64_t rshape[3], int64_t cshape[3], int64_t rstart[3], int64_t cstart[3],
+                     int64_t rshape_pad[3], int64_t grid[2], int64_t sub[2]) {
+  if (!p) return set_error(MFFT_ERR_INVALID, "null plan");
+  int64_t rs_[3], cs_[3], r0[3], c0_[3], rp[3];
+  if (p->d.decomp == MFFT_SLAB) {
+    rs_[0] = p->Np0; rs_[1] = p->N1; rs_[2] = p->N2;
+    cs_[0] = p->N0; cs_[1] = p->Np1; cs_[2] = p->Nf;
+    r0[0] = p->rank * p->Np0; r0[1] = 0; r0[2] = 0;
+    c0_[0] = 0; c0_[1] = p->rank * p->Np1; c0_[2] = 0;
+    rp[0] = p->M0 / p->P; rp[1] = p->M1; rp[2] = p->M2;
+    if (grid) { grid[0] = p->P; grid[1] = 1; }
+    if (sub) { sub[0] = p->rank; sub[1] = 0; }
+  } else {
+    rs_[0] = p->N1_0; rs_[1] = p->N2_1; rs_[2] = p->N2;
+    r0[0] = p->c0 * p->N1_0; r0[1] = p->c1 * p->N2_1; r0[2] = 0;
+    rp[0] = p->M0 / p->P1; rp[1] = p->M1 / p->P2; rp[2] = p->M2;
+    if (p->d.decomp == MFFT_PENCIL_X) {
+      cs_[0] = p->N0; cs_[1] = p->N1_1; cs_[2] = p->q;
+      c0_[0] = 0; c0_[1] = p->c0 * p->N1_1; c0_[2] = p->zstart;
+    } else {
+      cs_[0] = p->N2_0; cs_[1] = p->N1; cs_[2] = p->q;
+      c0_[0] = p->c1 * p->N2_0; c0_[1] = 0; c0_[2] = p->zstart;
+    }
+    if (grid) { grid[0] = p->P1; grid[1] = p->P2; }
+    if (sub) { sub[0] = p->c0; sub[1] = p->c1; }
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (rshape) rshape[i] = rs_[i];
+    if (cshape) cshape[i] = cs_[i];
+    if (rstart) rstart[i] = r0[i];
+    if (cstart) cstart[i] = c0_[i];
+    if (rshape_pad) rshape_pad[i] = rp[i];
+  }
+  return 0;
+}
+
+int mfft_plan_workspace_bytes(mfft_plan_t p, size_t* bytes) {
+  if (!p || !bytes) return set_error(MFFT_ERR_INVALID, "null argument");
+  *bytes = p->work_bytes[0] + p->work_bytes[1] + p->work_bytes[2];
+  return 0;
+}
+
+static int check_ready(mfft_plan_t p, const void* a, const void* b) {
+  if (!p || !a || !b) return set_error(MFFT_ERR_INVALID, "null argument");
+  int dev = -1;
+  MFFT_HIP(hipGetDevice(&dev));
+  if (dev != p->dev) MFFT_HIP(hipSetDevice(p->dev));
+  return 0;
+}
+
+int mfft_forward(mfft_plan_t p, const void* u, void* fu, int dealias) {
+  MFFT_TRY(check_ready(p, u, fu));
+  const bool pad = dealias == MFFT_DEALIAS_3_2;
+  if (p->d.decomp == MFFT_SLAB) return pad ? p->slab_forward_padded(u, fu) : p->slab_forward(u, fu);
+
+  return pad ? p->pencil_forward_padded(u, fu) : p->pencil_forward(u, fu);
+}
+
+int mfft_backward(mfft_plan_t p, const void* fu, void* u, int dealias) {
+  MFFT_TRY(check_ready(p, fu, u));
+  const bool pad = dealias == MFFT_DEALIAS_3_2, masked = dealias == MFFT_DEALIAS_2_3;
+  if (p->d.decomp == MFFT_SLAB) return pad ? p->slab_backward_padded(fu, u) : p->slab_backward(fu, u, masked);
+
+  return pad ? p->pencil_backward_padded(fu, u) : p->pencil_backward(fu, u, masked);
+}
+
+int mfft_plan_sync(mfft_plan_t p) {
+  if (!p) return set_error(MFFT_ERR_INVALID, "null plan");
+  MFFT_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int mfft_plan_set_dealias_mask(mfft_plan_t p, const uint8_t* mask_host, size_t count) {
+  if (!p || !mask_host) return set_error(MFFT_ERR_INVALID, "null argument");
+  if ((int64_t)count != p->local_complex_count()) return set_error(MFFT_ERR_INVALID, "mask has %zu entries, local spectrum has %lld", count, (long long)p->local_complex_count());
+  if (p->mask) MFFT_HIP(hipFree(p->mask));
+  p->mask = nullptr;
+  MFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p->mask), count));
+  MFFT_HIP(hipMemcpy(p->mask, mask_host, count, hipMemcpyHostToDevice));
+  p->mask_count = count;
+  return 0;
+}
+
+int mfft_plan_timing(mfft_plan_t p, int enable) {
+  if (!p) return set_error(MFFT_ERR_INVALID, "null plan");
+  p->timing = enable != 0;
+  return 0;
+}
+
+int mfft_plan_timing_reset(mfft_plan_t p) {
+  if (!p) return set_error(MFFT_ERR_INVALID, "null plan");
+  MFFT_TRY(p->collect_timing());
+  for (auto& t : p->timers) {
+    t.total_ms = 0;
+    t.calls = 0;
+  }
+  return 0;
+}
+
+int mfft_plan_timing_get(mfft_plan_t p, int max_stages, char names[][32], double* total_ms, int64_t* calls, double* alg_bytes) {
+  if (!p) return set_error(MFFT_ERR_INVALID, "null plan");
+  MFFT_TRY(p->collect_timing());
+  const int n = (int)p->timers.size();
+  for (int i = 0; i < n && i < max_stages; ++i) {
+    if (names) {
+      strncpy(names[i], p->timers[i].name.c_str(), 31);
+      names[i][31] = 0;
+    }
+    if (total_ms) total_ms[i] = p->timers[i].total_ms;
+    if (calls) calls[i] = p->timers[i].calls;
+    if (alg_bytes) alg_bytes[i] = p->timers[i].alg_bytes;
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// registry.h -- table of compiled gfx950 kernel instantiations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <vector>
+#include "fft_kernels.h"
+#include "twiddle.h"
+
+namespace mfft {
+
+enum Family { FAM_COL = 0, FAM_ROW = 1, FAM_R2C = 2, FAM_C2R = 3 };
+
+struct KernelEntry {
+  int family;
+  int n;            // transform length (R2C/C2R: the REAL length)
+  int prec;         // 0 single, 1 double
+  int inv;          // COL/ROW: 1 = inverse
+  int tile;         // COLS (COL) or ROWS (others)
+  int threads;
+  int lds_bytes;
+  int tw_count;     // entries of the inter-pass twiddle table
+  void (*build_tw)(void* host_dst);
+  void (*launch)(const void* params, int grid, hipStream_t s);
+  const void* func;
+  const char* name;
+};
+
+std::vector<KernelEntry>& kernel_registry();
+const KernelEntry* find_kernel(int family, int n, int prec, int inv);
+
+// ---- default tiling heuristics (tuned on MI355X) -------------
+template <class S, typename T> constexpr int col_cols() {
+  // widest tile with 128-byte segments whose exchange buffer still leaves room
+  // for >= 2 workgroups per CU (64 KiB); never narrower than 32 bytes.
+  int cols = 128 / (int)sizeof(cx<T>);
+  while (cols > 2 && (long long)S::N * cols * (int)sizeof(cx<T>) > 65536) cols /= 2;
+  while (cols > 1 && S::TPT * cols > 1024) cols /= 2;
+  while (S::TPT * cols < 64) cols *= 2;      // at least one full wave
+  return cols;
+}
+template <class S, typename T> constexpr bool col_twlds() {
+  return S::NP > 1 && (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) + S::TW * (int)sizeof(cx<T>) <= 65536;
+}
+template <class S, typename T> constexpr int row_rows() {
+  int rows = 256 / S::TPT;
+  if (rows < 1) rows = 1;
+  const long long per_row = (long long)(S::N + S::N / S::R(0) + 1) * (int)sizeof(cx<T>);
+  while (rows > 1 && per_row * rows > 40960) rows /= 2;
+  return rows;
+}
+template <class S, typename T> constexpr bool row_twlds() { return S::NP > 1; }
+
+// ---- generic __global__ wrapper + launch thunks ------------------------------
+template <class K, class P>
+__global__ __launch_bounds__(K::THREADS) void mfft_kern(P p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
+}
+
+template <class K, class P>
+void launch_thunk(const void* params, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((mfft_kern<K, P>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, s,
+                     *static_cast<const P*>(params));
+}
+
+template <class S, typename T>
+void tw_thunk(void* dst) {
+  auto v = build_pass_twiddles<S, T>();
+  memcpy(dst, v.data(), v.size() * sizeof(cx<T>));
+}
+
+template <class K, class P, class S, typename T>
+KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
+  KernelEntry e;
+  e.family = family;
+  e.n = n;
+  e.prec = sizeof(T) == 8 ? 1 : 0;
+  e.inv = inv;
+  e.tile = tile;
+  e.threads = K::THREADS;
+  e.lds_bytes = K::LDS_BYTES;
+  e.tw_count = S::TW;
+  e.build_tw = &tw_thunk<S, T>;
+  e.launch = &launch_thunk<K, P>;
+  e.func = reinterpret_cast<const void*>(&mfft_kern<K, P>);
+  e.name = name;
+  return e;
+}
+
+template <class S, typename T>
+void register_plan(const char* name) {
+  auto& reg = kernel_registry();
+  constexpr int C = col_cols<S, T>();
+  constexpr bool CT = col_twlds<S, T>();
+  constexpr int R = row_rows<S, T>();
+  constexpr bool RT = row_twlds<S, T>();
+  reg.push_back(make_entry<ColFft<S, T, C, false, CT>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
+  reg.push_back(make_entry<ColFft<S, T, C, true, CT>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+  reg.push_back(make_entry<RowFft<S, T, R, false, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
+  reg.push_back(make_entry<RowFft<S, T, R, true, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
+  reg.push_back(make_entry<R2CFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+  reg.push_back(make_entry<C2RFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
+}
+
+struct PlanRegistrar {
+  template <class F> explicit PlanRegistrar(F f) { f(); }
+};
+
+}  // namespace mfft

@@ -1,0 +1,108 @@
+"""DeviceArray: a minimal HBM-resident n-d array (hipMalloc-backed) so that
+fftn/ifftn can run without PCIe copies.  It is deliberately tiny: shape, dtype,
+pointer, get()/set().  numpy arrays are accepted everywhere too (copied in/out).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceArray(object):
+    def __init__(self, shape, dtype, ptr=None, owner=True):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if len(self.shape) else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._owner = owner and ptr is None
+        if ptr is None:
+            p = ctypes.c_void_p()
+            _lib.call("mfft_malloc", ctypes.byref(p), max(self.nbytes, 16))
+            ptr = p.value
+        self.ptr = ptr
+
+    # -- construction -------------------------------------------------------
+    @classmethod
+    def empty(cls, shape, dtype):
+        return cls(shape, dtype)
+
+    @classmethod
+    def zeros(cls, shape, dtype):
+        a = cls(shape, dtype)
+        _lib.call("mfft_memset", a.ptr, 0, a.nbytes)
+        return a
+
+    @classmethod
+    def from_numpy(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        a = cls(arr.shape, arr.dtype)
+        a.set(arr)
+        return a
+
+    @classmethod
+    def random(cls, shape, dtype, seed=0):
+        """U[0,1) synthetic data generated on the device (bench / large tests)."""
+        a = cls(shape, dtype)
+        dt = np.dtype(dtype)
+        count = a.size * (2 if dt.kind == "c" else 1)
+        _lib.call("mfft_fill_uniform", a.ptr, count, _lib.precision_code(dt), seed)
+        return a
+
+    # -- transfers ----------------------------------------------------------
+    def set(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        if arr.shape != self.shape:
+            raise ValueError("shape mismatch %s vs %s" % (arr.shape, self.shape))
+        _lib.call("mfft_memcpy_h2d", self.ptr, arr.ctypes.data, self.nbytes)
+        return self
+
+    def get(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        if out.shape != self.shape or out.dtype != self.dtype or not out.flags["C_CONTIGUOUS"]:
+            tmp = np.empty(self.shape, dtype=self.dtype)
+            _lib.call("mfft_memcpy_d2h", tmp.ctypes.data, self.ptr, self.nbytes)
+            out[...] = tmp
+            return out
+        _lib.call("mfft_memcpy_d2h", out.ctypes.data, self.ptr, self.nbytes)
+        return out
+
+    def copy_from(self, other):
+        assert other.nbytes == self.nbytes
+        _lib.call("mfft_memcpy_d2d", self.ptr, other.ptr, self.nbytes)
+        return self
+
+    def view(self, shape, dtype=None):
+        """Reinterpret the same memory (no ownership)."""
+        dtype = self.dtype if dtype is None else np.dtype(dtype)
+        v = DeviceArray(shape, dtype, ptr=self.ptr, owner=False)
+        if v.nbytes > self.nbytes:
+            raise ValueError("view larger than the allocation")
+        v._base = self
+        return v
+
+    def leading(self, i0, i1):
+        """Non-owning view of rows [i0, i1) of the leading axis."""
+        row = self.nbytes // self.shape[0]
+        v = DeviceArray((i1 - i0,) + self.shape[1:], self.dtype, ptr=self.ptr + i0 * row, owner=False)
+        v._base = self
+        return v
+
+    def free(self):
+        if self._owner and self.ptr:
+            _lib.call("mfft_free", self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return "DeviceArray(shape=%s, dtype=%s, ptr=0x%x)" % (self.shape, self.dtype, self.ptr or 0)
+
+
+def is_device_array(x):
+    return isinstance(x, DeviceArray)

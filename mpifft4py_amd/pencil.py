@@ -1,0 +1,189 @@
+"""Pencil decomposition on MI355X: counterparts of mpiFFT4py/pencil.py classes
+R2CY (pencil.py:145-883), R2CX (pencil.py:885-1477) and the R2C factory
+(pencil.py:1479-1484).
+
+Real data (N0/P1, N1/P2, N2); complex data aligned in y (R2CY:
+(N0/P2, N1, N1f)) or in x (R2CX: (N0, N1/P1, N2f)).  comm0 = P1 consecutive
+world ranks, comm1 = P2 ranks of stride P1 (pencil.py:192-195).
+"""
+import numpy as np
+from numpy.fft import fftfreq, rfftfreq
+
+from . import _lib
+from ._base import DistFFTBase, default_planner_effort
+from .comm import SubComm
+
+__all__ = ["R2C", "R2CX", "R2CY"]
+
+
+def _compute_dims(nprocs):
+    """MPI.Compute_dims(nprocs, 2): balanced, non-increasing."""
+    best = (nprocs, 1)
+    a = 1
+    while a * a <= nprocs:
+        if nprocs % a == 0:
+            best = (nprocs // a, a)
+        a += 1
+    return best
+
+
+class R2CY(DistFFTBase):
+    """Pencil R2C with the final complex data aligned in the y-direction.
+
+    `allow_single=True` lifts the reference's P > 1 assertion (pencil.py:176) so
+    that the degenerate 1x1 grid can serve as the single-GPU scaling baseline."""
+    _decomp = _lib.PENCIL_Y
+
+    def __init__(self, N, L, comm, precision, P1=None, communication='Alltoallw', padsize=1.5, threads=1,
+                 planner_effort=None, allow_single=False, pipeline=0):
+        self._init_common(N, L, comm, precision, communication, padsize, threads,
+                          planner_effort if planner_effort is not None else default_planner_effort())
+        N = self.N
+        self.Nf = int(N[2] // 2 + 1)
+        self.L = np.asarray(L).astype(float)
+        P = self.num_processes
+        if not allow_single:
+            assert P > 1
+        if communication == 'AlltoallN':
+            raise NotImplementedError("communication='AlltoallN' (lossy Nyquist-dropping variant) is not offered")
+        if communication not in ('Alltoall', 'Alltoallw'):
+            raise ValueError("unknown communication %r" % (communication,))
+        if P1 is None:
+            P1, P2 = _compute_dims(P)
+        else:
+            P2 = P // P1
+        self.P1, self.P2 = P1, P2
+        if not (P % 2 == 0 or P == 1):
+            raise IOError("Number of cpus must be even")
+        if P > 1 and ((P1 % 2 != 0) or (P2 % 2 != 0)):
+            raise IOError("Number of cpus in each direction must be even power of 2")
+        self.N1 = N // P1
+        self.N2 = N // P2
+        self.comm0_rank = self.rank % P1
+        self.comm1_rank = self.rank // P1
+        self.comm0 = SubComm(P1, self.comm0_rank)
+        self.comm1 = SubComm(P2, self.comm1_rank)
+        self.N1f = int(self.N1[2] // 2) if self.comm0_rank < P1 - 1 else int(self.N1[2] // 2 + 1)
+        self.N2f = int(self.N2[2] // 2) if self.comm1_rank < P2 - 1 else int(self.N2[2] // 2 + 1)
+        self._create_plan(_lib.R2C, self._decomp, p1=P1, pipeline=pipeline)
+        assert self._c_real_shape == tuple(self.real_shape())
+        assert self._c_complex_shape == tuple(self.complex_shape()), (self._c_complex_shape, self.complex_shape())
+
+    # -- shapes (pencil.py:248-287) ------------------------------------------------
+    def real_shape(self):
+        return (int(self.N1[0]), int(self.N2[1]), int(self.N[2]))
+
+    def complex_shape(self):
+        return (int(self.N2[0]), int(self.N[1]), self.N1f)
+
+    def real_shape_padded(self):
+        return (int(self.padsize * self.N1[0]), int(self.padsize * self.N2[1]), int(self.padsize * self.N[2]))
+
+    def work_shape(self, dealias):
+        return self.real_shape_padded() if dealias == '3/2-rule' else self.real_shape()
+
+    def global_real_shape(self):
+        return (int(self.N[0]), int(self.N[1]), int(self.N[2]))
+
+    def global_complex_shape(self, padsize=1.0):
+        return (int(padsize * self.N[0]), int(padsize * self.N[1]), int(padsize * self.N[2] // 2 + 1))
+
+    def real_local_slice(self, padsize=1):
+        c0, c1 = self.comm0_rank, self.comm1_rank
+        return (slice(int(padsize * c0 * self.N1[0]), int(padsize * (c0 + 1) * self.N1[0]), 1),
+                slice(int(padsize * c1 * self.N2[1]), int(padsize * (c1 + 1) * self.N2[1]), 1),
+                slice(0, int(padsize * self.N[2])))
+
+    def complex_local_slice(self):
+        c0, c1 = self.comm0_rank, self.comm1_rank
+        z0 = int(c0 * self.N1[2] // 2)
+        return (slice(int(c1 * self.N2[0]), int((c1 + 1) * self.N2[0]), 1),
+                slice(0, int(self.N[1])),
+                slice(z0, z0 + self.N1f, 1))
+
+    def get_P(self):
+        return self.P1, self.P2
+
+    # -- host-side mesh helpers (pencil.py:289-349) ----------------------------------
+    def complex_local_wavenumbers(self):
+        s = self.complex_local_slice()
+        return (fftfreq(self.N[0], 1. / self.N[0]).astype(int)[s[0]],
+                fftfreq(self.N[1], 1. / self.N[1]).astype(int)[s[1]],
+                rfftfreq(self.N[2], 1. / self.N[2]).astype(int)[s[2]])
+
+    def get_local_mesh(self):
+        s = self.real_local_slice()
+        X = list(np.ogrid[s[0], s[1], :self.N[2]])
+        for i in range(3):
+            X[i] = (X[i] * self.L[i] / self.N[i]).astype(self.float)
+        return [np.broadcast_to(x, self.real_shape()) for x in X]
+
+    def get_local_wavenumbermesh(self, scaled=False, broadcast=False, eliminate_highest_freq=False):
+        s = self.complex_local_slice()
+        kx = fftfreq(self.N[0], 1. / self.N[0]).astype(int)
+        ky = fftfreq(self.N[1], 1. / self.N[1]).astype(int)
+        kz = rfftfreq(self.N[2], 1. / self.N[2]).astype(int)
+        if eliminate_highest_freq:
+            for i, k in enumerate((kx, ky, kz)):
+                if self.N[i] % 2 == 0:
+                    k[self.N[i] // 2] = 0
+        Ks = list(np.meshgrid(kx[s[0]], ky[s[1]], kz[s[2]], indexing='ij', sparse=True))
+        if scaled is True:
+            Lp = 2 * np.pi / self.L
+            for i in range(3):
+                Ks[i] = (Ks[i] * Lp[i]).astype(self.float)
+        if broadcast is True:
+            return [np.broadcast_to(k, self.complex_shape()) for k in Ks]
+        return Ks
+
+    def get_dealias_filter(self):
+        K = self.get_local_wavenumbermesh()
+        kmax = 2. / 3. * (self.N // 2 + 1)
+        return np.array((abs(K[0]) < kmax[0]) * (abs(K[1]) < kmax[1]) * (abs(K[2]) < kmax[2]), dtype=np.uint8)
+
+    # -- transforms ----------------------------------------------------------------
+    def fftn(self, u, fu, dealias=None):
+        """Forward transform (pencil.py:634-883 / 1228-1475); returns fu."""
+        assert dealias in ('3/2-rule', '2/3-rule', 'None', None)
+        ushape = self.real_shape_padded() if dealias == '3/2-rule' else self.real_shape()
+        assert tuple(u.shape) == ushape
+        return self._run(True, u, fu, dealias, ushape, self.float, self.complex_shape(), self.complex)
+
+    def ifftn(self, fu, u, dealias=None):
+        """Inverse transform (pencil.py:386-632 / 1001-1224); fu is not modified."""
+        assert dealias in ('3/2-rule', '2/3-rule', 'None', None)
+        ushape = self.real_shape_padded() if dealias == '3/2-rule' else self.real_shape()
+        assert tuple(u.shape) == ushape
+        return self._run(False, fu, u, dealias, self.complex_shape(), self.complex, ushape, self.float)
+
+    fft3d = fftn
+    ifft3d = ifftn
+
+
+class R2CX(R2CY):
+    """Pencil R2C with the final complex data aligned in the x-direction."""
+    _decomp = _lib.PENCIL_X
+
+    def __init__(self, N, L, comm, precision, P1=None, communication='Alltoall', padsize=1.5, threads=1,
+                 planner_effort=None, allow_single=False, pipeline=0):
+        R2CY.__init__(self, N, L, comm, precision, P1=P1, communication=communication, padsize=padsize,
+                      threads=threads, planner_effort=planner_effort, allow_single=allow_single,
+                      pipeline=pipeline)
+
+    def complex_shape(self):
+        return (int(self.N[0]), int(self.N1[1]), self.N2f)
+
+    def complex_local_slice(self):
+        c0, c1 = self.comm0_rank, self.comm1_rank
+        z0 = int(c1 * self.N2[2] // 2)
+        return (slice(0, int(self.N[0])),
+                slice(int(c0 * self.N1[1]), int((c0 + 1) * self.N1[1]), 1),
+                slice(z0, z0 + self.N2f, 1))
+
+
+def R2C(N, L, comm, precision, P1=None, communication="Alltoall", padsize=1.5, threads=1,
+        alignment="X", planner_effort=None, **kw):
+    """Factory with the reference's signature (pencil.py:1479-1484)."""
+    if alignment == 'X':
+        return R2CX(N, L, comm, precision, P1, communication, padsize, threads, planner_effort, **kw)
+    return R2CY(N, L, comm, precision, P1, communication, padsize, threads, planner_effort, **kw)

@@ -1,0 +1,200 @@
+"""Slab decomposition on MI355X: drop-in counterparts of mpiFFT4py/slab.py
+classes R2C (slab.py:49-536) and C2C (slab.py:538-825).
+
+Real data (N0/P, N1, N2) <-> complex data (N0, N1/P, N2/2+1).  The transforms
+themselves run in libmpifft4py_amd.so (HIP kernels + RCCL all-to-all); this
+file keeps the reference's constructor signature, attributes, shape/slice
+methods, mesh helpers and exception types.
+"""
+import numpy as np
+from numpy.fft import fftfreq, rfftfreq
+
+from . import _lib
+from ._base import DistFFTBase, default_planner_effort
+
+__all__ = ["R2C", "C2C"]
+
+
+class R2C(DistFFTBase):
+    """3-D real <-> complex FFT, slab decomposition.
+
+    Args (as the reference, slab.py:67-71):
+        N, L, comm, precision ("single"/"double"),
+        communication ('Alltoall' | 'Alltoallw': identical results, both map to
+        the RCCL exchange), padsize, threads, planner_effort (accepted, unused).
+    """
+    _kind = _lib.R2C
+
+    def __init__(self, N, L, comm, precision, communication="Alltoallw", padsize=1.5, threads=1,
+                 planner_effort=None, pipeline=0):
+        self._init_common(N, L, comm, precision, communication, padsize, threads,
+                          planner_effort if planner_effort is not None else default_planner_effort())
+        N = self.N
+        self.Nf = int(N[2] // 2 + 1)
+        self.Nfp = int(padsize * N[2] // 2 + 1)
+        self.Np = N // self.num_processes
+        self.L = np.asarray(L).astype(self.float)
+        if communication == "Sendrecv_replace":
+            # dead code upstream (py2 xrange, shape bug for every P > 1); not offered
+            raise ValueError("communication='Sendrecv_replace' is not supported")
+        if communication not in ("Alltoall", "Alltoallw"):
+            raise ValueError("unknown communication %r" % (communication,))
+        if self.num_processes not in [2 ** i for i in range(int(np.log2(N[0])) + 1)]:
+            raise IOError("Number of cpus must be in ", [2 ** i for i in range(int(np.log2(N[0])) + 1)])
+        self._post_init()
+        self._create_plan(self._kind, _lib.SLAB, pipeline=pipeline)
+        assert self._c_real_shape == tuple(self.real_shape())
+        assert self._c_complex_shape == tuple(self.complex_shape())
+
+    def _post_init(self):
+        pass
+
+    # -- shapes (slab.py:98-144, 487-514) ---------------------------------------
+    def real_shape(self):
+        return (int(self.Np[0]), int(self.N[1]), int(self.N[2]))
+
+    def complex_shape(self):
+        return (int(self.N[0]), int(self.Np[1]), self.Nf)
+
+    def complex_shape_T(self):
+        return (int(self.Np[0]), int(self.N[1]), self.Nf)
+
+    def global_real_shape(self):
+        return (int(self.N[0]), int(self.N[1]), int(self.N[2]))
+
+    def global_complex_shape(self, padsize=1.):
+        return (int(padsize * self.N[0]), int(padsize * self.N[1]), int(padsize * self.N[2] // 2 + 1))
+
+    def work_shape(self, dealias):
+        return self.real_shape_padded() if dealias == '3/2-rule' else self.real_shape()
+
+    def real_shape_padded(self):
+        return (int(self.padsize * self.Np[0]), int(self.padsize * self.N[1]), int(self.padsize * self.N[2]))
+
+    def complex_shape_padded_0(self):
+        return (int(self.padsize * self.N[0]), int(self.Np[1]), self.Nf)
+
+    def complex_shape_padded_1(self):
+        return (int(self.padsize * self.Np[0]), int(self.N[1]), self.Nf)
+
+    def complex_shape_padded_2(self):
+        return (int(self.padsize * self.Np[0]), int(self.padsize * self.N[1]), self.Nf)
+
+    def complex_shape_padded_3(self):
+        return (int(self.padsize * self.Np[0]), int(self.padsize * self.N[1]), self.Nfp)
+
+    def real_local_slice(self, padsize=1):
+        return (slice(int(padsize * self.rank * self.Np[0]), int(padsize * (self.rank + 1) * self.Np[0]), 1),
+                slice(0, int(padsize * self.N[1]), 1),
+                slice(0, int(padsize * self.N[2]), 1))
+
+    def complex_local_slice(self):
+        return (slice(0, int(self.N[0]), 1),
+                slice(int(self.rank * self.Np[1]), int((self.rank + 1) * self.Np[1]), 1),
+                slice(0, self.Nf, 1))
+
+    # -- host-side mesh helpers (slab.py:146-197) ---------------------------------
+    def complex_local_wavenumbers(self):
+        return (fftfreq(self.N[0], 1. / self.N[0]).astype(self.float),
+                fftfreq(self.N[1], 1. / self.N[1])[self.complex_local_slice()[1]].astype(self.float),
+                rfftfreq(self.N[2], 1. / self.N[2]).astype(self.float))
+
+    def get_local_mesh(self):
+        X = list(np.ogrid[self.rank * self.Np[0]:(self.rank + 1) * self.Np[0], :self.N[1], :self.N[2]])
+        for i in range(3):
+            X[i] = (X[i] * self.L[i] / self.N[i]).astype(self.float)
+        return [np.broadcast_to(x, self.real_shape()) for x in X]
+
+    def get_local_wavenumbermesh(self, scaled=False, broadcast=False, eliminate_highest_freq=False):
+        kx, ky, kz = self.complex_local_wavenumbers()
+        if eliminate_highest_freq:
+            ky = fftfreq(self.N[1], 1. / float(self.N[1]))
+            for i, k in enumerate((kx, ky, kz)):
+                if self.N[i] % 2 == 0:
+                    k[self.N[i] // 2] = 0
+            ky = ky[self.complex_local_slice()[1]]
+        Ks = list(np.meshgrid(kx, ky, kz, indexing='ij', sparse=True))
+        for i in range(3):
+            Ks[i] = Ks[i].astype(self.float)
+        if scaled:
+            Lp = 2 * np.pi / self.L
+            for i in range(3):
+                Ks[i] = Ks[i] * Lp[i]
+        if broadcast is True:
+            return [np.broadcast_to(k, self.complex_shape()) for k in Ks]
+        return Ks
+
+    def get_dealias_filter(self):
+        K = self.get_local_wavenumbermesh()
+        kmax = 2. / 3. * (self.N // 2 + 1)
+        return np.array((abs(K[0]) < kmax[0]) * (abs(K[1]) < kmax[1]) * (abs(K[2]) < kmax[2]), dtype=np.uint8)
+
+    # -- transforms ---------------------------------------------------------------
+    def fftn(self, u, fu, dealias=None):
+        """Forward transform (slab.py:349-485).  u: real_shape() (or
+        real_shape_padded() with dealias='3/2-rule'); fu: complex_shape().
+        numpy arrays or DeviceArrays; returns fu."""
+        assert dealias in ('3/2-rule', '2/3-rule', 'None', None)
+        ushape = self.real_shape_padded() if dealias == '3/2-rule' else self.real_shape()
+        assert tuple(u.shape) == ushape
+        return self._run(True, u, fu, dealias, ushape, self._in_dtype(), self.complex_shape(), self.complex)
+
+    def ifftn(self, fu, u, dealias=None):
+        """Inverse transform (slab.py:214-346); fu is not modified."""
+        assert dealias in ('3/2-rule', '2/3-rule', 'None', None)
+        ushape = self.real_shape_padded() if dealias == '3/2-rule' else self.real_shape()
+        assert tuple(u.shape) == ushape
+        return self._run(False, fu, u, dealias, self.complex_shape(), self.complex, ushape, self._in_dtype())
+
+    # aliases named by the build brief
+    fft3d = fftn
+    ifft3d = ifftn
+
+    def _in_dtype(self):
+        return self.float
+
+
+class C2C(R2C):
+    """3-D complex <-> complex FFT, slab decomposition (slab.py:538-825)."""
+    _kind = _lib.C2C
+
+    def __init__(self, N, L, comm, precision, communication="Alltoall", padsize=1.5, threads=1,
+                 planner_effort=None, pipeline=0):
+        R2C.__init__(self, N, L, comm, precision, communication=communication, padsize=padsize,
+                     threads=threads, planner_effort=planner_effort, pipeline=pipeline)
+
+    def _post_init(self):
+        N = self.N
+        self.Nf = int(N[2])
+        self.Nfp = int(self.padsize * N[2])
+        self.original_shape_padded = self.real_shape_padded
+        self.original_shape = self.real_shape
+        self.transformed_shape = self.complex_shape
+        self.original_local_slice = self.real_local_slice
+        self.transformed_local_slice = self.complex_local_slice
+        self.ks = (fftfreq(N[2]) * N[2]).astype(int)
+
+    def global_shape(self, padsize=1.):
+        return (int(padsize * self.N[0]), int(padsize * self.N[1]), int(padsize * self.N[2]))
+
+    def transformed_local_wavenumbers(self):
+        return (fftfreq(self.N[0], 1. / self.N[0]),
+                fftfreq(self.N[1], 1. / self.N[1])[self.transformed_local_slice()[1]],
+                fftfreq(self.N[2], 1. / self.N[2]))
+
+    def complex_local_wavenumbers(self):
+        kx, ky, kz = self.transformed_local_wavenumbers()
+        return (kx.astype(self.float), ky.astype(self.float), kz.astype(self.float))
+
+    def _in_dtype(self):
+        return self.complex
+
+    def fftn(self, u, fu, dealias=None):
+        if dealias == '3/2-rule':
+            raise NotImplementedError("C2C 3/2-rule transforms are not implemented on the device yet")
+        return R2C.fftn(self, u, fu, dealias)
+
+    def ifftn(self, fu, u, dealias=None):
+        if dealias == '3/2-rule':
+            raise NotImplementedError("C2C 3/2-rule transforms are not implemented on the device yet")
+        return R2C.ifftn(self, fu, u, dealias)

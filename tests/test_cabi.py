@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly the symbols that
+include/mpifft4py_amd.h declares (no compute calls: there is no GPU here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mpifft4py_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "mpifft4py_amd", "csrc"), "-j8"])
+    return _lib.load()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "mpifft4py_amd.h")).read()
+    return sorted(set(re.findall(r"MFFT_API\s+[\w\s\*]+?\b(mfft_\w+)\s*\(", txt)))
+
+
+def test_header_matches_binding(lib):
+    from mpifft4py_amd import _lib
+    hs = header_symbols()
+    assert len(hs) >= 45
+    assert hs == _lib.exported_symbols()
+
+
+def test_every_symbol_is_exported(lib):
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_nm_exports_only_the_abi(lib):
+    from mpifft4py_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("mfft_"))
+    assert exported == header_symbols()
+
+
+def test_version_and_lengths(lib):
+    assert lib.mfft_version() >= 100
+    for n in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 48, 96, 192, 768, 1536, 3072, 80, 640):
+        assert lib.mfft_length_supported(n, 0) == 1, n
+    for n in (8, 64, 1024, 2048, 8192, 48, 96, 1536):
+        assert lib.mfft_length_supported(n, 1) == 1, n
+    for n in (7, 11, 13, 17, 4097):
+        assert lib.mfft_length_supported(n, 0) == 0, n
+    assert lib.mfft_length_supported(9, 1) == 0
+
+
+def test_fails_loudly_without_gpu(lib):
+    """On a box without a GPU the product path raises; it never falls back."""
+    from mpifft4py_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    import numpy as np
+    from mpifft4py_amd import Slab_R2C
+    with pytest.raises(_lib.MfftError):
+        Slab_R2C(np.array([8, 8, 8]), np.array([1., 1., 1.]), None, "double")
+
+
+def test_emulator_passes():
+    """The fibre-based workgroup emulator runs the exact kernel bodies on the CPU
+    against a long-double DFT for every plan in plans.h."""
+    csrc = os.path.join(ROOT, "mpifft4py_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "emu"])
+    out = subprocess.check_output([os.path.join(csrc, "build", "emu_test")]).decode()
+    assert "EMU TESTS PASSED" in out, out[-2000:]

@@ -1,0 +1,283 @@
+"""GPU parity of the distributed classes against the oracle, the reference's
+golden fixtures and numpy.fft: slab R2C / C2C and pencil R2CX / R2CY, P in
+{1, 2, 4, 8}, both precisions, un-padded / 3/2-rule / 2/3-rule.  Mirrors
+tests/test_FFT.py of the reference (test_FFT, test_FFT_padded, test_FFT_C2C)
+with its anisotropic mesh N = [32, 64, 128]."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import L, TOL, cdtype, have_gpu, orc, rdtype, run_ranks
+
+pytestmark = pytest.mark.gpu
+
+NREF = [32, 64, 128]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not have_gpu():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+
+
+def _slab_roundtrip(N, P, prec, mode, A):
+    from mpifft4py_amd import Slab_R2C
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, prec, communication=mode)
+        a = np.ascontiguousarray(A[F.real_local_slice()])
+        c = np.zeros(F.complex_shape(), dtype=F.complex)
+        r = F.fftn(a, c)
+        assert r is c
+        b = np.zeros(F.real_shape(), dtype=F.float)
+        b = F.ifftn(c, b)
+        return F.complex_local_slice(), c, F.real_local_slice(), b
+    return run_ranks(P, body)
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("mode", ["Alltoall", "Alltoallw"])
+@pytest.mark.parametrize("P", [1, 2, 4, 8])
+def test_slab_r2c(P, mode, prec):
+    rng = np.random.default_rng(100 + P)
+    A = rng.random(NREF).astype(rdtype(prec))
+    B2 = np.fft.rfftn(A.astype(np.float64))
+    lay = orc.SlabLayout(NREF, P)
+    want = orc.slab_r2c_forward(orc.scatter_real(A, lay), NREF, prec)
+    res = _slab_roundtrip(NREF, P, prec, mode, A)
+    rtol = 1e-8 if prec == "double" else 1e-4
+    for r, (cs, c, rs, b) in enumerate(res):
+        assert orc.rel_l2(c, want[r]) < TOL[prec]
+        assert orc.rel_l2(c, B2[cs]) < TOL[prec]
+        # the reference's own criterion (tests/test_FFT.py:85, 90)
+        assert np.all(np.abs((c - B2[cs]) / c.max()) < rtol)
+        assert np.all(np.abs((b - A[rs]) / b.max()) < rtol)
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("align", ["X", "Y"])
+@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2), (16, None)])
+def test_pencil_r2c(P, P1, align, prec):
+    from mpifft4py_amd import Pencil_R2C
+    rng = np.random.default_rng(200 + P)
+    A = rng.random(NREF).astype(rdtype(prec))
+    B2 = np.fft.rfftn(A.astype(np.float64))
+    lay = orc.PencilLayout(NREF, P, P1, align)
+    want = orc.pencil_r2c_forward(orc.scatter_real(A, lay), NREF, P1, align, prec)
+
+    def body(comm):
+        F = Pencil_R2C(np.array(NREF), L, comm, prec, P1=P1, communication="Alltoallw", alignment=align)
+        assert (F.P1, F.P2) == (lay.P1, lay.P2)
+        assert tuple(F.complex_shape()) == tuple(lay.complex_shape(comm.Get_rank()))
+        a = np.ascontiguousarray(A[F.real_local_slice()])
+        c = F.fftn(a, np.zeros(F.complex_shape(), dtype=F.complex))
+        b = F.ifftn(c, np.zeros(F.real_shape(), dtype=F.float))
+        return F.complex_local_slice(), c, F.real_local_slice(), b
+    for r, (cs, c, rs, b) in enumerate(run_ranks(P, body)):
+        assert orc.rel_l2(c, want[r]) < TOL[prec], (r,)
+        assert orc.rel_l2(c, B2[cs]) < TOL[prec]
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_slab_c2c(P, prec):
+    from mpifft4py_amd import Slab_C2C
+    rng = np.random.default_rng(300 + P)
+    A = (rng.random(NREF) + 1j * rng.random(NREF)).astype(cdtype(prec))
+    B2 = np.fft.fftn(A.astype(np.complex128))
+
+    def body(comm):
+        F = Slab_C2C(np.array(NREF), L, comm, prec)
+        assert F.global_shape() == tuple(NREF)
+        a = np.ascontiguousarray(A[F.original_local_slice()])
+        c = F.fftn(a, np.zeros(F.transformed_shape(), dtype=F.complex))
+        b = F.ifftn(c, np.zeros(F.original_shape(), dtype=F.complex))
+        return F.transformed_local_slice(), c, F.original_local_slice(), b
+    for cs, c, rs, b in run_ranks(P, body):
+        assert orc.rel_l2(c, B2[cs]) < TOL[prec]
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
+
+
+def _padded_case(make, P, C0, prec):
+    def body(comm):
+        F = make(comm)
+        c = np.ascontiguousarray(C0[F.complex_local_slice()])
+        ap = F.ifftn(c, np.zeros(F.real_shape_padded(), dtype=F.float), dealias="3/2-rule")
+        cp = F.fftn(ap, np.zeros(F.complex_shape(), dtype=F.complex), dealias="3/2-rule")
+        return F.real_local_slice(padsize=1.5), ap, F.complex_local_slice(), cp
+    return run_ranks(P, body)
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_slab_padded(P, prec):
+    """test_FFT_padded of the reference (tests/test_FFT.py:159-205)."""
+    from mpifft4py_amd import Slab_R2C
+    rng = np.random.default_rng(400)
+    N = NREF
+    A = rng.random(N)
+    C0 = np.fft.rfftn(A).astype(cdtype(prec))
+    C0[N[0] // 2] = 0
+    C0[:, N[1] // 2] = 0
+    C0[:, :, -1] = 0
+    lay = orc.SlabLayout(N, P)
+    want = orc.slab_r2c_backward_padded(orc.scatter_complex(C0, lay), N, prec)
+    res = _padded_case(lambda comm: Slab_R2C(np.array(N), L, comm, prec), P, C0, prec)
+    for r, (rs, ap, cs, cp) in enumerate(res):
+        assert orc.rel_l2(ap, want[r]) < 4 * TOL[prec]
+        assert orc.rel_l2(cp, C0[cs]) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("align", ["X", "Y"])
+@pytest.mark.parametrize("P", [4, 8])
+def test_pencil_padded(P, align, prec):
+    from mpifft4py_amd import Pencil_R2C
+    rng = np.random.default_rng(500)
+    N = NREF
+    A = rng.random(N)
+    C0 = np.fft.rfftn(A).astype(cdtype(prec))
+    C0[N[0] // 2] = 0
+    C0[:, N[1] // 2] = 0
+    C0[:, :, -1] = 0
+    lay = orc.PencilLayout(N, P, None, align)
+    want = orc.pencil_r2c_backward_padded(orc.scatter_complex(C0, lay), N, None, align, prec)
+    res = _padded_case(lambda comm: Pencil_R2C(np.array(N), L, comm, prec, communication="Alltoallw",
+                                               alignment=align), P, C0, prec)
+    for r, (rs, ap, cs, cp) in enumerate(res):
+        assert orc.rel_l2(ap, want[r]) < 4 * TOL[prec]
+        assert orc.rel_l2(cp, C0[cs]) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("decomp", ["slab", "pencilX", "pencilY"])
+def test_two_thirds_rule(decomp):
+    """ifftn(dealias='2/3-rule') == ifftn of the masked spectrum (slab.py:237-245)."""
+    from mpifft4py_amd import Pencil_R2C, Slab_R2C
+    rng = np.random.default_rng(600)
+    N = NREF
+    C = np.fft.rfftn(rng.random(N))
+    P = 2 if decomp == "slab" else 4
+
+    def body(comm):
+        F = (Slab_R2C(np.array(N), L, comm, "double") if decomp == "slab" else
+             Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=decomp[-1]))
+        c = np.ascontiguousarray(C[F.complex_local_slice()])
+        c_in = c.copy()
+        u = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule")
+        assert np.array_equal(c, c_in)          # input spectrum untouched
+        mask = np.broadcast_to(F.get_dealias_filter(), F.complex_shape())
+        u_ref = F.ifftn(c * mask, np.zeros(F.real_shape()))
+        return u, u_ref, F.complex_local_slice(), mask
+    kx = np.fft.fftfreq(N[0], 1. / N[0])
+    ky = np.fft.fftfreq(N[1], 1. / N[1])
+    kz = np.fft.rfftfreq(N[2], 1. / N[2])
+    gmask = orc.dealias_mask(N, kx, ky, kz)
+    for u, u_ref, cs, mask in run_ranks(P, body):
+        assert orc.rel_l2(u, u_ref) < 1e-12
+        assert np.array_equal(mask, gmask[cs])
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+def test_golden_fixtures(prec, golden_dir):
+    """Against the arrays the REAL reference produced (tests/golden, N = [8,16,32])."""
+    from mpifft4py_amd import Pencil_R2C, Slab_C2C, Slab_R2C
+    g = np.load(os.path.join(golden_dir, "ref_8x16x32_%s.npz" % prec))
+    N = [8, 16, 32]
+    A = g["A"]
+
+    def gather(res, shape, dtype):
+        G = np.zeros(shape, dtype=dtype)
+        for sl, part in res:
+            G[sl] = part
+        return G
+
+    for P in (1, 2, 4):
+        def body(comm):
+            F = Slab_R2C(np.array(N), L, comm, prec)
+            c = F.fftn(np.ascontiguousarray(A[F.real_local_slice()]), np.zeros(F.complex_shape(), dtype=F.complex))
+            return F.complex_local_slice(), c
+        C = gather(run_ranks(P, body), g["slab_P%d_Alltoallw_fwd" % P].shape, cdtype(prec))
+        assert orc.rel_l2(C, g["slab_P%d_Alltoallw_fwd" % P]) < TOL[prec]
+    for P, P1 in ((4, None), (8, None), (8, 2)):
+        for align in ("X", "Y"):
+            def body(comm):
+                F = Pencil_R2C(np.array(N), L, comm, prec, P1=P1, communication="Alltoallw", alignment=align)
+                c = F.fftn(np.ascontiguousarray(A[F.real_local_slice()]), np.zeros(F.complex_shape(), dtype=F.complex))
+                return F.complex_local_slice(), c
+            key = "pencil%s_P%d_P1%s_fwd" % (align, P, P1)
+            C = gather(run_ranks(P, body), g[key].shape, cdtype(prec))
+            assert orc.rel_l2(C, g[key]) < TOL[prec], key
+    # 3/2-rule, slab P = 2 and pencil P = 4
+    C0 = g["C0"]
+
+    def pad_body(make):
+        def body(comm):
+            F = make(comm)
+            ap = F.ifftn(np.ascontiguousarray(C0[F.complex_local_slice()]),
+                         np.zeros(F.real_shape_padded(), dtype=F.float), dealias="3/2-rule")
+            return F.real_local_slice(padsize=1.5), ap
+        return body
+    AP = gather(run_ranks(2, pad_body(lambda comm: Slab_R2C(np.array(N), L, comm, prec))), g["slab_P2_pad_bwd"].shape, rdtype(prec))
+    assert orc.rel_l2(AP, g["slab_P2_pad_bwd"]) < 4 * TOL[prec]
+    for align in ("X", "Y"):
+        AP = gather(run_ranks(4, pad_body(lambda comm: Pencil_R2C(np.array(N), L, comm, prec, communication="Alltoallw", alignment=align))),
+                    g["pencil%s_P4_pad_bwd" % align].shape, rdtype(prec))
+        assert orc.rel_l2(AP, g["pencil%s_P4_pad_bwd" % align]) < 4 * TOL[prec]
+    # C2C
+    Ac = g["Ac"]
+    for P in (1, 2):
+        def body(comm):
+            F = Slab_C2C(np.array(N), L, comm, prec)
+            c = F.fftn(np.ascontiguousarray(Ac[F.original_local_slice()]), np.zeros(F.transformed_shape(), dtype=F.complex))
+            return F.transformed_local_slice(), c
+        C = gather(run_ranks(P, body), g["slabc2c_P%d_fwd" % P].shape, cdtype(prec))
+        assert orc.rel_l2(C, g["slabc2c_P%d_fwd" % P]) < TOL[prec]
+
+
+def test_device_arrays_and_cubic_sizes():
+    """Device-resident in/out (the benchmark path) at 64^3 and 128^3, P = 1 and 4."""
+    from mpifft4py_amd import DeviceArray, Slab_R2C
+    for n, P in ((64, 1), (128, 4), (256, 2)):
+        N = [n, n, n]
+        rng = np.random.default_rng(n)
+        A = rng.random(N)
+        B2 = np.fft.rfftn(A)
+
+        def body(comm):
+            F = Slab_R2C(np.array(N), L, comm, "double")
+            u = DeviceArray.from_numpy(np.ascontiguousarray(A[F.real_local_slice()]))
+            fu = DeviceArray.empty(F.complex_shape(), F.complex)
+            u2 = DeviceArray.empty(F.real_shape(), F.float)
+            assert F.fftn(u, fu) is fu
+            F.ifftn(fu, u2)
+            F.sync()
+            assert np.array_equal(u.get(), A[F.real_local_slice()])       # input untouched
+            return F.complex_local_slice(), fu.get(), F.real_local_slice(), u2.get()
+        for cs, c, rs, b in run_ranks(P, body):
+            assert orc.rel_l2(c, B2[cs]) < 1e-10
+            assert orc.rel_l2(b, A[rs]) < 1e-10
+
+
+def test_errors_match_the_reference():
+    from mpifft4py_amd import LocalGroup, Pencil_R2C, SelfComm, Slab_R2C
+    N = np.array([8, 16, 32])
+    with pytest.raises(AssertionError):
+        Slab_R2C(np.array([8, 16]), L, SelfComm(0), "double")
+    with pytest.raises(AssertionError):
+        Slab_R2C(N, L, SelfComm(0), "half")
+    with pytest.raises(AssertionError):        # pencil needs more than one rank (pencil.py:176)
+        Pencil_R2C(N, L, SelfComm(0), "double")
+    F = Slab_R2C(N, L, SelfComm(0), "double")
+    with pytest.raises(AssertionError):
+        F.fftn(np.zeros(F.real_shape()), np.zeros(F.complex_shape(), dtype=complex), dealias="bogus")
+    with pytest.raises(AssertionError):
+        F.fftn(np.zeros((3, 3, 3)), np.zeros(F.complex_shape(), dtype=complex))
+    g = LocalGroup(3, devices=[0, 0, 0])
+    try:
+        with pytest.raises(RuntimeError):      # IOError("Number of cpus must be in ...") on every rank
+            g.run(lambda comm: Slab_R2C(N, L, comm, "double"))
+    finally:
+        g.free()

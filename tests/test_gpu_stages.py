@@ -1,0 +1,149 @@
+"""GPU parity, stage level: the serialFFT seam (fft/ifft/rfft/irfft/... of
+mpifft4py_amd.serialFFT, i.e. mfft_c2c_axis / mfft_r2c_last / mfft_c2r_last),
+slab pack/unpack and the dealias mask, against numpy.fft (the arithmetic the
+reference's numpy backend uses, numpy_fft.py:25-107)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from gpu_util import TOL, cdtype, have_gpu, orc, rdtype
+
+pytestmark = pytest.mark.gpu
+
+LENGTHS = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096,
+           6, 12, 24, 48, 96, 192, 384, 768, 1536, 3072,
+           10, 20, 40, 80, 160, 320, 640, 1280, 2560]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not have_gpu():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("n", LENGTHS)
+def test_c2c_every_length_every_axis(n, prec):
+    from mpifft4py_amd import fft, ifft
+    rng = np.random.default_rng(n)
+    for axis in (0, 1, 2):
+        shape = [3, 5, 7]
+        shape[axis] = n
+        a = (rng.random(shape) - 0.5 + 1j * (rng.random(shape) - 0.5)).astype(cdtype(prec))
+        ref = np.fft.fft(a.astype(np.complex128), axis=axis)
+        got = fft(a, axis=axis)
+        assert got.dtype == cdtype(prec)
+        assert orc.rel_l2(got, ref) < TOL[prec], (n, axis)
+        refi = np.fft.ifft(a.astype(np.complex128), axis=axis)
+        goti = ifft(a, axis=axis)
+        assert orc.rel_l2(goti, refi) < TOL[prec], (n, axis)
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("n", [2 * m for m in LENGTHS])
+def test_rfft_irfft_every_length(n, prec):
+    from mpifft4py_amd import rfft, irfft
+    rng = np.random.default_rng(n + 1)
+    a = (rng.random((3, 5, n)) - 0.5).astype(rdtype(prec))
+    ref = np.fft.rfft(a.astype(np.float64), axis=2)
+    got = rfft(a, axis=2)
+    assert got.shape == ref.shape
+    assert orc.rel_l2(got, ref) < TOL[prec]
+    # c2r convention: imaginary parts of the k=0 and k=n/2 bins are ignored
+    c = ref.astype(cdtype(prec)).copy()
+    c[..., 0] += 1j * 0.7
+    c[..., -1] -= 1j * 0.3
+    back = irfft(c, axis=2)
+    assert back.shape == a.shape
+    assert orc.rel_l2(back, np.fft.irfft(c.astype(np.complex128), n=n, axis=2)) < TOL[prec]
+    assert orc.rel_l2(back, a) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("shape", [(32, 64, 128), (8, 16, 32), (48, 24, 96), (1, 64, 64), (64, 1, 20)])
+def test_multi_axis_transforms(shape, prec):
+    import mpifft4py_amd as m
+    rng = np.random.default_rng(5)
+    a = rng.random(shape).astype(rdtype(prec))
+    a64 = a.astype(np.float64)
+    assert orc.rel_l2(m.rfftn(a, axes=(0, 1, 2)), np.fft.rfftn(a64)) < TOL[prec]
+    assert orc.rel_l2(m.rfft2(a, axes=(1, 2)), np.fft.rfft2(a64, axes=(1, 2))) < TOL[prec]
+    c = np.fft.rfftn(a64).astype(cdtype(prec))
+    assert orc.rel_l2(m.irfftn(c, axes=(0, 1, 2)), a64) < 4 * TOL[prec]
+    c2 = np.fft.rfft2(a64, axes=(1, 2)).astype(cdtype(prec))
+    assert orc.rel_l2(m.irfft2(c2, axes=(1, 2)), a64) < 4 * TOL[prec]
+    z = (a + 1j * rng.random(shape)).astype(cdtype(prec))
+    z128 = z.astype(np.complex128)
+    assert orc.rel_l2(m.fftn(z), np.fft.fftn(z128)) < TOL[prec]
+    assert orc.rel_l2(m.ifftn(z), np.fft.ifftn(z128)) < TOL[prec]
+    assert orc.rel_l2(m.fft2(z, axes=(1, 2)), np.fft.fft2(z128, axes=(1, 2))) < TOL[prec]
+    assert orc.rel_l2(m.ifft2(z, axes=(0, 1)), np.fft.ifft2(z128, axes=(0, 1))) < TOL[prec]
+    # output-array form: b is filled and returned
+    b = np.zeros(np.fft.rfftn(a64).shape, dtype=cdtype(prec))
+    r = m.rfftn(a, b, axes=(0, 1, 2))
+    assert r is b and orc.rel_l2(b, np.fft.rfftn(a64)) < TOL[prec]
+
+
+def test_input_is_not_modified():
+    import mpifft4py_amd as m
+    from mpifft4py_amd import DeviceArray
+    rng = np.random.default_rng(9)
+    z = (rng.random((16, 32, 64)) + 1j * rng.random((16, 32, 64)))
+    d = DeviceArray.from_numpy(z)
+    out = m.fftn(d)
+    assert np.array_equal(d.get(), z)
+    assert orc.rel_l2(out, np.fft.fftn(z)) < 1e-10
+
+
+def test_linearity_and_parseval_large():
+    """Size-independent properties at a size the O(N log N) host check would be slow for."""
+    import mpifft4py_amd as m
+    rng = np.random.default_rng(11)
+    shape = (64, 256, 512)
+    a = rng.random(shape)
+    b = rng.random(shape)
+    fa, fb = m.rfftn(a), m.rfftn(b)
+    fab = m.rfftn(2.0 * a - 3.0 * b)
+    assert orc.rel_l2(fab, 2.0 * fa - 3.0 * fb) < 1e-12
+    # Parseval for the half spectrum
+    w = np.full(shape[2] // 2 + 1, 2.0)
+    w[0] = w[-1] = 1.0
+    e_spec = float(np.sum((np.abs(fa) ** 2) * w)) / a.size
+    assert abs(e_spec - float(np.sum(a * a))) / float(np.sum(a * a)) < 1e-12
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+def test_slab_pack_unpack(prec):
+    """mfft_slab_pack == slab.py:403, mfft_slab_unpack == transpose_Uc (maths.pyx:21-31); bit exact."""
+    from mpifft4py_amd import DeviceArray, _lib
+    rng = np.random.default_rng(3)
+    P, Np0, Np1, Nf = 4, 6, 5, 17
+    T = (rng.random((Np0, P * Np1, Nf)) + 1j * rng.random((Np0, P * Np1, Nf))).astype(cdtype(prec))
+    dT = DeviceArray.from_numpy(T)
+    dM = DeviceArray.empty((P, Np0, Np1, Nf), T.dtype)
+    _lib.call("mfft_slab_pack", dT.ptr, dM.ptr, P, Np0, Np1, Nf, _lib.precision_code(prec))
+    assert np.array_equal(dM.get(), orc.slab_pack(T, P))
+    dT2 = DeviceArray.zeros(T.shape, T.dtype)
+    _lib.call("mfft_slab_unpack", dM.ptr, dT2.ptr, P, Np0, Np1, Nf, _lib.precision_code(prec))
+    assert np.array_equal(dT2.get(), T)
+    assert np.array_equal(orc.slab_unpack(orc.slab_pack(T, P)), T)
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+def test_dealias_filter(prec):
+    from mpifft4py_amd import DeviceArray, _lib
+    rng = np.random.default_rng(4)
+    fu = (rng.random((9, 10, 11)) + 1j * rng.random((9, 10, 11))).astype(cdtype(prec))
+    mask = (rng.random(fu.shape) > 0.4).astype(np.uint8)
+    d = DeviceArray.from_numpy(fu)
+    dm = DeviceArray.from_numpy(mask)
+    _lib.call("mfft_dealias_filter", d.ptr, dm.ptr, fu.size, _lib.precision_code(prec))
+    assert np.array_equal(d.get(), orc.apply_mask(fu, mask).astype(fu.dtype))
+
+
+def test_unsupported_length_raises():
+    import mpifft4py_amd as m
+    from mpifft4py_amd import _lib
+    with pytest.raises(_lib.MfftError):
+        m.fft(np.zeros((7, 4, 4), dtype=np.complex128), axis=0)
