@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--precision", default="double", choices=["double", "single"])
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--stage-timing", default="on", choices=["on", "off"],
+                    help="HIP events around every stage inside the timed region (roofline numbers)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,7 +121,7 @@ def main():
     b0 = u2.leading(0, k).get()
     rt_err = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
 
-    F.enable_timing(True)
+    F.enable_timing(args.stage_timing == "on")
     F.reset_timing()
     sync_all()
     t0 = time.perf_counter()

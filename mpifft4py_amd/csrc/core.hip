@@ -115,6 +115,7 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.ncols = (int)a.ncols;
   P.ntile_c = (int)((a.ncols + e->tile - 1) / e->tile);
   P.nouter = (int)a.nouter;
+  P.remap = a.remap;
   P.scale = (T)a.scale;
   const int64_t grid = (int64_t)P.ntile_c * a.nouter;
   if (grid <= 0) return 0;

@@ -271,24 +271,26 @@ MFFT_HD void pass_compute(cx<T> (&v)[S::E], int j, TwPtr tw) {
 }
 
 // Autosort scatter of pass P's outputs: value r of butterfly jb goes to
-// position (jb/Ns)*Ns*R + jb%Ns + r*Ns.  `put(pos, value)`.
-template <class S, int P, typename T, class Put>
-MFFT_HD void pass_scatter(const cx<T> (&v)[S::E], int j, Put put) {
+// position (jb/Ns)*Ns*R + jb%Ns + r*Ns.  `put(pos, reg)` receives the
+// (compile-time after unrolling) register index so that callers can move the
+// whole complex value or only one component.
+template <class S, int P, class Put>
+MFFT_HD void pass_scatter(int j, Put put) {
   constexpr int R = S::R(P), Ns = S::Ns(P), G = S::E / R;
 #pragma unroll
   for (int m = 0; m < G; ++m) {
     const int jb = j + m * S::TPT;
     const int base = (jb / Ns) * (Ns * R) + (jb % Ns);
 #pragma unroll
-    for (int r = 0; r < R; ++r) put(base + r * Ns, v[m + r * G]);
+    for (int r = 0; r < R; ++r) put(base + r * Ns, m + r * G);
   }
 }
 
-// Gather for the next pass: v[k] = get(j + k*TPT).
-template <class S, typename T, class Get>
-MFFT_HD void pass_gather(cx<T> (&v)[S::E], int j, Get get) {
+// Gather for the next pass: register k receives position j + k*TPT.
+template <class S, class Get>
+MFFT_HD void pass_gather(int j, Get get) {
 #pragma unroll
-  for (int k = 0; k < S::E; ++k) v[k] = get(j + k * S::TPT);
+  for (int k = 0; k < S::E; ++k) get(j + k * S::TPT, k);
 }
 
 }  // namespace mfft

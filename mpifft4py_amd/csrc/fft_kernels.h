@@ -81,6 +81,7 @@ struct ColParams {
   int ncols;             // contiguous columns per outer batch
   int ntile_c;           // ceil(ncols / COLS)
   int nouter;
+  int remap;             // 1: XCD-aware block -> tile mapping
   T scale;
 };
 
@@ -113,22 +114,68 @@ template <int PD> MFFT_HD int padpos(int pos) {
   else return pos;
 }
 template <int N, int PD> constexpr int padded_len() { return PD > 0 ? N + N / PD + 1 : N; }
+template <int PD> struct PadSlot {
+  MFFT_D int operator()(int pos) const { return padpos<PD>(pos); }
+};
 
 // ---------------------------------------------------------------------------
-// generic pass driver: runs passes P..NP-1 with LDS exchanges in between.
-//   put(pos, cx), get(pos) access this transform's exchange region.
-// On entry v holds the inputs of pass 0 (positions j + k*TPT).
+// LDS exchange policies.  slot(pos) maps a transform position to an element
+// index of the exchange buffer (column-interleaved or padded row layouts).
+//   XchFull  : whole complex values, buffer of N complex per transform
+//   XchSplit : real parts, then imaginary parts, through a buffer of N reals
+//              per transform (half the LDS, two more barriers per exchange)
 // ---------------------------------------------------------------------------
-template <class S, int P, typename T, class TwPtr, class Put, class Get>
-MFFT_D void run_passes(cx<T> (&v)[S::E], int j, TwPtr tw, Put put, Get get) {
+template <typename T, class Slot>
+struct XchFull {
+  cx<T>* buf;
+  Slot slot;
+  template <class S, int P>
+  MFFT_D void exchange(cx<T> (&v)[S::E], int j, bool pre_barrier) {
+    if (pre_barrier) MFFT_BARRIER();              // everyone finished the previous gather
+    pass_scatter<S, P>(j, [&](int pos, int reg) { buf[slot(pos)] = v[reg]; });
+    MFFT_BARRIER();
+    pass_gather<S>(j, [&](int pos, int reg) { v[reg] = buf[slot(pos)]; });
+  }
+  MFFT_D void put(int pos, cx<T> val) { buf[slot(pos)] = val; }
+  MFFT_D cx<T> get(int pos) { return buf[slot(pos)]; }
+};
+
+template <typename T, class Slot>
+struct XchSplit {
+  T* buf;
+  Slot slot;
+  template <class S, int P>
+  MFFT_D void exchange(cx<T> (&v)[S::E], int j, bool pre_barrier) {
+    if (pre_barrier) MFFT_BARRIER();
+    pass_scatter<S, P>(j, [&](int pos, int reg) { buf[slot(pos)] = v[reg].x; });
+    MFFT_BARRIER();
+    pass_gather<S>(j, [&](int pos, int reg) { v[reg].x = buf[slot(pos)]; });
+    MFFT_BARRIER();
+    pass_scatter<S, P>(j, [&](int pos, int reg) { buf[slot(pos)] = v[reg].y; });
+    MFFT_BARRIER();
+    pass_gather<S>(j, [&](int pos, int reg) { v[reg].y = buf[slot(pos)]; });
+  }
+};
+
+// generic pass driver: runs passes P..NP-1 with LDS exchanges in between.
+// On entry v holds the inputs of pass 0 (positions j + k*TPT).
+template <class S, int P, typename T, class TwPtr, class Xch>
+MFFT_D void run_passes(cx<T> (&v)[S::E], int j, TwPtr tw, Xch& xch) {
   pass_compute<S, P, T>(v, j, tw);
   if constexpr (P + 1 < S::NP) {
-    if constexpr (P > 0) MFFT_BARRIER();          // everyone finished the previous gather
-    pass_scatter<S, P, T>(v, j, put);
-    MFFT_BARRIER();
-    pass_gather<S, T>(v, j, get);
-    run_passes<S, P + 1, T>(v, j, tw, put, get);
+    xch.template exchange<S, P>(v, j, P > 0);
+    run_passes<S, P + 1, T>(v, j, tw, xch);
   }
+}
+
+// bijective XCD-aware block remap: workgroups are dealt round-robin over the 8
+// XCDs (MI355X_MICROARCH.md, "Workgroup dispatch"), so block b lands on XCD b%8.
+// Give each XCD a contiguous range of tiles so that neighbouring tiles, which
+// share boundary cache lines when rows are not 128-byte aligned, share an L2.
+MFFT_HD int xcd_remap(int b, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int x = b & 7, i = b >> 3;
+  return x * q + (x < r ? x : r) + i;
 }
 
 // stage the twiddle table into LDS (cooperatively), returns pointer to it
@@ -140,16 +187,21 @@ MFFT_D void stage_twiddles(cx<T>* lds_tw, const cx<T>* gtw, int tid, int nthread
 // ---------------------------------------------------------------------------
 // strided-axis c2c
 // ---------------------------------------------------------------------------
-template <class S, typename T, int COLS, bool INV, bool TWLDS>
+template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false>
 struct ColFft {
   static constexpr int THREADS = S::TPT * COLS;
   static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
-  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(S::N * COLS * sizeof(cx<T>)) : 0;
+  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(S::N * COLS * (SPLIT ? sizeof(T) : sizeof(cx<T>))) : 0;
   static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
 
-  static MFFT_D void body(const ColParams<T>& P, int bid, int tid, char* lds) {
+  struct Slot {
+    int c;
+    MFFT_D int operator()(int pos) const { return pos * COLS + c; }
+  };
+
+  static MFFT_D void body(const ColParams<T>& P, int bid_raw, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
-    cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES);
+    const int bid = P.remap ? xcd_remap(bid_raw, P.ntile_c * P.nouter) : bid_raw;
     const int outer = bid / P.ntile_c;
     const int tc = bid - outer * P.ntile_c;
     const int c = tid % COLS;
@@ -171,10 +223,15 @@ struct ColFft {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
     }
-    auto put = [&](int pos, cx<T> val) { xch[pos * COLS + c] = val; };
-    auto get = [&](int pos) { return xch[pos * COLS + c]; };
-    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, put, get);
-    else run_passes<S, 0, T>(v, j, P.tw, put, get);
+    if constexpr (SPLIT) {
+      XchSplit<T, Slot> xch{reinterpret_cast<T*>(lds + TW_BYTES), Slot{c}};
+      if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xch);
+      else run_passes<S, 0, T>(v, j, P.tw, xch);
+    } else {
+      XchFull<T, Slot> xch{reinterpret_cast<cx<T>*>(lds + TW_BYTES), Slot{c}};
+      if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xch);
+      else run_passes<S, 0, T>(v, j, P.tw, xch);
+    }
 
     if (active) {
 #pragma unroll
@@ -220,10 +277,9 @@ struct RowFft {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
     }
-    auto put = [&](int pos, cx<T> val) { xch[padpos<PD>(pos)] = val; };
-    auto get = [&](int pos) { return xch[padpos<PD>(pos)]; };
-    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, put, get);
-    else run_passes<S, 0, T>(v, j, P.tw, put, get);
+    XchFull<T, PadSlot<PD>> xc{xch, PadSlot<PD>{}};
+    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xc);
+    else run_passes<S, 0, T>(v, j, P.tw, xc);
 
     if (active) {
 #pragma unroll
@@ -270,16 +326,15 @@ struct R2CFft {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
     }
-    auto put = [&](int pos, cx<T> val) { xch[padpos<PD>(pos)] = val; };
-    auto get = [&](int pos) { return xch[padpos<PD>(pos)]; };
-    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, put, get);
-    else run_passes<S, 0, T>(v, j, P.tw, put, get);
+    XchFull<T, PadSlot<PD>> xc{xch, PadSlot<PD>{}};
+    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xc);
+    else run_passes<S, 0, T>(v, j, P.tw, xc);
 
     // split post-pass: X[k] = E[k] + w_k O[k],  E = (Z[k] + conj Z[M-k])/2,
     // O = -i (Z[k] - conj Z[M-k])/2,  w_k = exp(-2 pi i k / N)
     if constexpr (S::NP > 1) MFFT_BARRIER();
 #pragma unroll
-    for (int k = 0; k < S::E; ++k) put(j + k * S::TPT, v[k]);
+    for (int k = 0; k < S::E; ++k) xc.put(j + k * S::TPT, v[k]);
     MFFT_BARRIER();
     if (active) {
       const T half = (T)0.5;
@@ -288,7 +343,7 @@ struct R2CFft {
         const int pos = j + k * S::TPT;
         const int mp = pos == 0 ? 0 : M - pos;
         const cx<T> zk = v[k];
-        const cx<T> zm = conj(get(mp));
+        const cx<T> zm = conj(xc.get(mp));
         const cx<T> e = scale(zk + zm, half);
         const cx<T> o = mul_mi(scale(zk - zm, half));
         const cx<T> w = P.rtw[pos];
@@ -352,10 +407,9 @@ struct C2RFft {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
     }
-    auto put = [&](int pos, cx<T> val) { xch[padpos<PD>(pos)] = val; };
-    auto get = [&](int pos) { return xch[padpos<PD>(pos)]; };
-    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, put, get);
-    else run_passes<S, 0, T>(v, j, P.tw, put, get);
+    XchFull<T, PadSlot<PD>> xc{xch, PadSlot<PD>{}};
+    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xc);
+    else run_passes<S, 0, T>(v, j, P.tw, xc);
 
     if (active) {
       const T s = P.scale;

@@ -45,6 +45,7 @@ struct ColArgs {
   int64_t ncols = 0;     // contiguous columns per outer batch
   int64_t nouter = 1;
   double scale = 1.0;
+  int remap = 1;         // XCD-aware tile order
 };
 int launch_col(const ColArgs& a, hipStream_t s);
 

@@ -28,18 +28,24 @@ struct KernelEntry {
 std::vector<KernelEntry>& kernel_registry();
 const KernelEntry* find_kernel(int family, int n, int prec, int inv);
 
-// ---- default tiling heuristics (tuned on MI355X) -------------
+// ---- default tiling heuristics (measured on MI355X at 1024^3) -----
+// Strided-axis kernel: tiles are 128 bytes wide (one L2 line per row segment; with
+// narrower tiles every line is fetched once per tile that touches it).  The
+// exchange buffer may take up to 128 KiB of the CU's 160 KiB LDS; if whole complex
+// values do not fit, real and imaginary parts are exchanged one after the other.
 template <class S, typename T> constexpr int col_cols() {
-  // widest tile with 128-byte segments whose exchange buffer still leaves room
-  // for >= 2 workgroups per CU (64 KiB); never narrower than 32 bytes.
   int cols = 128 / (int)sizeof(cx<T>);
-  while (cols > 2 && (long long)S::N * cols * (int)sizeof(cx<T>) > 65536) cols /= 2;
   while (cols > 1 && S::TPT * cols > 1024) cols /= 2;
+  while (cols > 1 && (long long)S::N * cols * (int)sizeof(T) > 131072) cols /= 2;   // even split must fit
   while (S::TPT * cols < 64) cols *= 2;      // at least one full wave
   return cols;
 }
+template <class S, typename T> constexpr bool col_split() {
+  return S::NP > 1 && (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) > 131072;
+}
 template <class S, typename T> constexpr bool col_twlds() {
-  return S::NP > 1 && (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) + S::TW * (int)sizeof(cx<T>) <= 65536;
+  return S::NP > 1 && !col_split<S, T>() &&
+         (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) + S::TW * (int)sizeof(cx<T>) <= 65536;
 }
 template <class S, typename T> constexpr int row_rows() {
   int rows = 256 / S::TPT;
@@ -92,10 +98,11 @@ void register_plan(const char* name) {
   auto& reg = kernel_registry();
   constexpr int C = col_cols<S, T>();
   constexpr bool CT = col_twlds<S, T>();
+  constexpr bool CS = col_split<S, T>();
   constexpr int R = row_rows<S, T>();
   constexpr bool RT = row_twlds<S, T>();
-  reg.push_back(make_entry<ColFft<S, T, C, false, CT>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
-  reg.push_back(make_entry<ColFft<S, T, C, true, CT>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+  reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
+  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
   reg.push_back(make_entry<RowFft<S, T, R, false, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
   reg.push_back(make_entry<RowFft<S, T, R, true, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
   reg.push_back(make_entry<R2CFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
