@@ -28,6 +28,86 @@ __global__ __launch_bounds__(K::THREADS) void kern(P p) {
   K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
 }
 
+// ---- calibration kernels -------------------------------------------------------
+struct alignas(16) v16 { double a, b; };
+__global__ __launch_bounds__(256) void copy_stream(const v16* __restrict__ src, v16* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// same addressing as ColFft (COLS columns x 1024 rows per workgroup, E values per thread), no FFT
+template <int COLS, int E>
+__global__ __launch_bounds__(1024 / E * COLS) void copy_tile(ColParams<double> P) {
+  constexpr int TPT = 1024 / E;
+  const int bid = P.remap ? xcd_remap((int)blockIdx.x, P.ntile_c * P.nouter) : (int)blockIdx.x;
+  const int outer = bid / P.ntile_c, tc = bid - outer * P.ntile_c;
+  const int c = threadIdx.x % COLS, j = threadIdx.x / COLS, col = tc * COLS + c;
+  if (col >= P.ncols) return;
+  const cx<double>* ip = P.in + (i64)outer * P.in_outer + col;
+  cx<double>* op = P.out + (i64)outer * P.out_outer + col;
+  cx<double> v[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) v[k] = ip[row_off(P.in_map, (unsigned)(j + k * TPT))];
+#pragma unroll
+  for (int k = 0; k < E; ++k) op[row_off(P.out_map, (unsigned)(j + k * TPT))] = mk<double>(v[k].x + 1.0, v[k].y);
+}
+
+// persistent, register double-buffered variant of ColFft: the loads of the next
+// tile are in flight while the current tile is transformed and stored.
+template <class S, int COLS, bool SPLIT>
+__global__ __launch_bounds__(S::TPT * COLS) void col_persist(ColParams<double> P) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef double T;
+  const int ntiles = P.ntile_c * P.nouter;
+  const int G = (int)gridDim.x;                 // multiple of 8
+  const int b = (int)blockIdx.x;
+  const int lane_tile = (b & 7) * (G >> 3) + (b >> 3);   // XCD x owns G/8 consecutive tiles of every step
+  const int c = threadIdx.x % COLS, j = threadIdx.x / COLS;
+  struct Slot { int c; __device__ int operator()(int pos) const { return pos * COLS + c; } };
+  cx<T> cur[S::E], nxt[S::E];
+  auto tile_ptrs = [&](int t, const cx<T>*& ip, cx<T>*& op, bool& active) {
+    const int outer = t / P.ntile_c, tc = t - outer * P.ntile_c;
+    const int col = tc * COLS + c;
+    active = col < P.ncols;
+    ip = P.in + (i64)outer * P.in_outer + col;
+    op = P.out + (i64)outer * P.out_outer + col;
+  };
+  int t = lane_tile;
+  {
+    const cx<T>* ip; cx<T>* op; bool act;
+    if (t < ntiles) {
+      tile_ptrs(t, ip, op, act);
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) cur[k] = act ? ip[row_off(P.in_map, (unsigned)(j + k * S::TPT))] : mk<T>(0, 0);
+    }
+  }
+  for (; t < ntiles; t += G) {
+    const int tn = t + G;
+    if (tn < ntiles) {
+      const cx<T>* ip; cx<T>* op; bool act;
+      tile_ptrs(tn, ip, op, act);
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) nxt[k] = act ? ip[row_off(P.in_map, (unsigned)(j + k * S::TPT))] : mk<T>(0, 0);
+    }
+    if constexpr (SPLIT) {
+      XchSplit<T, Slot> xch{reinterpret_cast<T*>(lds), Slot{c}};
+      run_passes<S, 0, T>(cur, j, P.tw, xch);
+    } else {
+      XchFull<T, Slot> xch{reinterpret_cast<cx<T>*>(lds), Slot{c}};
+      run_passes<S, 0, T>(cur, j, P.tw, xch);
+    }
+    {
+      const cx<T>* ip; cx<T>* op; bool act;
+      tile_ptrs(t, ip, op, act);
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) op[row_off(P.out_map, (unsigned)(j + k * S::TPT))] = scale(cur[k], P.scale);
+      }
+    }
+    __syncthreads();      // the next tile's first scatter must not overtake this tile's last gather
+#pragma unroll
+    for (int k = 0; k < S::E; ++k) cur[k] = nxt[k];
+  }
+}
+
 struct Variant {
   std::string name;
   int cols, threads, lds;
@@ -46,6 +126,34 @@ void launch_k(const ColParams<double>& p, int grid) {
   hipLaunchKernelGGL((kern<K, ColParams<double>>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, 0, p);
 }
 
+static int g_persist_grid = 256;
+template <class S, int COLS, bool SPLIT>
+void launch_persist(const ColParams<double>& p, int) {
+  constexpr int LDS = S::N * COLS * (SPLIT ? 8 : 16);
+  static bool attr = false;
+  if (!attr) {
+    if (LDS > 65536) CK(hipFuncSetAttribute((const void*)col_persist<S, COLS, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr = true;
+  }
+  hipLaunchKernelGGL((col_persist<S, COLS, SPLIT>), dim3(g_persist_grid), dim3(S::TPT * COLS), LDS, 0, p);
+}
+template <class S, int COLS, bool SPLIT>
+Variant make_persist(const char* plan) {
+  char nm[128];
+  snprintf(nm, sizeof nm, "persist %s c%d%s", plan, COLS, SPLIT ? " split" : "");
+  return Variant{nm, COLS, S::TPT * COLS, S::N * COLS * (SPLIT ? 8 : 16), &launch_persist<S, COLS, SPLIT>, &build_pass_twiddles<S, double>};
+}
+template <int COLS, int E>
+void launch_copy_tile(const ColParams<double>& p, int grid) {
+  hipLaunchKernelGGL((copy_tile<COLS, E>), dim3(grid), dim3(1024 / E * COLS), 0, 0, p);
+}
+template <int COLS, int E>
+Variant make_copy() {
+  char nm[128];
+  snprintf(nm, sizeof nm, "copytile c%d e%d", COLS, E);
+  return Variant{nm, COLS, 1024 / E * COLS, 0, &launch_copy_tile<COLS, E>, &build_pass_twiddles<Spec<1024, 16, 8, 8>, double>};
+}
+
 template <class S, int COLS, bool TWLDS, bool SPLIT>
 Variant make(const char* plan) {
   typedef ColFft<S, double, COLS, false, TWLDS, SPLIT> K;
@@ -62,7 +170,11 @@ int main(int argc, char** argv) {
   typedef Spec<1024, 16, 16, 4> SC;
   typedef Spec<1024, 8, 8, 4, 4> SD;
   typedef Spec<1024, 32, 8, 4> SE;
+  if (getenv("KB_PGRID")) g_persist_grid = atoi(getenv("KB_PGRID"));
   std::vector<Variant> vs = {
+      make_copy<8, 16>(), make_copy<8, 32>(), make_copy<4, 16>(), make_copy<16, 16>(),
+      make_persist<SA, 8, false>("16x8x8"), make_persist<SA, 8, true>("16x8x8"), make_persist<SD, 8, true>("8x8x4x4"),
+      make_persist<SB, 8, false>("32x32"),
       make<SA, 4, false, false>("16x8x8"),  make<SA, 4, true, false>("16x8x8"),   make<SA, 4, false, true>("16x8x8"),
       make<SA, 4, true, true>("16x8x8"),    make<SA, 8, false, false>("16x8x8"),  make<SA, 8, true, false>("16x8x8"),
       make<SA, 8, false, true>("16x8x8"),   make<SA, 8, true, true>("16x8x8"),    make<SA, 2, true, false>("16x8x8"),
@@ -85,6 +197,18 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  {  // streaming-copy ceiling on this device: 8.6 GB -> 8.6 GB
+    const size_t n = (size_t)N * N * 256;       // v16 elements = 4.29 GB each way, two halves of buf
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(copy_stream, dim3(16384), dim3(256), 0, 0, (const v16*)buf, (v16*)(buf + n), n);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep == 2) printf("streaming copy: %.3f ms for %.2f GB moved -> %.0f GB/s\n", ms, 2.0 * n * 16 / 1e9, 2.0 * n * 16 / (ms * 1e-3) / 1e9);
+    }
+  }
   const double alg_bytes = 2.0 * N * N * NF * 16.0;
   printf("%-28s %5s %6s | %-34s\n", "variant", "thr", "ldsKB", "layout: ms (alg GB/s)");
   struct Layout { const char* name; int pitch; bool xdir; int remap; };
