@@ -26,10 +26,14 @@ from mpifft4py_amd import DeviceArray, Pencil_R2C, Slab_R2C  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def make_comm(world):
+def make_comm(world, rendezvous):
     if world == 1:
         return mcomm.SelfComm(int(os.environ.get("LOCAL_RANK", "0")) % max(_lib.device_count(), 1)), None
     bcast, dist = None, None
+    if rendezvous == "file":
+        # single node: rank 0 publishes the RCCL unique id in /tmp (keyed by MASTER_PORT and the
+        # launcher's pid); no second HIP runtime / process group is brought into the workers
+        return mcomm.from_env(None), None
     try:
         import torch.distributed as dist       # plumbing only: rendezvous for the RCCL id
         dist.init_process_group("gloo")
@@ -82,6 +86,8 @@ def main():
     ap.add_argument("--precision", default="double", choices=["double", "single"])
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--rendezvous", default="file", choices=["file", "torch"],
+                    help="how rank 0's RCCL unique id reaches the other ranks (torch = gloo process group)")
     ap.add_argument("--stage-timing", default="on", choices=["on", "off"],
                     help="HIP events around every stage inside the timed region (roofline numbers)")
     args = ap.parse_args()
@@ -93,7 +99,7 @@ def main():
             sys.stderr.write("bench.py --gpus %d must be launched with torch.distributed.run "
                              "(one process per GPU)\n" % args.gpus)
             sys.exit(2)
-    comm, dist = make_comm(world)
+    comm, dist = make_comm(world, args.rendezvous)
     n = args.n
     N = np.array([n, n, n])
     L = np.array([2 * np.pi] * 3)

@@ -73,21 +73,31 @@ struct mfft_plan_s {
   int64_t q = 0, zstart = 0;    // my z extent in spectral space
   // 3/2-rule
   int64_t M0 = 0, M1 = 0, M2 = 0, Mf = 0;
+  void* work3 = nullptr;        // y output of the pipelined inverse
   void* work[3] = {nullptr, nullptr, nullptr};
   size_t work_bytes[3] = {0, 0, 0};
   uint8_t* mask = nullptr;
   size_t mask_count = 0;
   bool timing = false;
   std::vector<StageTimer> timers;
+  // exchange pipeline (slab, P > 1): kz slices, a communication stream and events
+  int nslice = 1;
+  hipStream_t cstream = nullptr;
+  std::vector<hipEvent_t> ev_compute, ev_comm;
+  std::vector<Chunk> kslice;    // (len, start) of each kz slice
 
   ~mfft_plan_s() {
     for (void* w : work)
       if (w) (void)hipFree(w);
     if (mask) (void)hipFree(mask);
+    if (work3) (void)hipFree(work3);
     for (auto& t : timers) {
       for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
       for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     }
+    for (hipEvent_t e : ev_compute) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_comm) (void)hipEventDestroy(e);
+    if (cstream) (void)hipStreamDestroy(cstream);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -112,7 +122,10 @@ struct mfft_plan_s {
   }
 
   template <class F>
-  int stage(const char* name, double alg_bytes, F f) {
+  int stage(const char* name, double alg_bytes, F f) { return stage_on(stream, name, alg_bytes, f); }
+
+  template <class F>
+  int stage_on(hipStream_t stream, const char* name, double alg_bytes, F f) {
     if (!timing) return f();
     // NOTE: pointers into `timers` are not kept across calls (vector may grow)
     StageTimer* t = timer(name, alg_bytes);
@@ -187,14 +200,15 @@ struct mfft_plan_s {
   static RowSpec two_level(int64_t split, int64_t hi, int64_t lo) { RowSpec r; r.split = split; r.hi = hi; r.lo = lo; return r; }
 
   int exchange(const std::vector<int>& grp, const void* send, const std::vector<size_t>& sc, const std::vector<size_t>& sd,
-               void* recv, const std::vector<size_t>& rc, const std::vector<size_t>& rd) {
-    return comm->alltoallv(send, sc.data(), sd.data(), recv, rc.data(), rd.data(), grp.data(), (int)grp.size(), stream);
+               void* recv, const std::vector<size_t>& rc, const std::vector<size_t>& rd, hipStream_t on = nullptr) {
+    return comm->alltoallv(send, sc.data(), sd.data(), recv, rc.data(), rd.data(), grp.data(), (int)grp.size(),
+                           on ? on : stream);
   }
-  int exchange_equal(const std::vector<int>& grp, const void* send, void* recv, size_t chunk_bytes) {
+  int exchange_equal(const std::vector<int>& grp, const void* send, void* recv, size_t chunk_bytes, hipStream_t on = nullptr) {
     const int n = (int)grp.size();
     std::vector<size_t> c(n, chunk_bytes), dsp(n);
     for (int i = 0; i < n; ++i) dsp[i] = (size_t)i * chunk_bytes;
-    return exchange(grp, send, c, dsp, recv, c, dsp);
+    return exchange(grp, send, c, dsp, recv, c, dsp, on);
   }
   int box(const void* src, void* dst, int64_t e0, int64_t e1, int64_t e2, int64_t s0, int64_t s1, int64_t d0, int64_t d1,
           int mode = 0, double scale = 1.0) {
@@ -235,6 +249,8 @@ struct mfft_plan_s {
 
   int slab_forward(const void* u, void* fu);
   int slab_backward(const void* fu, void* u, bool masked);
+  int slab_forward_pipelined(const void* u, void* fu);
+  int slab_backward_pipelined(const void* src, void* u);
   int slab_forward_padded(const void* u, void* fu);
   int slab_backward_padded(const void* fu, void* u);
   int pencil_forward(const void* u, void* fu);
@@ -261,6 +277,7 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
     MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
     return 0;
   }
+  if (nslice > 1) return slab_forward_pipelined(u, fu);
   const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
   MFFT_TRY(ensure_work(0, cb));
   MFFT_TRY(ensure_work(1, cb));
@@ -303,6 +320,7 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A, u, N0 * N1, N2, Nf); }));
     return 0;
   }
+  if (nslice > 1) return slab_backward_pipelined(src, u);
   MFFT_TRY(ensure_work(1, cb));
   void* B = work[1];
   MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
@@ -312,6 +330,80 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     return col(B, A, N1, true, Np0, Nf, Np1 * Nf, two_level(Np1, Np0 * Np1 * Nf, Nf), N1 * Nf, plain(Nf));
   }));
   MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A, u, Np0 * N1, N2, Nf); }));
+  return 0;
+}
+
+// ---- exchange pipeline (P > 1): the spectrum is cut into kz slices; slice s is
+// transformed along y (written packed), exchanged on the communication stream
+// while slice s+1 is transformed, and the x transform of slice s starts as soon
+// as its exchange has landed.  Per slice the send layout is (P, Np0, Np1, kzs),
+// the receive layout (N0, Np1, kzs).
+int mfft_plan_s::slab_forward_pipelined(const void* u, void* fu) {
+  const double Cb = (double)(N0 * Np1 * Nf) * es, Rb = (double)(Np0 * N1 * N2) * rs;
+  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, cb));
+  char *A = static_cast<char*>(work[0]), *B = static_cast<char*>(work[1]), *Cr = static_cast<char*>(work[2]);
+  char* out = static_cast<char*>(fu);
+  MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, A, Np0 * N1, N2, Nf); }));
+  for (int s = 0; s < nslice; ++s) {
+    const int64_t k0 = kslice[s].start, kz = kslice[s].len;
+    const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es;
+    MFFT_TRY(stage("fwd_y", 2 * Cb / nslice, [&] {
+      return col(A + (size_t)k0 * es, B + boff, N1, false, Np0, kz, N1 * Nf, plain(Nf), Np1 * kz,
+                 two_level(Np1, Np0 * Np1 * kz, kz));
+    }));
+    MFFT_HIP(hipEventRecord(ev_compute[s], stream));
+    MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[s], 0));
+    MFFT_TRY(stage_on(cstream, "fwd_a2a", 0, [&] {
+      return exchange_equal(world, B + boff, Cr + boff, (size_t)(Np0 * Np1 * kz) * es, cstream);
+    }));
+    MFFT_HIP(hipEventRecord(ev_comm[s], cstream));
+  }
+  for (int s = 0; s < nslice; ++s) {
+    const int64_t k0 = kslice[s].start, kz = kslice[s].len;
+    const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es;
+    MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[s], 0));
+    MFFT_TRY(stage("fwd_x", 2 * Cb / nslice, [&] {
+      return col(Cr + boff, out + (size_t)k0 * es, N0, false, Np1, kz, kz, plain(Np1 * kz), Nf, plain(Np1 * Nf));
+    }));
+  }
+  return 0;
+}
+
+int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
+  const double Cb = (double)(N0 * Np1 * Nf) * es, Rb = (double)(Np0 * N1 * N2) * rs;
+  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, cb));
+  // work[2] may hold the masked copy of the spectrum (src): use a 4th buffer for the y output
+  if (!work3) {
+    hipError_t e = hipMalloc(&work3, cb);
+    if (e != hipSuccess) return set_error(MFFT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", cb, hipGetErrorString(e));
+  }
+  char *A = static_cast<char*>(work[0]), *B = static_cast<char*>(work[1]), *A2 = static_cast<char*>(work3);
+  const char* in = static_cast<const char*>(src);
+  for (int s = 0; s < nslice; ++s) {
+    const int64_t k0 = kslice[s].start, kz = kslice[s].len;
+    const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es;
+    MFFT_TRY(stage("bwd_x", 2 * Cb / nslice, [&] {
+      return col(in + (size_t)k0 * es, A + boff, N0, true, Np1, kz, Nf, plain(Np1 * Nf), kz, plain(Np1 * kz));
+    }));
+    MFFT_HIP(hipEventRecord(ev_compute[s], stream));
+    MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[s], 0));
+    MFFT_TRY(stage_on(cstream, "bwd_a2a", 0, [&] {
+      return exchange_equal(world, A + boff, B + boff, (size_t)(Np0 * Np1 * kz) * es, cstream);
+    }));
+    MFFT_HIP(hipEventRecord(ev_comm[s], cstream));
+  }
+  for (int s = 0; s < nslice; ++s) {
+    const int64_t k0 = kslice[s].start, kz = kslice[s].len;
+    const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es;
+    MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[s], 0));
+    MFFT_TRY(stage("bwd_y", 2 * Cb / nslice, [&] {
+      return col(B + boff, A2 + (size_t)k0 * es, N1, true, Np0, kz, Np1 * kz, two_level(Np1, Np0 * Np1 * kz, kz),
+                 N1 * Nf, plain(Nf));
+    }));
+  }
+  MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A2, u, Np0 * N1, N2, Nf); }));
   return 0;
 }
 
@@ -672,6 +764,26 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
   MFFT_TRY(need(p->N1, false));
   MFFT_TRY(need(p->N2, p->r2c));
   MFFT_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  if (desc->decomp == MFFT_SLAB && P > 1) {
+    // kz slices for the exchange pipeline: boundaries on 16-column (tile) multiples
+    int want = desc->pipeline > 0 ? desc->pipeline : 4;
+    const int64_t unit = 16;
+    int64_t per = (p->Nf / want) / unit * unit;
+    if (want > 1 && per >= unit) {
+      for (int s = 0; s < want; ++s) {
+        const int64_t st = per * s;
+        p->kslice.push_back(Chunk{s == want - 1 ? p->Nf - st : per, st});
+      }
+      p->nslice = want;
+      MFFT_HIP(hipStreamCreateWithFlags(&p->cstream, hipStreamNonBlocking));
+      p->ev_compute.resize(want);
+      p->ev_comm.resize(want);
+      for (int s = 0; s < want; ++s) {
+        MFFT_HIP(hipEventCreateWithFlags(&p->ev_compute[s], hipEventDisableTiming));
+        MFFT_HIP(hipEventCreateWithFlags(&p->ev_comm[s], hipEventDisableTiming));
+      }
+    }
+  }
   *out = p.release();
   return 0;
 }
@@ -721,7 +833,7 @@ int mfft_plan_layout(mfft_plan_t p, int64_t rshape[3], int64_t cshape[3], int64_
 
 int mfft_plan_workspace_bytes(mfft_plan_t p, size_t* bytes) {
   if (!p || !bytes) return set_error(MFFT_ERR_INVALID, "null argument");
-  *bytes = p->work_bytes[0] + p->work_bytes[1] + p->work_bytes[2];
+  *bytes = p->work_bytes[0] + p->work_bytes[1] + p->work_bytes[2] + (p->work3 ? (size_t)(p->Np0 * p->N1 * p->Nf) * p->es : 0);
   return 0;
 }
 
@@ -751,6 +863,7 @@ int mfft_backward(mfft_plan_t p, const void* fu, void* u, int dealias) {
 
 int mfft_plan_sync(mfft_plan_t p) {
   if (!p) return set_error(MFFT_ERR_INVALID, "null plan");
+  if (p->cstream) MFFT_HIP(hipStreamSynchronize(p->cstream));
   MFFT_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }

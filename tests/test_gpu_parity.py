@@ -281,3 +281,57 @@ def test_errors_match_the_reference():
             g.run(lambda comm: Slab_R2C(N, L, comm, "double"))
     finally:
         g.free()
+
+
+@pytest.mark.parametrize("pipeline", [1, 2, 4])
+def test_slab_exchange_pipeline(pipeline):
+    """The kz-sliced exchange pipeline (compute stream + communication stream) gives
+    the same numbers as the un-pipelined path."""
+    from mpifft4py_amd import DeviceArray, Slab_R2C
+    N = [64, 64, 128]
+    P = 4
+    rng = np.random.default_rng(77)
+    A = rng.random(N)
+    B2 = np.fft.rfftn(A)
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, "double", pipeline=pipeline)
+        u = DeviceArray.from_numpy(np.ascontiguousarray(A[F.real_local_slice()]))
+        fu = DeviceArray.empty(F.complex_shape(), F.complex)
+        u2 = DeviceArray.empty(F.real_shape(), F.float)
+        for _ in range(3):                      # back-to-back calls reuse the send/recv buffers
+            F.fftn(u, fu)
+            F.ifftn(fu, u2)
+        F.sync()
+        c = fu.get()
+        m = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule")
+        mref = F.ifftn(c * np.broadcast_to(F.get_dealias_filter(), c.shape), np.zeros(F.real_shape()))
+        return F.complex_local_slice(), c, F.real_local_slice(), u2.get(), m, mref
+    for cs, c, rs, b, m, mref in run_ranks(P, body):
+        assert orc.rel_l2(c, B2[cs]) < 1e-10
+        assert orc.rel_l2(b, A[rs]) < 1e-10
+        assert orc.rel_l2(m, mref) < 1e-12
+
+
+def test_rccl_communicator_single_rank():
+    """RCCL is dlopen'ed and usable: unique id, ncclCommInitRank, broadcast, all-reduce
+    (one rank is all a gpurun box has; the multi-rank wire is exercised by bench.py --gpus N)."""
+    from mpifft4py_amd import Pencil_R2C
+    from mpifft4py_amd.comm import MAX, DistComm, get_unique_id
+    uid = get_unique_id()
+    assert len(uid) == 128
+    c = DistComm(1, 0, uid, 0)
+    assert (c.Get_size(), c.Get_rank()) == (1, 0)
+    c.barrier()
+    assert c.allreduce(3.5) == 3.5
+    assert c.allreduce(2.0, op=MAX) == 2.0
+    # a pencil plan on the 1x1 grid drives comm->alltoallv (self chunks) on the RCCL communicator
+    N = np.array([16, 32, 64])
+    rng = np.random.default_rng(1)
+    A = rng.random(N)
+    for align in ("X", "Y"):
+        F = Pencil_R2C(N, L, c, "double", communication="Alltoallw", alignment=align, allow_single=True)
+        cc = F.fftn(A, np.zeros(F.complex_shape(), dtype=complex))
+        assert orc.rel_l2(cc, np.fft.rfftn(A)) < 1e-10
+        assert orc.rel_l2(F.ifftn(cc, np.zeros(F.real_shape())), A) < 1e-10
+    c.free()
