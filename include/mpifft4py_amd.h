@@ -105,6 +105,15 @@ MFFT_API int mfft_plan_layout(mfft_plan_t plan, int64_t real_shape[3], int64_t c
                               int64_t real_start[3], int64_t complex_start[3],
                               int64_t real_shape_padded[3], int64_t grid[2], int64_t subranks[2]);
 MFFT_API int mfft_plan_workspace_bytes(mfft_plan_t plan, size_t* bytes);
+/* The all-to-all-v a rank performs, computed on the host WITHOUT a device: the peer
+ * list (world ranks, in group order) and byte counts / displacements of every chunk.
+ * slab: which = 0.  pencil: which = 0 is the z-splitting exchange (uneven last chunk;
+ * comm1 for X, comm0 for Y), which = 1 the other one.  It is the schedule the executor
+ * itself uses; it describes what the reference expresses with Alltoall counts and the
+ * Alltoallw sub-array types (slab.py:199-211, 406, 281; pencil.py:218-246, 971-999). */
+MFFT_API int mfft_plan_exchange_schedule(const mfft_plan_desc* desc, int nranks, int rank, int which,
+                                         int forward, int padded, int max_peers, int* npeers, int* peers,
+                                         size_t* scount, size_t* sdisp, size_t* rcount, size_t* rdisp);
 
 /* fftn: slab.py:349-485 / pencil.py:634-883, 1228-1475.  `u` is never written. */
 MFFT_API int mfft_forward(mfft_plan_t plan, const void* u, void* fu, int dealias);

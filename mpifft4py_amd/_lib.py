@@ -58,6 +58,9 @@ _SIGNATURES = {
     "mfft_plan_destroy": ([c_void_p], c_int),
     "mfft_plan_layout": ([c_void_p] + [POINTER(c_int64)] * 7, c_int),
     "mfft_plan_workspace_bytes": ([c_void_p, POINTER(c_size_t)], c_int),
+    "mfft_plan_exchange_schedule": ([POINTER(PlanDesc), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),
+                                     POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t),
+                                     POINTER(c_size_t)], c_int),
     "mfft_forward": ([c_void_p, c_void_p, c_void_p, c_int], c_int),
     "mfft_backward": ([c_void_p, c_void_p, c_void_p, c_int], c_int),
     "mfft_plan_sync": ([c_void_p], c_int),
@@ -120,6 +123,26 @@ def call(name, *args):
             check(rc)
         return rc
     return check(rc)
+
+
+def exchange_schedule(N, nranks, rank, decomp, which=0, forward=True, padded=False, precision="double",
+                      kind=R2C, p1=0, padsize=1.5):
+    """Host-only query of the all-to-all-v schedule (no GPU needed): returns
+    dict(peers, scount, sdisp, rcount, rdisp) in bytes."""
+    d = PlanDesc()
+    for i in range(3):
+        d.n[i] = int(N[i])
+    d.precision = SINGLE if precision == "single" else DOUBLE
+    d.kind, d.decomp, d.p1, d.padsize, d.pipeline = kind, decomp, int(p1 or 0), float(padsize), 1
+    mx = 64
+    n = c_int(0)
+    peers = (c_int * mx)()
+    arrs = [(c_size_t * mx)() for _ in range(4)]
+    call("mfft_plan_exchange_schedule", ctypes.byref(d), nranks, rank, which, 1 if forward else 0,
+         1 if padded else 0, mx, ctypes.byref(n), peers, *arrs)
+    k = n.value
+    return dict(peers=list(peers[:k]), scount=list(arrs[0][:k]), sdisp=list(arrs[1][:k]),
+                rcount=list(arrs[2][:k]), rdisp=list(arrs[3][:k]))
 
 
 def device_count():

@@ -34,6 +34,11 @@ struct Chunk {
   int64_t len, start;
 };
 
+struct Sched {                 // one all-to-all-v inside a group, bytes
+  std::vector<int> peers;
+  std::vector<size_t> sc, sd, rc, rd;
+};
+
 std::vector<Chunk> pencil_chunks(int64_t n, int size) {   // pencil.py:80-90
   std::vector<Chunk> c(size);
   const int64_t q = n / size, r = n % size;
@@ -247,6 +252,16 @@ struct mfft_plan_s {
     return 0;
   }
 
+  int sched(int which, bool forward, bool padded, Sched* out) const;
+  int run_sched(const Sched& sc, const void* send, void* recv, hipStream_t on = nullptr) {
+    return comm->alltoallv(send, sc.sc.data(), sc.sd.data(), recv, sc.rc.data(), sc.rd.data(), sc.peers.data(),
+                           (int)sc.peers.size(), on ? on : stream);
+  }
+  int xchg(int which, bool forward, bool padded, const void* send, void* recv) {
+    Sched sc;
+    MFFT_TRY(sched(which, forward, padded, &sc));
+    return run_sched(sc, send, recv);
+  }
   int slab_forward(const void* u, void* fu);
   int slab_backward(const void* fu, void* u, bool masked);
   int slab_forward_pipelined(const void* u, void* fu);
@@ -264,6 +279,52 @@ struct mfft_plan_s {
     return N2_0 * N1 * q;
   }
 };
+
+// ===========================================================================
+// exchange schedules (host only)
+//   slab:   which = 0, equal chunks over all ranks (padded: x extent M0/P)
+//   pencil: which = 0 -> the z-splitting exchange (uneven last chunk), X: comm1, Y: comm0
+//           which = 1 -> the other exchange (equal chunks),            X: comm0, Y: comm1
+// ===========================================================================
+int mfft_plan_s::sched(int which, bool forward, bool padded, Sched* o) const {
+  auto equal = [&](const std::vector<int>& grp, size_t chunk) {
+    const int n = (int)grp.size();
+    o->peers = grp;
+    o->sc.assign(n, chunk);
+    o->rc.assign(n, chunk);
+    o->sd.resize(n);
+    o->rd.resize(n);
+    for (int i = 0; i < n; ++i) o->sd[i] = o->rd[i] = (size_t)i * chunk;
+  };
+  if (d.decomp == MFFT_SLAB) {
+    if (which != 0) return set_error(MFFT_ERR_INVALID, "slab plans have one exchange");
+    const int64_t x = padded ? M0 / P : Np0;
+    equal(world, (size_t)(x * Np1 * Nf) * es);
+    return 0;
+  }
+  const bool X = d.decomp == MFFT_PENCIL_X;
+  const int64_t m = padded ? M0 / P1 : N1_0, n = padded ? M1 / P2 : N2_1;
+  if (which == 0) {
+    const std::vector<int>& gz = X ? group1 : group0;
+    const int Pz = (int)gz.size();
+    o->peers = gz;
+    o->sc.resize(Pz); o->sd.resize(Pz); o->rc.resize(Pz); o->rd.resize(Pz);
+    size_t off = 0;
+    for (int l = 0; l < Pz; ++l) {
+      const size_t uneven = (size_t)(m * n * zc[l].len) * es, even = (size_t)(m * n * q) * es;
+      if (forward) { o->sc[l] = uneven; o->sd[l] = off; o->rc[l] = even; o->rd[l] = (size_t)l * even; }
+      else         { o->sc[l] = even; o->sd[l] = (size_t)l * even; o->rc[l] = uneven; o->rd[l] = off; }
+      off += uneven;
+    }
+    return 0;
+  }
+  if (which == 1) {
+    if (X) equal(group0, (size_t)(m * N1_1 * q) * es);
+    else   equal(group1, (size_t)(N2_0 * n * q) * es);
+    return 0;
+  }
+  return set_error(MFFT_ERR_INVALID, "pencil plans have two exchanges");
+}
 
 // ===========================================================================
 // slab
@@ -287,7 +348,7 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
   MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
     return col(A, B, N1, false, Np0, Nf, N1 * Nf, plain(Nf), Np1 * Nf, two_level(Np1, Np0 * Np1 * Nf, Nf));
   }));
-  MFFT_TRY(stage("fwd_a2a", 0, [&] { return exchange_equal(world, B, fu, (size_t)(Np0 * Np1 * Nf) * es); }));
+  MFFT_TRY(stage("fwd_a2a", 0, [&] { return xchg(0, true, false, B, fu); }));
   MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
   return 0;
 }
@@ -324,7 +385,7 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
   MFFT_TRY(ensure_work(1, cb));
   void* B = work[1];
   MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
-  MFFT_TRY(stage("bwd_a2a", 0, [&] { return exchange_equal(world, A, B, (size_t)(Np0 * Np1 * Nf) * es); }));
+  MFFT_TRY(stage("bwd_a2a", 0, [&] { return xchg(0, false, false, A, B); }));
   // y transform reads the (P, Np0, Np1, Nf) receive layout directly (transpose_Uc fused, maths.pyx:21-31)
   MFFT_TRY(stage("bwd_y", 2 * Cb, [&] {
     return col(B, A, N1, true, Np0, Nf, Np1 * Nf, two_level(Np1, Np0 * Np1 * Nf, Nf), N1 * Nf, plain(Nf));
@@ -422,7 +483,7 @@ int mfft_plan_s::slab_backward_padded(const void* fu, void* u) {
   MFFT_TRY(stage("bwd_x", 0, [&] { return col(W0, W0, M0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
   const void* yin = W0;
   if (P > 1) {
-    MFFT_TRY(stage("bwd_a2a", 0, [&] { return exchange_equal(world, W0, W1, (size_t)(Mp0 * Np1 * Nf) * es); }));
+    MFFT_TRY(stage("bwd_a2a", 0, [&] { return xchg(0, false, true, W0, W1); }));
     // unpack (P, Mp0, Np1, Nf) -> (Mp0, N1, Nf)
     MFFT_TRY(stage("unpack", 0, [&] {
       for (int p = 0; p < P; ++p)
@@ -467,7 +528,7 @@ int mfft_plan_s::slab_forward_padded(const void* u, void* fu) {
                      static_cast<char*>(W0) + (size_t)p * (Mp0 * Np1 * Nf) * es, Mp0, 1, Np1 * Nf, N1 * Nf, 0, Np1 * Nf, 0));
       return 0;
     }));
-    MFFT_TRY(stage("fwd_a2a", 0, [&] { return exchange_equal(world, W0, W2, (size_t)(Mp0 * Np1 * Nf) * es); }));
+    MFFT_TRY(stage("fwd_a2a", 0, [&] { return xchg(0, true, true, W0, W2); }));
     xin = W2;
   }
   MFFT_TRY(stage("fwd_x", 0, [&] { return col(xin, xin, M0, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
@@ -512,18 +573,18 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
     rc[l] = (size_t)(m * n * q) * es;
     rd[l] = (size_t)l * rc[l];
   }
-  MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return exchange(gz, W1, sc, sd, W0, rc, rd); }));
+  MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, false, W1, W0); }));
   if (X) {
     // W0 = P2 blocks (m, n, q) -> y transform (gathers y through two-level rows) -> P1 blocks (m, N1_1, q)
     MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
       return col(W0, W1, N1, false, m, q, n * q, two_level(n, m * n * q, q), N1_1 * q, two_level(N1_1, m * N1_1 * q, q));
     }));
-    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return exchange_equal(group0, W1, fu, (size_t)(m * N1_1 * q) * es); }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W1, fu); }));
     MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
   } else {
     // W0 = (N0, n, q): x transform in place, x chunks are contiguous -> exchange -> y transform gathers
     MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, W0, N0, false, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
-    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return exchange_equal(group1, W0, W1, (size_t)(N2_0 * n * q) * es); }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W0, W1); }));
     MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
       return col(W1, fu, N1, false, N2_0, q, n * q, two_level(n, N2_0 * n * q, q), N1 * q, plain(q));
     }));
@@ -549,7 +610,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
   void *W0 = work[0], *W1 = work[1];
   if (X) {
     MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, W0, N0, true, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
-    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return exchange_equal(group0, W0, W1, (size_t)(m * N1_1 * q) * es); }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, false, W0, W1); }));
     MFFT_TRY(stage("bwd_y", 2 * Cb, [&] {
       return col(W1, W0, N1, true, m, q, N1_1 * q, two_level(N1_1, m * N1_1 * q, q), n * q, two_level(n, m * n * q, q));
     }));
@@ -557,7 +618,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_y", 2 * Cb, [&] {
       return col(src, W0, N1, true, N2_0, q, N1 * q, plain(q), n * q, two_level(n, N2_0 * n * q, q));
     }));
-    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return exchange_equal(group1, W0, W1, (size_t)(N2_0 * n * q) * es); }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, false, W0, W1); }));
     MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(W1, W0, N0, true, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
   }
   // W0 holds Pz blocks (m, n, q) (for Y: x chunks of (N0, n, q), also contiguous)
@@ -570,7 +631,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
     rd[l] = off;
     off += rc[l];
   }
-  MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return exchange(gz, W0, sc, sd, W1, rc, rd); }));
+  MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, false, W0, W1); }));
   MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z(this, W0, W1, m * n, Nf, zc, true); }));
   MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(W0, u, m * n, N2, Nf); }));
   return 0;
@@ -591,7 +652,7 @@ int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
     // fu (N0, N1_1, q): pad x -> (M0, N1_1, q), ifft x
     MFFT_TRY(stage("pad_x", 0, [&] { return pad_axis(fu, W0, 1, N0, M0, N1_1 * q, sc3); }));
     MFFT_TRY(stage("bwd_x", 0, [&] { return col(W0, W0, M0, true, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
-    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return exchange_equal(group0, W0, W1, (size_t)(mp * N1_1 * q) * es); }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, true, W0, W1); }));
     // W1 = P1 blocks (mp, N1_1, q) -> gather to (mp, N1, q)
     MFFT_TRY(stage("unpack", 0, [&] {
       for (int g = 0; g < P1; ++g)
@@ -610,7 +671,7 @@ int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
     MFFT_TRY(stage("bwd_y", 0, [&] {
       return col(W0, W1, M1, true, N2_0, q, M1 * q, plain(q), np * q, two_level(np, N2_0 * np * q, q));
     }));
-    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return exchange_equal(group1, W1, W0, (size_t)(N2_0 * np * q) * es); }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, true, W1, W0); }));
     // W0 = (N0, np, q): pad x -> (M0, np, q), ifft x
     MFFT_TRY(stage("pad_x", 0, [&] { return pad_axis(W0, W1, 1, N0, M0, np * q, 1.0); }));
     MFFT_TRY(stage("bwd_x", 0, [&] { return col(W1, W1, M0, true, 1, np * q, 0, plain(np * q), 0, plain(np * q)); }));
@@ -625,7 +686,7 @@ int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
     rd[l] = off;
     off += rc[l];
   }
-  MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return exchange(gz, W1, sc, sd, W0, rc, rd); }));
+  MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, true, W1, W0); }));
   // unpack z into the zero-padded (mp*np, Mf) rows
   MFFT_TRY(stage("bwd_unpackz", 0, [&] {
     MFFT_TRY(zero(W2, (size_t)(mp * np * Mf) * es));
@@ -656,7 +717,7 @@ int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
     rc[l] = (size_t)(mp * np * q) * es;
     rd[l] = (size_t)l * rc[l];
   }
-  MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return exchange(gz, W1, sc, sd, W0, rc, rd); }));
+  MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, true, W1, W0); }));
   if (X) {
     // W0 = P2 blocks (mp, np, q): fft y over M1 = P2*np (gather), out (mp, M1, q)
     MFFT_TRY(stage("fwd_y", 0, [&] {
@@ -670,14 +731,14 @@ int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
                      mp, 1, N1_1 * q, N1 * q, 0, N1_1 * q, 0));
       return 0;
     }));
-    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return exchange_equal(group0, W1, W2, (size_t)(mp * N1_1 * q) * es); }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, true, W1, W2); }));
     MFFT_TRY(stage("fwd_x", 0, [&] { return col(W2, W2, M0, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
     MFFT_TRY(stage("trunc_x", 0, [&] { return trunc_axis(W2, fu, 1, N0, M0, N1_1 * q, N1_1 * q, isc3); }));
   } else {
     // W0 = (M0, np, q): fft x, truncate to (N0, np, q)
     MFFT_TRY(stage("fwd_x", 0, [&] { return col(W0, W0, M0, false, 1, np * q, 0, plain(np * q), 0, plain(np * q)); }));
     MFFT_TRY(stage("trunc_x", 0, [&] { return trunc_axis(W0, W1, 1, N0, M0, np * q, np * q, 1.0); }));
-    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return exchange_equal(group1, W1, W0, (size_t)(N2_0 * np * q) * es); }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, true, W1, W0); }));
     // W0 = P2 blocks (N2_0, np, q): fft y over M1 gathering, out (N2_0, M1, q)
     MFFT_TRY(stage("fwd_y", 0, [&] {
       return col(W0, W1, M1, false, N2_0, q, np * q, two_level(np, N2_0 * np * q, q), M1 * q, plain(q));
@@ -692,18 +753,17 @@ int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
 // ===========================================================================
 extern "C" {
 
-int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* out) {
-  if (!comm || !desc || !out) return set_error(MFFT_ERR_INVALID, "null argument");
-  std::unique_ptr<mfft_plan_s> p(new mfft_plan_s());
-  p->comm = comm;
+// host-only part of plan construction: decomposition bookkeeping (no HIP call)
+static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, int rank) {
   p->d = *desc;
-  p->P = comm->size;
-  p->rank = comm->rank;
+  p->P = nranks;
+  p->rank = rank;
   p->prec = desc->precision;
   p->r2c = desc->kind == MFFT_R2C;
   p->N0 = desc->n[0];
   p->N1 = desc->n[1];
   p->N2 = desc->n[2];
+  if (nranks < 1 || rank < 0 || rank >= nranks) return set_error(MFFT_ERR_INVALID, "bad rank %d of %d", rank, nranks);
   if (p->N0 < 1 || p->N1 < 1 || p->N2 < 1) return set_error(MFFT_ERR_INVALID, "bad mesh");
   if (desc->precision != MFFT_SINGLE && desc->precision != MFFT_DOUBLE) return set_error(MFFT_ERR_INVALID, "bad precision");
   p->Nf = p->r2c ? p->N2 / 2 + 1 : p->N2;
@@ -715,7 +775,6 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
   p->M1 = (int64_t)(ps * p->N1);
   p->M2 = (int64_t)(ps * p->N2);
   p->Mf = p->r2c ? (int64_t)(ps * p->N2) / 2 + 1 : p->M2;
-  MFFT_HIP(hipGetDevice(&p->dev));
   p->world.resize(p->P);
   for (int i = 0; i < p->P; ++i) p->world[i] = i;
   const int P = p->P;
@@ -724,6 +783,19 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
     if (p->N0 % P || p->N1 % P) return set_error(MFFT_ERR_INVALID, "N[0]=%lld and N[1]=%lld must be divisible by the number of ranks %d", (long long)p->N0, (long long)p->N1, P);
     p->Np0 = p->N0 / P;
     p->Np1 = p->N1 / P;
+    if (P > 1) {
+      // kz slices for the exchange pipeline: boundaries on 16-column (tile) multiples
+      const int want = desc->pipeline > 0 ? desc->pipeline : 4;
+      const int64_t unit = 16;
+      const int64_t per = (p->Nf / want) / unit * unit;
+      if (want > 1 && per >= unit) {
+        for (int s = 0; s < want; ++s) {
+          const int64_t st = per * s;
+          p->kslice.push_back(Chunk{s == want - 1 ? p->Nf - st : per, st});
+        }
+        p->nslice = want;
+      }
+    }
   } else if (desc->decomp == MFFT_PENCIL_X || desc->decomp == MFFT_PENCIL_Y) {
     if (!p->r2c) return set_error(MFFT_ERR_UNSUPPORTED, "pencil plans are R2C (the reference has no pencil C2C)");
     int P1 = desc->p1, P2;
@@ -763,28 +835,50 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
   MFFT_TRY(need(p->N0, false));
   MFFT_TRY(need(p->N1, false));
   MFFT_TRY(need(p->N2, p->r2c));
+  return 0;
+}
+
+int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* out) {
+  if (!comm || !desc || !out) return set_error(MFFT_ERR_INVALID, "null argument");
+  std::unique_ptr<mfft_plan_s> p(new mfft_plan_s());
+  p->comm = comm;
+  MFFT_TRY(decomp_init(p.get(), desc, comm->size, comm->rank));
+  MFFT_HIP(hipGetDevice(&p->dev));
   MFFT_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-  if (desc->decomp == MFFT_SLAB && P > 1) {
-    // kz slices for the exchange pipeline: boundaries on 16-column (tile) multiples
-    int want = desc->pipeline > 0 ? desc->pipeline : 4;
-    const int64_t unit = 16;
-    int64_t per = (p->Nf / want) / unit * unit;
-    if (want > 1 && per >= unit) {
-      for (int s = 0; s < want; ++s) {
-        const int64_t st = per * s;
-        p->kslice.push_back(Chunk{s == want - 1 ? p->Nf - st : per, st});
-      }
-      p->nslice = want;
-      MFFT_HIP(hipStreamCreateWithFlags(&p->cstream, hipStreamNonBlocking));
-      p->ev_compute.resize(want);
-      p->ev_comm.resize(want);
-      for (int s = 0; s < want; ++s) {
-        MFFT_HIP(hipEventCreateWithFlags(&p->ev_compute[s], hipEventDisableTiming));
-        MFFT_HIP(hipEventCreateWithFlags(&p->ev_comm[s], hipEventDisableTiming));
-      }
+  if (p->nslice > 1) {
+    MFFT_HIP(hipStreamCreateWithFlags(&p->cstream, hipStreamNonBlocking));
+    p->ev_compute.resize(p->nslice);
+    p->ev_comm.resize(p->nslice);
+    for (int s = 0; s < p->nslice; ++s) {
+      MFFT_HIP(hipEventCreateWithFlags(&p->ev_compute[s], hipEventDisableTiming));
+      MFFT_HIP(hipEventCreateWithFlags(&p->ev_comm[s], hipEventDisableTiming));
     }
   }
   *out = p.release();
+  return 0;
+}
+
+// Exchange schedule of a transform, computed WITHOUT a device: which peers a rank
+// exchanges with and the byte counts / displacements of every chunk.  This is the
+// same code the executor uses (mfft_plan_s::sched); tests drive it from CPU-only
+// multi-process runs (gloo) to validate the distributed bookkeeping.
+int mfft_plan_exchange_schedule(const mfft_plan_desc* desc, int nranks, int rank, int which, int forward, int padded,
+                                int max_peers, int* npeers, int* peers, size_t* scount, size_t* sdisp, size_t* rcount,
+                                size_t* rdisp) {
+  if (!desc || !npeers) return set_error(MFFT_ERR_INVALID, "null argument");
+  mfft_plan_s p;
+  MFFT_TRY(decomp_init(&p, desc, nranks, rank));
+  Sched sc;
+  MFFT_TRY(p.sched(which, forward != 0, padded != 0, &sc));
+  *npeers = (int)sc.peers.size();
+  if (*npeers > max_peers) return set_error(MFFT_ERR_INVALID, "schedule has %d peers, room for %d", *npeers, max_peers);
+  for (int i = 0; i < *npeers; ++i) {
+    if (peers) peers[i] = sc.peers[i];
+    if (scount) scount[i] = sc.sc[i];
+    if (sdisp) sdisp[i] = sc.sd[i];
+    if (rcount) rcount[i] = sc.rc[i];
+    if (rdisp) rdisp[i] = sc.rd[i];
+  }
   return 0;
 }
 

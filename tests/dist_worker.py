@@ -1,0 +1,143 @@
+"""Worker of tests/test_dist_gloo.py (CPU, torch.distributed/gloo, no GPU).
+
+Each rank runs the per-rank distributed algorithm with numpy stages and moves
+the data with gloo point-to-point messages whose peers, byte counts and
+displacements come from the C library's host-only schedule query
+(mfft_plan_exchange_schedule) -- the very schedule the HIP executor hands to
+RCCL.  The result must equal the oracle's world formulation.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from mpifft4py_amd import _lib  # noqa: E402
+from oracle import mpifft_oracle as orc  # noqa: E402
+
+ES = 16   # complex128
+
+
+def exchange(rank, sched, send, recv_bytes):
+    send = np.ascontiguousarray(send).view(np.uint8).reshape(-1)
+    recv = np.zeros(recv_bytes, dtype=np.uint8)
+    reqs, keep = [], []
+    for i, peer in enumerate(sched["peers"]):
+        sc, sd, rc, rd = (sched[k][i] for k in ("scount", "sdisp", "rcount", "rdisp"))
+        if peer == rank:
+            assert sc == rc
+            recv[rd:rd + rc] = send[sd:sd + sc]
+            continue
+        t_out = torch.from_numpy(send[sd:sd + sc].copy())
+        t_in = torch.from_numpy(recv[rd:rd + rc])
+        keep += [t_out, t_in]
+        reqs.append(dist.isend(t_out, dst=peer))
+        reqs.append(dist.irecv(t_in, src=peer))
+    for r in reqs:
+        r.wait()
+    assert sum(sched["rcount"]) == recv_bytes
+    return recv.view(np.complex128)
+
+
+def slab(rank, P, N, A):
+    lay = orc.SlabLayout(N, P)
+    want = orc.slab_r2c_forward(orc.scatter_real(A, lay), N)
+    Np0, Np1, Nf = int(lay.Np[0]), int(lay.Np[1]), lay.Nf
+    u = np.ascontiguousarray(A[lay.real_local_slice(rank)])
+    a = np.fft.rfft2(u, axes=(1, 2))
+    s = _lib.exchange_schedule(N, P, rank, _lib.SLAB, 0, True)
+    assert s["peers"] == list(range(P))
+    r = exchange(rank, s, orc.slab_pack(a, P), Np0 * N[1] * Nf * ES)
+    fu = np.fft.fft(r.reshape(N[0], Np1, Nf), axis=0)
+    assert orc.rel_l2(fu, want[rank]) < 1e-13
+    # inverse
+    b = np.fft.ifft(fu, axis=0)
+    s = _lib.exchange_schedule(N, P, rank, _lib.SLAB, 0, False)
+    r = exchange(rank, s, b, Np0 * N[1] * Nf * ES)
+    back = np.fft.irfft2(orc.slab_unpack(r.reshape(P, Np0, Np1, Nf)), s=(N[1], N[2]), axes=(1, 2))
+    assert orc.rel_l2(back, u) < 1e-13
+
+
+def pencil(rank, P, N, A, align, P1=None):
+    lay = orc.PencilLayout(N, P, P1, align)
+    want = orc.pencil_r2c_forward(orc.scatter_real(A, lay), N, P1, align)
+    c0, c1 = lay.ranks(rank)
+    m, n, Nf = int(lay.N1[0]), int(lay.N2[1]), lay.Nf
+    N1_1, N2_0 = int(lay.N1[1]), int(lay.N2[0])
+    dec = _lib.PENCIL_X if align == "X" else _lib.PENCIL_Y
+    u = np.ascontiguousarray(A[lay.real_local_slice(rank)])
+    a = np.fft.rfft(u, axis=2)
+    s0 = _lib.exchange_schedule(N, P, rank, dec, 0, True, p1=P1 or 0)
+    assert s0["peers"] == (lay.comm1_members(rank) if align == "X" else lay.comm0_members(rank))
+    # z chunks: lengths follow from the byte counts
+    lens = [c // (m * n * ES) for c in s0["scount"]]
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    send = np.concatenate([a[:, :, st:st + ln].ravel() for ln, st in zip(lens, starts)])
+    q = s0["rcount"][0] // (m * n * ES)
+    assert q == lay.complex_shape(rank)[2]
+    r = exchange(rank, s0, send, sum(s0["rcount"]))
+    blocks = r.reshape(len(lens), m, n, q)
+    s1 = _lib.exchange_schedule(N, P, rank, dec, 1, True, p1=P1 or 0)
+    if align == "X":
+        b = np.fft.fft(np.concatenate(list(blocks), axis=1), axis=1)              # (m, N1, q)
+        assert s1["peers"] == lay.comm0_members(rank)
+        send = np.concatenate([b[:, l * N1_1:(l + 1) * N1_1, :].ravel() for l in range(lay.P1)])
+        r = exchange(rank, s1, send, sum(s1["rcount"]))
+        fu = np.fft.fft(r.reshape(N[0], N1_1, q), axis=0)
+    else:
+        b = np.fft.fft(np.concatenate(list(blocks), axis=0), axis=0)              # (N0, n, q)
+        assert s1["peers"] == lay.comm1_members(rank)
+        r = exchange(rank, s1, b, sum(s1["rcount"]))
+        blocks = r.reshape(lay.P2, N2_0, n, q)
+        fu = np.fft.fft(np.concatenate(list(blocks), axis=1), axis=1)              # (N2_0, N1, q)
+    assert fu.shape == lay.complex_shape(rank)
+    assert orc.rel_l2(fu, want[rank]) < 1e-13, (align, rank)
+    # inverse: mirror
+    s1b = _lib.exchange_schedule(N, P, rank, dec, 1, False, p1=P1 or 0)
+    s0b = _lib.exchange_schedule(N, P, rank, dec, 0, False, p1=P1 or 0)
+    if align == "X":
+        b = np.fft.ifft(fu, axis=0)                                                  # x chunks contiguous
+        r = exchange(rank, s1b, b, sum(s1b["rcount"]))
+        blocks = r.reshape(lay.P1, m, N1_1, q)
+        b = np.fft.ifft(np.concatenate(list(blocks), axis=1), axis=1)               # (m, N1, q)
+        send = np.concatenate([b[:, l * n:(l + 1) * n, :].ravel() for l in range(lay.P2)])
+    else:
+        b = np.fft.ifft(fu, axis=1)                                                  # (N2_0, N1, q)
+        send = np.concatenate([b[:, l * n:(l + 1) * n, :].ravel() for l in range(lay.P2)])
+        r = exchange(rank, s1b, send, sum(s1b["rcount"]))
+        send = np.fft.ifft(r.reshape(N[0], n, q), axis=0)                            # x chunks contiguous
+    r = exchange(rank, s0b, send, sum(s0b["rcount"]))
+    z = np.zeros((m, n, Nf), dtype=complex)
+    off = 0
+    for ln, st in zip(lens, starts):
+        z[:, :, st:st + ln] = r[off:off + m * n * ln].reshape(m, n, ln)
+        off += m * n * ln
+    back = np.fft.irfft(z, n=N[2], axis=2)
+    assert orc.rel_l2(back, u) < 1e-13, (align, rank)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, P = dist.get_rank(), dist.get_world_size()
+    N = [16, 32, 64]
+    A = np.random.default_rng(2026).random(N)
+    slab(rank, P, N, A)
+    if P >= 4:
+        for align in ("X", "Y"):
+            pencil(rank, P, N, A, align)
+        if P == 8:
+            for align in ("X", "Y"):
+                pencil(rank, P, N, A, align, P1=2)
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK world=%d" % P)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""CPU: the N > 1 host logic (groups, peers, all-to-all-v counts/displacements of the
+slab and pencil plans) driven through real multi-process exchanges over gloo."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_schedules_over_gloo(world):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-3000:])
+    assert "DIST_OK world=%d" % world in outs[0]
+
+
+def test_schedule_matches_reference_message_sizes():
+    """Per-peer chunk sizes at 1024^3 fp64 from SURVEY.md section 2.1 (derived from the
+    reference's Alltoall / Alltoallw call sites)."""
+    from mpifft4py_amd import _lib
+    N = [1024] * 3
+    s = _lib.exchange_schedule(N, 8, 0, _lib.SLAB)
+    assert set(s["scount"]) == {128 * 128 * 513 * 16}                     # slab.py:406
+    # R2CY first exchange over comm0 (P1 = 4): 256*512*128*16, 129 columns on the last rank
+    s = _lib.exchange_schedule(N, 8, 0, _lib.PENCIL_Y, which=0)
+    assert s["peers"] == [0, 1, 2, 3]
+    assert s["scount"] == [256 * 512 * 128 * 16] * 3 + [256 * 512 * 129 * 16]
+    s = _lib.exchange_schedule(N, 8, 0, _lib.PENCIL_Y, which=1)            # comm1 (P2 = 2), stride P1
+    assert s["peers"] == [0, 4] and set(s["scount"]) == {512 * 512 * 128 * 16}
+    # R2CX: comm1 first (256 | 257 columns), then comm0
+    s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=0)
+    assert s["peers"] == [1, 5] and s["scount"] == [256 * 512 * 256 * 16, 256 * 512 * 257 * 16]
+    s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=1)
+    assert s["peers"] == [4, 5, 6, 7] and set(s["scount"]) == {256 * 256 * 257 * 16}
