@@ -99,7 +99,16 @@ def main():
             sys.stderr.write("bench.py --gpus %d must be launched with torch.distributed.run "
                              "(one process per GPU)\n" % args.gpus)
             sys.exit(2)
-    comm, dist = make_comm(world, args.rendezvous)
+    # RCCL prints a version banner on stdout at communicator creation; keep stdout for the JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        comm, dist = make_comm(world, args.rendezvous)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     n = args.n
     N = np.array([n, n, n])
     L = np.array([2 * np.pi] * 3)
