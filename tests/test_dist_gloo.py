@@ -59,3 +59,25 @@ def test_schedule_matches_reference_message_sizes():
     assert s["peers"] == [1, 5] and s["scount"] == [256 * 512 * 256 * 16, 256 * 512 * 257 * 16]
     s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=1)
     assert s["peers"] == [4, 5, 6, 7] and set(s["scount"]) == {256 * 256 * 257 * 16}
+
+
+def test_file_rendezvous_two_processes(tmp_path):
+    """comm._file_bcast: rank 0 publishes 128 bytes atomically, rank 1 polls (the bootstrap
+    bench.py uses under torch.distributed.run on one node)."""
+    code = (
+        "import os,sys; sys.path.insert(0, %r)\n"
+        "from mpifft4py_amd import comm\n"
+        "r=int(os.environ['RANK'])\n"
+        "payload = bytes(range(128)) if r == 0 else None\n"
+        "data, path = comm._file_bcast(r, payload, timeout=60)\n"
+        "assert data == bytes(range(128)), data\n"
+        "print('OK', r)\n" % ROOT)
+    path = str(tmp_path / "uid")
+    procs = []
+    for r in (1, 0):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_PORT="12345", MFFT_RENDEZVOUS_FILE=path)
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0 and b"OK" in out, out.decode()
