@@ -17,6 +17,7 @@ from .serialFFT import *  # noqa: F401,F403
 from .slab import R2C as Slab_R2C  # noqa: F401
 from .slab import C2C as Slab_C2C  # noqa: F401
 from .pencil import R2C as Pencil_R2C  # noqa: F401
+from .pencil import C2C as Pencil_C2C  # noqa: F401  (extension: no reference counterpart)
 from .mpibase import work_arrays, datatypes, empty, zeros  # noqa: F401
 from .device import DeviceArray  # noqa: F401
 from .comm import SelfComm, LocalGroup, DistComm, from_env, from_mpi4py  # noqa: F401

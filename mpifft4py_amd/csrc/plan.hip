@@ -640,6 +640,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
 // ---- 3/2-rule, pencil (Alltoallw branches; padding of an axis happens right
 // before the transform along it, when the axis is locally complete) -------------
 int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
+  if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
   const double ps = d.padsize, sc3 = ps * ps * ps;
   const bool X = d.decomp == MFFT_PENCIL_X;
   const std::vector<int>& gz = X ? group1 : group0;
@@ -697,6 +698,7 @@ int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
 }
 
 int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
+  if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
   const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
   const bool X = d.decomp == MFFT_PENCIL_X;
   const std::vector<int>& gz = X ? group1 : group0;
@@ -797,7 +799,6 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
       }
     }
   } else if (desc->decomp == MFFT_PENCIL_X || desc->decomp == MFFT_PENCIL_Y) {
-    if (!p->r2c) return set_error(MFFT_ERR_UNSUPPORTED, "pencil plans are R2C (the reference has no pencil C2C)");
     int P1 = desc->p1, P2;
     if (P1 <= 0) compute_dims(P, &P1, &P2);
     else {
@@ -818,7 +819,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
     for (int i = 0; i < P2; ++i) p->group1.push_back(p->c0 + i * P1);
     const int Pz = desc->decomp == MFFT_PENCIL_X ? P2 : P1;
     const int cz = desc->decomp == MFFT_PENCIL_X ? p->c1 : p->c0;
-    if (Pz > 1 && ((p->N2 / Pz) % 2)) return set_error(MFFT_ERR_UNSUPPORTED, "N[2]/%d must be even for the pencil z split", Pz);
+    if (p->r2c && Pz > 1 && ((p->N2 / Pz) % 2)) return set_error(MFFT_ERR_UNSUPPORTED, "N[2]/%d must be even for the pencil z split", Pz);
     if (p->Nf % Pz > 1) return set_error(MFFT_ERR_UNSUPPORTED, "Nf=%lld cannot be split over %d ranks", (long long)p->Nf, Pz);
     p->zc = pencil_chunks(p->Nf, Pz);
     p->q = p->zc[cz].len;

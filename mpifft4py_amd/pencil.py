@@ -13,7 +13,7 @@ from . import _lib
 from ._base import DistFFTBase, default_planner_effort
 from .comm import SubComm
 
-__all__ = ["R2C", "R2CX", "R2CY"]
+__all__ = ["R2C", "R2CX", "R2CY", "C2C", "C2CX", "C2CY"]
 
 
 def _compute_dims(nprocs):
@@ -33,6 +33,7 @@ class R2CY(DistFFTBase):
     `allow_single=True` lifts the reference's P > 1 assertion (pencil.py:176) so
     that the degenerate 1x1 grid can serve as the single-GPU scaling baseline."""
     _decomp = _lib.PENCIL_Y
+    _kind = _lib.R2C
 
     def __init__(self, N, L, comm, precision, P1=None, communication='Alltoallw', padsize=1.5, threads=1,
                  planner_effort=None, allow_single=False, pipeline=0):
@@ -63,9 +64,14 @@ class R2CY(DistFFTBase):
         self.comm1_rank = self.rank // P1
         self.comm0 = SubComm(P1, self.comm0_rank)
         self.comm1 = SubComm(P2, self.comm1_rank)
-        self.N1f = int(self.N1[2] // 2) if self.comm0_rank < P1 - 1 else int(self.N1[2] // 2 + 1)
-        self.N2f = int(self.N2[2] // 2) if self.comm1_rank < P2 - 1 else int(self.N2[2] // 2 + 1)
-        self._create_plan(_lib.R2C, self._decomp, p1=P1, pipeline=pipeline)
+        if self._kind == _lib.R2C:
+            self.N1f = int(self.N1[2] // 2) if self.comm0_rank < P1 - 1 else int(self.N1[2] // 2 + 1)
+            self.N2f = int(self.N2[2] // 2) if self.comm1_rank < P2 - 1 else int(self.N2[2] // 2 + 1)
+        else:                         # complex z axis: N2 columns, split evenly
+            self.Nf = int(N[2])
+            self.N1f = int(self.N1[2])
+            self.N2f = int(self.N2[2])
+        self._create_plan(self._kind, self._decomp, p1=P1, pipeline=pipeline)
         assert self._c_real_shape == tuple(self.real_shape())
         assert self._c_complex_shape == tuple(self.complex_shape()), (self._c_complex_shape, self.complex_shape())
 
@@ -96,7 +102,7 @@ class R2CY(DistFFTBase):
 
     def complex_local_slice(self):
         c0, c1 = self.comm0_rank, self.comm1_rank
-        z0 = int(c0 * self.N1[2] // 2)
+        z0 = int(c0 * self.N1[2] // 2) if self._kind == _lib.R2C else int(c0 * self.N1[2])
         return (slice(int(c1 * self.N2[0]), int((c1 + 1) * self.N2[0]), 1),
                 slice(0, int(self.N[1])),
                 slice(z0, z0 + self.N1f, 1))
@@ -147,17 +153,20 @@ class R2CY(DistFFTBase):
         assert dealias in ('3/2-rule', '2/3-rule', 'None', None)
         ushape = self.real_shape_padded() if dealias == '3/2-rule' else self.real_shape()
         assert tuple(u.shape) == ushape
-        return self._run(True, u, fu, dealias, ushape, self.float, self.complex_shape(), self.complex)
+        return self._run(True, u, fu, dealias, ushape, self._in_dtype(), self.complex_shape(), self.complex)
 
     def ifftn(self, fu, u, dealias=None):
         """Inverse transform (pencil.py:386-632 / 1001-1224); fu is not modified."""
         assert dealias in ('3/2-rule', '2/3-rule', 'None', None)
         ushape = self.real_shape_padded() if dealias == '3/2-rule' else self.real_shape()
         assert tuple(u.shape) == ushape
-        return self._run(False, fu, u, dealias, self.complex_shape(), self.complex, ushape, self.float)
+        return self._run(False, fu, u, dealias, self.complex_shape(), self.complex, ushape, self._in_dtype())
 
     fft3d = fftn
     ifft3d = ifftn
+
+    def _in_dtype(self):
+        return self.float if self._kind == _lib.R2C else self.complex
 
 
 class R2CX(R2CY):
@@ -175,10 +184,54 @@ class R2CX(R2CY):
 
     def complex_local_slice(self):
         c0, c1 = self.comm0_rank, self.comm1_rank
-        z0 = int(c1 * self.N2[2] // 2)
+        z0 = int(c1 * self.N2[2] // 2) if self._kind == _lib.R2C else int(c1 * self.N2[2])
         return (slice(0, int(self.N[0])),
                 slice(int(c0 * self.N1[1]), int((c0 + 1) * self.N1[1]), 1),
                 slice(z0, z0 + self.N2f, 1))
+
+
+class C2CX(R2CX):
+    """EXTENSION (no counterpart in the reference, which has no pencil C2C; asked for by
+    BASELINE.json config "2048^3 fp32 complex-to-complex pencil"): complex <-> complex
+    pencil transform, same layouts as R2CX with the full N2 columns split evenly.
+    original (N0/P1, N1/P2, N2) <-> transformed (N0, N1/P1, N2/P2); un-padded only."""
+    _kind = _lib.C2C
+
+    def global_shape(self, padsize=1.):
+        return (int(padsize * self.N[0]), int(padsize * self.N[1]), int(padsize * self.N[2]))
+
+    original_shape = R2CY.real_shape
+    original_local_slice = R2CY.real_local_slice
+
+    def transformed_shape(self):
+        return self.complex_shape()
+
+    def transformed_local_slice(self):
+        return self.complex_local_slice()
+
+
+class C2CY(R2CY):
+    """EXTENSION: complex <-> complex pencil transform aligned in y; transformed shape
+    (N0/P2, N1, N2/P1)."""
+    _kind = _lib.C2C
+
+    def global_shape(self, padsize=1.):
+        return (int(padsize * self.N[0]), int(padsize * self.N[1]), int(padsize * self.N[2]))
+
+    original_shape = R2CY.real_shape
+    original_local_slice = R2CY.real_local_slice
+
+    def transformed_shape(self):
+        return self.complex_shape()
+
+    def transformed_local_slice(self):
+        return self.complex_local_slice()
+
+
+def C2C(N, L, comm, precision, P1=None, communication="Alltoallw", padsize=1.5, threads=1,
+        alignment="X", planner_effort=None, **kw):
+    cls = C2CX if alignment == 'X' else C2CY
+    return cls(N, L, comm, precision, P1, communication, padsize, threads, planner_effort, **kw)
 
 
 def R2C(N, L, comm, precision, P1=None, communication="Alltoall", padsize=1.5, threads=1,

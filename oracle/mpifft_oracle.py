@@ -527,6 +527,62 @@ def pencil_r2c_backward(fus, N, P1=None, alignment="X", precision="double"):
 
 
 # --------------------------------------------------------------------------
+# EXTENSION, PARITY UNPINNED: pencil C2C.  The reference has no pencil C2C class
+# (pencil.py defines only R2CY / R2CX), so there is nothing to pin this against
+# except the DFT definition itself (numpy.fft.fftn of the gathered array).  Same
+# stage order and exchanges as the R2C pencils with Nf = N2 split evenly.
+# --------------------------------------------------------------------------
+
+class PencilC2CLayout(PencilLayout):
+    def __init__(self, N, P, P1=None, alignment="X"):
+        PencilLayout.__init__(self, N, P, P1, alignment)
+        self.Nf = int(self.N[2])
+
+    def N1f(self, c0):
+        return int(self.N1[2])
+
+    def N2f(self, c1):
+        return int(self.N2[2])
+
+    def complex_local_slice(self, rank):
+        c0, c1 = self.ranks(rank)
+        if self.alignment == "Y":
+            z0 = int(c0 * self.N1[2])
+            return (slice(int(c1 * self.N2[0]), int((c1 + 1) * self.N2[0]), 1),
+                    slice(0, int(self.N[1])), slice(z0, z0 + int(self.N1[2]), 1))
+        z0 = int(c1 * self.N2[2])
+        return (slice(0, int(self.N[0])),
+                slice(int(c0 * self.N1[1]), int((c0 + 1) * self.N1[1]), 1),
+                slice(z0, z0 + int(self.N2[2]), 1))
+
+    def global_complex_shape(self, padsize=1.0):
+        return tuple(int(padsize * n) for n in self.N)
+
+
+def pencil_c2c_forward(us, N, P1=None, alignment="X", precision="double"):
+    P = len(us)
+    lay = PencilC2CLayout(N, P, P1, alignment)
+    _, ctype = dtypes(precision)
+    N = lay.N
+    P1, P2 = lay.P1, lay.P2
+    N1, N2 = lay.N1, lay.N2
+    a = [np.fft.fft(u, axis=2).astype(ctype) for u in us]
+    if alignment == "Y":
+        b = _exchange_split_gather(a, _groups(lay, 0), 2, 0, pencil_chunks(int(N[2]), P1), None,
+                                   lambda r: (int(N[0]), int(N2[1]), int(N1[2])))
+        b = [np.fft.fft(x, axis=0).astype(ctype) for x in b]
+        c = _exchange_split_gather(b, _groups(lay, 1), 0, 1, pencil_chunks(int(N[0]), P2), None,
+                                   lambda r: (int(N2[0]), int(N[1]), int(N1[2])))
+        return [np.fft.fft(x, axis=1).astype(ctype) for x in c]
+    b = _exchange_split_gather(a, _groups(lay, 1), 2, 1, pencil_chunks(int(N[2]), P2), None,
+                               lambda r: (int(N1[0]), int(N[1]), int(N2[2])))
+    b = [np.fft.fft(x, axis=1).astype(ctype) for x in b]
+    c = _exchange_split_gather(b, _groups(lay, 0), 1, 0, pencil_chunks(int(N[1]), P1), None,
+                               lambda r: (int(N[0]), int(N1[1]), int(N2[2])))
+    return [np.fft.fft(x, axis=0).astype(ctype) for x in c]
+
+
+# --------------------------------------------------------------------------
 # pencil, 3/2-rule (Alltoallw branches: pencil.py:604-632, 858-883, 1196-1224,
 # 1440-1475).  Padding of a distributed axis happens right before the FFT
 # along it, when that axis is locally complete.

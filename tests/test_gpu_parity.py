@@ -335,3 +335,29 @@ def test_rccl_communicator_single_rank():
         assert orc.rel_l2(cc, np.fft.rfftn(A)) < 1e-10
         assert orc.rel_l2(F.ifftn(cc, np.zeros(F.real_shape())), A) < 1e-10
     c.free()
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("align", ["X", "Y"])
+@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2)])
+def test_pencil_c2c_extension(P, P1, align, prec):
+    """Pencil C2C (BASELINE config 5; no reference implementation exists) against the
+    oracle's restatement and numpy.fft.fftn."""
+    from mpifft4py_amd import Pencil_C2C
+    rng = np.random.default_rng(900 + P)
+    A = (rng.random(NREF) + 1j * rng.random(NREF)).astype(cdtype(prec))
+    B2 = np.fft.fftn(A.astype(np.complex128))
+    lay = orc.PencilC2CLayout(NREF, P, P1, align)
+    want = orc.pencil_c2c_forward(orc.scatter_real(A, lay), NREF, P1, align, prec)
+
+    def body(comm):
+        F = Pencil_C2C(np.array(NREF), L, comm, prec, P1=P1, alignment=align)
+        assert F.global_shape() == tuple(NREF)
+        a = np.ascontiguousarray(A[F.original_local_slice()])
+        c = F.fftn(a, np.zeros(F.transformed_shape(), dtype=F.complex))
+        b = F.ifftn(c, np.zeros(F.original_shape(), dtype=F.complex))
+        return F.transformed_local_slice(), c, F.original_local_slice(), b
+    for r, (cs, c, rs, b) in enumerate(run_ranks(P, body)):
+        assert orc.rel_l2(c, want[r]) < TOL[prec]
+        assert orc.rel_l2(c, B2[cs]) < TOL[prec]
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]

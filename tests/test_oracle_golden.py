@@ -121,3 +121,19 @@ def test_forward_is_rfftn(gold):
         c = g[key]
         rtol = 1e-8 if prec == "double" else 1e-4
         assert np.all(np.abs((c - B2) / c.max()) < rtol)
+
+
+@pytest.mark.parametrize("align", ["X", "Y"])
+def test_pencil_c2c_extension_is_a_dft(align):
+    """Pencil C2C has no reference counterpart (unpinned extension): the oracle for it is
+    checked against the DFT definition, numpy.fft.fftn of the gathered array."""
+    Nn = [8, 16, 32]
+    rng = np.random.default_rng(3)
+    A = rng.random(Nn) + 1j * rng.random(Nn)
+    for P, P1 in ((4, None), (8, None), (8, 2)):
+        lay = orc.PencilC2CLayout(Nn, P, P1, align)
+        fus = orc.pencil_c2c_forward(orc.scatter_real(A, lay), Nn, P1, align)
+        C = np.zeros(Nn, dtype=complex)
+        for r, part in enumerate(fus):
+            C[lay.complex_local_slice(r)] = part
+        assert orc.rel_l2(C, np.fft.fftn(A)) < 1e-14
