@@ -160,9 +160,9 @@ template <typename T> static double tol_of() { return sizeof(T) == 8 ? 1e-14 : 5
 template <typename T> static const char* pname() { return sizeof(T) == 8 ? "double" : "single"; }
 
 // ---------------------------------------------------------------------------
-template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false>
+template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false, int VEC = 1>
 static void test_col(bool two_level) {
-  typedef ColFft<S, T, COLS, INV, TWLDS, SPLIT> K;
+  typedef ColFft<S, T, COLS, INV, TWLDS, SPLIT, VEC> K;
   const int N = S::N;
   const int ncols = COLS * 2 + 3;          // ragged last tile
   const int nouter = 2;
@@ -215,7 +215,7 @@ static void test_col(bool two_level) {
       }
     }
   char name[64];
-  snprintf(name, sizeof name, "col c%d %s%s%s%s", COLS, INV ? "inv" : "fwd", TWLDS ? " twlds" : "", two_level ? " 2lvl" : "", SPLIT ? " split" : "");
+  snprintf(name, sizeof name, "col c%d v%d %s%s%s%s", COLS, VEC, INV ? "inv" : "fwd", TWLDS ? " twlds" : "", two_level ? " 2lvl" : "", SPLIT ? " split" : "");
   report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
 }
 
@@ -312,6 +312,9 @@ template <class S> static void test_spec_all() {
   test_col<S, float, 8, true, true>(false);
   test_col<S, double, 8, false, true, true>(true);
   test_col<S, float, 4, true, false, true>(false);
+  test_col<S, float, 8, false, true, false, 2>(true);
+  test_col<S, float, 8, true, false, true, 2>(false);
+  test_col<S, float, 16, false, false, false, 4>(true);
   test_row<S, double, 2, false, true>();
   test_row<S, double, 2, true, false>();
   test_row<S, float, 3, false, false>();

@@ -168,6 +168,81 @@ MFFT_D void run_passes(cx<T> (&v)[S::E], int j, TwPtr tw, Xch& xch) {
   }
 }
 
+// ---- multi-column variants: each thread owns VEC adjacent columns (VEC register
+// sets), so that one lane moves 16 bytes even in single precision and the
+// twiddles of a pass are loaded once for all of its columns.
+template <typename U, int VEC>
+struct PackV {
+  U e[VEC];
+};
+
+template <typename T, int VEC, class Slot>
+struct XchFullV {
+  PackV<cx<T>, VEC>* buf;
+  Slot slot;
+  template <class S, int P>
+  MFFT_D void exchange(cx<T> (&v)[VEC][S::E], int j, bool pre_barrier) {
+    if (pre_barrier) MFFT_BARRIER();
+    pass_scatter<S, P>(j, [&](int pos, int reg) {
+      PackV<cx<T>, VEC> p;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) p.e[i] = v[i][reg];
+      buf[slot(pos)] = p;
+    });
+    MFFT_BARRIER();
+    pass_gather<S>(j, [&](int pos, int reg) {
+      const PackV<cx<T>, VEC> p = buf[slot(pos)];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i][reg] = p.e[i];
+    });
+  }
+};
+
+template <typename T, int VEC, class Slot>
+struct XchSplitV {
+  PackV<T, VEC>* buf;
+  Slot slot;
+  template <class S, int P>
+  MFFT_D void exchange(cx<T> (&v)[VEC][S::E], int j, bool pre_barrier) {
+    if (pre_barrier) MFFT_BARRIER();
+    pass_scatter<S, P>(j, [&](int pos, int reg) {
+      PackV<T, VEC> p;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) p.e[i] = v[i][reg].x;
+      buf[slot(pos)] = p;
+    });
+    MFFT_BARRIER();
+    pass_gather<S>(j, [&](int pos, int reg) {
+      const PackV<T, VEC> p = buf[slot(pos)];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i][reg].x = p.e[i];
+    });
+    MFFT_BARRIER();
+    pass_scatter<S, P>(j, [&](int pos, int reg) {
+      PackV<T, VEC> p;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) p.e[i] = v[i][reg].y;
+      buf[slot(pos)] = p;
+    });
+    MFFT_BARRIER();
+    pass_gather<S>(j, [&](int pos, int reg) {
+      const PackV<T, VEC> p = buf[slot(pos)];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i][reg].y = p.e[i];
+    });
+  }
+};
+
+template <class S, int P, typename T, int VEC, class TwPtr, class Xch>
+MFFT_D void run_passes_v(cx<T> (&v)[VEC][S::E], int j, TwPtr tw, Xch& xch) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) pass_compute<S, P, T>(v[i], j, tw);
+  if constexpr (P + 1 < S::NP) {
+    xch.template exchange<S, P>(v, j, P > 0);
+    run_passes_v<S, P + 1, T, VEC>(v, j, tw, xch);
+  }
+}
+
 // bijective XCD-aware block remap: workgroups are dealt round-robin over the 8
 // XCDs (MI355X_MICROARCH.md, "Workgroup dispatch"), so block b lands on XCD b%8.
 // Give each XCD a contiguous range of tiles so that neighbouring tiles, which
@@ -187,58 +262,85 @@ MFFT_D void stage_twiddles(cx<T>* lds_tw, const cx<T>* gtw, int tid, int nthread
 // ---------------------------------------------------------------------------
 // strided-axis c2c
 // ---------------------------------------------------------------------------
-template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false>
+template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false, int VEC = 1>
 struct ColFft {
-  static constexpr int THREADS = S::TPT * COLS;
+  static_assert(COLS % VEC == 0, "VEC must divide COLS");
+  static constexpr int CG = COLS / VEC;            // lanes along the contiguous axis
+  static constexpr int THREADS = S::TPT * CG;
   static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
   static constexpr int XCH_BYTES = S::NP > 1 ? (int)(S::N * COLS * (SPLIT ? sizeof(T) : sizeof(cx<T>))) : 0;
   static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
 
   struct Slot {
     int c;
-    MFFT_D int operator()(int pos) const { return pos * COLS + c; }
+    MFFT_D int operator()(int pos) const { return pos * CG + c; }
   };
+  typedef PackV<cx<T>, VEC> GPack;                 // VEC adjacent complex values in global memory
 
   static MFFT_D void body(const ColParams<T>& P, int bid_raw, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
     const int bid = P.remap ? xcd_remap(bid_raw, P.ntile_c * P.nouter) : bid_raw;
     const int outer = bid / P.ntile_c;
     const int tc = bid - outer * P.ntile_c;
-    const int c = tid % COLS;
-    const int j = tid / COLS;
-    const int col = tc * COLS + c;
-    const bool active = col < P.ncols;
+    const int c = tid % CG;
+    const int j = tid / CG;
+    const int col = tc * COLS + c * VEC;
+    const int nact = P.ncols - col;                // columns of this thread inside the array (may be <= 0)
     const cx<T>* ip = P.in + (i64)outer * P.in_outer + col;
     cx<T>* op = P.out + (i64)outer * P.out_outer + col;
 
-    cx<T> v[S::E];
+    cx<T> v[VEC][S::E];
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
       const unsigned r = (unsigned)(j + k * S::TPT);
-      cx<T> x = mk<T>((T)0, (T)0);
-      if (active) x = ip[row_off(P.in_map, r)];
-      v[k] = INV ? swapri(x) : x;
+      const cx<T>* src = ip + row_off(P.in_map, r);
+      if (nact >= VEC) {
+        const GPack g = *reinterpret_cast<const GPack*>(src);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i][k] = INV ? swapri(g.e[i]) : g.e[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          cx<T> x = mk<T>((T)0, (T)0);
+          if (i < nact) x = src[i];
+          v[i][k] = INV ? swapri(x) : x;
+        }
+      }
     }
     if constexpr (TWLDS && S::NP > 1) {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
     }
     if constexpr (SPLIT) {
-      XchSplit<T, Slot> xch{reinterpret_cast<T*>(lds + TW_BYTES), Slot{c}};
-      if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xch);
-      else run_passes<S, 0, T>(v, j, P.tw, xch);
+      XchSplitV<T, VEC, Slot> xch{reinterpret_cast<PackV<T, VEC>*>(lds + TW_BYTES), Slot{c}};
+      if constexpr (TWLDS) run_passes_v<S, 0, T, VEC>(v, j, (const cx<T>*)ltw, xch);
+      else run_passes_v<S, 0, T, VEC>(v, j, P.tw, xch);
     } else {
-      XchFull<T, Slot> xch{reinterpret_cast<cx<T>*>(lds + TW_BYTES), Slot{c}};
-      if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xch);
-      else run_passes<S, 0, T>(v, j, P.tw, xch);
+      XchFullV<T, VEC, Slot> xch{reinterpret_cast<PackV<cx<T>, VEC>*>(lds + TW_BYTES), Slot{c}};
+      if constexpr (TWLDS) run_passes_v<S, 0, T, VEC>(v, j, (const cx<T>*)ltw, xch);
+      else run_passes_v<S, 0, T, VEC>(v, j, P.tw, xch);
     }
 
-    if (active) {
 #pragma unroll
-      for (int k = 0; k < S::E; ++k) {
-        const unsigned r = (unsigned)(j + k * S::TPT);
-        cx<T> x = scale(v[k], P.scale);
-        op[row_off(P.out_map, r)] = INV ? swapri(x) : x;
+    for (int k = 0; k < S::E; ++k) {
+      const unsigned r = (unsigned)(j + k * S::TPT);
+      cx<T>* dst = op + row_off(P.out_map, r);
+      if (nact >= VEC) {
+        GPack g;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const cx<T> x = scale(v[i][k], P.scale);
+          g.e[i] = INV ? swapri(x) : x;
+        }
+        *reinterpret_cast<GPack*>(dst) = g;
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          if (i < nact) {
+            const cx<T> x = scale(v[i][k], P.scale);
+            dst[i] = INV ? swapri(x) : x;
+          }
+        }
       }
     }
   }

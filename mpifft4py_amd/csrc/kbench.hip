@@ -34,6 +34,35 @@ __global__ __launch_bounds__(256) void copy_stream(const v16* __restrict__ src, 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 // same addressing as ColFft (COLS columns x 1024 rows per workgroup, E values per thread), no FFT
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <int COLS, int E, int NT>
+__global__ __launch_bounds__(1024 / E * COLS) void copy_tile_nt(ColParams<double> P) {
+  constexpr int TPT = 1024 / E;
+  const int bid = P.remap ? xcd_remap((int)blockIdx.x, P.ntile_c * P.nouter) : (int)blockIdx.x;
+  const int outer = bid / P.ntile_c, tc = bid - outer * P.ntile_c;
+  const int c = threadIdx.x % COLS, j = threadIdx.x / COLS, col = tc * COLS + c;
+  if (col >= P.ncols) return;
+  const d2* ip = reinterpret_cast<const d2*>(P.in + (i64)outer * P.in_outer + col);
+  d2* op = reinterpret_cast<d2*>(P.out + (i64)outer * P.out_outer + col);
+  d2 v[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const d2* a = ip + row_off(P.in_map, (unsigned)(j + k * TPT));
+    v[k] = (NT & 1) ? __builtin_nontemporal_load(a) : *a;
+  }
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    d2* a = op + row_off(P.out_map, (unsigned)(j + k * TPT));
+    d2 x = v[k];
+    x.x += 1.0;
+    if (NT & 2) __builtin_nontemporal_store(x, a); else *a = x;
+  }
+}
+template <int COLS, int E, int NT>
+void launch_copy_tile_nt(const ColParams<double>& p, int grid) {
+  hipLaunchKernelGGL((copy_tile_nt<COLS, E, NT>), dim3(grid), dim3(1024 / E * COLS), 0, 0, p);
+}
+
 template <int COLS, int E>
 __global__ __launch_bounds__(1024 / E * COLS) void copy_tile(ColParams<double> P) {
   constexpr int TPT = 1024 / E;
@@ -154,6 +183,13 @@ Variant make_copy() {
   return Variant{nm, COLS, 1024 / E * COLS, 0, &launch_copy_tile<COLS, E>, &build_pass_twiddles<Spec<1024, 16, 8, 8>, double>};
 }
 
+template <int COLS, int E, int NT>
+Variant make_copy_nt() {
+  char nm[128];
+  snprintf(nm, sizeof nm, "copytile c%d e%d nt%d", COLS, E, NT);
+  return Variant{nm, COLS, 1024 / E * COLS, 0, &launch_copy_tile_nt<COLS, E, NT>, &build_pass_twiddles<Spec<1024, 16, 8, 8>, double>};
+}
+
 template <class S, int COLS, bool TWLDS, bool SPLIT>
 Variant make(const char* plan) {
   typedef ColFft<S, double, COLS, false, TWLDS, SPLIT> K;
@@ -173,6 +209,7 @@ int main(int argc, char** argv) {
   if (getenv("KB_PGRID")) g_persist_grid = atoi(getenv("KB_PGRID"));
   std::vector<Variant> vs = {
       make_copy<8, 16>(), make_copy<8, 32>(), make_copy<4, 16>(), make_copy<16, 16>(),
+      make_copy_nt<8, 16, 0>(), make_copy_nt<8, 16, 1>(), make_copy_nt<8, 16, 2>(), make_copy_nt<8, 16, 3>(),
       make_persist<SA, 8, false>("16x8x8"), make_persist<SA, 8, true>("16x8x8"), make_persist<SD, 8, true>("8x8x4x4"),
       make_persist<SB, 8, false>("32x32"),
       make<SA, 4, false, false>("16x8x8"),  make<SA, 4, true, false>("16x8x8"),   make<SA, 4, false, true>("16x8x8"),

@@ -33,11 +33,13 @@ const KernelEntry* find_kernel(int family, int n, int prec, int inv);
 // narrower tiles every line is fetched once per tile that touches it).  The
 // exchange buffer may take up to 128 KiB of the CU's 160 KiB LDS; if whole complex
 // values do not fit, real and imaginary parts are exchanged one after the other.
+template <class S, typename T> constexpr int col_vec() { return 16 / (int)sizeof(cx<T>) > 0 ? 16 / (int)sizeof(cx<T>) : 1; }   // 16 B per lane
 template <class S, typename T> constexpr int col_cols() {
+  constexpr int vec = col_vec<S, T>();
   int cols = 128 / (int)sizeof(cx<T>);
-  while (cols > 1 && S::TPT * cols > 1024) cols /= 2;
-  while (cols > 1 && (long long)S::N * cols * (int)sizeof(T) > 131072) cols /= 2;   // even split must fit
-  while (S::TPT * cols < 64) cols *= 2;      // at least one full wave
+  while (cols > vec && S::TPT * (cols / vec) > 1024) cols /= 2;
+  while (cols > vec && (long long)S::N * cols * (int)sizeof(T) > 131072) cols /= 2;   // even split must fit
+  while (S::TPT * (cols / vec) < 64) cols *= 2;      // at least one full wave
   return cols;
 }
 template <class S, typename T> constexpr bool col_split() {
@@ -99,10 +101,11 @@ void register_plan(const char* name) {
   constexpr int C = col_cols<S, T>();
   constexpr bool CT = col_twlds<S, T>();
   constexpr bool CS = col_split<S, T>();
+  constexpr int CV = col_vec<S, T>();
   constexpr int R = row_rows<S, T>();
   constexpr bool RT = row_twlds<S, T>();
-  reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
-  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+  reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
+  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
   reg.push_back(make_entry<RowFft<S, T, R, false, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
   reg.push_back(make_entry<RowFft<S, T, R, true, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
   reg.push_back(make_entry<R2CFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
