@@ -27,9 +27,9 @@ std::vector<KernelEntry>& kernel_registry() {
   return reg;
 }
 
-const KernelEntry* find_kernel(int family, int n, int prec, int inv) {
+const KernelEntry* find_kernel(int family, int n, int prec, int inv, int nt) {
   for (const KernelEntry& e : kernel_registry())
-    if (e.family == family && e.n == n && e.prec == prec && e.inv == inv) return &e;
+    if (e.family == family && e.n == n && e.prec == prec && e.inv == inv && e.nt == nt) return &e;
   return nullptr;
 }
 
@@ -129,7 +129,14 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   if (a.n == 1) return set_error(MFFT_ERR_UNSUPPORTED, "length-1 transform along a strided axis");
   if (a.n >= 65536) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %d too large", a.n);
   if (a.ncols >= (1ll << 31)) return set_error(MFFT_ERR_UNSUPPORTED, "too many columns");
-  const KernelEntry* e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0);
+  // non-temporal variant only when every row segment of the tile is a whole, private L2 line
+  const int64_t per_line = 128 / (int64_t)elem_bytes(a.prec, true);
+  auto aligned = [&](const void* p, int64_t outer, const RowSpec& r) {
+    return ((uintptr_t)p % 128 == 0) && outer % per_line == 0 && r.lo % per_line == 0 && r.hi % per_line == 0;
+  };
+  const bool nt = a.allow_nt && aligned(a.in, a.in_outer, a.in_rows) && aligned(a.out, a.out_outer, a.out_rows);
+  const KernelEntry* e = nt ? find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1) : nullptr;
+  if (!e) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0);
   if (!e)
     return set_error(MFFT_ERR_UNSUPPORTED,
                      "no kernel for a complex transform of length %d (supported: 2^a, 3*2^a, 5*2^a up to 4096)", a.n);

@@ -262,7 +262,10 @@ MFFT_D void stage_twiddles(cx<T>* lds_tw, const cx<T>* gtw, int tid, int nthread
 // ---------------------------------------------------------------------------
 // strided-axis c2c
 // ---------------------------------------------------------------------------
-template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false, int VEC = 1>
+// NT: non-temporal global loads/stores.  Only for tiles whose rows are 128-byte
+// aligned (every L2 line belongs to exactly one workgroup): measured +12 % on
+// such layouts, 2x slower on unaligned ones, where neighbouring tiles share lines.
+template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false, int VEC = 1, bool NT = false>
 struct ColFft {
   static_assert(COLS % VEC == 0, "VEC must divide COLS");
   static constexpr int CG = COLS / VEC;            // lanes along the contiguous axis
@@ -276,6 +279,33 @@ struct ColFft {
     MFFT_D int operator()(int pos) const { return pos * CG + c; }
   };
   typedef PackV<cx<T>, VEC> GPack;                 // VEC adjacent complex values in global memory
+#if defined(__HIPCC__)
+  typedef T vec_t __attribute__((ext_vector_type(2 * VEC)));
+  static MFFT_D GPack load_pack(const cx<T>* src) {
+    if constexpr (NT) {
+      const vec_t x = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(src));
+      GPack g;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g.e[i] = mk<T>(x[2 * i], x[2 * i + 1]);
+      return g;
+    } else {
+      return *reinterpret_cast<const GPack*>(src);
+    }
+  }
+  static MFFT_D void store_pack(cx<T>* dst, const GPack& g) {
+    if constexpr (NT) {
+      vec_t x;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { x[2 * i] = g.e[i].x; x[2 * i + 1] = g.e[i].y; }
+      __builtin_nontemporal_store(x, reinterpret_cast<vec_t*>(dst));
+    } else {
+      *reinterpret_cast<GPack*>(dst) = g;
+    }
+  }
+#else
+  static MFFT_D GPack load_pack(const cx<T>* src) { return *reinterpret_cast<const GPack*>(src); }
+  static MFFT_D void store_pack(cx<T>* dst, const GPack& g) { *reinterpret_cast<GPack*>(dst) = g; }
+#endif
 
   static MFFT_D void body(const ColParams<T>& P, int bid_raw, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
@@ -295,7 +325,7 @@ struct ColFft {
       const unsigned r = (unsigned)(j + k * S::TPT);
       const cx<T>* src = ip + row_off(P.in_map, r);
       if (nact >= VEC) {
-        const GPack g = *reinterpret_cast<const GPack*>(src);
+        const GPack g = load_pack(src);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) v[i][k] = INV ? swapri(g.e[i]) : g.e[i];
       } else {
@@ -332,7 +362,7 @@ struct ColFft {
           const cx<T> x = scale(v[i][k], P.scale);
           g.e[i] = INV ? swapri(x) : x;
         }
-        *reinterpret_cast<GPack*>(dst) = g;
+        store_pack(dst, g);
       } else {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {

@@ -46,6 +46,7 @@ struct ColArgs {
   int64_t nouter = 1;
   double scale = 1.0;
   int remap = 1;         // XCD-aware tile order
+  bool allow_nt = true;  // use the non-temporal variant when the layout is 128-byte aligned
 };
 int launch_col(const ColArgs& a, hipStream_t s);
 

@@ -15,6 +15,7 @@ struct KernelEntry {
   int n;            // transform length (R2C/C2R: the REAL length)
   int prec;         // 0 single, 1 double
   int inv;          // COL/ROW: 1 = inverse
+  int nt;           // COL: 1 = non-temporal variant (128-byte aligned rows only)
   int tile;         // COLS (COL) or ROWS (others)
   int threads;
   int lds_bytes;
@@ -26,7 +27,7 @@ struct KernelEntry {
 };
 
 std::vector<KernelEntry>& kernel_registry();
-const KernelEntry* find_kernel(int family, int n, int prec, int inv);
+const KernelEntry* find_kernel(int family, int n, int prec, int inv, int nt = 0);
 
 // ---- default tiling heuristics (measured on MI355X at 1024^3) -----
 // Strided-axis kernel: tiles are 128 bytes wide (one L2 line per row segment; with
@@ -84,6 +85,7 @@ KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
   e.n = n;
   e.prec = sizeof(T) == 8 ? 1 : 0;
   e.inv = inv;
+  e.nt = 0;
   e.tile = tile;
   e.threads = K::THREADS;
   e.lds_bytes = K::LDS_BYTES;
@@ -106,6 +108,12 @@ void register_plan(const char* name) {
   constexpr bool RT = row_twlds<S, T>();
   reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
   reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+  if constexpr (S::N >= 256) {     // aligned-row variants for the large in-place passes
+    reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
+    reg.back().nt = 1;
+    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+    reg.back().nt = 1;
+  }
   reg.push_back(make_entry<RowFft<S, T, R, false, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
   reg.push_back(make_entry<RowFft<S, T, R, true, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
   reg.push_back(make_entry<R2CFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));

@@ -361,3 +361,50 @@ def test_pencil_c2c_extension(P, P1, align, prec):
         assert orc.rel_l2(c, want[r]) < TOL[prec]
         assert orc.rel_l2(c, B2[cs]) < TOL[prec]
         assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("N,P", [([48, 96, 80], 1), ([48, 96, 80], 2), ([24, 40, 12], 4), ([96, 20, 192], 4),
+                                 ([6, 10, 8], 2), ([2, 2, 4], 1), ([2, 2, 4], 2), ([4, 4, 4], 4)])
+def test_slab_non_power_of_two_and_tiny_meshes(N, P):
+    """Ragged / 3- and 5-smooth / minimum-size meshes (the reference only requires P = 2^i <= N[0])."""
+    from mpifft4py_amd import Slab_R2C
+    rng = np.random.default_rng(sum(N))
+    A = rng.random(N)
+    B2 = np.fft.rfftn(A)
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, "double")
+        a = np.ascontiguousarray(A[F.real_local_slice()])
+        c = F.fftn(a, np.zeros(F.complex_shape(), dtype=complex))
+        b = F.ifftn(c, np.zeros(F.real_shape()))
+        return F.complex_local_slice(), c, F.real_local_slice(), b
+    for cs, c, rs, b in run_ranks(P, body):
+        assert orc.rel_l2(c, B2[cs]) < 1e-10
+        assert orc.rel_l2(b, A[rs]) < 1e-10
+
+
+@pytest.mark.parametrize("align", ["X", "Y"])
+@pytest.mark.parametrize("N,P", [([48, 96, 80], 4), ([16, 16, 8], 4), ([40, 24, 48], 4)])
+def test_pencil_non_power_of_two_meshes(N, P, align):
+    from mpifft4py_amd import Pencil_R2C
+    rng = np.random.default_rng(sum(N) + 1)
+    A = rng.random(N)
+    B2 = np.fft.rfftn(A)
+
+    def body(comm):
+        F = Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=align)
+        a = np.ascontiguousarray(A[F.real_local_slice()])
+        c = F.fftn(a, np.zeros(F.complex_shape(), dtype=complex))
+        b = F.ifftn(c, np.zeros(F.real_shape()))
+        return F.complex_local_slice(), c, F.real_local_slice(), b
+    for cs, c, rs, b in run_ranks(P, body):
+        assert orc.rel_l2(c, B2[cs]) < 1e-10
+        assert orc.rel_l2(b, A[rs]) < 1e-10
+
+
+def test_unsupported_mesh_raises_cleanly():
+    from mpifft4py_amd import SelfComm, Slab_R2C, _lib
+    with pytest.raises(_lib.MfftError):          # 7 is not 2^a * {1,3,5}
+        Slab_R2C(np.array([7, 8, 8]), L, SelfComm(0), "double")
+    with pytest.raises(_lib.MfftError):          # odd real axis
+        Slab_R2C(np.array([8, 8, 9]), L, SelfComm(0), "double")
