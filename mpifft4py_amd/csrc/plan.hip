@@ -242,11 +242,18 @@ struct mfft_plan_s {
   }
   // truncation with Nyquist fold (slab.py:529-533): dst[:n/2+1] = src[:n/2+1]; dst[n/2:] += src[-n/2:]
   // src may have a longer contiguous run (a2s >= a2): only the first a2 are taken.
-  int trunc_axis(const void* src, void* dst, int64_t a0, int64_t n, int64_t npad, int64_t a2, int64_t a2s, double scale) {
+  int trunc_axis(const void* src, void* dst, int64_t a0, int64_t n, int64_t npad, int64_t a2, int64_t a2s, double scale,
+                 bool fold = true) {
     const char* s = static_cast<const char*>(src);
     char* dd = static_cast<char*>(dst);
-    MFFT_TRY(zero(dst, (size_t)(a0 * n * a2) * es));
     const int64_t h = n / 2;
+    if (!fold) {   // plain corner copies: dst[:n/2] = src[:n/2]; dst[n/2:] = src[-n/2:]   (slab.py:736-739, 796-797)
+      MFFT_TRY(box(s, dd, a0, h, a2, npad * a2s, a2s, n * a2, a2, 0, scale));
+      MFFT_TRY(box(s + (size_t)((npad - (n - h)) * a2s) * es, dd + (size_t)(h * a2) * es, a0, n - h, a2, npad * a2s, a2s,
+                   n * a2, a2, 0, scale));
+      return 0;
+    }
+    MFFT_TRY(zero(dst, (size_t)(a0 * n * a2) * es));
     MFFT_TRY(box(s, dd, a0, h + 1, a2, npad * a2s, a2s, n * a2, a2, 0, scale));
     MFFT_TRY(box(s + (size_t)((npad - h) * a2s) * es, dd + (size_t)(h * a2) * es, a0, h, a2, npad * a2s, a2s, n * a2, a2, 1, scale));
     return 0;
@@ -470,7 +477,6 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
 
 // ---- 3/2-rule, slab (R2C: slab.py:310-344, 445-483; P == 1: 250-268, 372-386) ----
 int mfft_plan_s::slab_backward_padded(const void* fu, void* u) {
-  if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
   if (P > 1 && P > N0 / 2) return set_error(MFFT_ERR_INVALID, "number of ranks cannot exceed N[0]/2 for the 3/2-rule");
   const double ps = d.padsize, sc3 = ps * ps * ps;
   const int64_t Mp0 = M0 / P;
@@ -497,28 +503,41 @@ int mfft_plan_s::slab_backward_padded(const void* fu, void* u) {
   void* ypad = (yin == W2) ? W1 : W2;
   MFFT_TRY(stage("pad_y", 0, [&] { return pad_axis(yin, ypad, Mp0, N1, M1, Nf, 1.0); }));
   MFFT_TRY(stage("bwd_y", 0, [&] { return col(ypad, ypad, M1, true, Mp0, Nf, M1 * Nf, plain(Nf), M1 * Nf, plain(Nf)); }));
-  // pad z: (Mp0*M1, Nf) -> (Mp0*M1, Mf)
+  // pad z: (Mp0*M1, Nf) -> (Mp0*M1, Mf); one-sided for the half spectrum, two-sided for C2C (slab.py:815-817)
   MFFT_TRY(stage("pad_z", 0, [&] {
+    if (!r2c) return pad_axis(ypad, W0, Mp0 * M1, N2, M2, 1, 1.0);
     MFFT_TRY(zero(W0, (size_t)(Mp0 * M1 * Mf) * es));
     return box(ypad, W0, 1, Mp0 * M1, Nf, 0, Nf, 0, Mf);
   }));
-  MFFT_TRY(stage("bwd_z", 0, [&] { return c2r_rows(W0, u, Mp0 * M1, M2, Mf, M2, 1.0 / (double)M2); }));
+  MFFT_TRY(stage("bwd_z", 0, [&] {
+    if (!r2c) return c2c_rows(W0, u, Mp0 * M1, M2, M2, M2, true, 1.0 / (double)M2);
+    return c2r_rows(W0, u, Mp0 * M1, M2, Mf, M2, 1.0 / (double)M2);
+  }));
   return 0;
 }
 
 int mfft_plan_s::slab_forward_padded(const void* u, void* fu) {
-  if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
   if (P > 1 && P > N0 / 2) return set_error(MFFT_ERR_INVALID, "number of ranks cannot exceed N[0]/2 for the 3/2-rule");
   const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
   const int64_t Mp0 = M0 / P;
   MFFT_TRY(ensure_work(0, (size_t)std::max(Mp0 * M1 * Mf, M0 * Np1 * Nf) * es));
   MFFT_TRY(ensure_work(1, (size_t)std::max(Mp0 * N1 * Nf, M0 * Np1 * Nf) * es));
-  MFFT_TRY(ensure_work(2, (size_t)(M0 * Np1 * Nf) * es));
+  MFFT_TRY(ensure_work(2, (size_t)std::max(M0 * Np1 * Nf, r2c ? (int64_t)0 : Mp0 * M1 * Nf) * es));
   void *W0 = work[0], *W1 = work[1], *W2 = work[2];
-  MFFT_TRY(stage("fwd_z", 0, [&] { return r2c_rows(u, W0, Mp0 * M1, M2, M2, Mf); }));
+  MFFT_TRY(stage("fwd_z", 0, [&] {
+    if (!r2c) return c2c_rows(u, W0, Mp0 * M1, M2, M2, M2, false, 1.0);
+    return r2c_rows(u, W0, Mp0 * M1, M2, M2, Mf);
+  }));
   MFFT_TRY(stage("fwd_y", 0, [&] { return col(W0, W0, M1, false, Mp0, Mf, M1 * Mf, plain(Mf), M1 * Mf, plain(Mf)); }));
-  // truncate y and z: (Mp0, M1, Mf) -> (Mp0, N1, Nf)   (slab.py:459 copy_from_padded axis 1)
-  MFFT_TRY(stage("trunc_y", 0, [&] { return trunc_axis(W0, W1, Mp0, N1, M1, Nf, Mf, 1.0); }));
+  // truncate y and z: (Mp0, M1, Mf) -> (Mp0, N1, Nf)   (slab.py:459 / C2C: 782 copy_from_padded axis 1).
+  // The reference's C2C folds the Nyquist modes of y and z for P > 1 and does plain corner
+  // copies (no fold) on one rank (slab.py:736-739); both are reproduced.
+  const bool c2c_fold = P > 1;
+  MFFT_TRY(stage("trunc_y", 0, [&] {
+    if (r2c) return trunc_axis(W0, W1, Mp0, N1, M1, Nf, Mf, 1.0);
+    MFFT_TRY(trunc_axis(W0, W2, Mp0 * M1, N2, M2, 1, 1, 1.0, c2c_fold));
+    return trunc_axis(W2, W1, Mp0, N1, M1, N2, N2, 1.0, c2c_fold);
+  }));
   void* xin = W1;
   if (P > 1) {
     // pack (Mp0, P, Np1, Nf) -> (P, Mp0, Np1, Nf) and exchange
@@ -532,7 +551,8 @@ int mfft_plan_s::slab_forward_padded(const void* u, void* fu) {
     xin = W2;
   }
   MFFT_TRY(stage("fwd_x", 0, [&] { return col(xin, xin, M0, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
-  MFFT_TRY(stage("trunc_x", 0, [&] { return trunc_axis(xin, fu, 1, N0, M0, Np1 * Nf, Np1 * Nf, isc3); }));
+  // R2C folds the x Nyquist plane (slab.py:480-482); C2C copies the two halves (slab.py:796-797)
+  MFFT_TRY(stage("trunc_x", 0, [&] { return trunc_axis(xin, fu, 1, N0, M0, Np1 * Nf, Np1 * Nf, isc3, r2c); }));
   return 0;
 }
 

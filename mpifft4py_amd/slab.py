@@ -188,13 +188,3 @@ class C2C(R2C):
 
     def _in_dtype(self):
         return self.complex
-
-    def fftn(self, u, fu, dealias=None):
-        if dealias == '3/2-rule':
-            raise NotImplementedError("C2C 3/2-rule transforms are not implemented on the device yet")
-        return R2C.fftn(self, u, fu, dealias)
-
-    def ifftn(self, fu, u, dealias=None):
-        if dealias == '3/2-rule':
-            raise NotImplementedError("C2C 3/2-rule transforms are not implemented on the device yet")
-        return R2C.ifftn(self, fu, u, dealias)

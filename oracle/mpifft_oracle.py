@@ -344,6 +344,70 @@ def slab_r2c_forward_padded(us, N, precision="double", padsize=1.5):
 
 
 # --------------------------------------------------------------------------
+# slab C2C, 3/2-rule (slab.py:618-632, 671-698, 727-741, 774-799).  The reference
+# treats the Nyquist modes differently for P == 1 (plain corner copies, no fold)
+# and P > 1 (copy_from_padded folds y and z, the final x truncation does not);
+# both branches are restated as they are.  Padded work arrays are zero outside
+# the copied corners (first-use state of the reference's work-array cache).
+# --------------------------------------------------------------------------
+
+def trunc_axis_nofold(fp, n, axis):
+    """out[:n/2] = fp[:n/2]; out[n/2:] = fp[-n/2:]   (slab.py:736-739, 796-797)."""
+    npad = fp.shape[axis]
+    lo = [slice(None)] * fp.ndim
+    hi = [slice(None)] * fp.ndim
+    lo[axis] = slice(0, n // 2)
+    hi[axis] = slice(npad - n // 2, npad)
+    return np.concatenate([fp[tuple(lo)], fp[tuple(hi)]], axis=axis)
+
+
+def slab_c2c_backward_padded(fus, N, precision="double", padsize=1.5):
+    P = len(fus)
+    lay = SlabLayout(N, P, kind="C2C", padsize=padsize)
+    _, ctype = dtypes(precision)
+    N = lay.N
+    M0, M1, M2 = (int(padsize * n) for n in N)
+    if P == 1:
+        f = fus[0] * padsize ** 3
+        f = pad_axis(pad_axis(pad_axis(f, M0, int(N[0]), 0), M1, int(N[1]), 1), M2, int(N[2]), 2)
+        return [np.fft.ifftn(f, axes=(0, 1, 2)).astype(ctype)]
+    Mp0, Np1, Nf = int(padsize * lay.Np[0]), int(lay.Np[1]), lay.Nf
+    a = [np.fft.ifft(pad_axis(f * padsize ** 3, M0, int(N[0]), 0), axis=0).astype(ctype) for f in fus]
+    recv = alltoall_world(a)
+    out = []
+    for r in recv:
+        x = slab_unpack(r.reshape(P, Mp0, Np1, Nf))
+        x = np.fft.ifft(pad_axis(x, M1, int(N[1]), 1), axis=1).astype(ctype)
+        x = np.fft.ifft(pad_axis(x, M2, int(N[2]), 2), axis=2).astype(ctype)
+        out.append(x)
+    return out
+
+
+def slab_c2c_forward_padded(us, N, precision="double", padsize=1.5):
+    P = len(us)
+    lay = SlabLayout(N, P, kind="C2C", padsize=padsize)
+    _, ctype = dtypes(precision)
+    N = lay.N
+    if P == 1:
+        fp = np.fft.fftn(us[0], axes=(0, 1, 2)).astype(ctype)
+        for ax in (2, 1, 0):
+            fp = trunc_axis_nofold(fp, int(N[ax]), ax)
+        return [(fp / padsize ** 3).astype(ctype)]
+    Mp0, Np1, Nf = int(padsize * lay.Np[0]), int(lay.Np[1]), lay.Nf
+    a = []
+    for u in us:
+        x = np.fft.fft2(u, axes=(1, 2)).astype(ctype)
+        x = trunc_axis(trunc_axis(x, int(N[2]), 2), int(N[1]), 1)     # copy_from_padded: folds in y and z
+        a.append(slab_pack(x, P))
+    recv = alltoall_world(a)
+    out = []
+    for r in recv:
+        x = np.fft.fft(r.reshape(P * Mp0, Np1, Nf), axis=0).astype(ctype)
+        out.append((trunc_axis_nofold(x, int(N[0]), 0) / padsize ** 3).astype(ctype))
+    return out
+
+
+# --------------------------------------------------------------------------
 # pencil layouts (pencil.py:190-199, 248-287, 908-943)
 # --------------------------------------------------------------------------
 

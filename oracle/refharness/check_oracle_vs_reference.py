@@ -40,6 +40,14 @@ def run_ref_slab(N, P, prec, mode, A, padded=False, kind="R2C"):
                    real_slice=F.real_local_slice(), complex_slice=F.complex_local_slice())
         ctype = F.complex
         rtype = F.float if kind == "R2C" else F.complex
+        if padded and kind == "C2C":
+            c = np.zeros(F.complex_shape(), dtype=ctype)
+            c[:] = A[F.complex_local_slice()]
+            ap = np.zeros(F.real_shape_padded(), dtype=ctype)
+            ap = F.ifftn(c, ap, dealias="3/2-rule")
+            cp = np.zeros(F.complex_shape(), dtype=ctype)
+            cp = F.fftn(ap.copy(), cp, dealias="3/2-rule")
+            return lay, ap.copy(), cp.copy()
         if not padded:
             a = np.zeros(F.real_shape(), dtype=rtype)
             a[:] = A[F.real_local_slice()]
@@ -138,6 +146,16 @@ def check_slab_c2c(N, P, prec, rng):
         assert rl["complex_shape"] == lay.complex_shape()
         worst = max(worst, orc.rel_l2(fus[r], rc), orc.rel_l2(back[r], rb))
     assert worst < _tol(prec), worst
+    # 3/2-rule (fresh reference objects: their padded work arrays are still zero)
+    C = np.fft.fftn(A.astype(np.complex128)).astype(ctype)
+    if P == 1 or P <= N[0] // 2:
+        refp = run_ref_slab(N, P, prec, "Alltoall", C, padded=True, kind="C2C")
+        cs = [np.ascontiguousarray(C[lay.complex_local_slice(r)]) for r in range(P)]
+        ap = orc.slab_c2c_backward_padded(cs, N, prec)
+        cp = orc.slab_c2c_forward_padded(ap, N, prec)
+        for r in range(P):
+            worst = max(worst, orc.rel_l2(ap[r], refp[r][1]), orc.rel_l2(cp[r], refp[r][2]))
+        assert worst < _tol(prec), worst
     return worst
 
 

@@ -90,7 +90,8 @@ def run_case(make, P, A, padded, real_dtype_of):
         cp = np.zeros(F.complex_shape(), dtype=F.complex)
         cp = F.fftn(ap.copy(), cp, dealias="3/2-rule")
         return (F.real_local_slice(padsize=1.5), ap.copy(), F.complex_local_slice(), cp.copy(),
-                tuple(int(1.5 * n) for n in F.N), F.global_complex_shape())
+                tuple(int(1.5 * n) for n in F.N),
+                F.global_shape() if hasattr(F, "global_shape") else F.global_complex_shape())
     res = fake_mpi.run(P, body)
     g1 = _gather([r[1] for r in res], [r[0] for r in res], res[0][4], res[0][1].dtype)
     g2 = _gather([r[3] for r in res], [r[2] for r in res], res[0][5], res[0][3].dtype)
@@ -204,6 +205,15 @@ def main():
             C, B = run_case(mk, P, Ac, False, lambda F: F.complex)
             out["slabc2c_P%d_fwd" % P] = C
             out["slabc2c_P%d_bwd" % P] = B
+        # slab C2C 3/2-rule (fresh objects per run: padded work arrays are zero, see oracle notes)
+        Cc = np.fft.fftn(Ac.astype(np.complex128)).astype(ct)
+        out["Cc"] = Cc
+        for P in (1, 2):
+            mk = lambda: RefSlabC2C(np.array(N), L, MPI.COMM_WORLD, prec)
+            AP, CP = run_case(mk, P, Cc, True, lambda F: F.complex)
+            if P == 2:
+                out["slabc2c_P%d_pad_bwd" % P] = AP
+            out["slabc2c_P%d_pad_fwd" % P] = CP
         np.savez_compressed(os.path.join(OUT, "ref_8x16x32_%s.npz" % prec), **out)
 
     demo = {"k_expected_demo": 0.124953117517}

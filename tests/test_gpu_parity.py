@@ -408,3 +408,54 @@ def test_unsupported_mesh_raises_cleanly():
         Slab_R2C(np.array([7, 8, 8]), L, SelfComm(0), "double")
     with pytest.raises(_lib.MfftError):          # odd real axis
         Slab_R2C(np.array([8, 8, 9]), L, SelfComm(0), "double")
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_slab_c2c_padded(P, prec, golden_dir):
+    """3/2-rule for the C2C class (the padded half of the reference's test_FFT_C2C,
+    tests/test_FFT.py:213-258), against the oracle (pinned to the reference, including its
+    different Nyquist handling for P == 1 and P > 1) and against the reference's own arrays."""
+    from mpifft4py_amd import Slab_C2C
+    rng = np.random.default_rng(700 + P)
+    N = NREF
+    A = (rng.random(N) + 1j * rng.random(N))
+    C = np.fft.fftn(A).astype(cdtype(prec))
+    lay = orc.SlabLayout(N, P, kind="C2C")
+    cs_in = [np.ascontiguousarray(C[lay.complex_local_slice(r)]) for r in range(P)]
+    want_ap = orc.slab_c2c_backward_padded(cs_in, N, prec)
+    want_cp = orc.slab_c2c_forward_padded(want_ap, N, prec)
+
+    def body(comm):
+        F = Slab_C2C(np.array(N), L, comm, prec)
+        r = comm.Get_rank()
+        ap = F.ifftn(cs_in[r], np.zeros(F.original_shape_padded(), dtype=F.complex), dealias="3/2-rule")
+        ap2 = F.ifftn(cs_in[r], np.zeros(F.original_shape_padded(), dtype=F.complex), dealias="3/2-rule")
+        assert np.array_equal(ap, ap2)          # repeatable (the reference's cached work arrays are not)
+        cp = F.fftn(ap, np.zeros(F.transformed_shape(), dtype=F.complex), dealias="3/2-rule")
+        return ap, cp
+    for r, (ap, cp) in enumerate(run_ranks(P, body)):
+        assert orc.rel_l2(ap, want_ap[r]) < 4 * TOL[prec]
+        assert orc.rel_l2(cp, want_cp[r]) < 4 * TOL[prec]
+    # the reference's arrays at N = [8, 16, 32]
+    g = np.load(os.path.join(golden_dir, "ref_8x16x32_%s.npz" % prec))
+    if P <= 2:
+        Ng = [8, 16, 32]
+        Cc = g["Cc"]
+
+        def body2(comm):
+            F = Slab_C2C(np.array(Ng), L, comm, prec)
+            c = np.ascontiguousarray(Cc[F.transformed_local_slice()])
+            ap = F.ifftn(c, np.zeros(F.original_shape_padded(), dtype=F.complex), dealias="3/2-rule")
+            cp = F.fftn(ap, np.zeros(F.transformed_shape(), dtype=F.complex), dealias="3/2-rule")
+            return F.original_local_slice(padsize=1.5), ap, F.transformed_local_slice(), cp
+        res = run_ranks(P, body2)
+        CP = np.zeros(Ng, dtype=cdtype(prec))
+        for _, _, cs, cp in res:
+            CP[cs] = cp
+        assert orc.rel_l2(CP, g["slabc2c_P%d_pad_fwd" % P]) < 4 * TOL[prec]
+        if P == 2:
+            AP = np.zeros([12, 24, 48], dtype=cdtype(prec))
+            for rs, ap, _, _ in res:
+                AP[rs] = ap
+            assert orc.rel_l2(AP, g["slabc2c_P2_pad_bwd"]) < 4 * TOL[prec]

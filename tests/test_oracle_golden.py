@@ -137,3 +137,19 @@ def test_pencil_c2c_extension_is_a_dft(align):
         for r, part in enumerate(fus):
             C[lay.complex_local_slice(r)] = part
         assert orc.rel_l2(C, np.fft.fftn(A)) < 1e-14
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_slab_c2c_padded(gold, P):
+    prec, g = gold
+    lay = orc.SlabLayout(N, P, kind="C2C")
+    cs = [np.ascontiguousarray(g["Cc"][lay.complex_local_slice(r)]) for r in range(P)]
+    ap = orc.slab_c2c_backward_padded(cs, N, prec)
+    cp = orc.slab_c2c_forward_padded(ap, N, prec)
+    CP = np.zeros(N, dtype=cp[0].dtype)
+    for r, part in enumerate(cp):
+        CP[lay.complex_local_slice(r)] = part
+    assert orc.rel_l2(CP, g["slabc2c_P%d_pad_fwd" % P]) < TOL[prec]
+    if P == 2:
+        AP = orc.gather_real(ap, lay, ap[0].dtype, 1.5)
+        assert orc.rel_l2(AP, g["slabc2c_P2_pad_bwd"]) < TOL[prec]
