@@ -48,6 +48,29 @@ def make_comm(world, rendezvous):
     return mcomm.from_env(bcast), dist
 
 
+def pmc_traffic(n, precision, decomp, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json, written by scripts/summarize_profiles.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None if no profile matches."""
+    import glob
+    if world != 1 or decomp != "slab":
+        return None, None
+    want = "ColFft n=%d" % n
+    tname = "double" if precision == "double" else "float"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            prof = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        if ("%d^3" % n) not in prof.get("workload", ""):
+            continue
+        vals = [v["hbm_bytes_per_launch"] for k, v in prof["kernels"].items()
+                if k.startswith(want + "x") and (" %s " % tname) in k]
+        if vals:
+            return sum(vals) / len(vals), os.path.basename(path)
+    return None, None
+
+
 def cpu_baseline(n_full, seconds_budget=30.0):
     """The oracle's path for P = 1 (numpy.fft semantics: rfftn + irfftn, slab.py:369/249)
     timed on the host cores with scipy.fft's pocketfft and all cores, on a bounded
@@ -165,6 +188,7 @@ def main():
         col_bytes = col[0][1][2] if col else 0.0
         avg_ms = col_ms / max(col_calls, 1)
         achieved = (col_bytes / (avg_ms * 1e-3)) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(n, args.precision, args.decomp, world)
         out = {
             "metric": "3D R2C+C2R pairs/sec, %d^3 fp64 %s" % (n, args.decomp),
             "value": args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -180,7 +204,7 @@ def main():
                        "stage_ms": {k_: v[0] / max(v[1], 1) for k_, v in sorted(stages.items())}},
             "roofline": {"bound": "hbm", "kernel": "col_fft (strided-axis c2c, stages *_x/*_y)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": col_bytes, "avg_launch_ms": avg_ms},
         }
         if world == 1 and args.cpu_baseline == "auto":

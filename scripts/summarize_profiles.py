@@ -1,0 +1,67 @@
+"""Turn rocprofv3 output directories (kernel trace + separate FETCH_SIZE / WRITE_SIZE
+--pmc passes of the same bench.py command) into the small files kept under profiles/.
+
+    python scripts/summarize_profiles.py <tag> <trace_dir> <fetch_dir> <write_dir> "<workload>"
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in
+KiB and on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced reads
+(MI355X_MICROARCH.md, "HBM"); calibrated here on the r2c kernel, whose read volume is
+exactly the real array.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+
+def short(name):
+    m = re.search(r"mfft::(ColFft|RowFft|R2CFft|C2RFft)<mfft::Spec<([\d, ]+)>, (\w+), (\d+), (\w+)([\w, ]*)>", name)
+    if not m:
+        return re.sub(r"\(.*", "", name)[:60]
+    fam, spec, prec, tile, flag, rest = m.groups()
+    extra = ""
+    if fam in ("ColFft", "RowFft"):
+        extra = " inv" if flag == "true" else " fwd"
+    if fam == "ColFft" and rest.strip().endswith("true"):
+        extra += " nt"
+    return "%s n=%s %s tile=%s%s" % (fam, spec.replace(", ", "x"), prec, tile, extra)
+
+
+def pmc(dirname):
+    f = glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True)[0]
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        agg[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+
+
+def main():
+    tag, trace_dir, fetch_dir, write_dir, workload = sys.argv[1:6]
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    stats = glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats, os.path.join(out_dir, "%s_kernel_stats.csv" % tag))
+    fetch, nf = pmc(fetch_dir)
+    write, _ = pmc(write_dir)
+    kern = {}
+    for row in csv.DictReader(open(stats)):
+        kern[short(row["Name"])] = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6}
+    res = {"workload": workload, "kernels": {}}
+    for k in fetch:
+        if k not in write:
+            continue
+        res["kernels"][k] = {
+            "FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write[k], "dispatches_sampled": nf[k],
+            "hbm_bytes_per_launch": (2.0 * fetch[k] + write[k]) * 1024.0,
+            "avg_ms_kernel_trace": kern.get(k, {}).get("avg_ms"),
+        }
+    with open(os.path.join(out_dir, "%s_pmc_traffic.json" % tag), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
