@@ -153,3 +153,25 @@ def test_slab_c2c_padded(gold, P):
     if P == 2:
         AP = orc.gather_real(ap, lay, ap[0].dtype, 1.5)
         assert orc.rel_l2(AP, g["slabc2c_P2_pad_bwd"]) < TOL[prec]
+
+
+def test_oracle_vs_reference_compiled_helpers():
+    """oracle/_ref/ref_maths = the reference's own Cython loops (cython/maths.pyx), compiled by
+    oracle/build_ref.py from /root/reference.  Bit-exact comparison of the oracle's restatements."""
+    from oracle import build_ref
+    ref = build_ref.load()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference not mounted)")
+    rng = np.random.default_rng(8)
+    for dt in (np.complex128, np.complex64):
+        P, Np0, Np1, Nf = 4, 3, 5, 9
+        U = (rng.random((P, Np0, Np1, Nf)) + 1j * rng.random((P, Np0, Np1, Nf))).astype(dt)
+        T = np.zeros((Np0, P * Np1, Nf), dtype=dt)
+        ref.transpose_Uc(T, U, P, Np0, Np1, Nf)                      # maths.pyx:21-31
+        assert np.array_equal(T, orc.slab_unpack(U))
+        assert np.array_equal(orc.slab_pack(T, P), U)
+        fu = (rng.random((6, 7, 5)) + 1j * rng.random((6, 7, 5))).astype(dt)
+        mask = (rng.random(fu.shape) > 0.5).astype(np.uint8)
+        want = orc.apply_mask(fu, mask).astype(dt)
+        got = ref.dealias_filter(fu.copy(), mask)                     # maths.pyx:9-19
+        assert np.array_equal(got, want)
