@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--rendezvous", default="file", choices=["file", "torch"],
                     help="how rank 0's RCCL unique id reaches the other ranks (torch = gloo process group)")
+    ap.add_argument("--pencil-extra", default="auto", choices=["auto", "on", "off"],
+                    help="also time the pencil (R2CX) decomposition of the same cube and report it under 'extras'")
     ap.add_argument("--stage-timing", default="on", choices=["on", "off"],
                     help="HIP events around every stage inside the timed region (roofline numbers)")
     args = ap.parse_args()
@@ -175,6 +177,40 @@ def main():
     b0 = u2.leading(0, k).get()
     rt_err = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
 
+    # ---- secondary measurement: the pencil path on the same cube (needs a P1 x P2 grid with
+    # even factors, i.e. 4 or 8 ranks, or the degenerate 1 x 1 grid as the 1-GPU denominator)
+    extras = {}
+    want_pencil = args.pencil_extra == "on" or (args.pencil_extra == "auto" and args.decomp == "slab"
+                                                 and world in (1, 4, 8, 16))
+    if want_pencil:
+        try:
+            del F
+            Fp = Pencil_R2C(N, L, comm, args.precision, communication="Alltoallw", alignment="X", allow_single=True)
+            up = DeviceArray.random(Fp.real_shape(), Fp.float, seed=99 + rank)
+            fup = DeviceArray.empty(Fp.complex_shape(), Fp.complex)
+            up2 = DeviceArray.empty(Fp.real_shape(), Fp.float)
+            for _ in range(2):
+                Fp.fftn(up, fup)
+                Fp.ifftn(fup, up2)
+            Fp.sync()
+            comm.barrier()
+            ksteps = max(3, min(args.steps, 10))
+            tp = time.perf_counter()
+            for _ in range(ksteps):
+                Fp.fftn(up, fup)
+                Fp.ifftn(fup, up2)
+            Fp.sync()
+            comm.barrier()
+            dtp = time.perf_counter() - tp
+            dtp = comm.allreduce(dtp, op=mcomm.MAX) if world > 1 else dtp
+            a0 = up.leading(0, 1).get()
+            b0 = up2.leading(0, 1).get()
+            extras["pencil_R2CX"] = {"grid": [int(Fp.P1), int(Fp.P2)], "pairs_per_s": ksteps / dtp,
+                                     "ms_per_pair": 1e3 * dtp / ksteps, "steps": ksteps,
+                                     "roundtrip_rel_l2": float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))}
+        except Exception as e:      # noqa: BLE001  - the headline (slab) line must survive
+            extras["pencil_R2CX"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         esz = 8 if args.precision == "double" else 4
         R = esz * n ** 3
@@ -207,6 +243,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": col_bytes, "avg_launch_ms": avg_ms},
         }
+        out["extras"] = extras
         if world == 1 and args.cpu_baseline == "auto":
             out["cpu_baseline"] = cpu_baseline(n)
         else:

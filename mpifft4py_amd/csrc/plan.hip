@@ -576,37 +576,35 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
   const int64_t m = N1_0, n = N2_1;                 // local real rows in x, y
   const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
   const bool X = d.decomp == MFFT_PENCIL_X;
-  const std::vector<int>& gz = X ? group1 : group0;  // group of the z-splitting exchange
-  const int Pz = (int)gz.size();
+  // a group of one rank exchanges nothing: its pack / copy steps are skipped altogether
+  const bool zsolo = (X ? P2 : P1) == 1, g2solo = (X ? P1 : P2) == 1;
   const size_t wb = (size_t)std::max(m * n * Nf, std::max(m * N1 * q, N0 * n * q)) * es;
   MFFT_TRY(ensure_work(0, wb));
   MFFT_TRY(ensure_work(1, wb));
   void *W0 = work[0], *W1 = work[1];
   MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, W0, m * n, N2, Nf); }));
-  MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, m * n, Nf, zc, false); }));
-  std::vector<size_t> sc(Pz), sd(Pz), rc(Pz), rd(Pz);
-  size_t off = 0;
-  for (int l = 0; l < Pz; ++l) {
-    sc[l] = (size_t)(m * n * zc[l].len) * es;
-    sd[l] = off;
-    off += sc[l];
-    rc[l] = (size_t)(m * n * q) * es;
-    rd[l] = (size_t)l * rc[l];
+  if (!zsolo) {
+    MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, m * n, Nf, zc, false); }));
+    MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, false, W1, W0); }));
   }
-  MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, false, W1, W0); }));
   if (X) {
     // W0 = P2 blocks (m, n, q) -> y transform (gathers y through two-level rows) -> P1 blocks (m, N1_1, q)
+    void* ydst = g2solo ? fu : W1;
     MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
-      return col(W0, W1, N1, false, m, q, n * q, two_level(n, m * n * q, q), N1_1 * q, two_level(N1_1, m * N1_1 * q, q));
+      return col(W0, ydst, N1, false, m, q, n * q, two_level(n, m * n * q, q), N1_1 * q, two_level(N1_1, m * N1_1 * q, q));
     }));
-    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W1, fu); }));
+    if (!g2solo) MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W1, fu); }));
     MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
   } else {
     // W0 = (N0, n, q): x transform in place, x chunks are contiguous -> exchange -> y transform gathers
     MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, W0, N0, false, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
-    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W0, W1); }));
+    void* ysrc = W0;
+    if (!g2solo) {
+      MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W0, W1); }));
+      ysrc = W1;
+    }
     MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
-      return col(W1, fu, N1, false, N2_0, q, n * q, two_level(n, N2_0 * n * q, q), N1 * q, plain(q));
+      return col(ysrc, fu, N1, false, N2_0, q, n * q, two_level(n, N2_0 * n * q, q), N1 * q, plain(q));
     }));
   }
   return 0;
@@ -616,8 +614,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
   const int64_t m = N1_0, n = N2_1;
   const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
   const bool X = d.decomp == MFFT_PENCIL_X;
-  const std::vector<int>& gz = X ? group1 : group0;
-  const int Pz = (int)gz.size();
+  const bool zsolo = (X ? P2 : P1) == 1, g2solo = (X ? P1 : P2) == 1;
   const void* src = fu;
   if (masked) {
     void* mm = nullptr;
@@ -628,32 +625,36 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
   MFFT_TRY(ensure_work(0, wb));
   MFFT_TRY(ensure_work(1, wb));
   void *W0 = work[0], *W1 = work[1];
+  void* cur = nullptr;     // buffer holding the Pz blocks (m, n, q) that enter the z-gathering exchange
   if (X) {
     MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, W0, N0, true, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
-    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, false, W0, W1); }));
+    void* ysrc = W0;
+    if (!g2solo) {
+      MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, false, W0, W1); }));
+      ysrc = W1;
+    }
+    cur = ysrc == W0 ? W1 : W0;
     MFFT_TRY(stage("bwd_y", 2 * Cb, [&] {
-      return col(W1, W0, N1, true, m, q, N1_1 * q, two_level(N1_1, m * N1_1 * q, q), n * q, two_level(n, m * n * q, q));
+      return col(ysrc, cur, N1, true, m, q, N1_1 * q, two_level(N1_1, m * N1_1 * q, q), n * q, two_level(n, m * n * q, q));
     }));
   } else {
     MFFT_TRY(stage("bwd_y", 2 * Cb, [&] {
       return col(src, W0, N1, true, N2_0, q, N1 * q, plain(q), n * q, two_level(n, N2_0 * n * q, q));
     }));
-    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, false, W0, W1); }));
-    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(W1, W0, N0, true, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+    cur = W0;
+    if (!g2solo) {
+      MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, false, W0, W1); }));
+      cur = W1;
+    }
+    // (N0, n, q): x transform in place; its x chunks are the contiguous blocks of the next exchange
+    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(cur, cur, N0, true, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
   }
-  // W0 holds Pz blocks (m, n, q) (for Y: x chunks of (N0, n, q), also contiguous)
-  std::vector<size_t> sc(Pz), sd(Pz), rc(Pz), rd(Pz);
-  size_t off = 0;
-  for (int l = 0; l < Pz; ++l) {
-    sc[l] = (size_t)(m * n * q) * es;
-    sd[l] = (size_t)l * sc[l];
-    rc[l] = (size_t)(m * n * zc[l].len) * es;
-    rd[l] = off;
-    off += rc[l];
+  if (!zsolo) {
+    void* other = cur == W0 ? W1 : W0;
+    MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, false, cur, other); }));
+    MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z(this, cur, other, m * n, Nf, zc, true); }));
   }
-  MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, false, W0, W1); }));
-  MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z(this, W0, W1, m * n, Nf, zc, true); }));
-  MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(W0, u, m * n, N2, Nf); }));
+  MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(cur, u, m * n, N2, Nf); }));
   return 0;
 }
 
