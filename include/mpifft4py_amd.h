@@ -148,6 +148,20 @@ MFFT_API int mfft_dealias_filter(void* fu, const uint8_t* mask_dev, size_t count
 /* 1 if a transform of length n along an axis is supported */
 MFFT_API int mfft_length_supported(int64_t n, int real_transform);
 
+/* ---- element-wise pieces of a pseudo-spectral Navier-Stokes step on device-resident
+ * fields (what the reference demo does with numpy on the host,
+ * demo/spectral_dns_solver.py:53-80).  Vector fields are (3, n) component-major; kx/ky/kz
+ * are 1-D device vectors of the local spectral extents shape[0..2].  Enqueued on the
+ * plan's stream (in order with its transforms); plan may be NULL (default stream). */
+MFFT_API int mfft_ew_cross(mfft_plan_t plan, const void* a, const void* b, void* out, size_t n, int precision);          /* demo:53-58 */
+MFFT_API int mfft_ew_curl_hat(mfft_plan_t plan, const void* U_hat, void* out, const void* kx, const void* ky, const void* kz,
+                              const int64_t shape[3], int precision);                                   /* demo:60-64 */
+MFFT_API int mfft_ew_ns_rhs(mfft_plan_t plan, void* dU, const void* U_hat, const void* kx, const void* ky, const void* kz,
+                            const int64_t shape[3], double nu, int precision);                          /* demo:73-77 */
+MFFT_API int mfft_ew_axpbz(mfft_plan_t plan, void* y, const void* x, const void* z, double alpha, double beta, size_t n_real,
+                           int precision);                                                              /* demo:94-97 */
+MFFT_API int mfft_ew_sumsq(mfft_plan_t plan, const void* x, size_t n_real, int precision, double* result_host);           /* demo:103 */
+
 /* ---- HIP-event timers on the default stream (bench.py) ------------------ */
 typedef struct mfft_timer_s* mfft_timer_t;
 MFFT_API int mfft_timer_create(mfft_timer_t* t);

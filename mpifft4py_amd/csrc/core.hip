@@ -217,19 +217,22 @@ int launch_c2r(const RealArgs& a, hipStream_t s) { return launch_real(FAM_C2R, a
 // ---------------------------------------------------------------------------
 // data-movement kernels
 // ---------------------------------------------------------------------------
-// One workgroup row-chunk per (i, j): threads stride over the contiguous k run
-// in 16-byte units when alignment allows (VEC elements of the scalar type R).
+// Work unit = (row (i, j), chunk of CHUNK contiguous elements of that row); threads of
+// blockDim.x stride over the chunk, blockDim.y units per block, grid-stride over units.
+// Long rows (pad / truncate of whole planes) and many short rows (z chunks) both fill the chip.
+constexpr int64_t BOX_CHUNK = 2048;
+
 template <typename R, int MODE>
 __global__ __launch_bounds__(256) void box_copy_kernel(const R* __restrict__ src, R* __restrict__ dst,
                                                        int64_t e1, int64_t e2, int64_t s0, int64_t s1,
-                                                       int64_t d0, int64_t d1, R scale, int64_t nrows) {
-  // e2, strides in units of R; grid-stride over rows (i*e1 + j), blockDim.y rows per block
-  for (int64_t row = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; row < nrows;
-       row += (int64_t)gridDim.x * blockDim.y) {
+                                                       int64_t d0, int64_t d1, R scale, int64_t nunits, int64_t nchunks) {
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; u < nunits; u += (int64_t)gridDim.x * blockDim.y) {
+    const int64_t row = u / nchunks, c = u - row * nchunks;
     const int64_t i = row / e1, j = row - i * e1;
     const R* sp = src + i * s0 + j * s1;
     R* dp = dst + i * d0 + j * d1;
-    for (int64_t k = threadIdx.x; k < e2; k += blockDim.x) {
+    const int64_t k1 = (c + 1) * BOX_CHUNK < e2 ? (c + 1) * BOX_CHUNK : e2;
+    for (int64_t k = c * BOX_CHUNK + threadIdx.x; k < k1; k += blockDim.x) {
       R v = sp[k] * scale;
       if (MODE == 1) v += dp[k];
       dp[k] = v;
@@ -241,31 +244,41 @@ struct alignas(16) vec16 { double a, b; };
 template <int MODE>
 __global__ __launch_bounds__(256) void box_copy16_kernel(const vec16* __restrict__ src, vec16* __restrict__ dst,
                                                          int64_t e1, int64_t e2, int64_t s0, int64_t s1,
-                                                         int64_t d0, int64_t d1, int64_t nrows) {
-  for (int64_t row = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; row < nrows;
-       row += (int64_t)gridDim.x * blockDim.y) {
+                                                         int64_t d0, int64_t d1, int64_t nunits, int64_t nchunks) {
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; u < nunits; u += (int64_t)gridDim.x * blockDim.y) {
+    const int64_t row = u / nchunks, c = u - row * nchunks;
     const int64_t i = row / e1, j = row - i * e1;
     const vec16* sp = src + i * s0 + j * s1;
     vec16* dp = dst + i * d0 + j * d1;
-    for (int64_t k = threadIdx.x; k < e2; k += blockDim.x) dp[k] = sp[k];
+    const int64_t k1 = (c + 1) * BOX_CHUNK < e2 ? (c + 1) * BOX_CHUNK : e2;
+    for (int64_t k = c * BOX_CHUNK + threadIdx.x; k < k1; k += blockDim.x) dp[k] = sp[k];
   }
 }
 
 int launch_box_copy(const BoxArgs& a, hipStream_t s) {
   const int64_t nrows = a.e0 * a.e1;
   if (nrows <= 0 || a.e2 <= 0) return 0;
-  // pick block shape: x covers the contiguous run, y packs several short rows
   const int unit = a.elem;    // bytes per element
   const bool plain = (a.mode == 0 && a.scale == 1.0);
+  auto shape = [&](int64_t e2, int* bx, int* by, int64_t* nchunks, int64_t* nunits, unsigned* grid) {
+    *nchunks = (e2 + BOX_CHUNK - 1) / BOX_CHUNK;
+    const int64_t run = e2 < BOX_CHUNK ? e2 : BOX_CHUNK;
+    int x = 64;
+    while (x < 256 && x < run) x *= 2;
+    *bx = x;
+    *by = 256 / x;
+    *nunits = nrows * *nchunks;
+    int64_t g = (*nunits + *by - 1) / *by;
+    if (g > 65536 * 2) g = 65536 * 2;
+    *grid = (unsigned)g;
+  };
+  int bx, by;
+  int64_t nchunks, nunits;
+  unsigned grid;
   if (plain && unit == 16) {
-    int bx = 64;
-    while (bx < 256 && bx < a.e2) bx *= 2;
-    const int by = 256 / bx;
-    int64_t grid = (nrows + by - 1) / by;
-    if (grid > 65536 * 4) grid = 65536 * 4;
-    hipLaunchKernelGGL(box_copy16_kernel<0>, dim3((unsigned)grid), dim3(bx, by), 0, s,
-                       static_cast<const vec16*>(a.src), static_cast<vec16*>(a.dst), a.e1, a.e2, a.s0, a.s1,
-                       a.d0, a.d1, nrows);
+    shape(a.e2, &bx, &by, &nchunks, &nunits, &grid);
+    hipLaunchKernelGGL(box_copy16_kernel<0>, dim3(grid), dim3(bx, by), 0, s, static_cast<const vec16*>(a.src),
+                       static_cast<vec16*>(a.dst), a.e1, a.e2, a.s0, a.s1, a.d0, a.d1, nunits, nchunks);
     MFFT_HIP(hipGetLastError());
     return 0;
   }
@@ -273,15 +286,11 @@ int launch_box_copy(const BoxArgs& a, hipStream_t s) {
   const int rbytes = a.prec == MFFT_DOUBLE ? 8 : 4;
   const int per = unit / rbytes;            // reals per element
   const int64_t e2 = a.e2 * per;
-  int bx = 64;
-  while (bx < 256 && bx < e2) bx *= 2;
-  const int by = 256 / bx;
-  int64_t grid = (nrows + by - 1) / by;
-  if (grid > 65536 * 4) grid = 65536 * 4;
+  shape(e2, &bx, &by, &nchunks, &nunits, &grid);
 #define MFFT_BOX(R, MODE)                                                                                   \
-  hipLaunchKernelGGL((box_copy_kernel<R, MODE>), dim3((unsigned)grid), dim3(bx, by), 0, s,                  \
+  hipLaunchKernelGGL((box_copy_kernel<R, MODE>), dim3(grid), dim3(bx, by), 0, s,                            \
                      static_cast<const R*>(a.src), static_cast<R*>(a.dst), a.e1, e2, a.s0 * per, a.s1 * per, \
-                     a.d0 * per, a.d1 * per, (R)a.scale, nrows)
+                     a.d0 * per, a.d1 * per, (R)a.scale, nunits, nchunks)
   if (a.prec == MFFT_DOUBLE) {
     if (a.mode == 1) MFFT_BOX(double, 1); else MFFT_BOX(double, 0);
   } else {

@@ -91,5 +91,6 @@ int launch_scale(void* data, size_t count_real, double scale, int prec, hipStrea
 int launch_fill_uniform(void* data, size_t count, int prec, uint64_t seed, hipStream_t s);
 
 bool length_supported(int64_t n, bool real_transform);
+hipStream_t plan_stream(mfft_plan_t plan);   // the plan's compute stream (nullptr plan -> default stream)
 
 }  // namespace mfft

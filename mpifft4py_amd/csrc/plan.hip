@@ -771,6 +771,10 @@ int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
   return 0;
 }
 
+namespace mfft {
+hipStream_t plan_stream(mfft_plan_t plan) { return plan ? plan->stream : nullptr; }
+}  // namespace mfft
+
 // ===========================================================================
 // C ABI
 // ===========================================================================

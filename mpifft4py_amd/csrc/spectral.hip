@@ -1,0 +1,168 @@
+// spectral.hip -- element-wise kernels of a pseudo-spectral Navier-Stokes step on
+// device-resident fields, so that the 36 transforms of an RK4 step are not
+// bracketed by PCIe copies (the reference demo does these in numpy on the host:
+// demo/spectral_dns_solver.py:53-80).  All HBM-bound, 16 B per lane where the
+// layout allows.  Fields are (3, n) component-major; wavenumbers are passed as
+// three 1-D device vectors of the local spectral extents.
+#include "mfft_internal.h"
+
+using namespace mfft;
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline unsigned ew_grid(size_t n) {
+  size_t g = (n + EW_BLOCK - 1) / EW_BLOCK;
+  return (unsigned)(g > 8192 ? 8192 : (g ? g : 1));
+}
+
+// out = a x b   (real space, demo:53-58)
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void cross_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                        T* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const T a0 = a[i], a1 = a[n + i], a2 = a[2 * n + i];
+    const T b0 = b[i], b1 = b[n + i], b2 = b[2 * n + i];
+    out[i] = a1 * b2 - a2 * b1;
+    out[n + i] = a2 * b0 - a0 * b2;
+    out[2 * n + i] = a0 * b1 - a1 * b0;
+  }
+}
+
+// out = i K x U   (spectral space, demo:60-64)
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void curl_kernel(const cx<T>* __restrict__ U, cx<T>* __restrict__ out,
+                                                       const T* __restrict__ kx, const T* __restrict__ ky,
+                                                       const T* __restrict__ kz, int64_t s1, int64_t s2, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int64_t k = (int64_t)(i % s2), j = (int64_t)((i / s2) % s1), l = (int64_t)(i / (s2 * s1));
+    const T K0 = kx[l], K1 = ky[j], K2 = kz[k];
+    const cx<T> u0 = U[i], u1 = U[n + i], u2 = U[2 * n + i];
+    // i * (a) = (-a.y, a.x)
+    const cx<T> c0 = mk<T>(K1 * u2.x - K2 * u1.x, K1 * u2.y - K2 * u1.y);
+    const cx<T> c1 = mk<T>(K2 * u0.x - K0 * u2.x, K2 * u0.y - K0 * u2.y);
+    const cx<T> c2 = mk<T>(K0 * u1.x - K1 * u0.x, K0 * u1.y - K1 * u0.y);
+    out[i] = mk<T>(-c0.y, c0.x);
+    out[n + i] = mk<T>(-c1.y, c1.x);
+    out[2 * n + i] = mk<T>(-c2.y, c2.x);
+  }
+}
+
+// pressure projection and viscous term (demo:73-77):
+//   P = sum_i dU_i K_i / |K|^2 ;  dU_i -= P K_i ;  dU_i -= nu |K|^2 U_i
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void rhs_kernel(cx<T>* __restrict__ dU, const cx<T>* __restrict__ U,
+                                                      const T* __restrict__ kx, const T* __restrict__ ky,
+                                                      const T* __restrict__ kz, int64_t s1, int64_t s2, size_t n, T nu) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int64_t k = (int64_t)(i % s2), j = (int64_t)((i / s2) % s1), l = (int64_t)(i / (s2 * s1));
+    const T K0 = kx[l], K1 = ky[j], K2 = kz[k];
+    const T k2 = K0 * K0 + K1 * K1 + K2 * K2;
+    const T inv = k2 == (T)0 ? (T)1 : (T)1 / k2;
+    cx<T> d0 = dU[i], d1 = dU[n + i], d2 = dU[2 * n + i];
+    const cx<T> P = mk<T>((d0.x * K0 + d1.x * K1 + d2.x * K2) * inv, (d0.y * K0 + d1.y * K1 + d2.y * K2) * inv);
+    const cx<T> u0 = U[i], u1 = U[n + i], u2 = U[2 * n + i];
+    const T v = nu * k2;
+    dU[i] = mk<T>(d0.x - P.x * K0 - v * u0.x, d0.y - P.y * K0 - v * u0.y);
+    dU[n + i] = mk<T>(d1.x - P.x * K1 - v * u1.x, d1.y - P.y * K1 - v * u1.y);
+    dU[2 * n + i] = mk<T>(d2.x - P.x * K2 - v * u2.x, d2.y - P.y * K2 - v * u2.y);
+  }
+}
+
+// y = alpha * x + beta * z   (any of the pointers may alias); counts in reals
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void axpbz_kernel(T* y, const T* x, const T* z, T alpha, T beta, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = alpha * x[i] + beta * z[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void sumsq_kernel(const T* __restrict__ x, size_t n, double* out) {
+  __shared__ double part[EW_BLOCK / 64];
+  double acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc += (double)x[i] * (double)x[i];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < EW_BLOCK / 64; ++w) t += part[w];
+    atomicAdd(out, t);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfft_ew_cross(mfft_plan_t plan, const void* a, const void* b, void* out, size_t n, int precision) {
+  hipStream_t st = plan_stream(plan);
+  if (!a || !b || !out) return set_error(MFFT_ERR_INVALID, "null argument");
+  if (precision == MFFT_DOUBLE)
+    hipLaunchKernelGGL(cross_kernel<double>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, (const double*)a, (const double*)b, (double*)out, n);
+  else
+    hipLaunchKernelGGL(cross_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, (const float*)a, (const float*)b, (float*)out, n);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+int mfft_ew_curl_hat(mfft_plan_t plan, const void* U_hat, void* out, const void* kx, const void* ky, const void* kz,
+                     const int64_t shape[3], int precision) {
+  hipStream_t st = plan_stream(plan);
+  if (!U_hat || !out || !kx || !ky || !kz || !shape) return set_error(MFFT_ERR_INVALID, "null argument");
+  const size_t n = (size_t)(shape[0] * shape[1] * shape[2]);
+  if (precision == MFFT_DOUBLE)
+    hipLaunchKernelGGL(curl_kernel<double>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, (const cx<double>*)U_hat,
+                       (cx<double>*)out, (const double*)kx, (const double*)ky, (const double*)kz, shape[1], shape[2], n);
+  else
+    hipLaunchKernelGGL(curl_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, (const cx<float>*)U_hat,
+                       (cx<float>*)out, (const float*)kx, (const float*)ky, (const float*)kz, shape[1], shape[2], n);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+int mfft_ew_ns_rhs(mfft_plan_t plan, void* dU, const void* U_hat, const void* kx, const void* ky, const void* kz,
+                   const int64_t shape[3], double nu, int precision) {
+  hipStream_t st = plan_stream(plan);
+  if (!dU || !U_hat || !kx || !ky || !kz || !shape) return set_error(MFFT_ERR_INVALID, "null argument");
+  const size_t n = (size_t)(shape[0] * shape[1] * shape[2]);
+  if (precision == MFFT_DOUBLE)
+    hipLaunchKernelGGL(rhs_kernel<double>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, (cx<double>*)dU,
+                       (const cx<double>*)U_hat, (const double*)kx, (const double*)ky, (const double*)kz, shape[1], shape[2], n, nu);
+  else
+    hipLaunchKernelGGL(rhs_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, (cx<float>*)dU,
+                       (const cx<float>*)U_hat, (const float*)kx, (const float*)ky, (const float*)kz, shape[1], shape[2], n, (float)nu);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+int mfft_ew_axpbz(mfft_plan_t plan, void* y, const void* x, const void* z, double alpha, double beta, size_t n_real, int precision) {
+  hipStream_t st = plan_stream(plan);
+  if (!y || !x || !z) return set_error(MFFT_ERR_INVALID, "null argument");
+  if (precision == MFFT_DOUBLE)
+    hipLaunchKernelGGL(axpbz_kernel<double>, dim3(ew_grid(n_real)), dim3(EW_BLOCK), 0, st, (double*)y, (const double*)x, (const double*)z, alpha, beta, n_real);
+  else
+    hipLaunchKernelGGL(axpbz_kernel<float>, dim3(ew_grid(n_real)), dim3(EW_BLOCK), 0, st, (float*)y, (const float*)x, (const float*)z, (float)alpha, (float)beta, n_real);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+int mfft_ew_sumsq(mfft_plan_t plan, const void* x, size_t n_real, int precision, double* result_host) {
+  hipStream_t st = plan_stream(plan);
+  if (!x || !result_host) return set_error(MFFT_ERR_INVALID, "null argument");
+  double* d = nullptr;
+  MFFT_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(double)));
+  MFFT_HIP(hipMemsetAsync(d, 0, sizeof(double), st));
+  if (precision == MFFT_DOUBLE)
+    hipLaunchKernelGGL(sumsq_kernel<double>, dim3(ew_grid(n_real)), dim3(EW_BLOCK), 0, st, (const double*)x, n_real, d);
+  else
+    hipLaunchKernelGGL(sumsq_kernel<float>, dim3(ew_grid(n_real)), dim3(EW_BLOCK), 0, st, (const float*)x, n_real, d);
+  MFFT_HIP(hipGetLastError());
+  MFFT_HIP(hipMemcpyAsync(result_host, d, sizeof(double), hipMemcpyDeviceToHost, st));
+  MFFT_HIP(hipStreamSynchronize(st));
+  MFFT_HIP(hipFree(d));
+  return 0;
+}
+
+}  // extern "C"

@@ -89,6 +89,13 @@ class DeviceArray(object):
         v._base = self
         return v
 
+    def component(self, i):
+        """View of self[i] (leading axis dropped)."""
+        row = self.nbytes // self.shape[0]
+        v = DeviceArray(self.shape[1:], self.dtype, ptr=self.ptr + i * row, owner=False)
+        v._base = self
+        return v
+
     def free(self):
         if self._owner and self.ptr:
             _lib.call("mfft_free", self.ptr)

@@ -1,0 +1,62 @@
+"""Element-wise pieces of a pseudo-spectral Navier-Stokes step on DeviceArrays
+(mfft_ew_* of the C ABI).  They are enqueued on the FFT object's own stream, so a
+whole RK4 step -- 36 transforms plus these kernels -- runs without a host copy
+or a host synchronisation.  Vector fields are DeviceArrays of shape (3,) + local
+shape; `Wavenumbers` holds the three 1-D scaled wavenumber vectors on the device."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray
+
+
+class Wavenumbers(object):
+    """Scaled local wavenumbers (2*pi/L * k) of an FFT object's complex layout."""
+
+    def __init__(self, FFT):
+        K = FFT.get_local_wavenumbermesh(scaled=True)
+        self.shape = tuple(int(s) for s in FFT.complex_shape())
+        vecs = [np.ascontiguousarray(np.asarray(K[i], dtype=FFT.float).reshape(-1)) for i in range(3)]
+        assert tuple(len(v) for v in vecs) == self.shape
+        self.dev = [DeviceArray.from_numpy(v) for v in vecs]
+        self.cshape = (ctypes.c_int64 * 3)(*self.shape)
+
+
+def _prec(FFT):
+    return _lib.precision_code(FFT.precision)
+
+
+def cross(FFT, a, b, out):
+    """out = a x b for real vector fields of shape (3,) + real shape."""
+    n = a.size // 3
+    _lib.call("mfft_ew_cross", FFT._plan, a.ptr, b.ptr, out.ptr, n, _prec(FFT))
+    return out
+
+
+def curl_hat(FFT, K, U_hat, out):
+    """out = i K x U_hat."""
+    _lib.call("mfft_ew_curl_hat", FFT._plan, U_hat.ptr, out.ptr, K.dev[0].ptr, K.dev[1].ptr, K.dev[2].ptr,
+              K.cshape, _prec(FFT))
+    return out
+
+
+def ns_rhs(FFT, K, dU, U_hat, nu):
+    """Pressure projection and viscous term, in place on dU."""
+    _lib.call("mfft_ew_ns_rhs", FFT._plan, dU.ptr, U_hat.ptr, K.dev[0].ptr, K.dev[1].ptr, K.dev[2].ptr,
+              K.cshape, float(nu), _prec(FFT))
+    return dU
+
+
+def axpbz(FFT, y, x, z, alpha, beta):
+    """y = alpha * x + beta * z (element-wise over the raw real storage; aliasing allowed)."""
+    n_real = y.size * (2 if y.dtype.kind == "c" else 1)
+    _lib.call("mfft_ew_axpbz", FFT._plan, y.ptr, x.ptr, z.ptr, float(alpha), float(beta), n_real, _prec(FFT))
+    return y
+
+
+def sumsq(FFT, x):
+    n_real = x.size * (2 if x.dtype.kind == "c" else 1)
+    r = ctypes.c_double(0.0)
+    _lib.call("mfft_ew_sumsq", FFT._plan, x.ptr, n_real, _prec(FFT), ctypes.byref(r))
+    return r.value
