@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1024)
+    ap.add_argument("--size", "--n", dest="n", type=int, default=1024,
+                    help="cube edge (use --size under torch.distributed.run: its parser rejects the abbreviation --n)")
     ap.add_argument("--decomp", default="slab", choices=["slab", "pencil"])
     ap.add_argument("--precision", default="double", choices=["double", "single"])
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])

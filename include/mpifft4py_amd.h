@@ -83,6 +83,9 @@ MFFT_API int mfft_comm_barrier(mfft_comm_t comm);
 MFFT_API int mfft_comm_bcast_host(mfft_comm_t comm, void* buf_host, size_t bytes, int root);
 MFFT_API int mfft_comm_allreduce_sum_host(mfft_comm_t comm, double* vals_host, int count);
 MFFT_API int mfft_comm_allreduce_max_host(mfft_comm_t comm, double* vals_host, int count);
+/* mark an in-process group broken so that ranks blocked in its barriers return an error
+ * (called when one rank's thread fails); no-op for the other transports */
+MFFT_API int mfft_comm_abort(mfft_comm_t comm);
 MFFT_API int mfft_comm_destroy(mfft_comm_t comm);
 
 /* ---- plans: slab.R2C / slab.C2C / pencil.R2CX / pencil.R2CY --------------

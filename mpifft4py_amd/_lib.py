@@ -53,6 +53,7 @@ _SIGNATURES = {
     "mfft_comm_bcast_host": ([c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_comm_allreduce_sum_host": ([c_void_p, POINTER(c_double), c_int], c_int),
     "mfft_comm_allreduce_max_host": ([c_void_p, POINTER(c_double), c_int], c_int),
+    "mfft_comm_abort": ([c_void_p], c_int),
     "mfft_comm_destroy": ([c_void_p], c_int),
     "mfft_plan_create": ([c_void_p, POINTER(PlanDesc), POINTER(c_void_p)], c_int),
     "mfft_plan_destroy": ([c_void_p], c_int),

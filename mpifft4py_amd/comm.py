@@ -245,6 +245,10 @@ class LocalGroup(object):
             except BaseException as e:      # noqa: BLE001 - re-raised on the caller
                 import traceback
                 errors.append((r, e, traceback.format_exc()))
+                try:                        # peers blocked in a group barrier must not wait for us
+                    _lib.call("mfft_comm_abort", self.comms[r]._handle)
+                except Exception:           # noqa: BLE001
+                    pass
 
         threads = [threading.Thread(target=body, args=(r,)) for r in range(self.nranks)]
         for t in threads:
@@ -252,6 +256,7 @@ class LocalGroup(object):
         for t in threads:
             t.join()
         if errors:
+            errors.sort(key=lambda t: "never reached the barrier" in str(t[1]))   # root cause first
             r, e, tb = errors[0]
             raise RuntimeError("rank %d failed: %s\n%s" % (r, e, tb))
         return results

@@ -110,6 +110,10 @@ int mfft_comm_allreduce_sum_host(mfft_comm_t c, double* v, int n) {
 int mfft_comm_allreduce_max_host(mfft_comm_t c, double* v, int n) {
   return c ? c->allreduce_host(v, n, 1) : set_error(MFFT_ERR_INVALID, "null comm");
 }
+int mfft_comm_abort(mfft_comm_t c) {
+  if (c) c->abort();
+  return 0;
+}
 int mfft_comm_destroy(mfft_comm_t c) {
   delete c;
   return 0;

@@ -26,6 +26,7 @@ struct mfft_comm_s {
   virtual int barrier() = 0;
   virtual int bcast_host(void* buf, size_t bytes, int root) = 0;
   virtual int allreduce_host(double* vals, int count, int op /*0 sum, 1 max*/) = 0;
+  virtual void abort() {}    // wake every rank blocked in a host-side barrier of this group
 };
 
 namespace mfft {

@@ -1,7 +1,9 @@
 // comm.hip -- Self / RCCL / in-process transports (see comm.h)
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -197,18 +199,36 @@ struct LocalShared {
   };
   std::vector<Post> posts;
 
-  void wait_all() {
+  // host barrier of the group's threads; false = a peer never arrived (it failed or
+  // deadlocked): every later barrier of the group then fails fast instead of hanging
+  bool broken = false;
+  bool wait_all() {
+    static const long timeout_s = getenv("MFFT_LOCAL_TIMEOUT") ? atol(getenv("MFFT_LOCAL_TIMEOUT")) : 180;
     std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
     const long gen = generation;
     if (++arrived == n) {
       arrived = 0;
       ++generation;
       cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return generation != gen; });
+      return true;
     }
+    const bool ok = cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return generation != gen || broken; });
+    if (!ok || broken) {
+      broken = true;
+      cv.notify_all();
+      return false;
+    }
+    return true;
   }
 };
+
+#define MFFT_LOCAL_WAIT()                                                                             \
+  do {                                                                                                \
+    if (!sh->wait_all())                                                                              \
+      return set_error(MFFT_ERR_INTERNAL, "in-process group: a peer rank never reached the barrier "  \
+                                          "(it failed, or the ranks diverged)");                      \
+  } while (0)
 
 struct LocalComm : mfft_comm_s {
   std::shared_ptr<LocalShared> sh;
@@ -238,7 +258,7 @@ struct LocalComm : mfft_comm_s {
     me.sdisp.assign(sdisp, sdisp + npeers);
     me.scount.assign(scount, scount + npeers);
     MFFT_HIP(hipEventRecord(me.ready, s));
-    sh->wait_all();                                   // every member has posted
+    MFFT_LOCAL_WAIT();                                // every member has posted
     char* rp = static_cast<char*>(recv);
     for (int i = 0; i < npeers; ++i) {
       LocalShared::Post& pe = sh->posts[peers[i]];
@@ -250,36 +270,41 @@ struct LocalComm : mfft_comm_s {
       MFFT_HIP(hipMemcpyAsync(rp + rdisp[i], pe.send + pe.sdisp[myidx], rcount[i], hipMemcpyDeviceToDevice, s));
     }
     MFFT_HIP(hipEventRecord(me.done, s));
-    sh->wait_all();                                   // every member has enqueued its pulls
+    MFFT_LOCAL_WAIT();                                // every member has enqueued its pulls
     // nobody may overwrite its send buffer before all peers have pulled from it
     for (int i = 0; i < npeers; ++i)
       if (peers[i] != rank) MFFT_HIP(hipStreamWaitEvent(s, sh->posts[peers[i]].done, 0));
-    sh->wait_all();                                   // events may be re-recorded only after everyone waited on them
+    MFFT_LOCAL_WAIT();                                // events may be re-recorded only after everyone waited on them
     return 0;
   }
+  void abort() override {
+    std::lock_guard<std::mutex> lk(sh->mu);
+    sh->broken = true;
+    sh->cv.notify_all();
+  }
   int barrier() override {
-    sh->wait_all();
+    MFFT_LOCAL_WAIT();
     return 0;
   }
   int bcast_host(void* buf, size_t bytes, int root) override {
     sh->posts[rank].host_ptr = buf;
-    sh->wait_all();
+    MFFT_LOCAL_WAIT();
     if (rank != root && bytes) memcpy(buf, sh->posts[root].host_ptr, bytes);
-    sh->wait_all();
+    MFFT_LOCAL_WAIT();
     return 0;
   }
   int allreduce_host(double* vals, int count, int op) override {
     sh->posts[rank].host_ptr = vals;
-    sh->wait_all();
+    MFFT_LOCAL_WAIT();
     std::vector<double> acc(vals, vals + count);
     for (int r = 0; r < size; ++r) {
       if (r == rank) continue;
       const double* o = static_cast<const double*>(sh->posts[r].host_ptr);
       for (int i = 0; i < count; ++i) acc[i] = op == 1 ? (o[i] > acc[i] ? o[i] : acc[i]) : acc[i] + o[i];
     }
-    sh->wait_all();
+    MFFT_LOCAL_WAIT();
     for (int i = 0; i < count; ++i) vals[i] = acc[i];
-    sh->wait_all();
+    MFFT_LOCAL_WAIT();
     return 0;
   }
 };

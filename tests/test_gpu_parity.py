@@ -459,3 +459,21 @@ def test_slab_c2c_padded(P, prec, golden_dir):
             for rs, ap, _, _ in res:
                 AP[rs] = ap
             assert orc.rel_l2(AP, g["slabc2c_P2_pad_bwd"]) < 4 * TOL[prec]
+
+
+def test_local_group_does_not_hang_when_one_rank_fails():
+    """A failing rank aborts the in-process group: its peers get an error instead of waiting forever."""
+    import time
+    from mpifft4py_amd import LocalGroup, Slab_R2C
+    N = np.array([16, 16, 32])
+    g = LocalGroup(2, devices=[0, 0])
+
+    def body(comm):
+        F = Slab_R2C(N, L, comm, "double")
+        if comm.Get_rank() == 1:
+            raise ValueError("boom")
+        return F.fftn(np.zeros(F.real_shape()), np.zeros(F.complex_shape(), dtype=complex))
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="boom"):
+        g.run(body)
+    assert time.time() - t0 < 60
