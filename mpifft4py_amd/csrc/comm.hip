@@ -58,9 +58,12 @@ static RcclApi* rccl_api() {
   static std::once_flag once;
   static bool ok = false;
   std::call_once(once, [] {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // MFFT_RCCL_LIB overrides the library (tests use it to put a shared-memory stand-in behind
+    // the same entry points, because RCCL refuses two ranks on one GPU)
+    const char* names[] = {getenv("MFFT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
-      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (!n || !*n) continue;
+      api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
       if (api.handle) break;
     }
     if (!api.handle) return;

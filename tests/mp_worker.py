@@ -1,0 +1,77 @@
+"""Worker of tests/test_gpu_multiprocess.py: one PROCESS per rank (launched by
+torch.distributed.run), all ranks on the box's single GPU, RcclComm over the
+shared-memory stand-in for librccl (tests/mock_rccl).  Checks the process-per-GPU
+product path -- from_env() rendezvous, DistComm, grouped send/recv all-to-all-v,
+the two-stream exchange pipeline -- against the oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from mpifft4py_amd import DeviceArray, Pencil_R2C, Slab_C2C, Slab_R2C, from_env  # noqa: E402
+from oracle import mpifft_oracle as orc  # noqa: E402
+
+L = np.array([2 * np.pi] * 3)
+
+
+def main():
+    comm = from_env()
+    rank, P = comm.Get_rank(), comm.Get_size()
+    N = [32, 64, 128]
+    A = np.random.default_rng(4242).random(N)
+    B2 = np.fft.rfftn(A)
+
+    # host helpers over the communicator
+    x = np.arange(5, dtype=np.float64) if rank == 0 else np.zeros(5)
+    comm.Bcast(x, root=0)
+    assert np.array_equal(x, np.arange(5.0))
+    assert comm.allreduce(float(rank)) == sum(range(P))
+    assert comm.bcast({"hello": P} if rank == 0 else None)["hello"] == P
+
+    for pipeline in (1, 4):
+        F = Slab_R2C(np.array(N), L, comm, "double", pipeline=pipeline)
+        u = DeviceArray.from_numpy(np.ascontiguousarray(A[F.real_local_slice()]))
+        fu = DeviceArray.empty(F.complex_shape(), F.complex)
+        u2 = DeviceArray.empty(F.real_shape(), F.float)
+        for _ in range(2):
+            F.fftn(u, fu)
+            F.ifftn(fu, u2)
+        F.sync()
+        assert orc.rel_l2(fu.get(), B2[F.complex_local_slice()]) < 1e-10, ("slab", pipeline)
+        assert orc.rel_l2(u2.get(), A[F.real_local_slice()]) < 1e-10
+    # padded + masked paths
+    C0 = B2.copy()
+    C0[N[0] // 2] = 0
+    C0[:, N[1] // 2] = 0
+    C0[:, :, -1] = 0
+    lay = orc.SlabLayout(N, P)
+    want = orc.slab_r2c_backward_padded(orc.scatter_complex(C0, lay), N)
+    F = Slab_R2C(np.array(N), L, comm, "double")
+    ap = F.ifftn(np.ascontiguousarray(C0[F.complex_local_slice()]), np.zeros(F.real_shape_padded()), dealias="3/2-rule")
+    assert orc.rel_l2(ap, want[rank]) < 4e-10
+    cp = F.fftn(ap, np.zeros(F.complex_shape(), dtype=complex), dealias="3/2-rule")
+    assert orc.rel_l2(cp, C0[F.complex_local_slice()]) < 4e-10
+    # C2C
+    Ac = A + 1j * np.random.default_rng(7).random(N)
+    Fc = Slab_C2C(np.array(N), L, comm, "single")
+    c = Fc.fftn(np.ascontiguousarray(Ac[Fc.original_local_slice()]).astype(np.complex64),
+                np.zeros(Fc.transformed_shape(), dtype=np.complex64))
+    assert orc.rel_l2(c, np.fft.fftn(Ac)[Fc.transformed_local_slice()]) < 1e-5
+    # pencils
+    if P >= 4:
+        for align in ("X", "Y"):
+            Fp = Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=align)
+            c = Fp.fftn(np.ascontiguousarray(A[Fp.real_local_slice()]), np.zeros(Fp.complex_shape(), dtype=complex))
+            assert orc.rel_l2(c, B2[Fp.complex_local_slice()]) < 1e-10, align
+            b = Fp.ifftn(c, np.zeros(Fp.real_shape()))
+            assert orc.rel_l2(b, A[Fp.real_local_slice()]) < 1e-10
+    comm.barrier()
+    if rank == 0:
+        print("MP_OK world=%d" % P)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""GPU: the process-per-GPU product path with 2, 4 and 8 PROCESSES launched by
+torch.distributed.run -- exactly as the benchmark driver launches bench.py -- on the single
+GPU of the box.  Real RCCL refuses two ranks on one device, so librccl is replaced behind
+the same dlsym'd entry points by tests/mock_rccl (shared-memory mailboxes); everything
+above the wire (rendezvous, DistComm, RcclComm.alltoallv, plans, pipeline, bench.py's
+rank-0 JSON line) is the shipped code."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from gpu_util import have_gpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK_DIR = os.path.join(ROOT, "tests", "mock_rccl")
+MOCK = os.path.join(MOCK_DIR, "libmockrccl.so")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def mock_lib():
+    if not have_gpu():
+        pytest.fail("no GPU visible")
+    src = os.path.join(MOCK_DIR, "mock_rccl.cpp")
+    if not os.path.exists(MOCK) or os.path.getmtime(MOCK) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-std=c++17", src, "-o", MOCK, "-lrt"])
+    return MOCK
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(nproc, script_args, timeout=600):
+    env = dict(os.environ, MFFT_RCCL_LIB=MOCK, MOCK_RCCL_SLOT_KB="2048", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_process_per_rank_parity(world):
+    rc, out, err = _torchrun(world, [os.path.join(ROOT, "tests", "mp_worker.py")])
+    assert rc == 0, (out[-2000:], err[-4000:])
+    assert "MP_OK world=%d" % world in out
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_under_torchrun_prints_one_json_line(world):
+    rc, out, err = _torchrun(world, [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "128",
+                                     "--steps", "3", "--warmup", "1", "--cpu-baseline", "off"])
+    assert rc == 0, (out[-2000:], err[-4000:])
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out                      # exactly one line on stdout, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["roundtrip_rel_l2"] < 1e-10
+    assert d["value"] > 0 and d["roofline"]["achieved"] > 0
+    if world == 4:
+        assert d["extras"]["pencil_R2CX"]["grid"] == [2, 2]
+        assert d["extras"]["pencil_R2CX"]["roundtrip_rel_l2"] < 1e-10
