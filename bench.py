@@ -72,31 +72,44 @@ def pmc_traffic(n, precision, decomp, world):
 
 
 def cpu_baseline(n_full, seconds_budget=30.0):
-    """The oracle's path for P = 1 (numpy.fft semantics: rfftn + irfftn, slab.py:369/249)
-    timed on the host cores with scipy.fft's pocketfft and all cores, on a bounded
-    sample: a smaller cube, scaled to the full cube by the N^3 log2 N^3 work ratio."""
+    """The oracle's P = 1 path (numpy.fft semantics: rfftn + irfftn, slab.py:369/249) timed on
+    the host cores with scipy.fft's pocketfft, all cores.  A 512^3 pair is timed first; if the
+    full cube fits the time and memory budget it is timed as well and reported directly,
+    otherwise the sample is scaled by the N^3 log2 N^3 work ratio."""
     import scipy.fft as sfft
     cores = os.cpu_count() or 1
-    n = min(n_full, 512)
-    rng = np.random.default_rng(1234)
-    a = rng.random((n, n, n))
-    t0 = time.perf_counter()
-    c = sfft.rfftn(a, workers=cores)
-    b = sfft.irfftn(c, s=a.shape, workers=cores)
-    first = time.perf_counter() - t0
-    reps = int(max(1, min(5, (seconds_budget - first) // max(first, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        c = sfft.rfftn(a, workers=cores)
-        b = sfft.irfftn(c, s=a.shape, workers=cores)
-    dt = (time.perf_counter() - t0) / reps
-    err = float(np.linalg.norm((b - a).ravel()) / np.linalg.norm(a.ravel()))
+
+    def pair(n, reps):
+        a = np.random.default_rng(1234).random((n, n, n))
+        best, err = None, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            c = sfft.rfftn(a, workers=cores)
+            b = sfft.irfftn(c, s=a.shape, workers=cores)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            if err is None:
+                err = float(np.linalg.norm((b[:8] - a[:8]).ravel()) / np.linalg.norm(a[:8].ravel()))
+        return best, err
+    ns = min(n_full, 512)
+    t_s, err = pair(ns, 2)
     work = lambda m: m ** 3 * 3 * np.log2(m)
-    scale = work(n) / work(n_full)
-    return {"value": (1.0 / dt) * scale, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d^3 fp64 rfftn+irfftn pair via scipy.fft(pocketfft, workers=%d): %.3f s/pair "
+    scale = work(ns) / work(n_full)
+    est_full = t_s / scale
+    try:
+        avail_kb = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1])
+    except Exception:  # noqa: BLE001
+        avail_kb = 0
+    need_kb = 5 * 8 * n_full ** 3 // 1024
+    if ns < n_full and est_full * 3 < seconds_budget and avail_kb > need_kb:
+        t_f, err_f = pair(n_full, 2)
+        return {"value": 1.0 / t_f, "unit": "pairs/s", "cores": cores, "kind": "port",
+                "sample": "FULL %d^3 fp64 rfftn+irfftn pair via scipy.fft (pocketfft, workers=%d): best of 2 = %.3f s "
+                          "(round-trip rel-L2 %.1e); 512^3 pair %.3f s" % (n_full, cores, t_f, err_f, t_s)}
+    return {"value": (1.0 / t_s) * scale, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d^3 fp64 rfftn+irfftn pair via scipy.fft (pocketfft, workers=%d): %.3f s/pair "
                       "(round-trip rel-L2 %.1e); scaled to %d^3 by N^3*log2(N^3) (x%.4f)"
-                      % (n, cores, dt, err, n_full, scale)}
+                      % (ns, cores, t_s, err, n_full, scale)}
 
 
 def main():
