@@ -28,9 +28,9 @@ std::vector<KernelEntry>& kernel_registry() {
   return reg;
 }
 
-const KernelEntry* find_kernel(int family, int n, int prec, int inv, int nt) {
+const KernelEntry* find_kernel(int family, int n, int prec, int inv, int nt, int pad) {
   for (const KernelEntry& e : kernel_registry())
-    if (e.family == family && e.n == n && e.prec == prec && e.inv == inv && e.nt == nt) return &e;
+    if (e.family == family && e.n == n && e.prec == prec && e.inv == inv && e.nt == nt && e.pad == pad) return &e;
   return nullptr;
 }
 
@@ -117,6 +117,7 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.ntile_c = (int)((a.ncols + e->tile - 1) / e->tile);
   P.nouter = (int)a.nouter;
   P.remap = a.remap;
+  P.fold = a.fold ? 1 : 0;
   P.scale = (T)a.scale;
   const int64_t grid = (int64_t)P.ntile_c * a.nouter;
   if (grid <= 0) return 0;
@@ -139,7 +140,13 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   static const int nt_mode = getenv("MFFT_NT") ? atoi(getenv("MFFT_NT")) : 1;   // 0 never, 1 out-of-place, 2 always
   const bool nt = a.allow_nt && nt_mode > 0 && (nt_mode == 2 || a.in != a.out) &&
                   aligned(a.in, a.in_outer, a.in_rows) && aligned(a.out, a.out_outer, a.out_rows);
-  const KernelEntry* e = nt ? find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1) : nullptr;
+  const KernelEntry* e = nullptr;
+  if (a.pad) {
+    if ((a.pad == 1) != a.inverse) return set_error(MFFT_ERR_INVALID, "pad-on-load is an inverse-transform mode, truncate-on-store a forward one");
+    e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0, a.pad);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no fused 3/2-rule kernel for length %d", a.n);
+  }
+  if (!e && nt) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1);
   if (!e) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0);
   if (!e)
     return set_error(MFFT_ERR_UNSUPPORTED,
@@ -187,6 +194,7 @@ static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void
   P.in_stride = a.in_stride;
   P.out_stride = a.out_stride;
   P.nrows = a.nrows;
+  P.valid = a.valid > 0 ? a.valid : a.n / 2 + 1;
   P.scale = (T)a.scale;
   const int64_t grid = (a.nrows + e->tile - 1) / e->tile;
   if (grid <= 0) return 0;

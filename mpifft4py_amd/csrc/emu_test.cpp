@@ -219,6 +219,96 @@ static void test_col(bool two_level) {
   report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
 }
 
+// 3/2-rule fusion: PAD == 1 (inverse, zero band on load) and PAD == 2 (forward, truncate on store,
+// with and without the Nyquist fold) against explicit pad / truncate around a plain DFT
+template <class S, typename T, int COLS, int VEC>
+static void test_col_pad() {
+  const int N = S::N, n = 2 * N / 3, h = n / 2;
+  const int ncols = COLS + 3, nouter = 2;
+  std::mt19937_64 rng(31 + N);
+  std::uniform_real_distribution<double> U(-1, 1);
+  auto tw = build_pass_twiddles<S, T>();
+  {  // PAD 1, inverse: in (nouter, n, pin) -> out (nouter, N, pout)
+    typedef ColFft<S, T, COLS, true, false, false, VEC, false, 1> K;
+    const int pin = ncols + 1, pout = ncols + 2;
+    std::vector<cx<T>> in((size_t)nouter * n * pin), out((size_t)nouter * N * pout);
+    for (auto& z : in) z = mk<T>((T)U(rng), (T)U(rng));
+    ColParams<T> P;
+    P.in = in.data(); P.out = out.data(); P.tw = tw.data();
+    P.in_outer = (i64)n * pin; P.out_outer = (i64)N * pout;
+    P.in_map = make_rowmap(0, pin, n, n); P.out_map = make_rowmap(0, pout, N, N);
+    P.ncols = ncols; P.ntile_c = (ncols + COLS - 1) / COLS; P.nouter = nouter; P.remap = 1; P.fold = 0;
+    P.scale = (T)(1.0 / N);
+    emu_launch(P.ntile_c * nouter, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    long double num = 0, den = 0;
+    for (int o = 0; o < nouter; ++o)
+      for (int c = 0; c < ncols; ++c) {
+        lvec x(N);
+        for (int r = 0; r < N; ++r) { x[r].x = 0; x[r].y = 0; }
+        for (int r = 0; r < h; ++r) { cx<T> z = in[(size_t)o * n * pin + (size_t)r * pin + c]; x[r].x = z.x; x[r].y = z.y; }
+        for (int r = h; r < n; ++r) { cx<T> z = in[(size_t)o * n * pin + (size_t)r * pin + c]; x[N - n + r].x = z.x; x[N - n + r].y = z.y; }
+        lvec X = naive_dft(x, +1);
+        for (int r = 0; r < N; ++r) {
+          cx<T> g = out[(size_t)o * N * pout + (size_t)r * pout + c];
+          long double ex = X[r].x / N, ey = X[r].y / N;
+          num += (g.x - ex) * (g.x - ex) + (g.y - ey) * (g.y - ey);
+          den += ex * ex + ey * ey;
+        }
+      }
+    char name[64];
+    snprintf(name, sizeof name, "col c%d v%d pad-on-load inv", COLS, VEC);
+    report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
+  }
+  for (int fold = 0; fold < 2; ++fold) {  // PAD 2, forward: in (nouter, N, pin) -> out (nouter, n, pout)
+    typedef ColFft<S, T, COLS, false, false, false, VEC, false, 2> K;
+    const int pin = ncols + 1, pout = ncols + 2;
+    std::vector<cx<T>> in((size_t)nouter * N * pin), out((size_t)nouter * n * pout, mk<T>((T)55, (T)55));
+    for (auto& z : in) z = mk<T>((T)U(rng), (T)U(rng));
+    ColParams<T> P;
+    P.in = in.data(); P.out = out.data(); P.tw = tw.data();
+    P.in_outer = (i64)N * pin; P.out_outer = (i64)n * pout;
+    P.in_map = make_rowmap(0, pin, N, N); P.out_map = make_rowmap(0, pout, n, n);
+    P.ncols = ncols; P.ntile_c = (ncols + COLS - 1) / COLS; P.nouter = nouter; P.remap = 0; P.fold = fold;
+    P.scale = (T)0.5;
+    emu_launch(P.ntile_c * nouter, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    long double num = 0, den = 0;
+    for (int o = 0; o < nouter; ++o)
+      for (int c = 0; c < ncols; ++c) {
+        lvec x(N);
+        for (int r = 0; r < N; ++r) { cx<T> z = in[(size_t)o * N * pin + (size_t)r * pin + c]; x[r].x = z.x; x[r].y = z.y; }
+        lvec X = naive_dft(x, -1);
+        lvec e(n);
+        for (int r = 0; r < n; ++r) { e[r].x = 0; e[r].y = 0; }
+        if (fold) {
+          for (int r = 0; r <= h; ++r) e[r] = X[r];
+          for (int r = 0; r < h; ++r) { e[h + r].x += X[N - h + r].x; e[h + r].y += X[N - h + r].y; }
+        } else {
+          for (int r = 0; r < h; ++r) e[r] = X[r];
+          for (int r = h; r < n; ++r) e[r] = X[N - n + r];
+        }
+        for (int r = 0; r < n; ++r) {
+          cx<T> g = out[(size_t)o * n * pout + (size_t)r * pout + c];
+          long double ex = e[r].x * 0.5L, ey = e[r].y * 0.5L;
+          num += (g.x - ex) * (g.x - ex) + (g.y - ey) * (g.y - ey);
+          den += ex * ex + ey * ey;
+        }
+      }
+    char name[64];
+    snprintf(name, sizeof name, "col c%d v%d trunc-on-store%s", COLS, VEC, fold ? " fold" : "");
+    report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
+  }
+}
+
+template <class S, bool HAS3 = (S::E % 3 == 0 && S::N >= 6)> struct PadTests {
+  static void run() {}
+};
+template <class S> struct PadTests<S, true> {
+  static void run() {
+    test_col_pad<S, double, 4, 1>();
+    test_col_pad<S, float, 8, 2>();
+  }
+};
+
 template <class S, typename T, int ROWS, bool INV, bool TWLDS>
 static void test_row() {
   typedef RowFft<S, T, ROWS, INV, TWLDS> K;
@@ -264,7 +354,7 @@ static void test_real() {
   auto rtw = build_real_twiddles<T>(N);
   {
     typedef R2CFft<S, T, ROWS, TWLDS> K;
-    RealParams<T> P{in.data(), out.data(), tw.data(), rtw.data(), pin, pout, nrows, (T)1};
+    RealParams<T> P{in.data(), out.data(), tw.data(), rtw.data(), pin, pout, nrows, M + 1, (T)1};
     emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
   }
@@ -290,7 +380,7 @@ static void test_real() {
   }
   {
     typedef C2RFft<S, T, ROWS, TWLDS> K;
-    RealParams<T> P{out.data(), back.data(), tw.data(), rtw.data(), pout, pin, nrows, (T)(1.0 / N)};
+    RealParams<T> P{out.data(), back.data(), tw.data(), rtw.data(), pout, pin, nrows, M + 1, (T)(1.0 / N)};
     emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
   }
@@ -303,6 +393,52 @@ static void test_real() {
     }
   snprintf(name, sizeof name, "c2r(r2c) r%d%s", ROWS, TWLDS ? " twlds" : "");
   report(name, N, pname<T>(), (double)sqrtl(num / den), 4 * tol_of<T>());
+  // 3/2-rule column handling: r2c keeps only the first `valid` bins, c2r treats the missing ones as zero
+  if (M >= 4) {
+    const int valid = M / 2 + 1;
+    std::vector<cx<T>> part((size_t)nrows * valid, mk<T>((T)9, (T)9));
+    {
+      typedef R2CFft<S, T, ROWS, TWLDS> K;
+      RealParams<T> P{in.data(), part.data(), tw.data(), rtw.data(), pin, valid, nrows, valid, (T)1};
+      emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
+                 [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    }
+    long double nn = 0, dd = 0;
+    for (int r = 0; r < nrows; ++r)
+      for (int k = 0; k < valid; ++k) {
+        cx<T> g = part[(size_t)r * valid + k], e = out[(size_t)r * pout + k];
+        if (k == 0) e.y = 0;        // out[] had its bin-0 imaginary part poisoned above
+        nn += (g.x - e.x) * (g.x - e.x) + (g.y - e.y) * (g.y - e.y);
+        dd += e.x * e.x + e.y * e.y;
+      }
+    snprintf(name, sizeof name, "r2c valid<M+1 r%d", ROWS);
+    report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
+    std::vector<T> b2((size_t)nrows * pin, (T)0);
+    {
+      typedef C2RFft<S, T, ROWS, TWLDS> K;
+      RealParams<T> P{part.data(), b2.data(), tw.data(), rtw.data(), valid, pin, nrows, valid, (T)(1.0 / N)};
+      emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
+                 [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    }
+    nn = dd = 0;
+    for (int r = 0; r < nrows; ++r) {
+      lvec X(N);
+      for (int k = 0; k < N; ++k) { X[k].x = 0; X[k].y = 0; }
+      for (int k = 0; k < valid; ++k) {
+        cx<T> z = part[(size_t)r * valid + k];
+        X[k].x = z.x; X[k].y = (k == 0) ? 0 : z.y;
+        if (k > 0) { X[N - k].x = z.x; X[N - k].y = -z.y; }
+      }
+      lvec x = naive_dft(X, +1);
+      for (int i = 0; i < N; ++i) {
+        long double e = x[i].x / N, g = b2[(size_t)r * pin + i];
+        nn += (g - e) * (g - e);
+        dd += e * e;
+      }
+    }
+    snprintf(name, sizeof name, "c2r valid<M+1 r%d", ROWS);
+    report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
+  }
 }
 
 template <class S> static void test_spec_all() {
@@ -320,6 +456,7 @@ template <class S> static void test_spec_all() {
   test_row<S, float, 3, false, false>();
   test_real<S, double, 2, true>();
   test_real<S, float, 3, false>();
+  PadTests<S>::run();
 }
 
 int main() {

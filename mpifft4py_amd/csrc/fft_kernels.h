@@ -82,6 +82,7 @@ struct ColParams {
   int ntile_c;           // ceil(ncols / COLS)
   int nouter;
   int remap;             // 1: XCD-aware block -> tile mapping
+  int fold;              // PAD == 2: 1 = add the Nyquist row N/3 into row 2N/3 before it is stored
   T scale;
 };
 
@@ -103,6 +104,8 @@ struct RealParams {            // r2c: in = real rows, out = complex rows; c2r t
   const cx<T>* rtw;            // exp(-2 pi i k / N), k = 0..N/2-1
   i64 in_stride, out_stride;   // row strides in elements of the respective type
   i64 nrows;
+  int valid;                   // complex columns that exist in memory (N/2+1 normally; fewer for the
+                               // 3/2-rule: r2c stores only the first `valid`, c2r reads the rest as 0)
   T scale;
 };
 
@@ -265,9 +268,21 @@ MFFT_D void stage_twiddles(cx<T>* lds_tw, const cx<T>* gtw, int tid, int nthread
 // NT: non-temporal global loads/stores.  Only for tiles whose rows are 128-byte
 // aligned (every L2 line belongs to exactly one workgroup): measured +12 % on
 // such layouts, 2x slower on unaligned ones, where neighbouring tiles share lines.
-template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false, int VEC = 1, bool NT = false>
+//
+// PAD fuses the 3/2-rule copies (reference slab.py:516-536, pencil.py:351-379) into the transform,
+// for N = 3n/2 (so E is a multiple of 3 and the regions are whole register ranges):
+//   PAD == 1: the input has n = 2N/3 physical rows; logical rows [N/3, 2N/3) are zeros
+//             (copy_to_padded: low half to the front, high half to the back)
+//   PAD == 2: only logical rows [0, N/3) and [2N/3, N) are stored, to n physical rows
+//             (copy_from_padded); with P.fold the Nyquist rows N/3 and 2N/3, which sit in the
+//             same thread (j = 0), are summed as `fu[n/2:] += fp[-n/2:]` does.
+template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false, int VEC = 1, bool NT = false,
+          int PAD = 0>
 struct ColFft {
   static_assert(COLS % VEC == 0, "VEC must divide COLS");
+  static_assert(PAD == 0 || S::E % 3 == 0, "pad/truncate fusion needs a radix-3 plan");
+  static constexpr int KLO = S::E / 3, KHI = 2 * (S::E / 3);     // register ranges of the three row regions
+  static constexpr int NSKIP = S::N / 3;
   static constexpr int CG = COLS / VEC;            // lanes along the contiguous axis
   static constexpr int THREADS = S::TPT * CG;
   static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
@@ -322,7 +337,15 @@ struct ColFft {
     cx<T> v[VEC][S::E];
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
-      const unsigned r = (unsigned)(j + k * S::TPT);
+      unsigned r = (unsigned)(j + k * S::TPT);
+      if (PAD == 1) {
+        if (k >= KLO && k < KHI) {               // the zero band of the padded spectrum: nothing to load
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i][k] = mk<T>((T)0, (T)0);
+          continue;
+        }
+        if (k >= KHI) r -= NSKIP;
+      }
       const cx<T>* src = ip + row_off(P.in_map, r);
       if (nact >= VEC) {
         const GPack g = load_pack(src);
@@ -353,7 +376,15 @@ struct ColFft {
 
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
-      const unsigned r = (unsigned)(j + k * S::TPT);
+      unsigned r = (unsigned)(j + k * S::TPT);
+      if (PAD == 2) {
+        if (k >= KLO && k < KHI) continue;       // truncated band
+        if (k >= KHI) r -= NSKIP;
+        if (k == KHI && j == 0 && P.fold) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i][k] = v[i][k] + v[i][KLO];
+        }
+      }
       cx<T>* dst = op + row_off(P.out_map, r);
       if (nact >= VEC) {
         GPack g;
@@ -481,8 +512,8 @@ struct R2CFft {
         const cx<T> w = P.rtw[pos];
         if (pos == 0) {
           op[0] = mk<T>((zk.x + zk.y) * P.scale, (T)0);
-          op[M] = mk<T>((zk.x - zk.y) * P.scale, (T)0);
-        } else {
+          if (M < P.valid) op[M] = mk<T>((zk.x - zk.y) * P.scale, (T)0);
+        } else if (pos < P.valid) {
           op[pos] = scale(e + w * o, P.scale);
         }
       }
@@ -522,8 +553,8 @@ struct C2RFft {
       const int pos = j + k * S::TPT;
       cx<T> z = mk<T>((T)0, (T)0);
       if (active) {
-        cx<T> xk = ip[pos];
-        cx<T> xm = conj(ip[M - pos]);
+        cx<T> xk = pos < P.valid ? ip[pos] : mk<T>((T)0, (T)0);
+        cx<T> xm = (M - pos) < P.valid ? conj(ip[M - pos]) : mk<T>((T)0, (T)0);
         if (pos == 0) {            // imaginary parts of the k=0 and k=N/2 bins are ignored
           xk.y = (T)0;
           xm.y = (T)0;

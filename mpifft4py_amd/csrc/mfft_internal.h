@@ -47,6 +47,8 @@ struct ColArgs {
   double scale = 1.0;
   int remap = 1;         // XCD-aware tile order
   bool allow_nt = true;  // use the non-temporal variant when the layout is 128-byte aligned
+  int pad = 0;           // 1: input has 2n/3 physical rows (zero band skipped); 2: output truncated to 2n/3 rows
+  bool fold = false;     // pad == 2: sum the two Nyquist rows (R2C convention)
 };
 int launch_col(const ColArgs& a, hipStream_t s);
 
@@ -68,6 +70,7 @@ struct RealArgs {
   int prec = MFFT_DOUBLE;
   int64_t in_stride = 0, out_stride = 0, nrows = 0;   // in elements of the respective types
   double scale = 1.0;
+  int valid = 0;         // complex columns present in memory (0 = all n/2+1)
 };
 int launch_r2c(const RealArgs& a, hipStream_t s);
 int launch_c2r(const RealArgs& a, hipStream_t s);

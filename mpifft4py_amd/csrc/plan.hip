@@ -166,16 +166,18 @@ struct mfft_plan_s {
   }
 
   // ---- kernel helpers (all on this->stream) -----------------------------------
-  int r2c_rows(const void* in, void* out, int64_t nrows, int64_t n, int64_t in_stride, int64_t out_stride, double scale = 1.0) {
+  int r2c_rows(const void* in, void* out, int64_t nrows, int64_t n, int64_t in_stride, int64_t out_stride, double scale = 1.0,
+               int valid = 0) {
     RealArgs a;
     a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.in_stride = in_stride; a.out_stride = out_stride;
-    a.nrows = nrows; a.scale = scale;
+    a.nrows = nrows; a.scale = scale; a.valid = valid;
     return launch_r2c(a, stream);
   }
-  int c2r_rows(const void* in, void* out, int64_t nrows, int64_t n, int64_t in_stride, int64_t out_stride, double scale) {
+  int c2r_rows(const void* in, void* out, int64_t nrows, int64_t n, int64_t in_stride, int64_t out_stride, double scale,
+               int valid = 0) {
     RealArgs a;
     a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.in_stride = in_stride; a.out_stride = out_stride;
-    a.nrows = nrows; a.scale = scale;
+    a.nrows = nrows; a.scale = scale; a.valid = valid;
     return launch_c2r(a, stream);
   }
   int c2c_rows(const void* in, void* out, int64_t nrows, int64_t n, int64_t in_stride, int64_t out_stride, bool inv, double scale) {
@@ -199,6 +201,14 @@ struct mfft_plan_s {
     a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.inverse = inv; a.nouter = nouter; a.ncols = ncols;
     a.in_outer = in_outer; a.out_outer = out_outer; a.in_rows = in_rows; a.out_rows = out_rows;
     a.scale = scale != 0.0 ? scale : (inv ? 1.0 / (double)n : 1.0);
+    return launch_col(a, stream);
+  }
+  int col_pad(const void* in, void* out, int64_t n, bool inv, int pad, bool fold, int64_t nouter, int64_t ncols,
+              int64_t in_outer, RowSpec in_rows, int64_t out_outer, RowSpec out_rows, double scale) {
+    ColArgs a;
+    a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.inverse = inv; a.nouter = nouter; a.ncols = ncols;
+    a.in_outer = in_outer; a.out_outer = out_outer; a.in_rows = in_rows; a.out_rows = out_rows;
+    a.scale = scale; a.pad = pad; a.fold = fold;
     return launch_col(a, stream);
   }
   static RowSpec plain(int64_t stride) { RowSpec r; r.lo = stride; r.hi = 0; r.split = 0; return r; }
@@ -275,6 +285,9 @@ struct mfft_plan_s {
   int slab_backward_pipelined(const void* src, void* u);
   int slab_forward_padded(const void* u, void* fu);
   int slab_backward_padded(const void* fu, void* u);
+  bool can_fuse_pad() const;
+  int slab_forward_padded_fused(const void* u, void* fu);
+  int slab_backward_padded_fused(const void* fu, void* u);
   int pencil_forward(const void* u, void* fu);
   int pencil_backward(const void* fu, void* u, bool masked);
   int pencil_forward_padded(const void* u, void* fu);
@@ -476,8 +489,74 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
 }
 
 // ---- 3/2-rule, slab (R2C: slab.py:310-344, 445-483; P == 1: 250-268, 372-386) ----
+// fused 3/2-rule (R2C, padsize 1.5): the zero band is never materialised -- the x and y
+// inverse transforms read the un-padded rows and skip the band (ColFft PAD = 1), c2r reads the
+// missing kz columns as zeros; forward: r2c stores only the kept columns, the y and x transforms
+// store only the kept rows and fold the Nyquist row in registers (PAD = 2).  Six kernels per
+// pair, like the un-padded path; pack / unpack ride on the two-level row maps.
+bool mfft_plan_s::can_fuse_pad() const {
+  if (!r2c || d.padsize != 1.5 || d.decomp != MFFT_SLAB) return false;
+  if (N0 % 2 || N1 % 2 || 2 * M0 != 3 * N0 || 2 * M1 != 3 * N1 || 2 * M2 != 3 * N2) return false;
+  return find_kernel(FAM_COL, (int)M0, prec, 1, 0, 1) && find_kernel(FAM_COL, (int)M0, prec, 0, 0, 2) &&
+         find_kernel(FAM_COL, (int)M1, prec, 1, 0, 1) && find_kernel(FAM_COL, (int)M1, prec, 0, 0, 2) &&
+         find_kernel(FAM_R2C, (int)M2, prec, 0) && getenv("MFFT_NO_PAD_FUSION") == nullptr;
+}
+
+int mfft_plan_s::slab_backward_padded_fused(const void* fu, void* u) {
+  const double ps = d.padsize, sc3 = ps * ps * ps;
+  const int64_t Mp0 = M0 / P;
+  MFFT_TRY(ensure_work(0, (size_t)(M0 * Np1 * Nf) * es));
+  MFFT_TRY(ensure_work(1, (size_t)(M0 * Np1 * Nf) * es));
+  MFFT_TRY(ensure_work(2, (size_t)(Mp0 * M1 * Nf) * es));
+  void *W0 = work[0], *W1 = work[1], *W2 = work[2];
+  MFFT_TRY(stage("bwd_x", 0, [&] {
+    return col_pad(fu, W0, M0, true, 1, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf), sc3 / (double)M0);
+  }));
+  if (P > 1) {
+    MFFT_TRY(stage("bwd_a2a", 0, [&] { return xchg(0, false, true, W0, W1); }));
+    MFFT_TRY(stage("bwd_y", 0, [&] {
+      return col_pad(W1, W2, M1, true, 1, false, Mp0, Nf, Np1 * Nf, two_level(Np1, Mp0 * Np1 * Nf, Nf), M1 * Nf, plain(Nf),
+                     1.0 / (double)M1);
+    }));
+  } else {
+    MFFT_TRY(stage("bwd_y", 0, [&] {
+      return col_pad(W0, W2, M1, true, 1, false, Mp0, Nf, N1 * Nf, plain(Nf), M1 * Nf, plain(Nf), 1.0 / (double)M1);
+    }));
+  }
+  MFFT_TRY(stage("bwd_z", 0, [&] { return c2r_rows(W2, u, Mp0 * M1, M2, Nf, M2, 1.0 / (double)M2, (int)Nf); }));
+  return 0;
+}
+
+int mfft_plan_s::slab_forward_padded_fused(const void* u, void* fu) {
+  const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
+  const int64_t Mp0 = M0 / P;
+  MFFT_TRY(ensure_work(0, (size_t)(M0 * Np1 * Nf) * es));
+  MFFT_TRY(ensure_work(1, (size_t)(M0 * Np1 * Nf) * es));
+  MFFT_TRY(ensure_work(2, (size_t)(Mp0 * M1 * Nf) * es));
+  void *W0 = work[0], *W1 = work[1], *W2 = work[2];
+  MFFT_TRY(stage("fwd_z", 0, [&] { return r2c_rows(u, W2, Mp0 * M1, M2, M2, Nf, 1.0, (int)Nf); }));
+  void* xin = W0;
+  if (P > 1) {
+    // truncate + fold in y, written straight into the packed (P, Mp0, Np1, Nf) send layout
+    MFFT_TRY(stage("fwd_y", 0, [&] {
+      return col_pad(W2, W0, M1, false, 2, true, Mp0, Nf, M1 * Nf, plain(Nf), Np1 * Nf, two_level(Np1, Mp0 * Np1 * Nf, Nf), 1.0);
+    }));
+    MFFT_TRY(stage("fwd_a2a", 0, [&] { return xchg(0, true, true, W0, W1); }));
+    xin = W1;
+  } else {
+    MFFT_TRY(stage("fwd_y", 0, [&] {
+      return col_pad(W2, W0, M1, false, 2, true, Mp0, Nf, M1 * Nf, plain(Nf), N1 * Nf, plain(Nf), 1.0);
+    }));
+  }
+  MFFT_TRY(stage("fwd_x", 0, [&] {
+    return col_pad(xin, fu, M0, false, 2, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf), isc3);
+  }));
+  return 0;
+}
+
 int mfft_plan_s::slab_backward_padded(const void* fu, void* u) {
   if (P > 1 && P > N0 / 2) return set_error(MFFT_ERR_INVALID, "number of ranks cannot exceed N[0]/2 for the 3/2-rule");
+  if (can_fuse_pad()) return slab_backward_padded_fused(fu, u);
   const double ps = d.padsize, sc3 = ps * ps * ps;
   const int64_t Mp0 = M0 / P;
   // W0: (M0, Np1, Nf) padded in x; W1: (Mp0, N1, Nf) after the exchange; then (Mp0, M1, Nf), (Mp0, M1, Mf)
@@ -518,6 +597,7 @@ int mfft_plan_s::slab_backward_padded(const void* fu, void* u) {
 
 int mfft_plan_s::slab_forward_padded(const void* u, void* fu) {
   if (P > 1 && P > N0 / 2) return set_error(MFFT_ERR_INVALID, "number of ranks cannot exceed N[0]/2 for the 3/2-rule");
+  if (can_fuse_pad()) return slab_forward_padded_fused(u, fu);
   const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
   const int64_t Mp0 = M0 / P;
   MFFT_TRY(ensure_work(0, (size_t)std::max(Mp0 * M1 * Mf, M0 * Np1 * Nf) * es));

@@ -16,6 +16,7 @@ struct KernelEntry {
   int prec;         // 0 single, 1 double
   int inv;          // COL/ROW: 1 = inverse
   int nt;           // COL: 1 = non-temporal variant (128-byte aligned rows only)
+  int pad;          // COL: 1 = zero-padded input (inverse), 2 = truncated output (forward)
   int tile;         // COLS (COL) or ROWS (others)
   int threads;
   int lds_bytes;
@@ -27,7 +28,7 @@ struct KernelEntry {
 };
 
 std::vector<KernelEntry>& kernel_registry();
-const KernelEntry* find_kernel(int family, int n, int prec, int inv, int nt = 0);
+const KernelEntry* find_kernel(int family, int n, int prec, int inv, int nt = 0, int pad = 0);
 
 // ---- default tiling heuristics (measured on MI355X at 1024^3) -----
 // Strided-axis kernel: tiles are 128 bytes wide (one L2 line per row segment; with
@@ -86,6 +87,7 @@ KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
   e.prec = sizeof(T) == 8 ? 1 : 0;
   e.inv = inv;
   e.nt = 0;
+  e.pad = 0;
   e.tile = tile;
   e.threads = K::THREADS;
   e.lds_bytes = K::LDS_BYTES;
@@ -108,6 +110,12 @@ void register_plan(const char* name) {
   constexpr bool RT = row_twlds<S, T>();
   reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
   reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+  if constexpr (S::E % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: pad-on-load (inverse) / truncate-on-store (forward)
+    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 1>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+    reg.back().pad = 1;
+    reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, false, 2>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
+    reg.back().pad = 2;
+  }
   if constexpr (S::N >= 256) {     // aligned-row variants for the large in-place passes
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
     reg.back().nt = 1;

@@ -1,0 +1,21 @@
+"""Stage times of one 3/2-rule ifftn+fftn pair (developer tool)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mpifft4py_amd import Slab_R2C, SelfComm, DeviceArray
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+N = np.array([n]*3); L = np.array([2*np.pi]*3)
+F = Slab_R2C(N, L, SelfComm(0), "double")
+fu = DeviceArray.random(F.complex_shape(), F.complex, seed=1)
+up = DeviceArray.empty(F.real_shape_padded(), F.float)
+fu2 = DeviceArray.empty(F.complex_shape(), F.complex)
+F.enable_timing(True)
+for _ in range(2):
+    F.ifftn(fu, up, '3/2-rule'); F.fftn(up, fu2, '3/2-rule')
+F.sync(); F.reset_timing()
+t=time.perf_counter()
+for _ in range(5):
+    F.ifftn(fu, up, '3/2-rule'); F.fftn(up, fu2, '3/2-rule')
+F.sync()
+print("n=%d padded pair ms %.3f" % (n, (time.perf_counter()-t)/5*1e3))
+print(" ".join("%s=%.3f" % (k, v[0]/max(v[1],1)) for k,v in sorted(F.stage_times().items())))
