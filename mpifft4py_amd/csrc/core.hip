@@ -205,7 +205,9 @@ static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void
 }
 
 static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
-  const KernelEntry* e = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0);
+  const bool limited = a.valid > 0 && a.valid < a.n / 2 + 1;
+  const KernelEntry* e = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, limited ? 3 : 0);
+  if (!e && limited) return set_error(MFFT_ERR_UNSUPPORTED, "no column-limited real kernel of length %d", a.n);
   if (!e)
     return set_error(MFFT_ERR_UNSUPPORTED,
                      "no kernel for a real transform of length %d (supported: even 2^a, 3*2^a, 5*2^a up to 8192)", a.n);

@@ -398,7 +398,7 @@ static void test_real() {
     const int valid = M / 2 + 1;
     std::vector<cx<T>> part((size_t)nrows * valid, mk<T>((T)9, (T)9));
     {
-      typedef R2CFft<S, T, ROWS, TWLDS> K;
+      typedef R2CFft<S, T, ROWS, TWLDS, true> K;
       RealParams<T> P{in.data(), part.data(), tw.data(), rtw.data(), pin, valid, nrows, valid, (T)1};
       emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                  [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
@@ -415,7 +415,7 @@ static void test_real() {
     report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
     std::vector<T> b2((size_t)nrows * pin, (T)0);
     {
-      typedef C2RFft<S, T, ROWS, TWLDS> K;
+      typedef C2RFft<S, T, ROWS, TWLDS, true> K;
       RealParams<T> P{part.data(), b2.data(), tw.data(), rtw.data(), valid, pin, nrows, valid, (T)(1.0 / N)};
       emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                  [&](int b, int t, char* lds) { K::body(P, b, t, lds); });

@@ -457,7 +457,10 @@ struct RowFft {
 // ---------------------------------------------------------------------------
 // real -> half-complex along the contiguous axis.  S describes M = N/2.
 // ---------------------------------------------------------------------------
-template <class S, typename T, int ROWS, bool TWLDS>
+// LIMIT: only the first P.valid complex columns exist in memory (3/2-rule): r2c does not
+// store the others, c2r reads them as zeros.  A template flag so that the regular kernels keep
+// unconditional loads (a runtime test costs the c2r kernel 7 % at 1024^3).
+template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false>
 struct R2CFft {
   static constexpr int M = S::N;
   static constexpr int THREADS = S::TPT * ROWS;
@@ -512,8 +515,8 @@ struct R2CFft {
         const cx<T> w = P.rtw[pos];
         if (pos == 0) {
           op[0] = mk<T>((zk.x + zk.y) * P.scale, (T)0);
-          if (M < P.valid) op[M] = mk<T>((zk.x - zk.y) * P.scale, (T)0);
-        } else if (pos < P.valid) {
+          if (!LIMIT || M < P.valid) op[M] = mk<T>((zk.x - zk.y) * P.scale, (T)0);
+        } else if (!LIMIT || pos < P.valid) {
           op[pos] = scale(e + w * o, P.scale);
         }
       }
@@ -525,7 +528,7 @@ struct R2CFft {
 // half-complex -> real along the contiguous axis.  S describes M = N/2.
 // out = irfft(in) * N * scale   (scale = 1/N gives numpy's irfft)
 // ---------------------------------------------------------------------------
-template <class S, typename T, int ROWS, bool TWLDS>
+template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false>
 struct C2RFft {
   static constexpr int M = S::N;
   static constexpr int THREADS = S::TPT * ROWS;
@@ -553,8 +556,14 @@ struct C2RFft {
       const int pos = j + k * S::TPT;
       cx<T> z = mk<T>((T)0, (T)0);
       if (active) {
-        cx<T> xk = pos < P.valid ? ip[pos] : mk<T>((T)0, (T)0);
-        cx<T> xm = (M - pos) < P.valid ? conj(ip[M - pos]) : mk<T>((T)0, (T)0);
+        cx<T> xk, xm;
+        if constexpr (LIMIT) {
+          xk = pos < P.valid ? ip[pos] : mk<T>((T)0, (T)0);
+          xm = (M - pos) < P.valid ? conj(ip[M - pos]) : mk<T>((T)0, (T)0);
+        } else {
+          xk = ip[pos];
+          xm = conj(ip[M - pos]);
+        }
         if (pos == 0) {            // imaginary parts of the k=0 and k=N/2 bins are ignored
           xk.y = (T)0;
           xm.y = (T)0;

@@ -499,7 +499,8 @@ bool mfft_plan_s::can_fuse_pad() const {
   if (N0 % 2 || N1 % 2 || 2 * M0 != 3 * N0 || 2 * M1 != 3 * N1 || 2 * M2 != 3 * N2) return false;
   return find_kernel(FAM_COL, (int)M0, prec, 1, 0, 1) && find_kernel(FAM_COL, (int)M0, prec, 0, 0, 2) &&
          find_kernel(FAM_COL, (int)M1, prec, 1, 0, 1) && find_kernel(FAM_COL, (int)M1, prec, 0, 0, 2) &&
-         find_kernel(FAM_R2C, (int)M2, prec, 0) && getenv("MFFT_NO_PAD_FUSION") == nullptr;
+         find_kernel(FAM_R2C, (int)M2, prec, 0, 0, 3) && find_kernel(FAM_C2R, (int)M2, prec, 1, 0, 3) &&
+         getenv("MFFT_NO_PAD_FUSION") == nullptr;
 }
 
 int mfft_plan_s::slab_backward_padded_fused(const void* fu, void* u) {

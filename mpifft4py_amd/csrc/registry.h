@@ -110,7 +110,13 @@ void register_plan(const char* name) {
   constexpr bool RT = row_twlds<S, T>();
   reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
   reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
-  if constexpr (S::E % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: pad-on-load (inverse) / truncate-on-store (forward)
+  if constexpr (S::E % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3) ...
+    reg.push_back(make_entry<R2CFft<S, T, R, RT, true>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+    reg.back().pad = 3;
+    reg.push_back(make_entry<C2RFft<S, T, R, RT, true>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
+    reg.back().pad = 3;
+  }
+  if constexpr (S::E % 3 == 0 && S::N >= 6) {   // ... and pad-on-load (inverse) / truncate-on-store (forward)
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 1>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
     reg.back().pad = 1;
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, false, 2>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));

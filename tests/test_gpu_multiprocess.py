@@ -38,25 +38,54 @@ def _free_port():
     return p
 
 
-def _torchrun(nproc, script_args, timeout=600):
-    env = dict(os.environ, MFFT_RCCL_LIB=MOCK, MOCK_RCCL_SLOT_KB="2048", OMP_NUM_THREADS="1")
+def _env():
+    return dict(os.environ, MFFT_RCCL_LIB=MOCK, MOCK_RCCL_SLOT_KB="2048", OMP_NUM_THREADS="1")
+
+
+def _torchrun(nproc, script_args, timeout=900):
+    """The driver's launch line (python -m torch.distributed.run ...)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
+    p = subprocess.run(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
     return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def _spawn(nproc, script_args, timeout=600):
+    """Same environment contract (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) without the launcher's
+    own start-up cost: one python process per rank started directly."""
+    port = _free_port()
+    procs = []
+    for r in range(nproc):
+        env = dict(_env(), RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable] + script_args, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, cwd=ROOT))
+    rc, outs, errs = 0, [], []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        rc = rc or p.returncode
+        outs.append(o.decode())
+        errs.append(e.decode())
+    return rc, "".join(outs), "\n".join(errs)
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_process_per_rank_parity(world):
-    rc, out, err = _torchrun(world, [os.path.join(ROOT, "tests", "mp_worker.py")])
+    rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker.py")])
     assert rc == 0, (out[-2000:], err[-4000:])
     assert "MP_OK world=%d" % world in out
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_under_torchrun_prints_one_json_line(world):
-    rc, out, err = _torchrun(world, [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "128",
-                                     "--steps", "3", "--warmup", "1", "--cpu-baseline", "off"])
+@pytest.mark.parametrize("world,launcher", [(2, "torchrun"), (4, "spawn")])
+def test_bench_multi_rank_prints_one_json_line(world, launcher):
+    run = _torchrun if launcher == "torchrun" else _spawn
+    rc, out, err = run(world, [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "128",
+                               "--steps", "3", "--warmup", "1", "--cpu-baseline", "off"])
     assert rc == 0, (out[-2000:], err[-4000:])
     lines = [l for l in out.splitlines() if l.strip()]
     assert len(lines) == 1, out                      # exactly one line on stdout, from rank 0
