@@ -26,8 +26,12 @@ def short(name):
     extra = ""
     if fam in ("ColFft", "RowFft"):
         extra = " inv" if flag == "true" else " fwd"
-    if fam == "ColFft" and rest.strip().endswith("true"):
-        extra += " nt"
+    if fam == "ColFft":
+        tail = [t.strip() for t in rest.split(",") if t.strip()]      # TWLDS, SPLIT, VEC, NT, PAD
+        if len(tail) >= 4 and tail[3] == "true":
+            extra += " nt"
+        if len(tail) >= 5 and tail[4] != "0":
+            extra += " pad%s" % tail[4]
     return "%s n=%s %s tile=%s%s" % (fam, spec.replace(", ", "x"), prec, tile, extra)
 
 
