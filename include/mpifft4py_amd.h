@@ -98,7 +98,9 @@ typedef struct {
   int p1;             /* pencil: ranks along the first axis, 0 = Compute_dims default */
   double padsize;     /* 3/2-rule pad factor (1.5) */
   int pipeline;       /* >1: split exchanges into this many overlapped sub-steps */
-  int reserved[7];
+  int drop_nyquist;   /* pencil 'AlltoallN' mode (pencil.py:410-432, 647-668): the kz = N2/2 column is
+                         neither exchanged nor returned; the inverse treats it as zero */
+  int reserved[6];
 } mfft_plan_desc;
 
 MFFT_API int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* plan);

@@ -658,7 +658,7 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
   const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
   const bool X = d.decomp == MFFT_PENCIL_X;
   // a group of one rank exchanges nothing: its pack / copy steps are skipped altogether
-  const bool zsolo = (X ? P2 : P1) == 1, g2solo = (X ? P1 : P2) == 1;
+  const bool zsolo = (X ? P2 : P1) == 1 && !d.drop_nyquist, g2solo = (X ? P1 : P2) == 1;
   const size_t wb = (size_t)std::max(m * n * Nf, std::max(m * N1 * q, N0 * n * q)) * es;
   MFFT_TRY(ensure_work(0, wb));
   MFFT_TRY(ensure_work(1, wb));
@@ -695,7 +695,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
   const int64_t m = N1_0, n = N2_1;
   const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
   const bool X = d.decomp == MFFT_PENCIL_X;
-  const bool zsolo = (X ? P2 : P1) == 1, g2solo = (X ? P1 : P2) == 1;
+  const bool zsolo = (X ? P2 : P1) == 1 && !d.drop_nyquist, g2solo = (X ? P1 : P2) == 1;
   const void* src = fu;
   if (masked) {
     void* mm = nullptr;
@@ -735,6 +735,8 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, false, cur, other); }));
     MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z(this, cur, other, m * n, Nf, zc, true); }));
   }
+  if (d.drop_nyquist)   // the neglected Nyquist column counts as zero (pencil.py:430, 1045)
+    MFFT_HIP(hipMemset2DAsync(static_cast<char*>(cur) + (size_t)(Nf - 1) * es, (size_t)Nf * es, 0, es, (size_t)(m * n), stream));
   MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(cur, u, m * n, N2, Nf); }));
   return 0;
 }
@@ -743,6 +745,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
 // before the transform along it, when the axis is locally complete) -------------
 int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
   if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
+  if (d.drop_nyquist) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule with communication='AlltoallN' is not implemented");
   const double ps = d.padsize, sc3 = ps * ps * ps;
   const bool X = d.decomp == MFFT_PENCIL_X;
   const std::vector<int>& gz = X ? group1 : group0;
@@ -801,6 +804,7 @@ int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
 
 int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
   if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
+  if (d.drop_nyquist) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule with communication='AlltoallN' is not implemented");
   const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
   const bool X = d.decomp == MFFT_PENCIL_X;
   const std::vector<int>& gz = X ? group1 : group0;
@@ -928,6 +932,10 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
     if (p->r2c && Pz > 1 && ((p->N2 / Pz) % 2)) return set_error(MFFT_ERR_UNSUPPORTED, "N[2]/%d must be even for the pencil z split", Pz);
     if (p->Nf % Pz > 1) return set_error(MFFT_ERR_UNSUPPORTED, "Nf=%lld cannot be split over %d ranks", (long long)p->Nf, Pz);
     p->zc = pencil_chunks(p->Nf, Pz);
+    if (desc->drop_nyquist) {      // 'AlltoallN': equal chunks of the N2/2 non-Nyquist columns
+      if (!p->r2c) return set_error(MFFT_ERR_INVALID, "drop_nyquist is an R2C mode");
+      p->zc = pencil_chunks(p->N2 / 2, Pz);
+    }
     p->q = p->zc[cz].len;
     p->zstart = p->zc[cz].start;
   } else {

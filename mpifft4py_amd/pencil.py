@@ -45,9 +45,7 @@ class R2CY(DistFFTBase):
         P = self.num_processes
         if not allow_single:
             assert P > 1
-        if communication == 'AlltoallN':
-            raise NotImplementedError("communication='AlltoallN' (lossy Nyquist-dropping variant) is not offered")
-        if communication not in ('Alltoall', 'Alltoallw'):
+        if communication not in ('Alltoall', 'Alltoallw', 'AlltoallN'):
             raise ValueError("unknown communication %r" % (communication,))
         if P1 is None:
             P1, P2 = _compute_dims(P)
@@ -71,7 +69,13 @@ class R2CY(DistFFTBase):
             self.Nf = int(N[2])
             self.N1f = int(self.N1[2])
             self.N2f = int(self.N2[2])
-        self._create_plan(self._kind, self._decomp, p1=P1, pipeline=pipeline)
+        drop = communication == 'AlltoallN'
+        if drop:
+            # the z-Nyquist mode is neglected so that all chunks are equal (pencil.py:198-199, 909-910)
+            assert self._kind == _lib.R2C
+            self.N1f = int(self.N1[2] // 2)
+            self.N2f = int(self.N2[2] // 2)
+        self._create_plan(self._kind, self._decomp, p1=P1, pipeline=pipeline, drop_nyquist=drop)
         assert self._c_real_shape == tuple(self.real_shape())
         assert self._c_complex_shape == tuple(self.complex_shape()), (self._c_complex_shape, self.complex_shape())
 

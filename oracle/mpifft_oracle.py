@@ -591,6 +591,72 @@ def pencil_r2c_backward(fus, N, P1=None, alignment="X", precision="double"):
 
 
 # --------------------------------------------------------------------------
+# pencil 'AlltoallN' mode (pencil.py:410-432, 647-668, 1024-1047, 1237-1261): the z-Nyquist
+# column is neglected so that every rank holds N2/(2*Pz) columns; the inverse sets it to zero.
+# --------------------------------------------------------------------------
+
+class PencilNLayout(PencilLayout):
+    def N1f(self, c0):
+        return int(self.N1[2] // 2)
+
+    def N2f(self, c1):
+        return int(self.N2[2] // 2)
+
+
+def pencil_r2c_forward_n(us, N, P1=None, alignment="X", precision="double"):
+    P = len(us)
+    lay = PencilNLayout(N, P, P1, alignment)
+    _, ctype = dtypes(precision)
+    N = lay.N
+    P1, P2 = lay.P1, lay.P2
+    N1, N2 = lay.N1, lay.N2
+    half = int(N[2] // 2)
+    a = [np.fft.rfft(u, axis=2).astype(ctype)[:, :, :half] for u in us]
+    if alignment == "Y":
+        b = _exchange_split_gather(a, _groups(lay, 0), 2, 0, pencil_chunks(half, P1), None,
+                                   lambda r: (int(N[0]), int(N2[1]), half // P1))
+        b = [np.fft.fft(x, axis=0).astype(ctype) for x in b]
+        c = _exchange_split_gather(b, _groups(lay, 1), 0, 1, pencil_chunks(int(N[0]), P2), None,
+                                   lambda r: (int(N2[0]), int(N[1]), half // P1))
+        return [np.fft.fft(x, axis=1).astype(ctype) for x in c]
+    b = _exchange_split_gather(a, _groups(lay, 1), 2, 1, pencil_chunks(half, P2), None,
+                               lambda r: (int(N1[0]), int(N[1]), half // P2))
+    b = [np.fft.fft(x, axis=1).astype(ctype) for x in b]
+    c = _exchange_split_gather(b, _groups(lay, 0), 1, 0, pencil_chunks(int(N[1]), P1), None,
+                               lambda r: (int(N[0]), int(N1[1]), half // P2))
+    return [np.fft.fft(x, axis=0).astype(ctype) for x in c]
+
+
+def pencil_r2c_backward_n(fus, N, P1=None, alignment="X", precision="double"):
+    P = len(fus)
+    lay = PencilNLayout(N, P, P1, alignment)
+    rtype, ctype = dtypes(precision)
+    N = lay.N
+    P1, P2 = lay.P1, lay.P2
+    N1, N2 = lay.N1, lay.N2
+    half = int(N[2] // 2)
+    zshape = lambda r: (int(N1[0]), int(N2[1]), half)
+    if alignment == "Y":
+        a = [np.fft.ifft(f, axis=1).astype(ctype) for f in fus]
+        b = _exchange_split_gather(a, _groups(lay, 1), 1, 0, pencil_chunks(int(N[1]), P2), None,
+                                   lambda r: (int(N[0]), int(N2[1]), half // P1))
+        b = [np.fft.ifft(x, axis=0).astype(ctype) for x in b]
+        c = _exchange_split_gather(b, _groups(lay, 0), 0, 2, pencil_chunks(int(N[0]), P1), None, zshape)
+    else:
+        a = [np.fft.ifft(f, axis=0).astype(ctype) for f in fus]
+        b = _exchange_split_gather(a, _groups(lay, 0), 0, 1, pencil_chunks(int(N[0]), P1), None,
+                                   lambda r: (int(N1[0]), int(N[1]), half // P2))
+        b = [np.fft.ifft(x, axis=1).astype(ctype) for x in b]
+        c = _exchange_split_gather(b, _groups(lay, 1), 1, 2, pencil_chunks(int(N[1]), P2), None, zshape)
+    out = []
+    for x in c:
+        z = np.zeros(x.shape[:2] + (half + 1,), dtype=ctype)
+        z[:, :, :half] = x
+        out.append(np.fft.irfft(z, n=int(N[2]), axis=2).astype(rtype))
+    return out
+
+
+# --------------------------------------------------------------------------
 # EXTENSION, PARITY UNPINNED: pencil C2C.  The reference has no pencil C2C class
 # (pencil.py defines only R2CY / R2CX), so there is nothing to pin this against
 # except the DFT definition itself (numpy.fft.fftn of the gathered array).  Same

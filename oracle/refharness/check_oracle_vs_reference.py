@@ -193,6 +193,28 @@ def check_pencil(N, P, prec, mode, align, rng, P1=None):
     return worst
 
 
+def check_pencil_n(N, P, prec, align, rng, P1=None):
+    """'AlltoallN': input projected to zero z-Nyquist as the reference's test does (tests/test_FFT.py:64-68)."""
+    rtype, ctype = orc.dtypes(prec)
+    A = rng.random(N).astype(rtype)
+    C = np.fft.rfftn(A.astype(np.float64))
+    C[:, :, -1] = 0
+    A = np.fft.irfftn(C, s=N, axes=(0, 1, 2)).astype(rtype)
+    ref = run_ref_pencil(N, P, prec, "AlltoallN", align, A, P1=P1)
+    lay = orc.PencilNLayout(N, P, P1, align)
+    us = orc.scatter_real(A, lay)
+    fus = orc.pencil_r2c_forward_n(us, N, P1, align, prec)
+    back = orc.pencil_r2c_backward_n(fus, N, P1, align, prec)
+    worst = 0.0
+    for r in range(P):
+        rl, rc, rb = ref[r]
+        assert rl["complex_shape"] == lay.complex_shape(r), (rl["complex_shape"], lay.complex_shape(r))
+        assert _slices_equal(rl["complex_slice"], lay.complex_local_slice(r))
+        worst = max(worst, orc.rel_l2(fus[r], rc), orc.rel_l2(back[r], rb))
+    assert worst < _tol(prec), worst
+    return worst
+
+
 def main():
     rng = np.random.default_rng(7)
     n = 0
@@ -215,6 +237,10 @@ def main():
                         print("pencil%s N=%s P=%d P1=%s %s %-9s worst rel-L2 %.2e"
                               % (align, N, P, P1, prec, mode, w))
                         n += 1
+                for align in ("X", "Y"):
+                    w = check_pencil_n(N, P, prec, align, rng, P1=P1)
+                    print("pencil%s N=%s P=%d P1=%s %s AlltoallN worst rel-L2 %.2e" % (align, N, P, P1, prec, w))
+                    n += 1
     print("OK: %d configurations, oracle == reference" % n)
 
 

@@ -514,3 +514,31 @@ def test_full_size_1024_cubed():
     assert np.array_equal(u.leading(0, 4).get(), A[:4])                          # input untouched
     C = sfft.rfftn(A, workers=os.cpu_count())
     assert rel(fu.get(), C, 32) < 1e-10                                          # forward vs pocketfft
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("align", ["X", "Y"])
+@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2)])
+def test_pencil_alltoalln(P, P1, align, prec):
+    """communication='AlltoallN' (pencil.py:410-432, 647-668): the z-Nyquist column is neglected.
+    Same protocol as the reference's test (tests/test_FFT.py:64-68): the input is first projected
+    onto fields without that mode."""
+    from mpifft4py_amd import Pencil_R2C
+    rng = np.random.default_rng(800 + P)
+    C = np.fft.rfftn(rng.random(NREF))
+    C[:, :, -1] = 0
+    A = np.fft.irfftn(C, s=NREF, axes=(0, 1, 2)).astype(rdtype(prec))
+    lay = orc.PencilNLayout(NREF, P, P1, align)
+    want = orc.pencil_r2c_forward_n(orc.scatter_real(A, lay), NREF, P1, align, prec)
+
+    def body(comm):
+        F = Pencil_R2C(np.array(NREF), L, comm, prec, P1=P1, communication="AlltoallN", alignment=align)
+        assert tuple(F.complex_shape()) == tuple(lay.complex_shape(comm.Get_rank()))
+        a = np.ascontiguousarray(A[F.real_local_slice()])
+        c = F.fftn(a, np.zeros(F.complex_shape(), dtype=F.complex))
+        b = F.ifftn(c, np.zeros(F.real_shape(), dtype=F.float))
+        return F.complex_local_slice(), c, F.real_local_slice(), b
+    for r, (cs, c, rs, b) in enumerate(run_ranks(P, body)):
+        assert orc.rel_l2(c, want[r]) < TOL[prec]
+        assert orc.rel_l2(c, C[cs]) < TOL[prec]
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
