@@ -473,6 +473,7 @@ int main() {
   // every plan in plans.h is exercised
 #define MFFT_PLAN(N, ...) test_spec_all<Spec<N, __VA_ARGS__>>();
   MFFT_FOR_EACH_PLAN(MFFT_PLAN)
+  MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN)
 #undef MFFT_PLAN
   printf("%s (%d failures)\n", g_fail ? "EMU TESTS FAILED" : "EMU TESTS PASSED", g_fail);
   return g_fail ? 1 : 0;

@@ -17,4 +17,24 @@
 #define MFFT_PLANS_F(X) X(10, 5, 2) X(20, 5, 4) X(40, 5, 4, 2) X(80, 5, 4, 4) X(160, 8, 4, 5)
 #define MFFT_PLANS_G(X) X(320, 8, 8, 5) X(640, 8, 4, 4, 5) X(1280, 8, 8, 4, 5) X(2560, 8, 8, 8, 5)
 
+// Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
+// axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
+// the CU of waves.  For the 3- and 5-smooth lengths >= 96 the row kernels therefore use radix
+// 4/2 passes around one radix-3/5 pass (E = 12 / 20) instead of the strided kernels' E = 24 / 40.
+// A length listed here is NOT given row kernels by its MFFT_PLANS_* entry.
+#define MFFT_ROWPLANS_D(X) X(96, 4, 4, 3, 2) X(192, 4, 4, 4, 3)
+#define MFFT_ROWPLANS_E(X) X(384, 4, 4, 4, 3, 2) X(768, 4, 4, 4, 4, 3) X(1536, 4, 4, 4, 4, 3, 2) X(3072, 4, 4, 4, 4, 4, 3)
+#define MFFT_ROWPLANS_F(X) X(160, 4, 4, 5, 2)
+#define MFFT_ROWPLANS_G(X) X(320, 4, 4, 4, 5) X(640, 4, 4, 4, 5, 2) X(1280, 4, 4, 4, 4, 5) X(2560, 4, 4, 4, 4, 5, 2)
+#define MFFT_ROWPLANS_A(X)
+#define MFFT_ROWPLANS_B(X)
+#define MFFT_ROWPLANS_C(X)
+#define MFFT_FOR_EACH_ROWPLAN(X) MFFT_ROWPLANS_D(X) MFFT_ROWPLANS_E(X) MFFT_ROWPLANS_F(X) MFFT_ROWPLANS_G(X)
+
+// true if complex length n takes its row kernels from MFFT_ROWPLANS_*
+constexpr bool mfft_has_row_override(int n) {
+  return n == 96 || n == 192 || n == 384 || n == 768 || n == 1536 || n == 3072 || n == 160 || n == 320 || n == 640 ||
+         n == 1280 || n == 2560;
+}
+
 #define MFFT_FOR_EACH_PLAN(X) MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X)

@@ -5,6 +5,7 @@
 #include <vector>
 #include "fft_kernels.h"
 #include "twiddle.h"
+#include "plans.h"
 
 namespace mfft {
 
@@ -55,7 +56,7 @@ template <class S, typename T> constexpr int row_rows() {
   int rows = 256 / S::TPT;
   if (rows < 1) rows = 1;
   const long long per_row = (long long)(S::N + S::N / S::R(0) + 1) * (int)sizeof(cx<T>);
-  while (rows > 1 && per_row * rows > 40960) rows /= 2;
+  while (rows > 1 && per_row * rows > 40960 && S::TPT * (rows / 2) >= 64) rows /= 2;   // never below one wave
   return rows;
 }
 template <class S, typename T> constexpr bool row_twlds() { return S::NP > 1; }
@@ -100,38 +101,50 @@ KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
 }
 
 template <class S, typename T>
-void register_plan(const char* name) {
+void register_col(const char* name) {
   auto& reg = kernel_registry();
   constexpr int C = col_cols<S, T>();
   constexpr bool CT = col_twlds<S, T>();
   constexpr bool CS = col_split<S, T>();
   constexpr int CV = col_vec<S, T>();
-  constexpr int R = row_rows<S, T>();
-  constexpr bool RT = row_twlds<S, T>();
   reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
   reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
-  if constexpr (S::E % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3) ...
-    reg.push_back(make_entry<R2CFft<S, T, R, RT, true>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
-    reg.back().pad = 3;
-    reg.push_back(make_entry<C2RFft<S, T, R, RT, true>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
-    reg.back().pad = 3;
-  }
-  if constexpr (S::E % 3 == 0 && S::N >= 6) {   // ... and pad-on-load (inverse) / truncate-on-store (forward)
+  if constexpr (S::E % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: pad-on-load (inverse) / truncate-on-store (forward)
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 1>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
     reg.back().pad = 1;
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, false, 2>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
     reg.back().pad = 2;
   }
-  if constexpr (S::N >= 256) {     // aligned-row variants for the large in-place passes
+  if constexpr (S::N >= 256) {     // aligned-row variants for the large out-of-place passes
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
     reg.back().nt = 1;
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
     reg.back().nt = 1;
   }
+}
+
+template <class S, typename T>
+void register_rows(const char* name) {
+  auto& reg = kernel_registry();
+  constexpr int R = row_rows<S, T>();
+  constexpr bool RT = row_twlds<S, T>();
   reg.push_back(make_entry<RowFft<S, T, R, false, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
   reg.push_back(make_entry<RowFft<S, T, R, true, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
   reg.push_back(make_entry<R2CFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
   reg.push_back(make_entry<C2RFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
+  if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
+    reg.push_back(make_entry<R2CFft<S, T, R, RT, true>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+    reg.back().pad = 3;
+    reg.push_back(make_entry<C2RFft<S, T, R, RT, true>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
+    reg.back().pad = 3;
+  }
+}
+
+// a plan of the main list: strided kernels always, row kernels unless the length has an override
+template <class S, typename T>
+void register_plan(const char* name) {
+  register_col<S, T>(name);
+  if constexpr (!mfft_has_row_override(S::N)) register_rows<S, T>(name);
 }
 
 struct PlanRegistrar {
