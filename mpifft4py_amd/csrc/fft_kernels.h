@@ -551,29 +551,69 @@ struct C2RFft {
     // pre-pass: Z[k] = (X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])
     // (twice the textbook value; the factor is folded into the normalisation)
     cx<T> v[S::E];
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool SHFL = S::TPT <= 64 && (64 % S::TPT) == 0;
+#else
+    constexpr bool SHFL = false;      // the host emulator has no cross-lane shuffle: it takes the load path
+#endif
+    if constexpr (SHFL) {
+      // Every bin is read from memory ONCE.  The mirrored partner X[M-pos] of (lane j, register k)
+      // is register E-1-k of lane TPT-j of the same row (all inside one wave), fetched with a
+      // wave shuffle; lane 0's partners are its own registers E-k and the extra bin X[M].
+      cx<T> x[S::E];
 #pragma unroll
-    for (int k = 0; k < S::E; ++k) {
-      const int pos = j + k * S::TPT;
-      cx<T> z = mk<T>((T)0, (T)0);
-      if (active) {
-        cx<T> xk, xm;
-        if constexpr (LIMIT) {
-          xk = pos < P.valid ? ip[pos] : mk<T>((T)0, (T)0);
-          xm = (M - pos) < P.valid ? conj(ip[M - pos]) : mk<T>((T)0, (T)0);
-        } else {
-          xk = ip[pos];
-          xm = conj(ip[M - pos]);
-        }
-        if (pos == 0) {            // imaginary parts of the k=0 and k=N/2 bins are ignored
+      for (int k = 0; k < S::E; ++k) {
+        const int pos = j + k * S::TPT;
+        x[k] = mk<T>((T)0, (T)0);
+        if (active && (!LIMIT || pos < P.valid)) x[k] = ip[pos];
+      }
+      cx<T> xM = mk<T>((T)0, (T)0);
+      if (active && j == 0 && (!LIMIT || M < P.valid)) xM = ip[M];
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int src = (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));     // lane of thread TPT-j (mod TPT) of this row
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const cx<T> give = x[S::E - 1 - k];
+        cx<T> pm = mk<T>(__shfl(give.x, src, 64), __shfl(give.y, src, 64));
+        if (j == 0) pm = (k == 0) ? xM : x[(S::E - k) % S::E];
+        const int pos = j + k * S::TPT;
+        cx<T> xk = x[k];
+        cx<T> xm = conj(pm);
+        if (pos == 0) {              // imaginary parts of the k=0 and k=N/2 bins are ignored
           xk.y = (T)0;
           xm.y = (T)0;
         }
         const cx<T> e = xk + xm;
-        const cx<T> d = xk - xm;
-        const cx<T> o = d * conj(P.rtw[pos]);
-        z = e + mul_pi(o);
+        const cx<T> dd = xk - xm;
+        const cx<T> w = active ? P.rtw[pos] : mk<T>((T)1, (T)0);
+        v[k] = swapri(e + mul_pi(dd * conj(w)));   // inverse transform through the swap identity
       }
-      v[k] = swapri(z);            // inverse transform through the swap identity
+#endif
+    } else {
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const int pos = j + k * S::TPT;
+        cx<T> z = mk<T>((T)0, (T)0);
+        if (active) {
+          cx<T> xk, xm;
+          if constexpr (LIMIT) {
+            xk = pos < P.valid ? ip[pos] : mk<T>((T)0, (T)0);
+            xm = (M - pos) < P.valid ? conj(ip[M - pos]) : mk<T>((T)0, (T)0);
+          } else {
+            xk = ip[pos];
+            xm = conj(ip[M - pos]);
+          }
+          if (pos == 0) {            // imaginary parts of the k=0 and k=N/2 bins are ignored
+            xk.y = (T)0;
+            xm.y = (T)0;
+          }
+          const cx<T> e = xk + xm;
+          const cx<T> d = xk - xm;
+          const cx<T> o = d * conj(P.rtw[pos]);
+          z = e + mul_pi(o);
+        }
+        v[k] = swapri(z);            // inverse transform through the swap identity
+      }
     }
     if constexpr (TWLDS && S::NP > 1) {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
