@@ -498,26 +498,46 @@ struct R2CFft {
 
     // split post-pass: X[k] = E[k] + w_k O[k],  E = (Z[k] + conj Z[M-k])/2,
     // O = -i (Z[k] - conj Z[M-k])/2,  w_k = exp(-2 pi i k / N)
-    if constexpr (S::NP > 1) MFFT_BARRIER();
-#pragma unroll
-    for (int k = 0; k < S::E; ++k) xc.put(j + k * S::TPT, v[k]);
-    MFFT_BARRIER();
-    if (active) {
-      const T half = (T)0.5;
-#pragma unroll
-      for (int k = 0; k < S::E; ++k) {
-        const int pos = j + k * S::TPT;
-        const int mp = pos == 0 ? 0 : M - pos;
-        const cx<T> zk = v[k];
-        const cx<T> zm = conj(xc.get(mp));
+    const T half = (T)0.5;
+    auto emit = [&](int pos, cx<T> zk, cx<T> zpartner) {
+      if (pos == 0) {
+        op[0] = mk<T>((zk.x + zk.y) * P.scale, (T)0);
+        if (!LIMIT || M < P.valid) op[M] = mk<T>((zk.x - zk.y) * P.scale, (T)0);
+      } else if (!LIMIT || pos < P.valid) {
+        const cx<T> zm = conj(zpartner);
         const cx<T> e = scale(zk + zm, half);
         const cx<T> o = mul_mi(scale(zk - zm, half));
-        const cx<T> w = P.rtw[pos];
-        if (pos == 0) {
-          op[0] = mk<T>((zk.x + zk.y) * P.scale, (T)0);
-          if (!LIMIT || M < P.valid) op[M] = mk<T>((zk.x - zk.y) * P.scale, (T)0);
-        } else if (!LIMIT || pos < P.valid) {
-          op[pos] = scale(e + w * o, P.scale);
+        op[pos] = scale(e + P.rtw[pos] * o, P.scale);
+      }
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool SHFL = S::TPT <= 64 && (64 % S::TPT) == 0;
+#else
+    constexpr bool SHFL = false;      // host emulator: partner through LDS
+#endif
+    if constexpr (SHFL) {
+      // Z[M-pos] of (lane j, register k) is register E-1-k of lane TPT-j of the same row: one
+      // wave shuffle instead of an LDS round trip and two barriers (lane 0: its own register E-k)
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int src = (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const cx<T> give = v[S::E - 1 - k];
+        cx<T> pm = mk<T>(__shfl(give.x, src, 64), __shfl(give.y, src, 64));
+        if (j == 0) pm = v[(S::E - k) % S::E];
+        if (active) emit(j + k * S::TPT, v[k], pm);
+      }
+#endif
+    } else {
+      if constexpr (S::NP > 1) MFFT_BARRIER();
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) xc.put(j + k * S::TPT, v[k]);
+      MFFT_BARRIER();
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) {
+          const int pos = j + k * S::TPT;
+          emit(pos, v[k], xc.get(pos == 0 ? 0 : M - pos));
         }
       }
     }
