@@ -542,3 +542,36 @@ def test_pencil_alltoalln(P, P1, align, prec):
         assert orc.rel_l2(c, want[r]) < TOL[prec]
         assert orc.rel_l2(c, C[cs]) < TOL[prec]
         assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
+
+
+def test_hipgraph_replay_opt_in(monkeypatch):
+    """MFFT_GRAPH=1: the kernel sequence of a (direction, buffers, dealias) combination is captured on its
+    second use and replayed afterwards; results are identical and survive work-buffer growth."""
+    from mpifft4py_amd import DeviceArray, SelfComm, Slab_R2C
+    monkeypatch.setenv("MFFT_GRAPH", "1")
+    N = np.array([32, 64, 16])
+    rng = np.random.default_rng(21)
+    A = rng.random(tuple(N))
+    F = Slab_R2C(N, L, SelfComm(0), "double")
+    u = DeviceArray.from_numpy(A)
+    fu = DeviceArray.empty(F.complex_shape(), F.complex)
+    u2 = DeviceArray.empty(F.real_shape(), F.float)
+    up = DeviceArray.empty(F.real_shape_padded(), F.float)
+    fu2 = DeviceArray.empty(F.complex_shape(), F.complex)
+    ref = np.fft.rfftn(A)
+    for it in range(5):                      # direct, capture, replay, replay, replay
+        F.fftn(u, fu)
+        F.ifftn(fu, u2)
+        F.sync()
+        assert orc.rel_l2(fu.get(), ref) < 1e-10, it
+        assert orc.rel_l2(u2.get(), A) < 1e-10, it
+        if it == 2:                          # padded path grows the work buffers: graphs must be rebuilt
+            F.ifftn(fu, up, "3/2-rule")
+            F.fftn(up, fu2, "3/2-rule")
+            F.sync()
+    # new data through the same buffers goes through the replayed graph
+    B = rng.random(tuple(N))
+    u.set(B)
+    F.fftn(u, fu)
+    F.sync()
+    assert orc.rel_l2(fu.get(), np.fft.rfftn(B)) < 1e-10
