@@ -1,10 +1,12 @@
 // core.hip -- kernel registry, twiddle cache, launch layer and the small
 // data-movement kernels (box copy / mask / scale / synthetic fill).
 #include <cstdarg>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include "mfft_internal.h"
 
 namespace mfft {
@@ -34,10 +36,19 @@ const KernelEntry* find_kernel(int family, int n, int prec, int inv, int nt, int
   return nullptr;
 }
 
+const KernelEntry* find_chirpz(int family, int n, int prec, int inv) {
+  const KernelEntry* best = nullptr;
+  for (const KernelEntry& e : kernel_registry())
+    if (e.family == family && e.prec == prec && e.inv == inv && e.n >= 2 * n - 1 && (!best || e.n < best->n)) best = &e;
+  return best;
+}
+
 bool length_supported(int64_t n, bool real_transform) {
   if (n <= 0 || n > (1 << 20)) return false;
-  if (real_transform) return find_kernel(FAM_R2C, (int)n, MFFT_DOUBLE, 0) != nullptr;
-  return n == 1 || find_kernel(FAM_COL, (int)n, MFFT_DOUBLE, 0) != nullptr;
+  if (real_transform)
+    return find_kernel(FAM_R2C, (int)n, MFFT_DOUBLE, 0) != nullptr || find_chirpz(FAM_R2CZ, (int)n, MFFT_DOUBLE, 0) != nullptr;
+  return n == 1 || find_kernel(FAM_COL, (int)n, MFFT_DOUBLE, 0) != nullptr ||
+         find_chirpz(FAM_COLZ, (int)n, MFFT_DOUBLE, 0) != nullptr;
 }
 
 // ---------------------------------------------------------------------------
@@ -48,6 +59,7 @@ struct DevCache {
   std::map<const KernelEntry*, void*> tw;
   std::map<std::pair<int, int>, void*> rtw;
   std::map<const void*, bool> attr_done;
+  std::map<std::tuple<int, int, int>, std::pair<void*, void*>> ztab;   // (n, M, prec) -> (chirp, bhat)
 };
 static std::mutex g_cache_mu;
 static std::map<int, DevCache> g_cache;
@@ -100,12 +112,46 @@ static int real_twiddles(int n, int prec, void** out) {
   return 0;
 }
 
+// chirp-z tables of logical length n on convolution length M (fft_chirpz.h)
+template <typename T>
+static int upload_chirpz(int n, int M, void** chirp, void** bhat) {
+  auto c = build_chirp<T>(n);
+  auto b = build_chirp_filter<T>(n, M);
+  MFFT_HIP(hipMalloc(chirp, c.size() * sizeof(c[0])));
+  MFFT_HIP(hipMemcpy(*chirp, c.data(), c.size() * sizeof(c[0]), hipMemcpyHostToDevice));
+  MFFT_HIP(hipMalloc(bhat, b.size() * sizeof(b[0])));
+  MFFT_HIP(hipMemcpy(*bhat, b.data(), b.size() * sizeof(b[0]), hipMemcpyHostToDevice));
+  return 0;
+}
+static int chirpz_tables(int n, int M, int prec, void** chirp, void** bhat) {
+  int dev = 0;
+  MFFT_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  DevCache& c = g_cache[dev];
+  auto key = std::make_tuple(n, M, prec);
+  auto it = c.ztab.find(key);
+  if (it == c.ztab.end()) {
+    void *ch = nullptr, *bh = nullptr;
+    MFFT_TRY(prec == MFFT_DOUBLE ? upload_chirpz<double>(n, M, &ch, &bh) : upload_chirpz<float>(n, M, &ch, &bh));
+    it = c.ztab.emplace(key, std::make_pair(ch, bh)).first;
+  }
+  *chirp = it->second.first;
+  *bhat = it->second.second;
+  return 0;
+}
+
 static RowMap to_map(const RowSpec& r, int n) { return make_rowmap(r.hi, r.lo, r.split, n); }
 
 // ---------------------------------------------------------------------------
-template <typename T>
-static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStream_t s) {
-  ColParams<T> P;
+template <typename T, class PT = ColParams<T>>
+static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStream_t s, const void* chirp = nullptr,
+                        const void* bhat = nullptr) {
+  PT P;
+  if constexpr (!std::is_same<PT, ColParams<T>>::value) {
+    P.chirp = static_cast<const cx<T>*>(chirp);
+    P.bhat = static_cast<const cx<T>*>(bhat);
+    P.n = a.n;
+  }
   P.in = static_cast<const cx<T>*>(a.in);
   P.out = static_cast<cx<T>*>(a.out);
   P.tw = static_cast<const cx<T>*>(tw);
@@ -148,17 +194,29 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   }
   if (!e && nt) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1);
   if (!e) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0);
-  if (!e)
-    return set_error(MFFT_ERR_UNSUPPORTED,
-                     "no kernel for a complex transform of length %d (supported: 2^a, 3*2^a, 5*2^a up to 4096)", a.n);
   void* tw = nullptr;
+  if (!e) {   // no radix plan for this length: chirp-z on the next compiled length >= 2n-1
+    e = find_chirpz(FAM_COLZ, a.n, a.prec, a.inverse ? 1 : 0);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d (maximum 2048 for lengths other than 2^a, 3*2^a, 5*2^a)", a.n);
+    void *chirp = nullptr, *bhat = nullptr;
+    MFFT_TRY(prepare_kernel(e, &tw));
+    MFFT_TRY(chirpz_tables(a.n, e->n, a.prec, &chirp, &bhat));
+    return a.prec == MFFT_DOUBLE ? launch_col_t<double, ColParamsZ<double>>(e, a, tw, s, chirp, bhat)
+                                 : launch_col_t<float, ColParamsZ<float>>(e, a, tw, s, chirp, bhat);
+  }
   MFFT_TRY(prepare_kernel(e, &tw));
   return a.prec == MFFT_DOUBLE ? launch_col_t<double>(e, a, tw, s) : launch_col_t<float>(e, a, tw, s);
 }
 
-template <typename T>
-static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStream_t s) {
-  RowParams<T> P;
+template <typename T, class PT = RowParams<T>>
+static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStream_t s, const void* chirp = nullptr,
+                        const void* bhat = nullptr) {
+  PT P;
+  if constexpr (!std::is_same<PT, RowParams<T>>::value) {
+    P.chirp = static_cast<const cx<T>*>(chirp);
+    P.bhat = static_cast<const cx<T>*>(bhat);
+    P.n = a.n;
+  }
   P.in = static_cast<const cx<T>*>(a.in);
   P.out = static_cast<cx<T>*>(a.out);
   P.tw = static_cast<const cx<T>*>(tw);
@@ -176,17 +234,29 @@ static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStr
 
 int launch_row(const RowArgs& a, hipStream_t s) {
   const KernelEntry* e = find_kernel(FAM_ROW, a.n, a.prec, a.inverse ? 1 : 0);
-  if (!e)
-    return set_error(MFFT_ERR_UNSUPPORTED,
-                     "no kernel for a complex transform of length %d (supported: 2^a, 3*2^a, 5*2^a up to 4096)", a.n);
   void* tw = nullptr;
+  if (!e) {
+    e = find_chirpz(FAM_ROWZ, a.n, a.prec, a.inverse ? 1 : 0);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d (maximum 2048 for lengths other than 2^a, 3*2^a, 5*2^a)", a.n);
+    void *chirp = nullptr, *bhat = nullptr;
+    MFFT_TRY(prepare_kernel(e, &tw));
+    MFFT_TRY(chirpz_tables(a.n, e->n, a.prec, &chirp, &bhat));
+    return a.prec == MFFT_DOUBLE ? launch_row_t<double, RowParamsZ<double>>(e, a, tw, s, chirp, bhat)
+                                 : launch_row_t<float, RowParamsZ<float>>(e, a, tw, s, chirp, bhat);
+  }
   MFFT_TRY(prepare_kernel(e, &tw));
   return a.prec == MFFT_DOUBLE ? launch_row_t<double>(e, a, tw, s) : launch_row_t<float>(e, a, tw, s);
 }
 
-template <typename T>
-static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void* rtw, hipStream_t s) {
-  RealParams<T> P;
+template <typename T, class PT = RealParams<T>>
+static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void* rtw, hipStream_t s,
+                         const void* chirp = nullptr, const void* bhat = nullptr) {
+  PT P;
+  if constexpr (!std::is_same<PT, RealParams<T>>::value) {
+    P.chirp = static_cast<const cx<T>*>(chirp);
+    P.bhat = static_cast<const cx<T>*>(bhat);
+    P.n = a.n;
+  }
   P.in = a.in;
   P.out = a.out;
   P.tw = static_cast<const cx<T>*>(tw);
@@ -208,14 +278,20 @@ static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
   const bool limited = a.valid > 0 && a.valid < a.n / 2 + 1;
   const KernelEntry* e = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, limited ? 3 : 0);
   if (!e && limited) return set_error(MFFT_ERR_UNSUPPORTED, "no column-limited real kernel of length %d", a.n);
-  if (!e)
-    return set_error(MFFT_ERR_UNSUPPORTED,
-                     "no kernel for a real transform of length %d (supported: even 2^a, 3*2^a, 5*2^a up to 8192)", a.n);
-  // a real row is read as (n/2) complex values: rows must stay 2-element aligned
+  // the radix kernels read a real row as (n/2) complex values: rows must stay 2-element aligned
   const int64_t real_stride = fam == FAM_R2C ? a.in_stride : a.out_stride;
+  void *tw = nullptr, *rtw = nullptr;
+  if (!e || (real_stride % 2 != 0 && !limited)) {   // any other length / odd pitch: full-length chirp-z on the real row
+    e = find_chirpz(fam == FAM_R2C ? FAM_R2CZ : FAM_C2RZ, a.n, a.prec, fam == FAM_C2R ? 1 : 0);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a real transform of length %d (maximum 2048 for lengths other than 2^a, 3*2^a, 5*2^a)", a.n);
+    void *chirp = nullptr, *bhat = nullptr;
+    MFFT_TRY(prepare_kernel(e, &tw));
+    MFFT_TRY(chirpz_tables(a.n, e->n, a.prec, &chirp, &bhat));
+    return a.prec == MFFT_DOUBLE ? launch_real_t<double, RealParamsZ<double>>(e, a, tw, nullptr, s, chirp, bhat)
+                                 : launch_real_t<float, RealParamsZ<float>>(e, a, tw, nullptr, s, chirp, bhat);
+  }
   if (real_stride % 2 != 0)
     return set_error(MFFT_ERR_UNSUPPORTED, "real row stride %lld must be even", (long long)real_stride);
-  void *tw = nullptr, *rtw = nullptr;
   MFFT_TRY(prepare_kernel(e, &tw));
   MFFT_TRY(real_twiddles(a.n, a.prec, &rtw));
   return a.prec == MFFT_DOUBLE ? launch_real_t<double>(e, a, tw, rtw, s) : launch_real_t<float>(e, a, tw, rtw, s);

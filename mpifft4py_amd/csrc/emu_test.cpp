@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "fft_kernels.h"
+#include "fft_chirpz.h"
 #include "twiddle.h"
 #include "plans.h"
 
@@ -441,6 +442,148 @@ static void test_real() {
   }
 }
 
+// ---------------------------------------------------------------------------
+// chirp-z (Bluestein) kernels: runtime length n on the compiled plan S of length M >= 2n-1
+// ---------------------------------------------------------------------------
+template <class S, typename T, int COLS, bool INV, bool SPLIT, int VEC>
+static void test_col_z(int n) {
+  typedef ColFftZ<S, T, COLS, INV, SPLIT, VEC> K;
+  const int ncols = COLS + 3, nouter = 2;
+  std::mt19937_64 rng(4321 + n);
+  std::uniform_real_distribution<double> U(-1, 1);
+  const int pin = ncols + 2, pout = ncols + 5;
+  std::vector<cx<T>> in((size_t)nouter * n * pin), out((size_t)nouter * n * pout, mk<T>((T)777, (T)777));
+  for (auto& z : in) z = mk<T>((T)U(rng), (T)U(rng));
+  auto tw = build_pass_twiddles<S, T>();
+  auto ch = build_chirp<T>(n);
+  auto bh = build_chirp_filter<T>(n, S::N);
+  ColParamsZ<T> P;
+  P.in = in.data(); P.out = out.data(); P.tw = tw.data();
+  P.in_outer = (i64)n * pin; P.out_outer = (i64)n * pout;
+  P.in_map = make_rowmap(0, pin, n, n); P.out_map = make_rowmap(0, pout, n, n);
+  P.ncols = ncols; P.ntile_c = (ncols + COLS - 1) / COLS; P.nouter = nouter; P.remap = 1; P.fold = 0;
+  P.scale = INV ? (T)(1.0 / n) : (T)1;
+  P.chirp = ch.data(); P.bhat = bh.data(); P.n = n;
+  emu_launch(P.ntile_c * nouter, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  long double num = 0, den = 0;
+  for (int o = 0; o < nouter; ++o)
+    for (int c = 0; c < ncols; ++c) {
+      lvec x(n);
+      for (int r = 0; r < n; ++r) { cx<T> z = in[(size_t)o * n * pin + (size_t)r * pin + c]; x[r].x = z.x; x[r].y = z.y; }
+      lvec X = naive_dft(x, INV ? +1 : -1);
+      for (int r = 0; r < n; ++r) {
+        cx<T> g = out[(size_t)o * n * pout + (size_t)r * pout + c];
+        long double sc = INV ? 1.0L / n : 1.0L, ex = X[r].x * sc, ey = X[r].y * sc;
+        num += (g.x - ex) * (g.x - ex) + (g.y - ey) * (g.y - ey);
+        den += ex * ex + ey * ey;
+      }
+    }
+  char name[64];
+  snprintf(name, sizeof name, "chirpz col M=%d c%d v%d %s%s", S::N, COLS, VEC, INV ? "inv" : "fwd", SPLIT ? " split" : "");
+  report(name, n, pname<T>(), (double)sqrtl(num / den), 8 * tol_of<T>());
+}
+
+template <class S, typename T, int ROWS, bool INV>
+static void test_row_z(int n) {
+  typedef RowFftZ<S, T, ROWS, 0, INV> K;
+  const int nrows = ROWS * 2 + 1;
+  std::mt19937_64 rng(990 + n);
+  std::uniform_real_distribution<double> U(-1, 1);
+  const int pin = n + 3, pout = n + 1;
+  std::vector<cx<T>> in((size_t)nrows * pin), out((size_t)nrows * pout);
+  for (auto& z : in) z = mk<T>((T)U(rng), (T)U(rng));
+  auto tw = build_pass_twiddles<S, T>();
+  auto ch = build_chirp<T>(n);
+  auto bh = build_chirp_filter<T>(n, S::N);
+  RowParamsZ<T> P;
+  P.in = in.data(); P.out = out.data(); P.tw = tw.data(); P.in_stride = pin; P.out_stride = pout; P.nrows = nrows;
+  P.scale = INV ? (T)(1.0 / n) : (T)1; P.chirp = ch.data(); P.bhat = bh.data(); P.n = n;
+  emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  long double num = 0, den = 0;
+  for (int r = 0; r < nrows; ++r) {
+    lvec x(n);
+    for (int i = 0; i < n; ++i) { x[i].x = in[(size_t)r * pin + i].x; x[i].y = in[(size_t)r * pin + i].y; }
+    lvec X = naive_dft(x, INV ? +1 : -1);
+    for (int i = 0; i < n; ++i) {
+      long double s = INV ? 1.0L / n : 1.0L;
+      cx<T> g = out[(size_t)r * pout + i];
+      num += (g.x - X[i].x * s) * (g.x - X[i].x * s) + (g.y - X[i].y * s) * (g.y - X[i].y * s);
+      den += X[i].x * s * X[i].x * s + X[i].y * s * X[i].y * s;
+    }
+  }
+  char name[64];
+  snprintf(name, sizeof name, "chirpz row M=%d r%d %s", S::N, ROWS, INV ? "inv" : "fwd");
+  report(name, n, pname<T>(), (double)sqrtl(num / den), 8 * tol_of<T>());
+}
+
+template <class S, typename T, int ROWS>
+static void test_real_z(int n) {
+  const int nh = n / 2, nrows = ROWS + 2;
+  std::mt19937_64 rng(70 + n);
+  std::uniform_real_distribution<double> U(-1, 1);
+  const int pin = n + 1, pout = nh + 1 + 2;         // odd real pitch on purpose
+  std::vector<T> in((size_t)nrows * pin), back((size_t)nrows * pin, (T)0);
+  std::vector<cx<T>> out((size_t)nrows * pout);
+  for (auto& z : in) z = (T)U(rng);
+  auto tw = build_pass_twiddles<S, T>();
+  auto ch = build_chirp<T>(n);
+  auto bh = build_chirp_filter<T>(n, S::N);
+  RealParamsZ<T> P;
+  P.in = in.data(); P.out = out.data(); P.tw = tw.data(); P.rtw = nullptr; P.in_stride = pin; P.out_stride = pout;
+  P.nrows = nrows; P.valid = nh + 1; P.scale = (T)1; P.chirp = ch.data(); P.bhat = bh.data(); P.n = n;
+  {
+    typedef RowFftZ<S, T, ROWS, 1, false> K;
+    emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  }
+  long double num = 0, den = 0;
+  for (int r = 0; r < nrows; ++r) {
+    lvec x(n);
+    for (int i = 0; i < n; ++i) { x[i].x = in[(size_t)r * pin + i]; x[i].y = 0; }
+    lvec X = naive_dft(x, -1);
+    for (int k = 0; k <= nh; ++k) {
+      cx<T> g = out[(size_t)r * pout + k];
+      num += (g.x - X[k].x) * (g.x - X[k].x) + (g.y - X[k].y) * (g.y - X[k].y);
+      den += X[k].x * X[k].x + X[k].y * X[k].y;
+    }
+  }
+  char name[64];
+  snprintf(name, sizeof name, "chirpz r2c M=%d r%d", S::N, ROWS);
+  report(name, n, pname<T>(), (double)sqrtl(num / den), 8 * tol_of<T>());
+  for (int r = 0; r < nrows; ++r) {                 // garbage where c2r must not look
+    out[(size_t)r * pout + 0].y = (T)3.5;
+    if (n % 2 == 0) out[(size_t)r * pout + nh].y = (T)-2.25;
+  }
+  P.in = out.data(); P.out = back.data(); P.in_stride = pout; P.out_stride = pin; P.scale = (T)(1.0 / n);
+  {
+    typedef RowFftZ<S, T, ROWS, 2, true> K;
+    emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  }
+  num = den = 0;
+  for (int r = 0; r < nrows; ++r)
+    for (int i = 0; i < n; ++i) {
+      long double d = (long double)back[(size_t)r * pin + i] - in[(size_t)r * pin + i];
+      num += d * d;
+      den += (long double)in[(size_t)r * pin + i] * in[(size_t)r * pin + i];
+    }
+  snprintf(name, sizeof name, "chirpz c2r(r2c) M=%d r%d", S::N, ROWS);
+  report(name, n, pname<T>(), (double)sqrtl(num / den), 16 * tol_of<T>());
+}
+
+template <class S> static void test_chirpz_all() {
+  const int nmax = (S::N + 1) / 2;
+  for (int n : {nmax, nmax - 1, (S::N / 4) + 1, 7}) {
+    if (n < 2 || 2 * n - 1 > S::N) continue;
+    test_col_z<S, double, 4, false, false, 1>(n);
+    test_col_z<S, double, 4, true, true, 1>(n);
+    test_col_z<S, float, 8, false, false, 2>(n);
+    test_col_z<S, float, 8, true, true, 2>(n);
+    test_row_z<S, double, 2, false>(n);
+    test_row_z<S, float, 3, true>(n);
+    test_real_z<S, double, 2>(n);
+    test_real_z<S, float, 3>(n);
+  }
+}
+
 template <class S> static void test_spec_all() {
   test_col<S, double, 4, false, true>(false);
   test_col<S, double, 4, true, false>(true);
@@ -475,6 +618,11 @@ int main() {
   MFFT_FOR_EACH_PLAN(MFFT_PLAN)
   MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN)
 #undef MFFT_PLAN
+  test_chirpz_all<Spec<16, 16>>();
+  test_chirpz_all<Spec<64, 8, 8>>();
+  test_chirpz_all<Spec<96, 8, 4, 3>>();
+  test_chirpz_all<Spec<512, 8, 8, 8>>();
+  test_chirpz_all<Spec<160, 4, 4, 5, 2>>();
   printf("%s (%d failures)\n", g_fail ? "EMU TESTS FAILED" : "EMU TESTS PASSED", g_fail);
   return g_fail ? 1 : 0;
 }

@@ -4,12 +4,17 @@
 #include <cstring>
 #include <vector>
 #include "fft_kernels.h"
+#include "fft_chirpz.h"
 #include "twiddle.h"
 #include "plans.h"
 
 namespace mfft {
 
-enum Family { FAM_COL = 0, FAM_ROW = 1, FAM_R2C = 2, FAM_C2R = 3 };
+enum Family {
+  FAM_COL = 0, FAM_ROW = 1, FAM_R2C = 2, FAM_C2R = 3,
+  // chirp-z (Bluestein) variants: entry.n is the convolution length M, the logical length is a launch parameter
+  FAM_COLZ = 4, FAM_ROWZ = 5, FAM_R2CZ = 6, FAM_C2RZ = 7
+};
 
 struct KernelEntry {
   int family;
@@ -30,6 +35,8 @@ struct KernelEntry {
 
 std::vector<KernelEntry>& kernel_registry();
 const KernelEntry* find_kernel(int family, int n, int prec, int inv, int nt = 0, int pad = 0);
+// chirp-z kernel with the smallest convolution length M >= 2n-1 (nullptr: n too long)
+const KernelEntry* find_chirpz(int family, int n, int prec, int inv);
 
 // ---- default tiling heuristics (measured on MI355X at 1024^3) -----
 // Strided-axis kernel: tiles are 128 bytes wide (one L2 line per row segment; with
@@ -140,11 +147,45 @@ void register_rows(const char* name) {
   }
 }
 
+// chirp-z variants (fft_chirpz.h): every plan of length >= 16 also serves as the convolution length M
+// of the arbitrary-length kernels
+template <class S, typename T>
+void register_col_z(const char* name) {
+  if constexpr (S::N >= 16) {
+    auto& reg = kernel_registry();
+    constexpr int C = col_cols<S, T>();
+    constexpr bool CS = col_split<S, T>();
+    constexpr int CV = col_vec<S, T>();
+    reg.push_back(make_entry<ColFftZ<S, T, C, false, CS, CV>, ColParamsZ<T>, S, T>(FAM_COLZ, S::N, 0, C, name));
+    reg.push_back(make_entry<ColFftZ<S, T, C, true, CS, CV>, ColParamsZ<T>, S, T>(FAM_COLZ, S::N, 1, C, name));
+  }
+}
+template <class S, typename T>
+void register_rows_z(const char* name) {
+  if constexpr (S::N >= 16) {
+    auto& reg = kernel_registry();
+    constexpr int R = row_rows<S, T>();
+    reg.push_back(make_entry<RowFftZ<S, T, R, 0, false>, RowParamsZ<T>, S, T>(FAM_ROWZ, S::N, 0, R, name));
+    reg.push_back(make_entry<RowFftZ<S, T, R, 0, true>, RowParamsZ<T>, S, T>(FAM_ROWZ, S::N, 1, R, name));
+    reg.push_back(make_entry<RowFftZ<S, T, R, 1, false>, RealParamsZ<T>, S, T>(FAM_R2CZ, S::N, 0, R, name));
+    reg.push_back(make_entry<RowFftZ<S, T, R, 2, true>, RealParamsZ<T>, S, T>(FAM_C2RZ, S::N, 1, R, name));
+  }
+}
+
 // a plan of the main list: strided kernels always, row kernels unless the length has an override
 template <class S, typename T>
 void register_plan(const char* name) {
   register_col<S, T>(name);
-  if constexpr (!mfft_has_row_override(S::N)) register_rows<S, T>(name);
+  register_col_z<S, T>(name);
+  if constexpr (!mfft_has_row_override(S::N)) {
+    register_rows<S, T>(name);
+    register_rows_z<S, T>(name);
+  }
+}
+template <class S, typename T>
+void register_rowplan(const char* name) {
+  register_rows<S, T>(name);
+  register_rows_z<S, T>(name);
 }
 
 struct PlanRegistrar {

@@ -39,4 +39,47 @@ std::vector<cx<T>> build_real_twiddles(int N) {
   return tw;
 }
 
+// ---- chirp-z (Bluestein) tables, fft_chirpz.h ------------------------------------
+// chirp w[r] = exp(-i pi r^2 / n), r = 0..n-1; the angle is reduced exactly: r^2 mod 2n
+template <typename T>
+std::vector<cx<T>> build_chirp(int n) {
+  std::vector<cx<T>> w(n);
+  const long double pi = 3.141592653589793238462643383279503L;
+  for (long long r = 0; r < n; ++r) {
+    const long long q = (r * r) % (2LL * n);
+    const long double a = pi * (long double)q / (long double)n;
+    w[r] = mk<T>((T)cosl(a), (T)(-sinl(a)));
+  }
+  return w;
+}
+
+// bhat = FFT_M(b) / M for the wrapped filter b[m] = b[M-m] = conj(w[m]) (|m| < n), 0 elsewhere.
+// b is even, so bhat[k] = (b[0] + 2 sum_{m=1}^{n-1} b[m] cos(2 pi k m / M)) / M: a direct O(M n)
+// long-double sum (<= 8.4M terms at M = 4096), done once per (n, M).
+template <typename T>
+std::vector<cx<T>> build_chirp_filter(int n, int M) {
+  const long double pi = 3.141592653589793238462643383279503L;
+  std::vector<long double> br(n), bi(n), cs(M);
+  for (long long m = 0; m < n; ++m) {
+    const long long q = (m * m) % (2LL * n);
+    const long double a = pi * (long double)q / (long double)n;
+    br[m] = cosl(a);
+    bi[m] = sinl(a);
+  }
+  for (int t = 0; t < M; ++t) cs[t] = cosl(2.0L * pi * (long double)t / (long double)M);
+  std::vector<cx<T>> out(M);
+  for (int k = 0; k < M; ++k) {
+    long double sr = 0, si = 0;
+    int t = 0;                         // k*m mod M, advanced incrementally
+    for (int m = 1; m < n; ++m) {
+      t += k;
+      if (t >= M) t -= M;
+      sr += br[m] * cs[t];
+      si += bi[m] * cs[t];
+    }
+    out[k] = mk<T>((T)((br[0] + 2 * sr) / M), (T)((bi[0] + 2 * si) / M));
+  }
+  return out;
+}
+
 }  // namespace mfft

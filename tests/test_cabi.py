@@ -47,9 +47,12 @@ def test_version_and_lengths(lib):
         assert lib.mfft_length_supported(n, 0) == 1, n
     for n in (8, 64, 1024, 2048, 8192, 48, 96, 1536):
         assert lib.mfft_length_supported(n, 1) == 1, n
-    for n in (7, 11, 13, 17, 4097):
+    for n in (7, 11, 13, 17, 36, 1000, 2047):           # chirp-z range: 2n-1 <= 4096
+        assert lib.mfft_length_supported(n, 0) == 1, n
+        assert lib.mfft_length_supported(n, 1) == 1, n
+    for n in (2049, 4097, 5000):
         assert lib.mfft_length_supported(n, 0) == 0, n
-    assert lib.mfft_length_supported(9, 1) == 0
+    assert lib.mfft_length_supported(2050, 1) == 0
 
 
 def test_fails_loudly_without_gpu(lib):

@@ -404,8 +404,8 @@ def test_pencil_non_power_of_two_meshes(N, P, align):
 
 def test_unsupported_mesh_raises_cleanly():
     from mpifft4py_amd import SelfComm, Slab_R2C, _lib
-    with pytest.raises(_lib.MfftError):          # 7 is not 2^a * {1,3,5}
-        Slab_R2C(np.array([7, 8, 8]), L, SelfComm(0), "double")
+    with pytest.raises(_lib.MfftError):          # beyond the chirp-z range (2n-1 <= 4096)
+        Slab_R2C(np.array([2050, 8, 8]), L, SelfComm(0), "double")
     with pytest.raises(_lib.MfftError):          # odd real axis
         Slab_R2C(np.array([8, 8, 9]), L, SelfComm(0), "double")
 
@@ -575,3 +575,89 @@ def test_hipgraph_replay_opt_in(monkeypatch):
     F.fftn(u, fu)
     F.sync()
     assert orc.rel_l2(fu.get(), np.fft.rfftn(B)) < 1e-10
+
+
+# ---- arbitrary lengths: chirp-z (Bluestein) kernels, csrc/fft_chirpz.h ---------------------------------
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("N,P", [([7, 9, 22], 1), ([36, 60, 100], 1), ([36, 60, 100], 2), ([36, 60, 100], 4),
+                                 ([13, 17, 38], 1), ([130, 66, 258], 2), ([1025, 3, 6], 1), ([4, 1026, 14], 2)])
+def test_slab_r2c_arbitrary_lengths(N, P, prec):
+    """numpy/FFTW take any mesh (numpy_fft.py:25-107); lengths without a radix plan go through the chirp-z
+    kernels with the same fused pack / unpack row maps."""
+    from mpifft4py_amd import Slab_R2C
+    rng = np.random.default_rng(sum(N))
+    A = rng.random(N).astype(rdtype(prec))
+    B2 = np.fft.rfftn(A.astype(np.float64))
+    lay = orc.SlabLayout(N, P)
+    want = orc.slab_r2c_forward(orc.scatter_real(A, lay), N, prec)
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, prec)
+        a = np.ascontiguousarray(A[F.real_local_slice()])
+        c = F.fftn(a, np.zeros(F.complex_shape(), dtype=F.complex))
+        b = F.ifftn(c, np.zeros(F.real_shape(), dtype=F.float))
+        return F.complex_local_slice(), c, F.real_local_slice(), b
+    for r, (cs, c, rs, b) in enumerate(run_ranks(P, body)):
+        assert orc.rel_l2(c, want[r]) < TOL[prec]
+        assert orc.rel_l2(c, B2[cs]) < TOL[prec]
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("align", ["X", "Y"])
+@pytest.mark.parametrize("N,P", [([36, 60, 100], 4), ([28, 44, 72], 4), ([72, 56, 200], 8)])
+def test_pencil_r2c_arbitrary_lengths(N, P, align):
+    from mpifft4py_amd import Pencil_R2C
+    rng = np.random.default_rng(sum(N) + 5)
+    A = rng.random(N)
+    B2 = np.fft.rfftn(A)
+
+    def body(comm):
+        F = Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=align)
+        a = np.ascontiguousarray(A[F.real_local_slice()])
+        c = F.fftn(a, np.zeros(F.complex_shape(), dtype=complex))
+        b = F.ifftn(c, np.zeros(F.real_shape()))
+        return F.complex_local_slice(), c, F.real_local_slice(), b
+    for cs, c, rs, b in run_ranks(P, body):
+        assert orc.rel_l2(c, B2[cs]) < 1e-10
+        assert orc.rel_l2(b, A[rs]) < 1e-10
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("N,P", [([15, 21, 25], 1), ([18, 14, 11], 2), ([36, 60, 49], 4)])
+def test_slab_c2c_arbitrary_lengths(N, P, prec):
+    from mpifft4py_amd.slab import C2C
+    rng = np.random.default_rng(sum(N) + 9)
+    A = (rng.random(N) + 1j * rng.random(N)).astype(cdtype(prec))
+    B2 = np.fft.fftn(A.astype(np.complex128))
+
+    def body(comm):
+        F = C2C(np.array(N), L, comm, prec)
+        a = np.ascontiguousarray(A[F.original_local_slice()])
+        c = F.fftn(a, np.zeros(F.transformed_shape(), dtype=F.complex))
+        b = F.ifftn(c, np.zeros(F.original_shape(), dtype=F.complex))
+        return F.transformed_local_slice(), c, F.original_local_slice(), b
+    for cs, c, rs, b in run_ranks(P, body):
+        assert orc.rel_l2(c, B2[cs]) < TOL[prec]
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("N,P", [([24, 40, 20], 1), ([24, 40, 20], 2), ([12, 28, 36], 1), ([40, 24, 28], 4)])
+def test_slab_padded_arbitrary_lengths(N, P):
+    """3/2-rule on meshes whose padded lengths (36, 60, 30, 18, 42, 54, 66, 78) have no radix plan."""
+    from mpifft4py_amd import Slab_R2C
+    rng = np.random.default_rng(sum(N) + 11)
+    A = rng.random(N)
+    lay = orc.SlabLayout(N, P)
+    fu_ranks = orc.slab_r2c_forward(orc.scatter_real(A, lay), N, "double")
+    want_up = orc.slab_r2c_backward_padded(fu_ranks, N, "double")
+    want_fu = orc.slab_r2c_forward_padded(want_up, N, "double")
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, "double")
+        r = comm.Get_rank()
+        up = F.ifftn(fu_ranks[r].copy(), np.zeros(F.real_shape_padded()), "3/2-rule")
+        fu = F.fftn(up, np.zeros(F.complex_shape(), dtype=complex), "3/2-rule")
+        return up, fu
+    for r, (up, fu) in enumerate(run_ranks(P, body)):
+        assert orc.rel_l2(up, want_up[r]) < 1e-10
+        assert orc.rel_l2(fu, want_fu[r]) < 1e-10

@@ -145,8 +145,51 @@ def test_dealias_filter(prec):
 def test_unsupported_length_raises():
     import mpifft4py_amd as m
     from mpifft4py_amd import _lib
+    with pytest.raises(_lib.MfftError):          # chirp-z needs 2n-1 <= 4096
+        m.fft(np.zeros((2049, 4, 4), dtype=np.complex128), axis=0)
     with pytest.raises(_lib.MfftError):
-        m.fft(np.zeros((7, 4, 4), dtype=np.complex128), axis=0)
+        m.rfft(np.zeros((2, 2, 2050)), axis=2)
+
+
+# lengths without a radix plan: chirp-z kernels (csrc/fft_chirpz.h); primes, prime powers, 7-smooth,
+# 9*2^a / 15*2^a (the 3/2-rule images of 3*2^a / 5*2^a), and the range ends of several convolution lengths
+CHIRPZ = [3, 5, 7, 9, 11, 13, 15, 17, 18, 25, 27, 31, 33, 36, 49, 60, 72, 100, 127, 129, 144, 240, 255, 257, 500,
+          576, 729, 1000, 1023, 1025, 1152, 1537, 2047]
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("n", CHIRPZ)
+def test_c2c_arbitrary_length_every_axis(n, prec):
+    from mpifft4py_amd import fft, ifft
+    rng = np.random.default_rng(n)
+    for axis in (0, 1, 2):
+        shape = [3, 5, 7]
+        shape[axis] = n
+        a = (rng.random(shape) - 0.5 + 1j * (rng.random(shape) - 0.5)).astype(cdtype(prec))
+        got = fft(a, axis=axis)
+        assert orc.rel_l2(got, np.fft.fft(a.astype(np.complex128), axis=axis)) < TOL[prec], (n, axis)
+        goti = ifft(a, axis=axis)
+        assert orc.rel_l2(goti, np.fft.ifft(a.astype(np.complex128), axis=axis)) < TOL[prec], (n, axis)
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("n", CHIRPZ + [14, 22, 30, 126, 258, 1026, 2046])
+def test_rfft_irfft_arbitrary_length(n, prec):
+    """Real transforms of any length, odd ones included (numpy_fft.py:39-51 with n given by the output)."""
+    from mpifft4py_amd import rfft, irfft
+    rng = np.random.default_rng(n + 1)
+    a = (rng.random((3, 5, n)) - 0.5).astype(rdtype(prec))
+    ref = np.fft.rfft(a.astype(np.float64), axis=2)
+    got = rfft(a, axis=2)
+    assert got.shape == ref.shape
+    assert orc.rel_l2(got, ref) < TOL[prec]
+    c = ref.astype(cdtype(prec)).copy()
+    c[..., 0] += 1j * 0.7                      # ignored by c2r
+    if n % 2 == 0:
+        c[..., -1] -= 1j * 0.3
+    back = irfft(c, np.zeros(a.shape, dtype=a.dtype), axis=2)
+    assert orc.rel_l2(back, np.fft.irfft(c.astype(np.complex128), n=n, axis=2)) < TOL[prec]
+    assert orc.rel_l2(back, a) < 4 * TOL[prec]
 
 
 def test_unpack_and_mask_vs_reference_compiled_loops():
