@@ -516,6 +516,56 @@ def test_full_size_1024_cubed():
     assert rel(fu.get(), C, 32) < 1e-10                                          # forward vs pocketfft
 
 
+def test_full_size_1024_cubed_eight_ranks():
+    """BASELINE configs 3 and 4 at full size with the decomposition of an 8-GPU node: 1024^3 fp64 over 8 ranks
+    (all on this GPU, exchanging by device copies) as slab (pipelined exchange), pencil X and pencil Y (4x2).
+    Every rank's spectrum block against the host's pocketfft on the same global input, and the round trip."""
+    import os
+    import scipy.fft as sfft
+    from mpifft4py_amd import DeviceArray, Pencil_R2C, Slab_R2C
+    try:
+        avail_kb = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1])
+    except Exception:  # noqa: BLE001
+        avail_kb = 0
+    if avail_kb < 60 * 1024 * 1024:
+        pytest.skip("host RAM too small for the full-size reference")
+    N = np.array([1024] * 3)
+    A = np.random.default_rng(77).random(tuple(N))
+    C = sfft.rfftn(A, workers=os.cpu_count())
+
+    def rel(X, Y):
+        d = X - Y
+        return (float(np.vdot(d, d).real) / float(np.vdot(Y, Y).real)) ** 0.5
+
+    def make(kind):
+        def body(comm):
+            if kind == "slab":
+                F = Slab_R2C(N, L, comm, "double")
+            else:
+                F = Pencil_R2C(N, L, comm, "double", communication="Alltoallw", alignment=kind)
+            u = DeviceArray.from_numpy(np.ascontiguousarray(A[F.real_local_slice()]))
+            fu = DeviceArray.empty(F.complex_shape(), F.complex)
+            u2 = DeviceArray.empty(F.real_shape(), F.float)
+            F.fftn(u, fu)
+            F.ifftn(fu, u2)
+            F.sync()
+            e1 = rel(fu.get(), C[F.complex_local_slice()])
+            e2 = rel(u2.get(), A[F.real_local_slice()])
+            return F.complex_shape(), e1, e2
+        return body
+    for kind in ("slab", "X", "Y"):
+        res = run_ranks(8, make(kind))
+        shapes = [r[0] for r in res]
+        if kind == "slab":
+            assert shapes == [(1024, 128, 513)] * 8
+        elif kind == "X":                       # SURVEY.md Appendix B
+            assert shapes == [(1024, 256, 256)] * 4 + [(1024, 256, 257)] * 4
+        else:
+            assert shapes == [(512, 1024, 128)] * 3 + [(512, 1024, 129)] + [(512, 1024, 128)] * 3 + [(512, 1024, 129)]
+        for _, e1, e2 in res:
+            assert e1 < 1e-10 and e2 < 1e-10, (kind, e1, e2)
+
+
 @pytest.mark.parametrize("prec", ["double", "single"])
 @pytest.mark.parametrize("align", ["X", "Y"])
 @pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2)])
