@@ -88,24 +88,30 @@ struct ColFftZ {
     const cx<T>* ip = P.in + (i64)outer * P.in_outer + col;
     cx<T>* op = P.out + (i64)outer * P.out_outer + col;
 
+    // Loads are unconditional (rows >= n re-read row n-1 and are zeroed by a select afterwards): with the
+    // value used inside a branch the compiler waits after every single load.
     cx<T> v[VEC][S::E];
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
       const int r = j + k * S::TPT;
+      const cx<T>* src = ip + row_off(P.in_map, (unsigned)(r < n ? r : n - 1));
+      if (nact >= VEC) {
+        const GPack g = *reinterpret_cast<const GPack*>(src);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) v[i][k] = mk<T>((T)0, (T)0);
-      if (r < n) {
-        const cx<T> w = P.chirp[r];
-        const cx<T>* src = ip + row_off(P.in_map, (unsigned)r);
-        if (nact >= VEC) {
-          const GPack g = *reinterpret_cast<const GPack*>(src);
+        for (int i = 0; i < VEC; ++i) v[i][k] = g.e[i];
+      } else {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) v[i][k] = (INV ? swapri(g.e[i]) : g.e[i]) * w;
-        } else {
+        for (int i = 0; i < VEC; ++i) v[i][k] = i < nact ? src[i] : mk<T>((T)0, (T)0);
+      }
+    }
 #pragma unroll
-          for (int i = 0; i < VEC; ++i)
-            if (i < nact) v[i][k] = (INV ? swapri(src[i]) : src[i]) * w;
-        }
+    for (int k = 0; k < S::E; ++k) {
+      const int r = j + k * S::TPT;
+      const cx<T> w = P.chirp[r < n ? r : n - 1];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const cx<T> x = (INV ? swapri(v[i][k]) : v[i][k]) * w;
+        v[i][k] = r < n ? x : mk<T>((T)0, (T)0);
       }
     }
     if constexpr (SPLIT) {
@@ -163,29 +169,38 @@ struct RowFftZ {
     const bool active = row < P.nrows;
     const int n = P.n;
     const int nh = n / 2;
+    const i64 lrow = active ? row : P.nrows - 1;     // rows past the end re-read the last row, store nothing
 
+    // unconditional loads (positions >= n re-read position n-1 and are zeroed by a select): see ColFftZ
     cx<T> v[S::E];
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
       const int r = j + k * S::TPT;
-      cx<T> x = mk<T>((T)0, (T)0);
-      if (active && r < n) {
-        if constexpr (KIND == 0) {
-          const cx<T>* ip = static_cast<const cx<T>*>(P.in) + row * P.in_stride;
-          x = ip[r];
-          if (INV) x = swapri(x);
-        } else if constexpr (KIND == 1) {
-          const T* ip = static_cast<const T*>(P.in) + row * P.in_stride;
-          x = mk<T>(ip[r], (T)0);
-        } else {
-          const cx<T>* ip = static_cast<const cx<T>*>(P.in) + row * P.in_stride;
-          x = r <= nh ? ip[r] : conj(ip[n - r]);
-          if (r == 0 || 2 * r == n) x.y = (T)0;
-          x = swapri(x);                      // inverse through the swap identity
-        }
-        x = x * P.chirp[r];
+      const int rc = r < n ? r : n - 1;
+      if constexpr (KIND == 0) {
+        const cx<T>* ip = static_cast<const cx<T>*>(P.in) + lrow * P.in_stride;
+        v[k] = ip[rc];
+      } else if constexpr (KIND == 1) {
+        const T* ip = static_cast<const T*>(P.in) + lrow * P.in_stride;
+        v[k] = mk<T>(ip[rc], (T)0);
+      } else {
+        const cx<T>* ip = static_cast<const cx<T>*>(P.in) + lrow * P.in_stride;
+        v[k] = ip[rc <= nh ? rc : n - rc];
       }
-      v[k] = x;
+    }
+#pragma unroll
+    for (int k = 0; k < S::E; ++k) {
+      const int r = j + k * S::TPT;
+      cx<T> x = v[k];
+      if constexpr (KIND == 0) {
+        if (INV) x = swapri(x);
+      } else if constexpr (KIND == 2) {
+        if (r > nh) x = conj(x);              // Hermitian extension
+        if (r == 0 || 2 * r == n) x.y = (T)0;
+        x = swapri(x);                        // inverse through the swap identity
+      }
+      x = x * P.chirp[r < n ? r : n - 1];
+      v[k] = r < n ? x : mk<T>((T)0, (T)0);
     }
     XchFull<T, PadSlot<PD>> xc{xch, PadSlot<PD>{}};
     chirpz_conv<S, T>(v, j, P.tw, P.bhat, xc);

@@ -426,14 +426,15 @@ struct RowFft {
     cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;
-    const cx<T>* ip = P.in + row * P.in_stride;
+    // rows past the end re-read the last row (and store nothing): unconditional loads let the
+    // compiler issue all E of them before the first wait
+    const cx<T>* ip = P.in + (active ? row : P.nrows - 1) * P.in_stride;
     cx<T>* op = P.out + row * P.out_stride;
 
     cx<T> v[S::E];
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
-      cx<T> x = mk<T>((T)0, (T)0);
-      if (active) x = ip[j + k * S::TPT];
+      const cx<T> x = ip[j + k * S::TPT];
       v[k] = INV ? swapri(x) : x;
     }
     if constexpr (TWLDS && S::NP > 1) {
@@ -478,16 +479,13 @@ struct R2CFft {
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;
     // a row of N reals read as N/2 complex (x[2n], x[2n+1])
-    const cx<T>* ip = reinterpret_cast<const cx<T>*>(static_cast<const T*>(P.in) + row * P.in_stride);
+    const cx<T>* ip =
+        reinterpret_cast<const cx<T>*>(static_cast<const T*>(P.in) + (active ? row : P.nrows - 1) * P.in_stride);
     cx<T>* op = static_cast<cx<T>*>(P.out) + row * P.out_stride;
 
     cx<T> v[S::E];
 #pragma unroll
-    for (int k = 0; k < S::E; ++k) {
-      cx<T> x = mk<T>((T)0, (T)0);
-      if (active) x = ip[j + k * S::TPT];
-      v[k] = x;
-    }
+    for (int k = 0; k < S::E; ++k) v[k] = ip[j + k * S::TPT];   // unconditional: see RowFft
     if constexpr (TWLDS && S::NP > 1) {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
@@ -565,7 +563,8 @@ struct C2RFft {
     cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;
-    const cx<T>* ip = static_cast<const cx<T>*>(P.in) + row * P.in_stride;
+    // rows past the end re-read the last row (unconditional loads: see RowFft) and store nothing
+    const cx<T>* ip = static_cast<const cx<T>*>(P.in) + (active ? row : P.nrows - 1) * P.in_stride;
     cx<T>* op = reinterpret_cast<cx<T>*>(static_cast<T*>(P.out) + row * P.out_stride);
 
     // pre-pass: Z[k] = (X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])
@@ -584,11 +583,15 @@ struct C2RFft {
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {
         const int pos = j + k * S::TPT;
-        x[k] = mk<T>((T)0, (T)0);
-        if (active && (!LIMIT || pos < P.valid)) x[k] = ip[pos];
+        if constexpr (LIMIT) {
+          x[k] = mk<T>((T)0, (T)0);
+          if (pos < P.valid) x[k] = ip[pos];
+        } else {
+          x[k] = ip[pos];
+        }
       }
       cx<T> xM = mk<T>((T)0, (T)0);
-      if (active && j == 0 && (!LIMIT || M < P.valid)) xM = ip[M];
+      if (j == 0 && (!LIMIT || M < P.valid)) xM = ip[M];
 #if defined(__HIP_DEVICE_COMPILE__)
       const int src = (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));     // lane of thread TPT-j (mod TPT) of this row
 #pragma unroll
@@ -605,16 +608,15 @@ struct C2RFft {
         }
         const cx<T> e = xk + xm;
         const cx<T> dd = xk - xm;
-        const cx<T> w = active ? P.rtw[pos] : mk<T>((T)1, (T)0);
-        v[k] = swapri(e + mul_pi(dd * conj(w)));   // inverse transform through the swap identity
+        v[k] = swapri(e + mul_pi(dd * conj(P.rtw[pos])));   // inverse transform through the swap identity
       }
 #endif
     } else {
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {
         const int pos = j + k * S::TPT;
-        cx<T> z = mk<T>((T)0, (T)0);
-        if (active) {
+        cx<T> z;
+        {
           cx<T> xk, xm;
           if constexpr (LIMIT) {
             xk = pos < P.valid ? ip[pos] : mk<T>((T)0, (T)0);
