@@ -6,7 +6,7 @@
 // "LDS" buffer.  It checks every kernel family and radix plan against an
 // O(N^2) long-double DFT, so index/twiddle mistakes are found without a GPU.
 //
-//   make emu && ./emu_test
+//   make -j6 emu && for b in build/emu_test_?; do $b; done
 #include <ucontext.h>
 #include <cstdio>
 #include <cstdlib>
@@ -602,7 +602,15 @@ template <class S> static void test_spec_all() {
   PadTests<S>::run();
 }
 
+// The plan list is split over EMU_PART = 0..5 so that the parts compile (and run) in parallel;
+// without EMU_PART everything goes into one binary.
+#ifndef EMU_PART
+#define EMU_PART -1
+#endif
+#define EMU_HAS(p) (EMU_PART < 0 || EMU_PART == (p))
+
 int main() {
+#if EMU_HAS(0)
   {  // validate the fast reference against the plain O(N^2) sum
     for (int n : {12, 40, 96, 250}) {
       lvec x(n);
@@ -613,16 +621,33 @@ int main() {
       report("reference self-check", n, "ldbl", (double)sqrtl(d / r), 1e-17);
     }
   }
+#endif
   // every plan in plans.h is exercised
 #define MFFT_PLAN(N, ...) test_spec_all<Spec<N, __VA_ARGS__>>();
-  MFFT_FOR_EACH_PLAN(MFFT_PLAN)
-  MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN)
-#undef MFFT_PLAN
+#if EMU_HAS(0)
+  MFFT_PLANS_A(MFFT_PLAN)
   test_chirpz_all<Spec<16, 16>>();
   test_chirpz_all<Spec<64, 8, 8>>();
   test_chirpz_all<Spec<96, 8, 4, 3>>();
   test_chirpz_all<Spec<512, 8, 8, 8>>();
   test_chirpz_all<Spec<160, 4, 4, 5, 2>>();
+#endif
+#if EMU_HAS(1)
+  MFFT_PLANS_B(MFFT_PLAN) MFFT_PLANS_C(MFFT_PLAN)
+#endif
+#if EMU_HAS(2)
+  MFFT_PLANS_D(MFFT_PLAN) MFFT_PLANS_E(MFFT_PLAN)
+#endif
+#if EMU_HAS(3)
+  MFFT_PLANS_F(MFFT_PLAN) MFFT_PLANS_G(MFFT_PLAN)
+#endif
+#if EMU_HAS(4)
+  MFFT_PLANS_H(MFFT_PLAN) MFFT_PLANS_I(MFFT_PLAN) MFFT_PLANS_J(MFFT_PLAN)
+#endif
+#if EMU_HAS(5)
+  MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN)
+#endif
+#undef MFFT_PLAN
   printf("%s (%d failures)\n", g_fail ? "EMU TESTS FAILED" : "EMU TESTS PASSED", g_fail);
   return g_fail ? 1 : 0;
 }

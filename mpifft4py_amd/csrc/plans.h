@@ -5,8 +5,10 @@
 //
 // Lengths covered: 2^a (2..4096), 3*2^a (6..3072), 5*2^a (10..2560): these are
 // what the reference's power-of-two meshes and their 3/2-rule padded
-// counterparts (slab.py:75-76, 487-489) produce.  The groups only exist so the
-// instantiations can be compiled in parallel translation units.
+// counterparts (slab.py:75-76, 487-489) produce; 9*2^a (18..2304) are the 3/2-rule
+// images of the 3*2^a meshes, 25*2^a (50..1600) round off the 5-smooth sizes.  Every
+// other length goes through the chirp-z kernels (fft_chirpz.h).  The groups only exist
+// so the instantiations can be compiled in parallel translation units.
 #pragma once
 
 #define MFFT_PLANS_A(X) X(2, 2) X(4, 4) X(8, 8) X(16, 16) X(32, 8, 4) X(64, 8, 8) X(128, 16, 8) X(256, 16, 16)
@@ -16,6 +18,9 @@
 #define MFFT_PLANS_E(X) X(384, 8, 8, 3, 2) X(768, 8, 8, 4, 3) X(1536, 8, 8, 8, 3) X(3072, 8, 8, 4, 4, 3)
 #define MFFT_PLANS_F(X) X(10, 5, 2) X(20, 5, 4) X(40, 5, 4, 2) X(80, 5, 4, 4) X(160, 8, 4, 5)
 #define MFFT_PLANS_G(X) X(320, 8, 8, 5) X(640, 8, 4, 4, 5) X(1280, 8, 8, 4, 5) X(2560, 8, 8, 8, 5)
+#define MFFT_PLANS_H(X) X(18, 3, 3, 2) X(36, 4, 3, 3) X(72, 8, 3, 3) X(144, 8, 3, 3, 2) X(288, 8, 4, 3, 3) X(576, 8, 8, 3, 3)
+#define MFFT_PLANS_I(X) X(1152, 8, 8, 3, 3, 2) X(2304, 8, 8, 4, 3, 3)
+#define MFFT_PLANS_J(X) X(50, 5, 5, 2) X(100, 5, 5, 4) X(200, 5, 5, 4, 2) X(400, 5, 5, 4, 4) X(800, 5, 5, 4, 4, 2) X(1600, 5, 5, 4, 4, 4)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -26,15 +31,21 @@
 #define MFFT_ROWPLANS_E(X) X(384, 4, 4, 4, 3, 2) X(768, 4, 4, 4, 4, 3) X(1536, 4, 4, 4, 4, 3, 2) X(3072, 4, 4, 4, 4, 4, 3)
 #define MFFT_ROWPLANS_F(X) X(160, 4, 4, 5, 2)
 #define MFFT_ROWPLANS_G(X) X(320, 4, 4, 4, 5) X(640, 4, 4, 4, 5, 2) X(1280, 4, 4, 4, 4, 5) X(2560, 4, 4, 4, 4, 5, 2)
+#define MFFT_ROWPLANS_H(X) X(144, 4, 4, 3, 3) X(288, 4, 4, 3, 3, 2) X(576, 4, 4, 4, 3, 3)
+#define MFFT_ROWPLANS_I(X) X(1152, 4, 4, 4, 3, 3, 2) X(2304, 4, 4, 4, 4, 3, 3)
+#define MFFT_ROWPLANS_J(X)
 #define MFFT_ROWPLANS_A(X)
 #define MFFT_ROWPLANS_B(X)
 #define MFFT_ROWPLANS_C(X)
-#define MFFT_FOR_EACH_ROWPLAN(X) MFFT_ROWPLANS_D(X) MFFT_ROWPLANS_E(X) MFFT_ROWPLANS_F(X) MFFT_ROWPLANS_G(X)
+#define MFFT_FOR_EACH_ROWPLAN(X) \
+  MFFT_ROWPLANS_D(X) MFFT_ROWPLANS_E(X) MFFT_ROWPLANS_F(X) MFFT_ROWPLANS_G(X) MFFT_ROWPLANS_H(X) MFFT_ROWPLANS_I(X)
 
 // true if complex length n takes its row kernels from MFFT_ROWPLANS_*
 constexpr bool mfft_has_row_override(int n) {
   return n == 96 || n == 192 || n == 384 || n == 768 || n == 1536 || n == 3072 || n == 160 || n == 320 || n == 640 ||
-         n == 1280 || n == 2560;
+         n == 1280 || n == 2560 || n == 144 || n == 288 || n == 576 || n == 1152 || n == 2304;
 }
 
-#define MFFT_FOR_EACH_PLAN(X) MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X)
+#define MFFT_FOR_EACH_PLAN(X)                                                                                     \
+  MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
+  MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X)

@@ -691,9 +691,11 @@ def test_slab_c2c_arbitrary_lengths(N, P, prec):
         assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
 
 
-@pytest.mark.parametrize("N,P", [([24, 40, 20], 1), ([24, 40, 20], 2), ([12, 28, 36], 1), ([40, 24, 28], 4)])
+@pytest.mark.parametrize("N,P", [([24, 40, 20], 1), ([24, 40, 20], 2), ([12, 28, 36], 1), ([40, 24, 28], 4),
+                                 ([96, 48, 192], 1), ([96, 48, 192], 2), ([24, 48, 96], 4)])
 def test_slab_padded_arbitrary_lengths(N, P):
-    """3/2-rule on meshes whose padded lengths (36, 60, 30, 18, 42, 54, 66, 78) have no radix plan."""
+    """3/2-rule on meshes whose padded lengths have no radix plan (60, 30, 42, 54: chirp-z, copy-based pad)
+    and on 3*2^a meshes, whose padded lengths 9*2^a do (fused pad / truncate)."""
     from mpifft4py_amd import Slab_R2C
     rng = np.random.default_rng(sum(N) + 11)
     A = rng.random(N)
