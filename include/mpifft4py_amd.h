@@ -100,7 +100,10 @@ typedef struct {
   int pipeline;       /* >1: split exchanges into this many overlapped sub-steps */
   int drop_nyquist;   /* pencil 'AlltoallN' mode (pencil.py:410-432, 647-668): the kz = N2/2 column is
                          neither exchanged nor returned; the inverse treats it as zero */
-  int reserved[6];
+  int line2d;         /* 1: the 2-D class of line.py:41-340, expressed as an x-aligned pencil plan of the mesh
+                         (1, Nx, Ny) on a 1 x P grid: padsize^2 scaling, no Nyquist fold on one rank (line.py:185)
+                         and, for P > 1, the Nyquist packing of line.py:231 in the padded forward transform */
+  int reserved[5];
 } mfft_plan_desc;
 
 MFFT_API int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* plan);

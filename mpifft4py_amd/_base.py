@@ -40,7 +40,7 @@ class DistFFTBase(object):
         self._stage = {}
         self._mask_set = False
 
-    def _create_plan(self, kind, decomp, p1=0, pipeline=0, drop_nyquist=False):
+    def _create_plan(self, kind, decomp, p1=0, pipeline=0, drop_nyquist=False, line2d=False):
         d = _lib.PlanDesc()
         for i in range(3):
             d.n[i] = int(self.N[i])
@@ -51,6 +51,7 @@ class DistFFTBase(object):
         d.padsize = float(self.padsize)
         d.pipeline = int(pipeline)
         d.drop_nyquist = 1 if drop_nyquist else 0
+        d.line2d = 1 if line2d else 0
         self.comm.use_device()
         h = ctypes.c_void_p()
         _lib.call("mfft_plan_create", self.comm._handle, ctypes.byref(d), ctypes.byref(h))

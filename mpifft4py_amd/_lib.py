@@ -22,7 +22,7 @@ UNIQUE_ID_BYTES = 128
 class PlanDesc(ctypes.Structure):
     _fields_ = [("n", c_int64 * 3), ("precision", c_int), ("kind", c_int), ("decomp", c_int),
                 ("p1", c_int), ("padsize", c_double), ("pipeline", c_int), ("drop_nyquist", c_int),
-                ("reserved", c_int * 6)]
+                ("line2d", c_int), ("reserved", c_int * 5)]
 
 
 class MfftError(RuntimeError):

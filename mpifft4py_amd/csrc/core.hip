@@ -1,5 +1,6 @@
 // core.hip -- kernel registry, twiddle cache, launch layer and the small
 // data-movement kernels (box copy / mask / scale / synthetic fill).
+#include <algorithm>
 #include <cstdarg>
 #include <type_traits>
 #include <cstdio>
@@ -174,7 +175,13 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
 }
 
 int launch_col(const ColArgs& a, hipStream_t s) {
-  if (a.n == 1) return set_error(MFFT_ERR_UNSUPPORTED, "length-1 transform along a strided axis");
+  if (a.n == 1) {   // a length-1 transform is a (scaled) copy of its single row
+    if (a.in == a.out && a.in_outer == a.out_outer && a.scale == 1.0) return 0;
+    BoxArgs b;
+    b.src = a.in; b.dst = a.out; b.e0 = a.nouter; b.e1 = 1; b.e2 = a.ncols; b.s0 = a.in_outer; b.d0 = a.out_outer;
+    b.elem = (int)elem_bytes(a.prec, true); b.scale = a.scale; b.prec = a.prec;
+    return launch_box_copy(b, s);
+  }
   if (a.n >= 65536) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %d too large", a.n);
   if (a.ncols >= (1ll << 31)) return set_error(MFFT_ERR_UNSUPPORTED, "too many columns");
   // non-temporal variant only when every row segment of the tile is a whole, private L2 line
@@ -406,6 +413,27 @@ int launch_mask(void* fu, const uint8_t* mask, size_t count, int prec, hipStream
     hipLaunchKernelGGL(mask_kernel<double>, dim3((unsigned)grid), dim3(256), 0, s, static_cast<cx<double>*>(fu), mask, count);
   else
     hipLaunchKernelGGL(mask_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, static_cast<cx<float>*>(fu), mask, count);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void line_nyquist_kernel(cx<T>* rows, int64_t nrows, int64_t pitch, int64_t coln) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    cx<T>* p = rows + r * pitch;
+    const cx<T> c0 = p[0], cn = p[coln];
+    p[0] = mk<T>(c0.x - cn.y, (T)0);
+    p[coln] = mk<T>(cn.x, (T)0);
+  }
+}
+
+int launch_line_nyquist(void* rows, int64_t nrows, int64_t pitch, int64_t coln, int prec, hipStream_t s) {
+  if (nrows <= 0) return 0;
+  const unsigned grid = (unsigned)std::min<int64_t>((nrows + 255) / 256, 4096);
+  if (prec == MFFT_DOUBLE)
+    hipLaunchKernelGGL(line_nyquist_kernel<double>, dim3(grid), dim3(256), 0, s, static_cast<cx<double>*>(rows), nrows, pitch, coln);
+  else
+    hipLaunchKernelGGL(line_nyquist_kernel<float>, dim3(grid), dim3(256), 0, s, static_cast<cx<float>*>(rows), nrows, pitch, coln);
   MFFT_HIP(hipGetLastError());
   return 0;
 }

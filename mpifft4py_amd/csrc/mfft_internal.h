@@ -89,6 +89,8 @@ struct BoxArgs {
   int prec = MFFT_DOUBLE;
 };
 int launch_box_copy(const BoxArgs& a, hipStream_t s);
+// rows (nrows, pitch) of complex values: col0 <- (Re col0 - Im colN, 0), colN <- (Re colN, 0)   (line.py:231, 27-39)
+int launch_line_nyquist(void* rows, int64_t nrows, int64_t pitch, int64_t coln, int prec, hipStream_t s);
 int launch_mask(void* fu, const uint8_t* mask, size_t count, int prec, hipStream_t s);
 int launch_scale(void* data, size_t count_real, double scale, int prec, hipStream_t s);
 int launch_fill_uniform(void* data, size_t count, int prec, uint64_t seed, hipStream_t s);

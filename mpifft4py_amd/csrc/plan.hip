@@ -264,7 +264,7 @@ struct mfft_plan_s {
     MFFT_TRY(zero(dst, (size_t)(a0 * npad * a2) * es));
     const int64_t h = n / 2;
     MFFT_TRY(box(s, dd, a0, 1, h * a2, n * a2, 0, npad * a2, 0, 0, scale));
-    MFFT_TRY(box(s + (size_t)(h * a2) * es, dd + (size_t)((npad - h) * a2) * es, a0, 1, (n - h) * a2, n * a2, 0,
+    MFFT_TRY(box(s + (size_t)(h * a2) * es, dd + (size_t)((npad - (n - h)) * a2) * es, a0, 1, (n - h) * a2, n * a2, 0,
                  npad * a2, 0, 0, scale));
     return 0;
   }
@@ -287,6 +287,12 @@ struct mfft_plan_s {
     return 0;
   }
 
+  // 3/2-rule normalisation: padsize per padded axis (slab.py:256, 330; line.py:184, 287 for the 2-D class)
+  double padscale() const {
+    double v = 1.0;
+    for (int64_t n : {N0, N1, N2}) if (n > 1) v *= d.padsize;
+    return v;
+  }
   int sched(int which, bool forward, bool padded, Sched* out) const;
   int run_sched(const Sched& sc, const void* send, void* recv, hipStream_t on = nullptr) {
     return comm->alltoallv(send, sc.sc.data(), sc.sd.data(), recv, sc.rc.data(), sc.rd.data(), sc.peers.data(),
@@ -522,7 +528,7 @@ bool mfft_plan_s::can_fuse_pad() const {
 }
 
 int mfft_plan_s::slab_backward_padded_fused(const void* fu, void* u) {
-  const double ps = d.padsize, sc3 = ps * ps * ps;
+  const double sc3 = padscale();
   const int64_t Mp0 = M0 / P;
   MFFT_TRY(ensure_work(0, (size_t)(M0 * Np1 * Nf) * es));
   MFFT_TRY(ensure_work(1, (size_t)(M0 * Np1 * Nf) * es));
@@ -547,7 +553,7 @@ int mfft_plan_s::slab_backward_padded_fused(const void* fu, void* u) {
 }
 
 int mfft_plan_s::slab_forward_padded_fused(const void* u, void* fu) {
-  const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
+  const double isc3 = 1.0 / padscale();
   const int64_t Mp0 = M0 / P;
   MFFT_TRY(ensure_work(0, (size_t)(M0 * Np1 * Nf) * es));
   MFFT_TRY(ensure_work(1, (size_t)(M0 * Np1 * Nf) * es));
@@ -576,7 +582,7 @@ int mfft_plan_s::slab_forward_padded_fused(const void* u, void* fu) {
 int mfft_plan_s::slab_backward_padded(const void* fu, void* u) {
   if (P > 1 && P > N0 / 2) return set_error(MFFT_ERR_INVALID, "number of ranks cannot exceed N[0]/2 for the 3/2-rule");
   if (can_fuse_pad()) return slab_backward_padded_fused(fu, u);
-  const double ps = d.padsize, sc3 = ps * ps * ps;
+  const double sc3 = padscale();
   const int64_t Mp0 = M0 / P;
   // W0: (M0, Np1, Nf) padded in x; W1: (Mp0, N1, Nf) after the exchange; then (Mp0, M1, Nf), (Mp0, M1, Mf)
   MFFT_TRY(ensure_work(0, (size_t)std::max(M0 * Np1 * Nf, Mp0 * M1 * Mf) * es));
@@ -617,7 +623,7 @@ int mfft_plan_s::slab_backward_padded(const void* fu, void* u) {
 int mfft_plan_s::slab_forward_padded(const void* u, void* fu) {
   if (P > 1 && P > N0 / 2) return set_error(MFFT_ERR_INVALID, "number of ranks cannot exceed N[0]/2 for the 3/2-rule");
   if (can_fuse_pad()) return slab_forward_padded_fused(u, fu);
-  const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
+  const double isc3 = 1.0 / padscale();
   const int64_t Mp0 = M0 / P;
   MFFT_TRY(ensure_work(0, (size_t)std::max(Mp0 * M1 * Mf, M0 * Np1 * Nf) * es));
   MFFT_TRY(ensure_work(1, (size_t)std::max(Mp0 * N1 * Nf, M0 * Np1 * Nf) * es));
@@ -764,7 +770,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
 int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
   if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
   if (d.drop_nyquist) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule with communication='AlltoallN' is not implemented");
-  const double ps = d.padsize, sc3 = ps * ps * ps;
+  const double sc3 = padscale();
   const bool X = d.decomp == MFFT_PENCIL_X;
   const std::vector<int>& gz = X ? group1 : group0;
   const int Pz = (int)gz.size();
@@ -823,7 +829,7 @@ int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
 int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
   if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
   if (d.drop_nyquist) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule with communication='AlltoallN' is not implemented");
-  const double ps = d.padsize, isc3 = 1.0 / (ps * ps * ps);
+  const double isc3 = 1.0 / padscale();
   const bool X = d.decomp == MFFT_PENCIL_X;
   const std::vector<int>& gz = X ? group1 : group0;
   const int Pz = (int)gz.size();
@@ -832,6 +838,8 @@ int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
   for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
   void *W0 = work[0], *W1 = work[1], *W2 = work[2];
   MFFT_TRY(stage("fwd_z", 0, [&] { return r2c_rows(u, W0, mp * np, M2, M2, Mf); }));
+  if (d.line2d && P > 1)   // line.py:231 + swap_Nq: c0 <- Re c0 - Im cN, cN <- Re cN (cN = column Nf-1, not real here)
+    MFFT_TRY(stage("fwd_nyq", 0, [&] { return launch_line_nyquist(W0, mp * np, Mf, Nf - 1, prec, stream); }));
   // only the first Nf modes travel (truncation in z); pack z chunks
   MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, mp * np, Mf, zc, false); }));
   std::vector<size_t> sc(Pz), sd(Pz), rc(Pz), rd(Pz);
@@ -849,7 +857,8 @@ int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
     MFFT_TRY(stage("fwd_y", 0, [&] {
       return col(W0, W1, M1, false, mp, q, np * q, two_level(np, mp * np * q, q), M1 * q, plain(q));
     }));
-    MFFT_TRY(stage("trunc_y", 0, [&] { return trunc_axis(W1, W0, mp, N1, M1, q, q, 1.0); }));
+    // (the 2-D class truncates without the Nyquist fold on one rank: line.py:185 `fu_padded[ks, :Nf]`)
+    MFFT_TRY(stage("trunc_y", 0, [&] { return trunc_axis(W1, W0, mp, N1, M1, q, q, 1.0, !(d.line2d && P == 1)); }));
     // pack y chunks (mp, P1, N1_1, q) -> (P1, mp, N1_1, q)
     MFFT_TRY(stage("pack", 0, [&] {
       for (int g = 0; g < P1; ++g)
@@ -937,8 +946,12 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
     p->P2 = P2;
     p->c0 = p->rank % P1;       // comm0 = consecutive ranks (pencil.py:192-195)
     p->c1 = p->rank / P1;
-    if (p->N0 % P1 || p->N1 % P1 || p->N0 % P2 || p->N1 % P2 || p->N2 % P1 || p->N2 % P2)
+    // real (N0/P1, N1/P2, N2); X: complex (N0, N1/P1, N2/P2-chunk); Y: complex (N0/P2, N1, N2/P1-chunk)
+    const bool alignX = desc->decomp == MFFT_PENCIL_X;
+    if (p->N0 % P1 || p->N1 % P2 || (alignX ? (p->N1 % P1 || p->N2 % P2) : (p->N0 % P2 || p->N2 % P1)))
       return set_error(MFFT_ERR_INVALID, "mesh not divisible by the %dx%d process grid", P1, P2);
+    if (desc->line2d && !(alignX && P1 == 1 && p->N0 == 1 && p->r2c))
+      return set_error(MFFT_ERR_INVALID, "line2d is an x-aligned R2C pencil plan of a (1, Nx, Ny) mesh on a 1 x P grid");
     p->N1_0 = p->N0 / P1;
     p->N1_1 = p->N1 / P1;
     p->N2_0 = p->N0 / P2;

@@ -36,6 +36,7 @@ Reference map (all paths relative to /root/reference):
   pencil Y forward/inv   mpiFFT4py/pencil.py:730-754 / 483-507
   pencil X forward/inv   mpiFFT4py/pencil.py:1312-1337 / 1082-1105
   pencil 3/2-rule        mpiFFT4py/pencil.py:351-379, 604-632, 858-883, 1196-1224, 1440-1475
+  line (2-D) class       mpiFFT4py/line.py:41-340
   transpose_Uc           mpiFFT4py/cython/maths.pyx:21-31
   dealias_filter         mpiFFT4py/cython/maths.pyx:9-19
 """
@@ -786,6 +787,157 @@ def pencil_r2c_forward_padded(us, N, P1=None, alignment="X",
         lambda r: (M0, int(N[1]) // P1, lay.N2f(lay.ranks(r)[1])))
     return [(trunc_axis(np.fft.fft(x, axis=0).astype(ctype), int(N[0]), 0)
              / padsize ** 3).astype(ctype) for x in c]
+
+
+# --------------------------------------------------------------------------
+# 2-D "line" transforms (line.py:41-340): real (N0/P, N1), complex (N0, Npf) with
+# the ky axis split over the ranks and the Nyquist column on the last one.
+# --------------------------------------------------------------------------
+
+class LineLayout:
+    """line.py:64-103."""
+    def __init__(self, N, P, padsize=1.5):
+        self.N = [int(n) for n in N]
+        self.P = int(P)
+        self.padsize = padsize
+        self.Np = [self.N[0] // P, self.N[1] // P]
+        self.Nf = self.N[1] // 2 + 1
+
+    def Npf(self, r):
+        return self.Np[1] // 2 + 1 if r + 1 == self.P else self.Np[1] // 2
+
+    def real_shape(self):
+        return (self.Np[0], self.N[1])
+
+    def complex_shape(self, r):
+        return (self.N[0], self.Npf(r))
+
+    def real_shape_padded(self):
+        return (int(self.padsize * self.Np[0]), int(self.padsize * self.N[1]))
+
+    def real_slice(self, r, padsize=1):
+        return (slice(int(padsize * r * self.Np[0]), int(padsize * (r + 1) * self.Np[0])),
+                slice(0, int(padsize * self.N[1])))
+
+    def complex_slice(self, r):
+        s = r * self.Np[1] // 2
+        return (slice(0, self.N[0]), slice(s, s + self.Npf(r)))
+
+
+def _line_gather_x(cols, P):
+    """The exchange of line.py:196-207 / 225-236 without the Nyquist packing: every rank ends up with all
+    x rows of its own ky chunk.  cols[r] has shape (rows_r, Nf)."""
+    lay_q = (cols[0].shape[1] - 1) // P
+    full = np.concatenate(cols, axis=0)                 # (sum rows, Nf): x is rank-major
+    out = []
+    for r in range(P):
+        hi = (r + 1) * lay_q + (1 if r == P - 1 else 0)
+        out.append(np.ascontiguousarray(full[:, r * lay_q:hi]))
+    return out
+
+
+def _line_scatter_x(cols, P, rows):
+    """Inverse of _line_gather_x: cols[r] (P*rows, chunk_r) -> per rank (rows, Nf)."""
+    full = np.concatenate(cols, axis=1)
+    return [np.ascontiguousarray(full[r * rows:(r + 1) * rows]) for r in range(P)]
+
+
+def line_r2c_forward(us, N, precision="double"):
+    """line.py:177-215 (P = 1: rfft2; P > 1: rfft y -> exchange -> fft x; the Nyquist packing of
+    line.py:194, 209-215 is exact for real rows, so the result is the plain 2-D transform)."""
+    rt, ct = dtypes(precision)
+    P = len(us)
+    if P == 1:
+        return [np.fft.rfft2(us[0].astype(rt), axes=(0, 1)).astype(ct)]
+    y = [np.fft.rfft(u.astype(rt), axis=1).astype(ct) for u in us]
+    for a in y:                                        # bins 0 and N1/2 of a real row are real
+        a[:, 0] = a[:, 0].real
+        a[:, -1] = a[:, -1].real
+    g = _line_gather_x(y, P)
+    return [np.fft.fft(a, axis=0).astype(ct) for a in g]
+
+
+def line_r2c_backward(fus, N, precision="double"):
+    """line.py:275-311."""
+    rt, ct = dtypes(precision)
+    P = len(fus)
+    if P == 1:
+        return [np.fft.irfft2(fus[0].astype(ct), s=(int(N[0]), int(N[1])), axes=(0, 1)).astype(rt)]
+    x = [np.fft.ifft(f.astype(ct), axis=0).astype(ct) for f in fus]
+    rows = int(N[0]) // P
+    parts = _line_scatter_x(x, P, rows)
+    return [np.fft.irfft(a, n=int(N[1]), axis=1).astype(rt) for a in parts]
+
+
+def line_r2c_backward_padded(fus, N, precision="double", padsize=1.5):
+    """line.py:283-287 (P = 1) and 313-338 (P > 1)."""
+    rt, ct = dtypes(precision)
+    P = len(fus)
+    N0, N1 = int(N[0]), int(N[1])
+    M0, M1 = int(padsize * N0), int(padsize * N1)
+    Nf, Mf = N1 // 2 + 1, int(padsize * N1 / 2 + 1)
+    if P == 1:
+        ks = (np.fft.fftfreq(N0) * N0).astype(int)
+        fp = np.zeros((M0, Mf), dtype=ct)
+        fp[ks, :Nf] = fus[0]
+        return [np.fft.irfft2(fp * padsize ** 2, s=(M0, M1), axes=(0, 1)).astype(rt)]
+    x = []
+    for f in fus:
+        fp = np.zeros((M0, f.shape[1]), dtype=ct)
+        fp[:N0 // 2] = f[:N0 // 2]
+        fp[-(N0 // 2):] = f[N0 // 2:]
+        x.append(np.fft.ifft(fp, axis=0).astype(ct))
+    rows = M0 // P
+    parts = _line_scatter_x(x, P, rows)
+    out = []
+    for a in parts:
+        fp = np.zeros((rows, Mf), dtype=ct)
+        fp[:, :Nf] = a
+        out.append(np.fft.irfft(fp * padsize ** 2, n=M1, axis=1).astype(rt))
+    return out
+
+
+def line_r2c_forward_padded(us, N, precision="double", padsize=1.5):
+    """line.py:182-185 (P = 1: plain truncation, no fold) and 217-248 (P > 1).  For P > 1 the reference packs
+    column Nf-1 of the padded y spectrum into the imaginary part of column 0 (line.py:231) although that bin
+    is not real there; after the separation by Hermitian symmetry (swap_Nq, line.py:27-39) column 0 is the
+    transform of Re(c0) - Im(cN) and the last column that of Re(cN).  Reproduced as such."""
+    rt, ct = dtypes(precision)
+    P = len(us)
+    N0, N1 = int(N[0]), int(N[1])
+    M0 = int(padsize * N0)
+    Nf = N1 // 2 + 1
+    if P == 1:
+        ks = (np.fft.fftfreq(N0) * N0).astype(int)
+        fp = np.fft.rfft2(us[0].astype(rt) / padsize ** 2, axes=(0, 1)).astype(ct)
+        return [np.ascontiguousarray(fp[ks, :Nf])]
+    y = []
+    for u in us:
+        a = np.fft.rfft(u.astype(rt) / padsize, axis=1).astype(ct)[:, :Nf].copy()
+        c0 = a[:, 0].real - a[:, -1].imag
+        cN = a[:, -1].real.copy()
+        a[:, 0] = c0
+        a[:, -1] = cN
+        y.append(a)
+    g = _line_gather_x(y, P)
+    out = []
+    for a in g:
+        U = np.fft.fft(a / padsize, axis=0).astype(ct)
+        fu = np.zeros((N0, a.shape[1]), dtype=ct)
+        fu[:N0 // 2 + 1] = U[:N0 // 2 + 1]
+        fu[N0 // 2:] += U[M0 - N0 // 2:]
+        out.append(fu)
+    return out
+
+
+def line_dealias_mask(N, L, lay, r):
+    """line.py:129-134 (kmax from N//2+1 per axis, scaled wavenumbers as get_local_wavenumbermesh() defaults)."""
+    N = np.asarray(N)
+    L = np.asarray(L, dtype=float)
+    kx = np.fft.fftfreq(int(N[0]), 1. / N[0]) * (2 * np.pi / L[0])
+    ky = np.fft.rfftfreq(int(N[1]), 1. / N[1])[lay.complex_slice(r)[1]] * (2 * np.pi / L[1])
+    kmax = 2. / 3. * (N // 2 + 1)
+    return np.array((abs(kx[:, None]) < kmax[0]) * (abs(ky[None, :]) < kmax[1]), dtype=np.uint8)
 
 
 # --------------------------------------------------------------------------

@@ -155,8 +155,44 @@ def taylor_green_k(P, dealias):
     return fake_mpi.run(P, body)[0]
 
 
+def line_golden():
+    """2-D class (mpiFFT4py/line.py): per-rank inputs and the reference's outputs for the plain transform pair,
+    the inverse on an arbitrary spectrum and the 3/2-rule both ways, P = 1, 2, 4."""
+    from mpiFFT4py.line import R2C as RefLine
+    N = [16, 48]
+    L2 = np.array([2 * np.pi, 4 * np.pi])
+    for prec, rt, ct in (("double", np.float64, np.complex128), ("single", np.float32, np.complex64)):
+        rng = np.random.default_rng(20260211)
+        A = rng.random(N).astype(rt)
+        Ap = rng.random((int(1.5 * N[0]), int(1.5 * N[1]))).astype(rt)
+        out = dict(N=np.array(N), L=L2)
+        for P in (1, 2, 4):
+            seeds = [np.random.default_rng(1000 + 10 * P + r) for r in range(P)]
+
+            def body(rank):
+                F = RefLine(np.array(N), L2, MPI.COMM_WORLD, prec)
+                u = np.ascontiguousarray(A[F.real_local_slice()])
+                fu = F.fft2(u, np.zeros(F.complex_shape(), dtype=ct)).copy()
+                g = seeds[rank]
+                crnd = (g.random(F.complex_shape()) + 1j * g.random(F.complex_shape())).astype(ct)
+                b = F.ifft2(crnd.copy(), np.zeros(F.real_shape(), dtype=rt)).copy()
+                bp = F.ifft2(crnd.copy(), np.zeros(F.real_shape_padded(), dtype=rt), dealias="3/2-rule").copy()
+                up = np.ascontiguousarray(Ap[F.real_local_slice(padsize=1.5)])
+                cp = F.fft2(up, np.zeros(F.complex_shape(), dtype=ct), dealias="3/2-rule").copy()
+                return dict(u=u, fu=fu, crnd=crnd, b=b, bp=bp, up=up, cp=cp)
+            for r, d in enumerate(fake_mpi.run(P, body)):
+                for k, v in d.items():
+                    out["P%d_r%d_%s" % (P, r, k)] = v
+        np.savez_compressed(os.path.join(OUT, "line_16x48_%s.npz" % prec), **out)
+    print("line fixtures written")
+
+
 def main():
+    import sys
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "line":
+        return line_golden()
+    line_golden()
     with open(os.path.join(OUT, "layouts.json"), "w") as f:
         json.dump(layouts(), f, separators=(",", ":"))
 

@@ -175,3 +175,28 @@ def test_oracle_vs_reference_compiled_helpers():
         want = orc.apply_mask(fu, mask).astype(dt)
         got = ref.dealias_filter(fu.copy(), mask)                     # maths.pyx:9-19
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_line_2d(golden_dir, P, prec):
+    """2-D class: the oracle's restatement of line.py against the reference's own outputs
+    (tests/golden/line_16x48_*.npz, written by oracle/refharness/make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "line_16x48_%s.npz" % prec))
+    Nl = [int(x) for x in g["N"]]
+    lay = orc.LineLayout(Nl, P)
+    key = lambda r, k: "P%d_r%d_%s" % (P, r, k)
+    us = [g[key(r, "u")] for r in range(P)]
+    crnd = [g[key(r, "crnd")] for r in range(P)]
+    ups = [g[key(r, "up")] for r in range(P)]
+    fwd = orc.line_r2c_forward(us, Nl, prec)
+    bwd = orc.line_r2c_backward(crnd, Nl, prec)
+    bp = orc.line_r2c_backward_padded(crnd, Nl, prec)
+    cp = orc.line_r2c_forward_padded(ups, Nl, prec)
+    for r in range(P):
+        assert us[r].shape == lay.real_shape() and crnd[r].shape == lay.complex_shape(r)
+        assert ups[r].shape == lay.real_shape_padded()
+        assert orc.rel_l2(fwd[r], g[key(r, "fu")]) < TOL[prec]
+        assert orc.rel_l2(bwd[r], g[key(r, "b")]) < TOL[prec]
+        assert orc.rel_l2(bp[r], g[key(r, "bp")]) < TOL[prec]
+        assert orc.rel_l2(cp[r], g[key(r, "cp")]) < TOL[prec]
