@@ -312,6 +312,8 @@ struct mfft_plan_s {
   bool can_fuse_pad() const;
   int slab_forward_padded_fused(const void* u, void* fu);
   int slab_backward_padded_fused(const void* fu, void* u);
+  int pencil_forward_padded_fused(const void* u, void* fu);
+  int pencil_backward_padded_fused(const void* fu, void* u);
   int pencil_forward(const void* u, void* fu);
   int pencil_backward(const void* fu, void* u, bool masked);
   int pencil_forward_padded(const void* u, void* fu);
@@ -519,7 +521,7 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
 // store only the kept rows and fold the Nyquist row in registers (PAD = 2).  Six kernels per
 // pair, like the un-padded path; pack / unpack ride on the two-level row maps.
 bool mfft_plan_s::can_fuse_pad() const {
-  if (!r2c || d.padsize != 1.5 || d.decomp != MFFT_SLAB) return false;
+  if (!r2c || d.padsize != 1.5 || d.drop_nyquist || d.line2d) return false;
   if (N0 % 2 || N1 % 2 || 2 * M0 != 3 * N0 || 2 * M1 != 3 * N1 || 2 * M2 != 3 * N2) return false;
   return find_kernel(FAM_COL, (int)M0, prec, 1, 0, 1) && find_kernel(FAM_COL, (int)M0, prec, 0, 0, 2) &&
          find_kernel(FAM_COL, (int)M1, prec, 1, 0, 1) && find_kernel(FAM_COL, (int)M1, prec, 0, 0, 2) &&
@@ -765,11 +767,87 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
   return 0;
 }
 
+// ---- fused 3/2-rule, pencil: same idea as the slab (see can_fuse_pad): pad-on-load / truncate-on-store
+// column kernels whose two-level row maps also do the y-chunk pack / unpack, column-limited real kernels.
+// Only the z-chunk pack / unpack around the z-splitting exchange remain as copies.
+int mfft_plan_s::pencil_backward_padded_fused(const void* fu, void* u) {
+  const double sc3 = padscale();
+  const bool X = d.decomp == MFFT_PENCIL_X;
+  const int64_t mp = M0 / P1, np = M1 / P2;          // padded local real rows in x, y
+  const size_t wb = (size_t)std::max(std::max(M0 * N1_1 * q, mp * M1 * q), std::max(std::max(N2_0 * M1 * q, M0 * np * q), mp * np * Nf)) * es;
+  for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
+  void *W0 = work[0], *W1 = work[1], *W2 = work[2];
+  if (X) {
+    // fu (N0, N1_1, q) -> ifft x over M0 rows, the zero band never read
+    MFFT_TRY(stage("bwd_x", 0, [&] {
+      return col_pad(fu, W0, M0, true, 1, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q), sc3 / (double)M0);
+    }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, true, W0, W1); }));
+    // W1 = P1 blocks (mp, N1_1, q): gather y through the input row map, pad on load, write P2 blocks (mp, np, q)
+    MFFT_TRY(stage("bwd_y", 0, [&] {
+      return col_pad(W1, W0, M1, true, 1, false, mp, q, N1_1 * q, two_level(N1_1, mp * N1_1 * q, q), np * q,
+                     two_level(np, mp * np * q, q), 1.0 / (double)M1);
+    }));
+  } else {
+    // fu (N2_0, N1, q) -> ifft y over M1 rows, written as P2 blocks (N2_0, np, q)
+    MFFT_TRY(stage("bwd_y", 0, [&] {
+      return col_pad(fu, W0, M1, true, 1, false, N2_0, q, N1 * q, plain(q), np * q, two_level(np, N2_0 * np * q, q),
+                     sc3 / (double)M1);
+    }));
+    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, true, W0, W1); }));
+    // W1 = (N0, np, q) -> ifft x over M0 rows; its x chunks (mp rows) are the blocks of the next exchange
+    MFFT_TRY(stage("bwd_x", 0, [&] {
+      return col_pad(W1, W0, M0, true, 1, false, 1, np * q, 0, plain(np * q), 0, plain(np * q), 1.0 / (double)M0);
+    }));
+  }
+  MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, true, W0, W1); }));
+  // only the Nf kept columns exist: c2r reads the others as zeros
+  MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z(this, W2, W1, mp * np, Nf, zc, true); }));
+  MFFT_TRY(stage("bwd_z", 0, [&] { return c2r_rows(W2, u, mp * np, M2, Nf, M2, 1.0 / (double)M2, (int)Nf); }));
+  return 0;
+}
+
+int mfft_plan_s::pencil_forward_padded_fused(const void* u, void* fu) {
+  const double isc3 = 1.0 / padscale();
+  const bool X = d.decomp == MFFT_PENCIL_X;
+  const int64_t mp = M0 / P1, np = M1 / P2;
+  const size_t wb = (size_t)std::max(std::max(M0 * N1_1 * q, mp * M1 * q), std::max(std::max(N2_0 * M1 * q, M0 * np * q), mp * np * Nf)) * es;
+  for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
+  void *W0 = work[0], *W1 = work[1];
+  MFFT_TRY(stage("fwd_z", 0, [&] { return r2c_rows(u, W0, mp * np, M2, M2, Nf, 1.0, (int)Nf); }));
+  MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, mp * np, Nf, zc, false); }));
+  MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, true, W1, W0); }));
+  if (X) {
+    // W0 = P2 blocks (mp, np, q): fft y gathering over M1 rows, truncate + fold on store, straight into
+    // the P1 blocks (mp, N1_1, q) of the next exchange
+    MFFT_TRY(stage("fwd_y", 0, [&] {
+      return col_pad(W0, W1, M1, false, 2, true, mp, q, np * q, two_level(np, mp * np * q, q), N1_1 * q,
+                     two_level(N1_1, mp * N1_1 * q, q), 1.0);
+    }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, true, W1, W0); }));
+    MFFT_TRY(stage("fwd_x", 0, [&] {
+      return col_pad(W0, fu, M0, false, 2, true, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q), isc3);
+    }));
+  } else {
+    // W0 = (M0, np, q): fft x, truncate + fold to (N0, np, q)
+    MFFT_TRY(stage("fwd_x", 0, [&] {
+      return col_pad(W0, W1, M0, false, 2, true, 1, np * q, 0, plain(np * q), 0, plain(np * q), 1.0);
+    }));
+    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, true, W1, W0); }));
+    // W0 = P2 blocks (N2_0, np, q): fft y gathering over M1 rows, truncate + fold into fu (N2_0, N1, q)
+    MFFT_TRY(stage("fwd_y", 0, [&] {
+      return col_pad(W0, fu, M1, false, 2, true, N2_0, q, np * q, two_level(np, N2_0 * np * q, q), N1 * q, plain(q), isc3);
+    }));
+  }
+  return 0;
+}
+
 // ---- 3/2-rule, pencil (Alltoallw branches; padding of an axis happens right
 // before the transform along it, when the axis is locally complete) -------------
 int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
   if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
   if (d.drop_nyquist) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule with communication='AlltoallN' is not implemented");
+  if (can_fuse_pad()) return pencil_backward_padded_fused(fu, u);
   const double sc3 = padscale();
   const bool X = d.decomp == MFFT_PENCIL_X;
   const std::vector<int>& gz = X ? group1 : group0;
@@ -829,6 +907,7 @@ int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
 int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
   if (!r2c) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule is implemented for R2C plans");
   if (d.drop_nyquist) return set_error(MFFT_ERR_UNSUPPORTED, "3/2-rule with communication='AlltoallN' is not implemented");
+  if (can_fuse_pad()) return pencil_forward_padded_fused(u, fu);
   const double isc3 = 1.0 / padscale();
   const bool X = d.decomp == MFFT_PENCIL_X;
   const std::vector<int>& gz = X ? group1 : group0;

@@ -152,6 +152,46 @@ def test_pencil_padded(P, align, prec):
         assert orc.rel_l2(cp, C0[cs]) < 4 * TOL[prec]
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("decomp,P", [("slab", 1), ("slab", 2), ("slab", 4), ("pencilX", 4), ("pencilY", 4),
+                                      ("pencilX", 8), ("pencilY", 8)])
+def test_padded_generic_data(decomp, P, prec, fused, monkeypatch):
+    """3/2-rule on data that is NOT of the reference test's special form: a random padded real field forward
+    (the Nyquist folds of slab.py:480-482 / pencil.py:364-379 matter) and a random spectrum backward, through
+    the fused kernels (pad-on-load / truncate-on-store) and through the copy-based path (MFFT_NO_PAD_FUSION)."""
+    from mpifft4py_amd import Pencil_R2C, Slab_R2C
+    if not fused:
+        monkeypatch.setenv("MFFT_NO_PAD_FUSION", "1")
+    N = NREF
+    rt, ct = rdtype(prec), cdtype(prec)
+    rng = np.random.default_rng(510 + P)
+    Ap = rng.random([int(1.5 * n) for n in N]).astype(rt)
+    Cr = (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5 + 1j * (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5)).astype(ct)
+    if decomp == "slab":
+        lay = orc.SlabLayout(N, P)
+        want_c = orc.slab_r2c_forward_padded(orc.scatter_real(Ap, lay, 1.5), N, prec)
+        want_a = orc.slab_r2c_backward_padded(orc.scatter_complex(Cr, lay), N, prec)
+        make = lambda comm: Slab_R2C(np.array(N), L, comm, prec)
+    else:
+        align = decomp[-1]
+        lay = orc.PencilLayout(N, P, None, align)
+        want_c = orc.pencil_r2c_forward_padded(orc.scatter_real(Ap, lay, 1.5), N, None, align, prec)
+        want_a = orc.pencil_r2c_backward_padded(orc.scatter_complex(Cr, lay), N, None, align, prec)
+        make = lambda comm: Pencil_R2C(np.array(N), L, comm, prec, communication="Alltoallw", alignment=align)
+
+    def body(comm):
+        F = make(comm)
+        ap = np.ascontiguousarray(Ap[F.real_local_slice(padsize=1.5)])
+        cp = F.fftn(ap, np.zeros(F.complex_shape(), dtype=ct), dealias="3/2-rule")
+        c = np.ascontiguousarray(Cr[F.complex_local_slice()])
+        a = F.ifftn(c, np.zeros(F.real_shape_padded(), dtype=rt), dealias="3/2-rule")
+        return cp, a
+    for r, (cp, a) in enumerate(run_ranks(P, body)):
+        assert orc.rel_l2(cp, want_c[r]) < 4 * TOL[prec], (r, "forward")
+        assert orc.rel_l2(a, want_a[r]) < 4 * TOL[prec], (r, "backward")
+
+
 @pytest.mark.parametrize("decomp", ["slab", "pencilX", "pencilY"])
 def test_two_thirds_rule(decomp):
     """ifftn(dealias='2/3-rule') == ifftn of the masked spectrum (slab.py:237-245)."""
