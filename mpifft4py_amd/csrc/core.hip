@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <unordered_map>
 #include <tuple>
 #include "mfft_internal.h"
 
@@ -31,16 +32,34 @@ std::vector<KernelEntry>& kernel_registry() {
   return reg;
 }
 
+// The registry is complete once the static initialisers of the kernels_*.hip units have run; lookups go
+// through hash maps built on first use (a linear scan of ~2000 entries per launch costs ~0.3 us, visible at 32^3).
+static uint64_t kernel_key(int family, int n, int prec, int inv, int nt, int pad) {
+  return ((uint64_t)(unsigned)n << 12) | ((uint64_t)family << 8) | ((uint64_t)pad << 4) | ((uint64_t)nt << 2) |
+         ((uint64_t)inv << 1) | (uint64_t)prec;
+}
+
 const KernelEntry* find_kernel(int family, int n, int prec, int inv, int nt, int pad) {
-  for (const KernelEntry& e : kernel_registry())
-    if (e.family == family && e.n == n && e.prec == prec && e.inv == inv && e.nt == nt && e.pad == pad) return &e;
-  return nullptr;
+  static std::unordered_map<uint64_t, const KernelEntry*> index;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const KernelEntry& e : kernel_registry()) index.emplace(kernel_key(e.family, e.n, e.prec, e.inv, e.nt, e.pad), &e);
+  });
+  auto it = index.find(kernel_key(family, n, prec, inv, nt, pad));
+  return it == index.end() ? nullptr : it->second;
 }
 
 const KernelEntry* find_chirpz(int family, int n, int prec, int inv) {
+  static std::unordered_map<uint64_t, const KernelEntry*> cache;
+  static std::mutex mu;
+  const uint64_t key = kernel_key(family, n, prec, inv, 0, 0);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
   const KernelEntry* best = nullptr;
   for (const KernelEntry& e : kernel_registry())
     if (e.family == family && e.prec == prec && e.inv == inv && e.n >= 2 * n - 1 && (!best || e.n < best->n)) best = &e;
+  cache.emplace(key, best);
   return best;
 }
 
