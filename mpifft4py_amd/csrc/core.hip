@@ -66,7 +66,8 @@ const KernelEntry* find_chirpz(int family, int n, int prec, int inv) {
 bool length_supported(int64_t n, bool real_transform) {
   if (n <= 0 || n > (1 << 20)) return false;
   if (real_transform)
-    return find_kernel(FAM_R2C, (int)n, MFFT_DOUBLE, 0) != nullptr || find_chirpz(FAM_R2CZ, (int)n, MFFT_DOUBLE, 0) != nullptr;
+    return find_kernel(FAM_R2C, (int)n, MFFT_DOUBLE, 0) != nullptr || find_chirpz(FAM_R2CZ, (int)n, MFFT_DOUBLE, 0) != nullptr ||
+           (n % 2 == 0 && n >= 4 && find_chirpz(FAM_R2CZH, (int)(n / 2), MFFT_DOUBLE, 0) != nullptr);
   return n == 1 || find_kernel(FAM_COL, (int)n, MFFT_DOUBLE, 0) != nullptr ||
          find_chirpz(FAM_COLZ, (int)n, MFFT_DOUBLE, 0) != nullptr;
 }
@@ -307,14 +308,21 @@ static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
   // the radix kernels read a real row as (n/2) complex values: rows must stay 2-element aligned
   const int64_t real_stride = fam == FAM_R2C ? a.in_stride : a.out_stride;
   void *tw = nullptr, *rtw = nullptr;
-  if (!e || (real_stride % 2 != 0 && !limited)) {   // any other length / odd pitch: full-length chirp-z on the real row
-    e = find_chirpz(fam == FAM_R2C ? FAM_R2CZ : FAM_C2RZ, a.n, a.prec, fam == FAM_C2R ? 1 : 0);
+  if (!e || (real_stride % 2 != 0 && !limited)) {   // no radix plan (or an odd pitch): chirp-z on the real row
+    const bool r2c = fam == FAM_R2C;
+    // even length and pitch: n/2 complex values + split pass (half the convolution length); else full length
+    const bool half = a.n % 2 == 0 && a.n >= 4 && real_stride % 2 == 0;
+    const int nz = half ? a.n / 2 : a.n;
+    e = find_chirpz(half ? (r2c ? FAM_R2CZH : FAM_C2RZH) : (r2c ? FAM_R2CZ : FAM_C2RZ), nz, a.prec, r2c ? 0 : 1);
     if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a real transform of length %d (maximum 2048 for lengths other than 2^a, 3*2^a, 5*2^a)", a.n);
     void *chirp = nullptr, *bhat = nullptr;
     MFFT_TRY(prepare_kernel(e, &tw));
-    MFFT_TRY(chirpz_tables(a.n, e->n, a.prec, &chirp, &bhat));
-    return a.prec == MFFT_DOUBLE ? launch_real_t<double, RealParamsZ<double>>(e, a, tw, nullptr, s, chirp, bhat)
-                                 : launch_real_t<float, RealParamsZ<float>>(e, a, tw, nullptr, s, chirp, bhat);
+    MFFT_TRY(chirpz_tables(nz, e->n, a.prec, &chirp, &bhat));
+    if (half) MFFT_TRY(real_twiddles(a.n, a.prec, &rtw));
+    RealArgs az = a;
+    az.n = a.n;
+    return a.prec == MFFT_DOUBLE ? launch_real_t<double, RealParamsZ<double>>(e, az, tw, rtw, s, chirp, bhat)
+                                 : launch_real_t<float, RealParamsZ<float>>(e, az, tw, rtw, s, chirp, bhat);
   }
   if (real_stride % 2 != 0)
     return set_error(MFFT_ERR_UNSUPPORTED, "real row stride %lld must be even", (long long)real_stride);

@@ -569,6 +569,61 @@ static void test_real_z(int n) {
   report(name, n, pname<T>(), (double)sqrtl(num / den), 16 * tol_of<T>());
 }
 
+// half-length real chirp-z (KIND 3 / 4): even real length n = 2m, chirp-z of length m on the plan S (M >= 2m-1)
+template <class S, typename T, int ROWS>
+static void test_real_zh(int m) {
+  const int n = 2 * m, nrows = ROWS + 2;
+  std::mt19937_64 rng(170 + n);
+  std::uniform_real_distribution<double> U(-1, 1);
+  const int pin = n + 2, pout = m + 1 + 2;
+  std::vector<T> in((size_t)nrows * pin), back((size_t)nrows * pin, (T)0);
+  std::vector<cx<T>> out((size_t)nrows * pout);
+  for (auto& z : in) z = (T)U(rng);
+  auto tw = build_pass_twiddles<S, T>();
+  auto ch = build_chirp<T>(m);
+  auto bh = build_chirp_filter<T>(m, S::N);
+  auto rtw = build_real_twiddles<T>(n);
+  RealParamsZ<T> P;
+  P.in = in.data(); P.out = out.data(); P.tw = tw.data(); P.rtw = rtw.data(); P.in_stride = pin; P.out_stride = pout;
+  P.nrows = nrows; P.valid = m + 1; P.scale = (T)1; P.chirp = ch.data(); P.bhat = bh.data(); P.n = n;
+  {
+    typedef RowFftZ<S, T, ROWS, 3, false> K;
+    emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  }
+  long double num = 0, den = 0;
+  for (int r = 0; r < nrows; ++r) {
+    lvec x(n);
+    for (int i = 0; i < n; ++i) { x[i].x = in[(size_t)r * pin + i]; x[i].y = 0; }
+    lvec X = naive_dft(x, -1);
+    for (int k = 0; k <= m; ++k) {
+      cx<T> g = out[(size_t)r * pout + k];
+      num += (g.x - X[k].x) * (g.x - X[k].x) + (g.y - X[k].y) * (g.y - X[k].y);
+      den += X[k].x * X[k].x + X[k].y * X[k].y;
+    }
+  }
+  char name[64];
+  snprintf(name, sizeof name, "chirpz/2 r2c M=%d r%d", S::N, ROWS);
+  report(name, n, pname<T>(), (double)sqrtl(num / den), 8 * tol_of<T>());
+  for (int r = 0; r < nrows; ++r) {
+    out[(size_t)r * pout + 0].y = (T)3.5;
+    out[(size_t)r * pout + m].y = (T)-2.25;
+  }
+  P.in = out.data(); P.out = back.data(); P.in_stride = pout; P.out_stride = pin; P.scale = (T)(1.0 / n);
+  {
+    typedef RowFftZ<S, T, ROWS, 4, true> K;
+    emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  }
+  num = den = 0;
+  for (int r = 0; r < nrows; ++r)
+    for (int i = 0; i < n; ++i) {
+      long double d = (long double)back[(size_t)r * pin + i] - in[(size_t)r * pin + i];
+      num += d * d;
+      den += (long double)in[(size_t)r * pin + i] * in[(size_t)r * pin + i];
+    }
+  snprintf(name, sizeof name, "chirpz/2 c2r(r2c) M=%d r%d", S::N, ROWS);
+  report(name, n, pname<T>(), (double)sqrtl(num / den), 16 * tol_of<T>());
+}
+
 template <class S> static void test_chirpz_all() {
   const int nmax = (S::N + 1) / 2;
   for (int n : {nmax, nmax - 1, (S::N / 4) + 1, 7}) {
@@ -581,6 +636,8 @@ template <class S> static void test_chirpz_all() {
     test_row_z<S, float, 3, true>(n);
     test_real_z<S, double, 2>(n);
     test_real_z<S, float, 3>(n);
+    test_real_zh<S, double, 2>(n);
+    test_real_zh<S, float, 3>(n);
   }
 }
 

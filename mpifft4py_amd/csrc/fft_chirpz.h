@@ -149,16 +149,21 @@ struct ColFftZ {
 };
 
 // ---------------------------------------------------------------------------
-// contiguous-axis transforms of runtime length P.n.  KIND 0: c2c, 1: real -> half-complex
-// (n/2+1 bins stored), 2: half-complex -> real (Hermitian extension built on load; the
-// imaginary parts of bin 0 and, for even n, bin n/2 are ignored as pocketfft/FFTW c2r do).
+// contiguous-axis transforms.  KIND 0: c2c of runtime length P.n.
+// Real rows of length P.n, full-length flavours (any n, any row pitch):
+//   KIND 1: real -> half-complex (n/2+1 bins stored);
+//   KIND 2: half-complex -> real (Hermitian extension built on load).
+// Real rows of EVEN length and even pitch, half-length flavours (the n reals are n/2 complex values, one
+// chirp-z of length n/2 plus the split pass of the radix kernels: half the convolution length):
+//   KIND 3: real -> half-complex;  KIND 4: half-complex -> real.
+// c2r ignores the imaginary parts of bin 0 and, for even n, bin n/2 (as pocketfft/FFTW do).
 // ---------------------------------------------------------------------------
 template <class S, typename T, int ROWS, int KIND, bool INV>
 struct RowFftZ {
   static constexpr int THREADS = S::TPT * ROWS;
   static constexpr int PD = S::R(0);
   static constexpr int PLEN = padded_len<S::N, PD>();
-  static constexpr int LDS_BYTES = S::NP > 1 ? (int)(PLEN * ROWS * sizeof(cx<T>)) : 0;
+  static constexpr int LDS_BYTES = (S::NP > 1 || KIND == 3) ? (int)(PLEN * ROWS * sizeof(cx<T>)) : 0;
 
   template <class PZ>
   static MFFT_D void body(const PZ& P, int bid, int tid, char* lds) {
@@ -167,12 +172,13 @@ struct RowFftZ {
     cx<T>* xch = reinterpret_cast<cx<T>*>(lds) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;
-    const int n = P.n;
-    const int nh = n / 2;
+    const int nh = P.n / 2;
+    const int n = KIND >= 3 ? nh : P.n;              // logical length of the complex chirp-z
     const i64 lrow = active ? row : P.nrows - 1;     // rows past the end re-read the last row, store nothing
 
     // unconditional loads (positions >= n re-read position n-1 and are zeroed by a select): see ColFftZ
     cx<T> v[S::E];
+    cx<T> vm[KIND == 4 ? S::E : 1];                  // KIND 4: the mirrored bins X[n - r]
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
       const int r = j + k * S::TPT;
@@ -183,14 +189,22 @@ struct RowFftZ {
       } else if constexpr (KIND == 1) {
         const T* ip = static_cast<const T*>(P.in) + lrow * P.in_stride;
         v[k] = mk<T>(ip[rc], (T)0);
-      } else {
+      } else if constexpr (KIND == 2) {
         const cx<T>* ip = static_cast<const cx<T>*>(P.in) + lrow * P.in_stride;
         v[k] = ip[rc <= nh ? rc : n - rc];
+      } else if constexpr (KIND == 3) {              // (x[2r], x[2r+1]) as one complex value
+        const cx<T>* ip = reinterpret_cast<const cx<T>*>(static_cast<const T*>(P.in) + lrow * P.in_stride);
+        v[k] = ip[rc];
+      } else {
+        const cx<T>* ip = static_cast<const cx<T>*>(P.in) + lrow * P.in_stride;
+        v[k] = ip[rc];
+        vm[k] = ip[n - rc];
       }
     }
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
       const int r = j + k * S::TPT;
+      const int rc = r < n ? r : n - 1;
       cx<T> x = v[k];
       if constexpr (KIND == 0) {
         if (INV) x = swapri(x);
@@ -198,12 +212,50 @@ struct RowFftZ {
         if (r > nh) x = conj(x);              // Hermitian extension
         if (r == 0 || 2 * r == n) x.y = (T)0;
         x = swapri(x);                        // inverse through the swap identity
+      } else if constexpr (KIND == 4) {
+        // Z[r] = (X[r] + conj X[n-r]) + i conj(w_r) (X[r] - conj X[n-r])   (twice the textbook value)
+        cx<T> xm = conj(vm[k]);
+        if (r == 0) { x.y = (T)0; xm.y = (T)0; }
+        x = swapri((x + xm) + mul_pi((x - xm) * conj(P.rtw[rc])));
       }
-      x = x * P.chirp[r < n ? r : n - 1];
+      x = x * P.chirp[rc];
       v[k] = r < n ? x : mk<T>((T)0, (T)0);
     }
     XchFull<T, PadSlot<PD>> xc{xch, PadSlot<PD>{}};
     chirpz_conv<S, T>(v, j, P.tw, P.bhat, xc);
+    if constexpr (KIND == 3) {
+      // split pass: X[r] = E[r] + w_r O[r], E = (Z[r] + conj Z[n-r])/2, O = -i (Z[r] - conj Z[n-r])/2; partner via LDS
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const int r = j + k * S::TPT;
+        v[k] = swapri(v[k]) * P.chirp[r < n ? r : n - 1];
+      }
+      if constexpr (S::NP > 1) MFFT_BARRIER();       // everyone finished the last gather of the convolution
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const int r = j + k * S::TPT;
+        if (r < n) xc.put(r, v[k]);
+      }
+      MFFT_BARRIER();
+      if (active) {
+        cx<T>* op = static_cast<cx<T>*>(P.out) + row * P.out_stride;
+        const T half = (T)0.5;
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) {
+          const int r = j + k * S::TPT;
+          if (r == 0) {
+            op[0] = mk<T>((v[k].x + v[k].y) * P.scale, (T)0);
+            op[n] = mk<T>((v[k].x - v[k].y) * P.scale, (T)0);
+          } else if (r < n) {
+            const cx<T> zm = conj(xc.get(n - r));
+            const cx<T> e = scale(v[k] + zm, half);
+            const cx<T> o = mul_mi(scale(v[k] - zm, half));
+            op[r] = scale(e + P.rtw[r] * o, P.scale);
+          }
+        }
+      }
+      return;
+    }
     if (active) {
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {
@@ -216,9 +268,12 @@ struct RowFftZ {
           } else if constexpr (KIND == 1) {
             cx<T>* op = static_cast<cx<T>*>(P.out) + row * P.out_stride;
             if (r <= nh) op[r] = x;
-          } else {
+          } else if constexpr (KIND == 2) {
             T* op = static_cast<T*>(P.out) + row * P.out_stride;
             op[r] = x.y;                      // Re of the un-swapped value
+          } else {
+            cx<T>* op = reinterpret_cast<cx<T>*>(static_cast<T*>(P.out) + row * P.out_stride);
+            op[r] = swapri(x);                // (x[2r], x[2r+1])
           }
         }
       }

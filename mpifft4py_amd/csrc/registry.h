@@ -13,7 +13,8 @@ namespace mfft {
 enum Family {
   FAM_COL = 0, FAM_ROW = 1, FAM_R2C = 2, FAM_C2R = 3,
   // chirp-z (Bluestein) variants: entry.n is the convolution length M, the logical length is a launch parameter
-  FAM_COLZ = 4, FAM_ROWZ = 5, FAM_R2CZ = 6, FAM_C2RZ = 7
+  FAM_COLZ = 4, FAM_ROWZ = 5, FAM_R2CZ = 6, FAM_C2RZ = 7,
+  FAM_R2CZH = 8, FAM_C2RZH = 9     // even real length: chirp-z of n/2 complex values + split pass
 };
 
 struct KernelEntry {
@@ -149,12 +150,24 @@ void register_rows(const char* name) {
 
 // chirp-z variants (fft_chirpz.h): every plan of length >= 16 also serves as the convolution length M
 // of the arbitrary-length kernels
+// chirp-z tiles: a 1024-thread workgroup is capped at 128 VGPRs and the two chained transforms then spill
+// (M = 2048: 160 bytes of scratch per lane); there a half-width (64-byte) tile with 512 threads and whole-complex
+// exchanges is faster (1000^3 fp64: 10.3 -> 8.2 ms per pass).  With 512 threads or fewer the 128-byte tile with
+// split exchanges stays ahead (720^3, M = 1536: 3.5 vs 4.5 ms).
+template <class S, typename T> constexpr int colz_cols() {
+  constexpr int c = col_cols<S, T>(), v = col_vec<S, T>();
+  return (col_split<S, T>() && S::TPT * (c / v) > 512 && c / 2 >= v && c / 2 >= 64 / (int)sizeof(cx<T>) &&
+          (long long)S::N * (c / 2) * (int)sizeof(cx<T>) <= 131072 && S::TPT * (c / 2 / v) >= 64) ? c / 2 : c;
+}
+template <class S, typename T> constexpr bool colz_split() {
+  return S::NP > 1 && (long long)S::N * colz_cols<S, T>() * (int)sizeof(cx<T>) > 131072;
+}
 template <class S, typename T>
 void register_col_z(const char* name) {
   if constexpr (S::N >= 16) {
     auto& reg = kernel_registry();
-    constexpr int C = col_cols<S, T>();
-    constexpr bool CS = col_split<S, T>();
+    constexpr int C = colz_cols<S, T>();
+    constexpr bool CS = colz_split<S, T>();
     constexpr int CV = col_vec<S, T>();
     reg.push_back(make_entry<ColFftZ<S, T, C, false, CS, CV>, ColParamsZ<T>, S, T>(FAM_COLZ, S::N, 0, C, name));
     reg.push_back(make_entry<ColFftZ<S, T, C, true, CS, CV>, ColParamsZ<T>, S, T>(FAM_COLZ, S::N, 1, C, name));
@@ -169,6 +182,8 @@ void register_rows_z(const char* name) {
     reg.push_back(make_entry<RowFftZ<S, T, R, 0, true>, RowParamsZ<T>, S, T>(FAM_ROWZ, S::N, 1, R, name));
     reg.push_back(make_entry<RowFftZ<S, T, R, 1, false>, RealParamsZ<T>, S, T>(FAM_R2CZ, S::N, 0, R, name));
     reg.push_back(make_entry<RowFftZ<S, T, R, 2, true>, RealParamsZ<T>, S, T>(FAM_C2RZ, S::N, 1, R, name));
+    reg.push_back(make_entry<RowFftZ<S, T, R, 3, false>, RealParamsZ<T>, S, T>(FAM_R2CZH, S::N, 0, R, name));
+    reg.push_back(make_entry<RowFftZ<S, T, R, 4, true>, RealParamsZ<T>, S, T>(FAM_C2RZH, S::N, 1, R, name));
   }
 }
 

@@ -52,7 +52,8 @@ def test_version_and_lengths(lib):
         assert lib.mfft_length_supported(n, 1) == 1, n
     for n in (2049, 4097, 5000):
         assert lib.mfft_length_supported(n, 0) == 0, n
-    assert lib.mfft_length_supported(2050, 1) == 0
+    assert lib.mfft_length_supported(2050, 1) == 1      # even real rows: chirp-z of n/2 complex values
+    assert lib.mfft_length_supported(2051, 1) == 0 and lib.mfft_length_supported(4100, 1) == 0
 
 
 def test_fails_loudly_without_gpu(lib):

@@ -149,7 +149,7 @@ def test_unsupported_length_raises():
     with pytest.raises(_lib.MfftError):          # chirp-z needs 2n-1 <= 4096
         m.fft(np.zeros((2049, 4, 4), dtype=np.complex128), axis=0)
     with pytest.raises(_lib.MfftError):
-        m.rfft(np.zeros((2, 2, 2050)), axis=2)
+        m.rfft(np.zeros((2, 2, 2051)), axis=2)
 
 
 # lengths without a radix plan: chirp-z kernels (csrc/fft_chirpz.h); primes, prime powers, 7-smooth,
@@ -174,7 +174,7 @@ def test_c2c_arbitrary_length_every_axis(n, prec):
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("n", CHIRPZ + [14, 22, 30, 126, 258, 1026, 2046])
+@pytest.mark.parametrize("n", CHIRPZ + [14, 22, 30, 126, 258, 1026, 2046, 2050, 3000, 4094])
 def test_rfft_irfft_arbitrary_length(n, prec):
     """Real transforms of any length, odd ones included (numpy_fft.py:39-51 with n given by the output)."""
     from mpifft4py_amd import rfft, irfft
