@@ -46,6 +46,13 @@ constexpr bool mfft_has_row_override(int n) {
          n == 1280 || n == 2560 || n == 144 || n == 288 || n == 576 || n == 1152 || n == 2304;
 }
 
+// Strided-kernel overrides for SINGLE precision: the longest lengths run with E = 32 plans, one column per lane,
+// 1024 threads and 128-byte tiles (kbench2: 2048 2.7 -> 3.8 TB/s, 4096 2.0 -> 3.1 TB/s; the E = 16 plans would need
+// two columns per lane at 1024 threads, which spills).  A length listed here gets its fp32 strided kernels from
+// this list, everything else from its MFFT_PLANS_* entry.
+#define MFFT_COLPLANS_F32_C(X) X(2048, 32, 8, 8) X(4096, 32, 32, 4)
+template <typename T> constexpr bool mfft_has_col_override(int n) { return sizeof(T) == 4 && (n == 2048 || n == 4096); }
+
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
   MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X)

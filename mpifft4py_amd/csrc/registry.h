@@ -44,7 +44,15 @@ const KernelEntry* find_chirpz(int family, int n, int prec, int inv);
 // narrower tiles every line is fetched once per tile that touches it).  The
 // exchange buffer may take up to 128 KiB of the CU's 160 KiB LDS; if whole complex
 // values do not fit, real and imaginary parts are exchanged one after the other.
-template <class S, typename T> constexpr int col_vec() { return 16 / (int)sizeof(cx<T>) > 0 ? 16 / (int)sizeof(cx<T>) : 1; }   // 16 B per lane
+// Single precision: one lane may own VEC = 2 adjacent columns (16 bytes per lane, twiddles loaded once).  That pays
+// only while a thread holds at most 32 complex values and the workgroup stays at 512 threads (2^a <= 1024: +5..17 %);
+// measured with kbench2 (profiles/r01_kbench2_long_and_fp32.txt): VEC = 1 is ahead for the E = 20/24/40 plans
+// (640: +20 %, 1280: 2x, 768: +5 %, 1536: +12 %) and for 2048 / 4096, where VEC = 2 needs 1024 threads and spills.
+template <class S, typename T> constexpr int col_vec() {
+  constexpr int lanes16 = 16 / (int)sizeof(cx<T>) > 0 ? 16 / (int)sizeof(cx<T>) : 1;   // columns in 16 bytes
+  constexpr int full = 128 / (int)sizeof(cx<T>);                                         // columns in a 128-byte tile
+  return (lanes16 > 1 && S::E * lanes16 <= 32 && S::TPT * (full / lanes16) <= 512) ? lanes16 : 1;
+}
 template <class S, typename T> constexpr int col_cols() {
   constexpr int vec = col_vec<S, T>();
   int cols = 128 / (int)sizeof(cx<T>);
@@ -190,12 +198,19 @@ void register_rows_z(const char* name) {
 // a plan of the main list: strided kernels always, row kernels unless the length has an override
 template <class S, typename T>
 void register_plan(const char* name) {
-  register_col<S, T>(name);
-  register_col_z<S, T>(name);
+  if constexpr (!mfft_has_col_override<T>(S::N)) {
+    register_col<S, T>(name);
+    register_col_z<S, T>(name);
+  }
   if constexpr (!mfft_has_row_override(S::N)) {
     register_rows<S, T>(name);
     register_rows_z<S, T>(name);
   }
+}
+template <class S, typename T>
+void register_colplan(const char* name) {
+  register_col<S, T>(name);
+  register_col_z<S, T>(name);
 }
 template <class S, typename T>
 void register_rowplan(const char* name) {
