@@ -579,28 +579,26 @@ struct C2RFft {
       // Every bin is read from memory ONCE.  The mirrored partner X[M-pos] of (lane j, register k)
       // is register E-1-k of lane TPT-j of the same row (all inside one wave), fetched with a
       // wave shuffle; lane 0's partners are its own registers E-k and the extra bin X[M].
-      cx<T> x[S::E];
+      // The bins are loaded straight into v and turned into the pre-pass values IN PLACE, two registers
+      // (k, E-1-k) at a time: a second register array would cost E complex registers (256 VGPRs for the
+      // E = 20 plans in fp64).  Lane 0 only ever reads its own shuffle operand, so it simply offers the
+      // registers it needs itself: X[M] first, then its register E-k, carried over from the previous step.
+      static_assert(S::E % 2 == 0, "register pairing needs an even number of values per thread");
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {
         const int pos = j + k * S::TPT;
         if constexpr (LIMIT) {
-          x[k] = mk<T>((T)0, (T)0);
-          if (pos < P.valid) x[k] = ip[pos];
+          v[k] = mk<T>((T)0, (T)0);
+          if (pos < P.valid) v[k] = ip[pos];
         } else {
-          x[k] = ip[pos];
+          v[k] = ip[pos];
         }
       }
-      cx<T> xM = mk<T>((T)0, (T)0);
-      if (j == 0 && (!LIMIT || M < P.valid)) xM = ip[M];
+      cx<T> carry = mk<T>((T)0, (T)0);
+      if (j == 0 && (!LIMIT || M < P.valid)) carry = ip[M];
 #if defined(__HIP_DEVICE_COMPILE__)
       const int src = (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));     // lane of thread TPT-j (mod TPT) of this row
-#pragma unroll
-      for (int k = 0; k < S::E; ++k) {
-        const cx<T> give = x[S::E - 1 - k];
-        cx<T> pm = mk<T>(__shfl(give.x, src, 64), __shfl(give.y, src, 64));
-        if (j == 0) pm = (k == 0) ? xM : x[(S::E - k) % S::E];
-        const int pos = j + k * S::TPT;
-        cx<T> xk = x[k];
+      auto prepass = [&](cx<T> xk, cx<T> pm, int pos) {
         cx<T> xm = conj(pm);
         if (pos == 0) {              // imaginary parts of the k=0 and k=N/2 bins are ignored
           xk.y = (T)0;
@@ -608,7 +606,20 @@ struct C2RFft {
         }
         const cx<T> e = xk + xm;
         const cx<T> dd = xk - xm;
-        v[k] = swapri(e + mul_pi(dd * conj(P.rtw[pos])));   // inverse transform through the swap identity
+        return swapri(e + mul_pi(dd * conj(P.rtw[pos])));   // inverse transform through the swap identity
+      };
+#pragma unroll
+      for (int k = 0; k < S::E / 2; ++k) {
+        constexpr int E = S::E;
+        const int kp = E - 1 - k;
+        const cx<T> a = v[k], b = v[kp];
+        const cx<T> give1 = j == 0 ? carry : b;          // partner of position j + k*TPT
+        const cx<T> give2 = j == 0 ? v[k + 1] : a;       // partner of position j + kp*TPT (lane 0: its register E-kp = k+1)
+        const cx<T> pm1 = mk<T>(__shfl(give1.x, src, 64), __shfl(give1.y, src, 64));
+        const cx<T> pm2 = mk<T>(__shfl(give2.x, src, 64), __shfl(give2.y, src, 64));
+        carry = b;                                       // lane 0's partner register of the next step
+        v[k] = prepass(a, pm1, j + k * S::TPT);
+        v[kp] = prepass(b, pm2, j + kp * S::TPT);
       }
 #endif
     } else {
