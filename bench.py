@@ -151,6 +151,28 @@ def main():
     n = args.n
     N = np.array([n, n, n])
     L = np.array([2 * np.pi] * 3)
+    tuning = None
+    if args.decomp == "slab" and world > 1 and args.pipeline == 0:
+        # exchange-pipeline depth (kz slices in flight) measured on this machine's links before the warm-up,
+        # like a planner's MEASURE mode: 2 untimed + 2 timed pairs per candidate, slowest rank counts
+        tuning = {}
+        ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
+        for depth in (1, 2, 4, 8):
+            Ft = Slab_R2C(N, L, comm, args.precision, pipeline=depth)
+            fut = DeviceArray.empty(Ft.complex_shape(), Ft.complex)
+            for it in range(4):
+                if it == 2:
+                    Ft.sync()
+                    comm.barrier()
+                    tt = time.perf_counter()
+                Ft.fftn(ut, fut)
+                Ft.ifftn(fut, ut)
+            Ft.sync()
+            comm.barrier()
+            tuning[depth] = comm.allreduce((time.perf_counter() - tt) / 2, op=mcomm.MAX) * 1e3
+            del Ft, fut
+        del ut
+        args.pipeline = min(tuning, key=tuning.get)
     if args.decomp == "slab":
         F = Slab_R2C(N, L, comm, args.precision, pipeline=args.pipeline)
     else:
@@ -240,7 +262,7 @@ def main():
         achieved = (col_bytes / (avg_ms * 1e-3)) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(n, args.precision, args.decomp, world)
         out = {
-            "metric": "3D R2C+C2R pairs/sec, %d^3 fp64 %s" % (n, args.decomp),
+            "metric": "3D R2C+C2R pairs/sec, %d^3 %s %s" % (n, "fp64" if args.precision == "double" else "fp32", args.decomp),
             "value": args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64" if args.precision == "double" else "f32",
@@ -248,6 +270,8 @@ def main():
             "config": {"workload": "%d^3 %s %s R2C forward+inverse, device-resident, %d rank(s)"
                                    % (n, "fp64" if args.precision == "double" else "fp32", args.decomp, world),
                        "roundtrip_rel_l2": rt_err,
+                       "exchange_pipeline_depth": args.pipeline if world > 1 else None,
+                       "exchange_pipeline_tuning_ms_per_pair": tuning,
                        "alg_bytes_per_pair": alg_pair,
                        "whole_path_hbm_GBs_per_gpu": alg_pair / world / (ms * 1e-3) / 1e9,
                        "whole_path_frac_of_8TBs": alg_pair / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
