@@ -1,0 +1,113 @@
+"""Randomised parity sweep (developer tool): random meshes / rank counts / decompositions / precisions / dealias
+modes against the oracle.  python scripts/fuzz_parity.py [ncases] [seed]"""
+import os, sys, time, traceback
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gpu_util import L, TOL, cdtype, rdtype, orc, run_ranks
+from mpifft4py_amd import Pencil_R2C, Slab_R2C
+from mpifft4py_amd.slab import C2C as Slab_C2C
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+NICE = [4, 6, 8, 10, 12, 16, 18, 20, 24, 32, 36, 40, 48, 50, 64, 72, 80, 96, 100, 128, 144, 160, 192, 200, 256]
+ODD = [14, 22, 26, 28, 30, 34, 42, 44, 52, 54, 56, 60, 66, 70, 84, 90, 98, 110, 126, 130, 150, 170, 210, 250]
+
+
+def pick(P, need_div, even_quot=False):
+    for _ in range(200):
+        n = int(rng.choice(NICE if rng.random() < 0.6 else ODD))
+        if n % need_div == 0 and n >= 2 * P and (not even_quot or (n // need_div) % 2 == 0):
+            return n
+    return 64 * need_div
+
+
+fails = 0
+t0 = time.time()
+for case in range(ncases):
+    kind = rng.choice(["slab", "slab", "pencilX", "pencilY", "slabc2c"])
+    prec = str(rng.choice(["double", "single"]))
+    dealias = rng.choice([None, None, "3/2-rule", "2/3-rule"])
+    if kind == "slab":
+        P = int(rng.choice([1, 1, 2, 4, 8]))
+        N = [pick(P, P), pick(P, P), pick(1, 2)]
+    elif kind == "slabc2c":
+        P = int(rng.choice([1, 2, 4]))
+        N = [pick(P, P), pick(P, P), pick(1, 1)]
+        if dealias == "2/3-rule":
+            dealias = None
+    else:
+        P = int(rng.choice([4, 8]))
+        P1, P2 = (2, 2) if P == 4 else (4, 2)
+        N = [pick(P, P1 * P2), pick(P, P1 * P2), pick(P, 2 * P1 * P2, True)]
+    if dealias == "3/2-rule":       # the reference needs padded extents divisible as well: use multiples of 4P
+        N = [n - n % (4 * P) or 4 * P for n in N]
+        if kind.startswith("pencil"):
+            N = [max(n - n % 16, 16) for n in N]
+    rt, ct = rdtype(prec), cdtype(prec)
+    tag = "%s N=%s P=%d %s dealias=%s" % (kind, N, P, prec, dealias)
+    try:
+        if kind == "slabc2c":
+            A = (rng.random(N) + 1j * rng.random(N)).astype(ct)
+            lay = orc.SlabLayout(N, P)
+        else:
+            A = rng.random(N).astype(rt)
+        if kind == "slab":
+            lay = orc.SlabLayout(N, P)
+            make = lambda comm: Slab_R2C(np.array(N), L, comm, prec)
+            fwd, bwd = orc.slab_r2c_forward, orc.slab_r2c_backward
+            fwdp, bwdp = orc.slab_r2c_forward_padded, orc.slab_r2c_backward_padded
+            extra = ()
+        elif kind == "slabc2c":
+            make = lambda comm: Slab_C2C(np.array(N), L, comm, prec)
+            fwd, bwd = orc.slab_c2c_forward, orc.slab_c2c_backward
+            fwdp, bwdp = orc.slab_c2c_forward_padded, orc.slab_c2c_backward_padded
+            extra = ()
+        else:
+            al = kind[-1]
+            lay = orc.PencilLayout(N, P, None, al)
+            make = lambda comm: Pencil_R2C(np.array(N), L, comm, prec, communication="Alltoallw", alignment=al)
+            fwd = lambda us, N_, p: orc.pencil_r2c_forward(us, N_, None, al, p)
+            bwd = lambda fs, N_, p: orc.pencil_r2c_backward(fs, N_, None, al, p)
+            fwdp = lambda us, N_, p: orc.pencil_r2c_forward_padded(us, N_, None, al, p)
+            bwdp = lambda fs, N_, p: orc.pencil_r2c_backward_padded(fs, N_, None, al, p)
+        us = orc.scatter_real(A, lay)
+        want_c = fwd(us, N, prec)
+        if dealias == "3/2-rule":
+            want_b = bwdp(want_c, N, prec)
+            want_c2 = fwdp(want_b, N, prec)
+        else:
+            want_b = bwd(want_c, N, prec)
+
+        def body(comm):
+            F = make(comm)
+            r = comm.Get_rank()
+            c = F.fftn(np.ascontiguousarray(us[r]), np.zeros(want_c[r].shape, dtype=ct))
+            if dealias == "3/2-rule":
+                b = F.ifftn(c, np.zeros(want_b[r].shape, dtype=want_b[r].dtype), "3/2-rule")
+                c2 = F.fftn(b, np.zeros(want_c[r].shape, dtype=ct), "3/2-rule")
+                return c, b, c2
+            if dealias == "2/3-rule":
+                b = F.ifftn(c, np.zeros(want_b[r].shape, dtype=want_b[r].dtype), "2/3-rule")
+                m = F.get_dealias_filter()
+                return c, b, m
+            b = F.ifftn(c, np.zeros(want_b[r].shape, dtype=want_b[r].dtype))
+            return c, b, None
+        res = run_ranks(P, body)
+        if dealias == "2/3-rule":
+            want_b = bwd([want_c[r] * res[r][2] for r in range(P)], N, prec)
+        worst = 0.0
+        for r, (c, b, x) in enumerate(res):
+            worst = max(worst, orc.rel_l2(c, want_c[r]), orc.rel_l2(b, want_b[r]))
+            if dealias == "3/2-rule":
+                worst = max(worst, orc.rel_l2(x, want_c2[r]))
+        ok = worst < 4 * TOL[prec]
+        print("%-70s %.2e %s" % (tag, worst, "ok" if ok else "FAIL"))
+        fails += 0 if ok else 1
+    except Exception as e:      # noqa: BLE001
+        fails += 1
+        print("%-70s EXCEPTION %s: %s" % (tag, type(e).__name__, str(e)[:300]))
+        traceback.print_exc(limit=3)
+print("fuzz: %d cases, %d failures, %.0f s" % (ncases, fails, time.time() - t0))
+sys.exit(1 if fails else 0)
