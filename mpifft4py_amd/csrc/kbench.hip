@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024 / E * COLS) void copy_tile(ColParams<double> P
 
 // persistent, register double-buffered variant of ColFft: the loads of the next
 // tile are in flight while the current tile is transformed and stored.
-template <class S, int COLS, bool SPLIT>
+template <class S, int COLS, bool SPLIT, bool LATE = false>
 __global__ __launch_bounds__(S::TPT * COLS) void col_persist(ColParams<double> P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef double T;
@@ -110,12 +110,15 @@ __global__ __launch_bounds__(S::TPT * COLS) void col_persist(ColParams<double> P
   }
   for (; t < ntiles; t += G) {
     const int tn = t + G;
-    if (tn < ntiles) {
-      const cx<T>* ip; cx<T>* op; bool act;
-      tile_ptrs(tn, ip, op, act);
+    auto prefetch = [&] {
+      if (tn < ntiles) {
+        const cx<T>* ip; cx<T>* op; bool act;
+        tile_ptrs(tn, ip, op, act);
 #pragma unroll
-      for (int k = 0; k < S::E; ++k) nxt[k] = act ? ip[row_off(P.in_map, (unsigned)(j + k * S::TPT))] : mk<T>(0, 0);
-    }
+        for (int k = 0; k < S::E; ++k) nxt[k] = act ? ip[row_off(P.in_map, (unsigned)(j + k * S::TPT))] : mk<T>(0, 0);
+      }
+    };
+    if constexpr (!LATE) prefetch();
     if constexpr (SPLIT) {
       XchSplit<T, Slot> xch{reinterpret_cast<T*>(lds), Slot{c}};
       run_passes<S, 0, T>(cur, j, P.tw, xch);
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(S::TPT * COLS) void col_persist(ColParams<double> P
       XchFull<T, Slot> xch{reinterpret_cast<cx<T>*>(lds), Slot{c}};
       run_passes<S, 0, T>(cur, j, P.tw, xch);
     }
+    if constexpr (LATE) prefetch();      // next tile's loads in flight while this tile's stores drain
     {
       const cx<T>* ip; cx<T>* op; bool act;
       tile_ptrs(t, ip, op, act);
@@ -156,21 +160,21 @@ void launch_k(const ColParams<double>& p, int grid) {
 }
 
 static int g_persist_grid = 256;
-template <class S, int COLS, bool SPLIT>
+template <class S, int COLS, bool SPLIT, bool LATE = false>
 void launch_persist(const ColParams<double>& p, int) {
   constexpr int LDS = S::N * COLS * (SPLIT ? 8 : 16);
   static bool attr = false;
   if (!attr) {
-    if (LDS > 65536) CK(hipFuncSetAttribute((const void*)col_persist<S, COLS, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    if (LDS > 65536) CK(hipFuncSetAttribute((const void*)col_persist<S, COLS, SPLIT, LATE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr = true;
   }
-  hipLaunchKernelGGL((col_persist<S, COLS, SPLIT>), dim3(g_persist_grid), dim3(S::TPT * COLS), LDS, 0, p);
+  hipLaunchKernelGGL((col_persist<S, COLS, SPLIT, LATE>), dim3(g_persist_grid), dim3(S::TPT * COLS), LDS, 0, p);
 }
-template <class S, int COLS, bool SPLIT>
+template <class S, int COLS, bool SPLIT, bool LATE = false>
 Variant make_persist(const char* plan) {
   char nm[128];
-  snprintf(nm, sizeof nm, "persist %s c%d%s", plan, COLS, SPLIT ? " split" : "");
-  return Variant{nm, COLS, S::TPT * COLS, S::N * COLS * (SPLIT ? 8 : 16), &launch_persist<S, COLS, SPLIT>, &build_pass_twiddles<S, double>};
+  snprintf(nm, sizeof nm, "persist%s %s c%d%s", LATE ? "-late" : "", plan, COLS, SPLIT ? " split" : "");
+  return Variant{nm, COLS, S::TPT * COLS, S::N * COLS * (SPLIT ? 8 : 16), &launch_persist<S, COLS, SPLIT, LATE>, &build_pass_twiddles<S, double>};
 }
 template <int COLS, int E>
 void launch_copy_tile(const ColParams<double>& p, int grid) {
@@ -212,6 +216,8 @@ int main(int argc, char** argv) {
       make_copy_nt<8, 16, 0>(), make_copy_nt<8, 16, 1>(), make_copy_nt<8, 16, 2>(), make_copy_nt<8, 16, 3>(),
       make_persist<SA, 8, false>("16x8x8"), make_persist<SA, 8, true>("16x8x8"), make_persist<SD, 8, true>("8x8x4x4"),
       make_persist<SB, 8, false>("32x32"),
+      make_persist<SA, 8, false, true>("16x8x8"), make_persist<SA, 8, true, true>("16x8x8"), make_persist<SB, 8, false, true>("32x32"),
+      make_persist<SD, 8, true, true>("8x8x4x4"),
       make<SA, 4, false, false>("16x8x8"),  make<SA, 4, true, false>("16x8x8"),   make<SA, 4, false, true>("16x8x8"),
       make<SA, 4, true, true>("16x8x8"),    make<SA, 8, false, false>("16x8x8"),  make<SA, 8, true, false>("16x8x8"),
       make<SA, 8, false, true>("16x8x8"),   make<SA, 8, true, true>("16x8x8"),    make<SA, 2, true, false>("16x8x8"),
