@@ -755,3 +755,31 @@ def test_slab_padded_arbitrary_lengths(N, P):
     for r, (up, fu) in enumerate(run_ranks(P, body)):
         assert orc.rel_l2(up, want_up[r]) < 1e-10
         assert orc.rel_l2(fu, want_fu[r]) < 1e-10
+
+
+@pytest.mark.parametrize("N,P", [([1, 8, 8], 1), ([8, 1, 8], 1), ([1, 1, 8], 1), ([2, 1, 4], 1), ([1, 16, 2], 1),
+                                 ([4, 4, 2], 2), ([1, 1, 2], 1)])
+def test_meshes_with_unit_axes(N, P):
+    """Length-1 axes (a transform of length 1 is a copy) and the shortest real axis."""
+    from mpifft4py_amd import Slab_R2C
+    A = np.random.default_rng(1).random(N)
+    B = np.fft.rfftn(A)
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, "double")
+        c = F.fftn(np.ascontiguousarray(A[F.real_local_slice()]), np.zeros(F.complex_shape(), dtype=complex))
+        b = F.ifftn(c, np.zeros(F.real_shape()))
+        return F.complex_local_slice(), c, F.real_local_slice(), b
+    for cs, c, rs, b in run_ranks(P, body):
+        assert orc.rel_l2(c, B[cs]) < 1e-12 and orc.rel_l2(b, A[rs]) < 1e-12
+
+
+@pytest.mark.parametrize("N", [[1, 8, 5], [8, 1, 3], [1, 1, 7], [3, 1, 1]])
+def test_c2c_meshes_with_unit_axes(N):
+    from mpifft4py_amd import SelfComm
+    from mpifft4py_amd.slab import C2C
+    A = np.random.default_rng(2).random(N) + 1j * np.random.default_rng(3).random(N)
+    F = C2C(np.array(N), L, SelfComm(0), "double")
+    c = F.fftn(A.copy(), np.zeros(F.transformed_shape(), dtype=complex))
+    b = F.ifftn(c, np.zeros(F.original_shape(), dtype=complex))
+    assert orc.rel_l2(c, np.fft.fftn(A)) < 1e-12 and orc.rel_l2(b, A) < 1e-12
