@@ -81,7 +81,7 @@ def test_process_per_rank_parity(world):
     assert "MP_OK world=%d" % world in out
 
 
-@pytest.mark.parametrize("world,launcher", [(2, "torchrun"), (4, "spawn")])
+@pytest.mark.parametrize("world,launcher", [(2, "torchrun"), (4, "spawn"), (8, "spawn")])
 def test_bench_multi_rank_prints_one_json_line(world, launcher):
     run = _torchrun if launcher == "torchrun" else _spawn
     rc, out, err = run(world, [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "128",
