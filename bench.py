@@ -213,41 +213,7 @@ def main():
     b0 = u2.leading(0, k).get()
     rt_err = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
 
-    # ---- secondary measurement: the pencil path on the same cube (needs a P1 x P2 grid with
-    # even factors, i.e. 4 or 8 ranks, or the degenerate 1 x 1 grid as the 1-GPU denominator)
-    extras = {}
-    want_pencil = args.pencil_extra == "on" or (args.pencil_extra == "auto" and args.decomp == "slab"
-                                                 and world in (1, 4, 8, 16))
-    if want_pencil:
-        try:
-            del F
-            Fp = Pencil_R2C(N, L, comm, args.precision, communication="Alltoallw", alignment="X", allow_single=True)
-            up = DeviceArray.random(Fp.real_shape(), Fp.float, seed=99 + rank)
-            fup = DeviceArray.empty(Fp.complex_shape(), Fp.complex)
-            up2 = DeviceArray.empty(Fp.real_shape(), Fp.float)
-            for _ in range(2):
-                Fp.fftn(up, fup)
-                Fp.ifftn(fup, up2)
-            Fp.sync()
-            comm.barrier()
-            ksteps = max(3, min(args.steps, 10))
-            tp = time.perf_counter()
-            for _ in range(ksteps):
-                Fp.fftn(up, fup)
-                Fp.ifftn(fup, up2)
-            Fp.sync()
-            comm.barrier()
-            dtp = time.perf_counter() - tp
-            dtp = comm.allreduce(dtp, op=mcomm.MAX) if world > 1 else dtp
-            a0 = up.leading(0, 1).get()
-            b0 = up2.leading(0, 1).get()
-            extras["pencil_R2CX"] = {"grid": [int(Fp.P1), int(Fp.P2)], "pairs_per_s": ksteps / dtp,
-                                     "ms_per_pair": 1e3 * dtp / ksteps, "steps": ksteps,
-                                     "roundtrip_rel_l2": float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))}
-        except Exception as e:      # noqa: BLE001  - the headline (slab) line must survive
-            extras["pencil_R2CX"] = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    if rank == 0:
+    def headline():
         esz = 8 if args.precision == "double" else 4
         R = esz * n ** 3
         C = 2 * esz * n * n * (n // 2 + 1)
@@ -281,6 +247,64 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": col_bytes, "avg_launch_ms": avg_ms},
         }
+        return out
+
+    out = headline() if rank == 0 else None
+
+    # ---- secondary measurement: the pencil path on the same cube (needs a P1 x P2 grid with
+    # even factors, i.e. 4 or 8 ranks, or the degenerate 1 x 1 grid as the 1-GPU denominator)
+    extras = {}
+    want_pencil = args.pencil_extra == "on" or (args.pencil_extra == "auto" and args.decomp == "slab"
+                                                 and world in (1, 4, 8, 16))
+    watchdog = None
+    if want_pencil and world > 1:
+        # The headline number must survive whatever happens in this secondary measurement: if it has not finished
+        # after 5 minutes (e.g. a transport problem that only shows up in the sub-group exchanges), rank 0 prints
+        # the line without it and every rank leaves.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["extras"] = {"pencil_R2CX": {"error": "timed out after 300 s"}}
+                out["cpu_baseline"] = None
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+        watchdog = threading.Timer(300.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    if want_pencil:
+        try:
+            del F
+            Fp = Pencil_R2C(N, L, comm, args.precision, communication="Alltoallw", alignment="X", allow_single=True)
+            up = DeviceArray.random(Fp.real_shape(), Fp.float, seed=99 + rank)
+            fup = DeviceArray.empty(Fp.complex_shape(), Fp.complex)
+            up2 = DeviceArray.empty(Fp.real_shape(), Fp.float)
+            for _ in range(2):
+                Fp.fftn(up, fup)
+                Fp.ifftn(fup, up2)
+            Fp.sync()
+            comm.barrier()
+            ksteps = max(3, min(args.steps, 10))
+            tp = time.perf_counter()
+            for _ in range(ksteps):
+                Fp.fftn(up, fup)
+                Fp.ifftn(fup, up2)
+            Fp.sync()
+            comm.barrier()
+            dtp = time.perf_counter() - tp
+            dtp = comm.allreduce(dtp, op=mcomm.MAX) if world > 1 else dtp
+            a0 = up.leading(0, 1).get()
+            b0 = up2.leading(0, 1).get()
+            extras["pencil_R2CX"] = {"grid": [int(Fp.P1), int(Fp.P2)], "pairs_per_s": ksteps / dtp,
+                                     "ms_per_pair": 1e3 * dtp / ksteps, "steps": ksteps,
+                                     "roundtrip_rel_l2": float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))}
+        except Exception as e:      # noqa: BLE001  - the headline (slab) line must survive
+            extras["pencil_R2CX"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if watchdog is not None:
+        watchdog.cancel()
+
+    if rank == 0:
         out["extras"] = extras
         if world == 1 and args.cpu_baseline == "auto":
             out["cpu_baseline"] = cpu_baseline(n)
