@@ -850,8 +850,6 @@ int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
   if (can_fuse_pad()) return pencil_backward_padded_fused(fu, u);
   const double sc3 = padscale();
   const bool X = d.decomp == MFFT_PENCIL_X;
-  const std::vector<int>& gz = X ? group1 : group0;
-  const int Pz = (int)gz.size();
   const int64_t mp = M0 / P1, np = M1 / P2;          // padded local real rows in x, y
   const size_t wb = (size_t)std::max(std::max(M0 * N1_1 * q, mp * M1 * q), std::max(std::max(N2_0 * M1 * q, M0 * np * q), mp * np * Mf)) * es;
   for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
@@ -885,15 +883,6 @@ int mfft_plan_s::pencil_backward_padded(const void* fu, void* u) {
     MFFT_TRY(stage("bwd_x", 0, [&] { return col(W1, W1, M0, true, 1, np * q, 0, plain(np * q), 0, plain(np * q)); }));
   }
   // W1 holds Pz blocks (mp, np, q) (X: y chunks; Y: contiguous x chunks)
-  std::vector<size_t> sc(Pz), sd(Pz), rc(Pz), rd(Pz);
-  size_t off = 0;
-  for (int l = 0; l < Pz; ++l) {
-    sc[l] = (size_t)(mp * np * q) * es;
-    sd[l] = (size_t)l * sc[l];
-    rc[l] = (size_t)(mp * np * zc[l].len) * es;
-    rd[l] = off;
-    off += rc[l];
-  }
   MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, true, W1, W0); }));
   // unpack z into the zero-padded (mp*np, Mf) rows
   MFFT_TRY(stage("bwd_unpackz", 0, [&] {
@@ -910,8 +899,6 @@ int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
   if (can_fuse_pad()) return pencil_forward_padded_fused(u, fu);
   const double isc3 = 1.0 / padscale();
   const bool X = d.decomp == MFFT_PENCIL_X;
-  const std::vector<int>& gz = X ? group1 : group0;
-  const int Pz = (int)gz.size();
   const int64_t mp = M0 / P1, np = M1 / P2;
   const size_t wb = (size_t)std::max(std::max(M0 * N1_1 * q, mp * M1 * q), std::max(std::max(N2_0 * M1 * q, M0 * np * q), mp * np * Mf)) * es;
   for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
@@ -921,15 +908,6 @@ int mfft_plan_s::pencil_forward_padded(const void* u, void* fu) {
     MFFT_TRY(stage("fwd_nyq", 0, [&] { return launch_line_nyquist(W0, mp * np, Mf, Nf - 1, prec, stream); }));
   // only the first Nf modes travel (truncation in z); pack z chunks
   MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, mp * np, Mf, zc, false); }));
-  std::vector<size_t> sc(Pz), sd(Pz), rc(Pz), rd(Pz);
-  size_t off = 0;
-  for (int l = 0; l < Pz; ++l) {
-    sc[l] = (size_t)(mp * np * zc[l].len) * es;
-    sd[l] = off;
-    off += sc[l];
-    rc[l] = (size_t)(mp * np * q) * es;
-    rd[l] = (size_t)l * rc[l];
-  }
   MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, true, W1, W0); }));
   if (X) {
     // W0 = P2 blocks (mp, np, q): fft y over M1 = P2*np (gather), out (mp, M1, q)
