@@ -18,7 +18,7 @@ Two P > 1 behaviours of the reference are handled explicitly:
 import numpy as np
 from numpy.fft import fftfreq, rfftfreq
 
-from . import _lib
+from . import _lib, _padding
 from ._base import DistFFTBase, default_planner_effort
 from .comm import as_comm
 from .mpibase import datatypes, work_arrays
@@ -101,6 +101,18 @@ class R2C(DistFFTBase):
 
     def work_shape(self, dealias):
         return self.real_shape_padded() if dealias == '3/2-rule' else self.real_shape()
+
+    # host-side numpy helpers of the reference's API (line.py:164-175)
+    def copy_to_padded_x(self, fu, fp):
+        return _padding.spread(fu, fp, self.N[0], 0)
+
+    def copy_to_padded_y(self, fu, fp):
+        fp[:, :self.Nf] = fu
+        return fp
+
+    def copy_from_padded_y(self, fp, fu):
+        fu[:] = fp[:, :self.Nf]
+        return fu
 
     # -- host-side mesh helpers (line.py:105-134) -------------------------------------
     def get_local_mesh(self):

@@ -9,7 +9,7 @@ world ranks, comm1 = P2 ranks of stride P1 (pencil.py:192-195).
 import numpy as np
 from numpy.fft import fftfreq, rfftfreq
 
-from . import _lib
+from . import _lib, _padding
 from ._base import DistFFTBase, default_planner_effort
 from .comm import SubComm
 
@@ -113,6 +113,29 @@ class R2CY(DistFFTBase):
 
     def get_P(self):
         return self.P1, self.P2
+
+    # host-side numpy helpers of the reference's API (pencil.py:351-379); the device path fuses these copies
+    def copy_to_padded_x(self, fu, fp):
+        return _padding.spread(fu, fp, self.N[0], 0)
+
+    def copy_to_padded_y(self, fu, fp):
+        return _padding.spread(fu, fp, self.N[1], 1)
+
+    def copy_to_padded_z(self, fu, fp):
+        fp[:, :, :self.Nf] = fu
+        return fp
+
+    def copy_from_padded_z(self, fp, fu):
+        fu[:] = fp[:, :, :self.Nf]
+        return fu
+
+    def copy_from_padded_x(self, fp, fu):
+        fu.fill(0)
+        return _padding.gather_fold(fp, fu, self.N[0], 0)
+
+    def copy_from_padded_y(self, fp, fu):
+        fu.fill(0)
+        return _padding.gather_fold(fp, fu, self.N[1], 1)
 
     # -- host-side mesh helpers (pencil.py:289-349) ----------------------------------
     def complex_local_wavenumbers(self):

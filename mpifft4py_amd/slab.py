@@ -9,7 +9,7 @@ methods, mesh helpers and exception types.
 import numpy as np
 from numpy.fft import fftfreq, rfftfreq
 
-from . import _lib
+from . import _lib, _padding
 from ._base import DistFFTBase, default_planner_effort
 
 __all__ = ["R2C", "C2C"]
@@ -82,6 +82,16 @@ class R2C(DistFFTBase):
 
     def complex_shape_padded_3(self):
         return (int(self.padsize * self.Np[0]), int(self.padsize * self.N[1]), self.Nfp)
+
+    def complex_shape_padded_0_I(self):
+        return (self.num_processes, int(self.padsize * self.Np[0]), int(self.Np[1]), self.Nf)
+
+    def complex_shape_padded_I(self):
+        return (int(self.padsize * self.Np[0]), self.num_processes, int(self.Np[1]), self.Nf)
+
+    # host-side numpy helpers of the reference's API (slab.py:516-536); the device path fuses these copies
+    copy_to_padded = staticmethod(_padding.r2c_copy_to_padded)
+    copy_from_padded = staticmethod(_padding.r2c_copy_from_padded)
 
     def real_local_slice(self, padsize=1):
         return (slice(int(padsize * self.rank * self.Np[0]), int(padsize * (self.rank + 1) * self.Np[0]), 1),
@@ -162,6 +172,9 @@ class C2C(R2C):
                  planner_effort=None, pipeline=0):
         R2C.__init__(self, N, L, comm, precision, communication=communication, padsize=padsize,
                      threads=threads, planner_effort=planner_effort, pipeline=pipeline)
+
+    copy_to_padded = staticmethod(_padding.c2c_copy_to_padded)        # slab.py:803-825
+    copy_from_padded = staticmethod(_padding.c2c_copy_from_padded)
 
     def _post_init(self):
         N = self.N

@@ -1,0 +1,70 @@
+"""Host-side numpy helpers the classes carry for API parity with the reference (copy_to_padded / copy_from_padded
+families: slab.py:516-536, 803-825; pencil.py:351-379; line.py:164-175) against the oracle's pad / truncate."""
+import types
+
+import numpy as np
+import pytest
+
+from mpifft4py_amd import _padding
+from mpifft4py_amd.line import R2C as LineR2C
+from mpifft4py_amd.pencil import R2CX, R2CY
+from mpifft4py_amd.slab import C2C, R2C
+from oracle import mpifft_oracle as orc
+
+N = np.array([8, 12, 16])
+M = (N * 3) // 2
+rng = np.random.default_rng(3)
+
+
+def cplx(shape):
+    return rng.random(shape) + 1j * rng.random(shape)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_slab_r2c_copy_to_padded(axis):
+    fu = cplx((8, 12, 9))
+    shp = [8, 12, 9]
+    shp[axis] = int(M[axis]) if axis < 2 else int(M[2]) // 2 + 1
+    fp = R2C.copy_to_padded(fu, np.zeros(shp, dtype=complex), N, axis)
+    want = orc.pad_axis(fu, shp[axis], int(N[axis]), axis) if axis < 2 else orc.pad_z(fu, shp[2])
+    assert np.array_equal(fp, want)
+
+
+def test_slab_r2c_copy_from_padded():
+    fp = cplx((8, 18, 13))
+    fu = R2C.copy_from_padded(fp, np.ones((8, 12, 9), dtype=complex), N, 1)
+    assert np.allclose(fu, orc.trunc_axis(fp[:, :, :9], 12, 1), atol=0)
+    fz = R2C.copy_from_padded(fp, np.zeros((8, 18, 9), dtype=complex), N, 2)
+    assert np.array_equal(fz, fp[:, :, :9])
+
+
+def test_slab_c2c_helpers():
+    fu = cplx((8, 12, 16))
+    for axis in (0, 1, 2):
+        shp = [8, 12, 16]
+        shp[axis] = int(M[axis])
+        assert np.array_equal(C2C.copy_to_padded(fu, np.zeros(shp, dtype=complex), N, axis),
+                              orc.pad_axis(fu, shp[axis], int(N[axis]), axis))
+    fp = cplx((8, 18, 24))
+    got = C2C.copy_from_padded(fp, np.ones((8, 12, 16), dtype=complex), N, 1)
+    assert np.allclose(got, orc.trunc_axis(orc.trunc_axis(fp, 16, 2), 12, 1), atol=1e-15)
+
+
+def test_pencil_and_line_helpers():
+    me = types.SimpleNamespace(N=N, Nf=9)
+    fu = cplx((8, 12, 9))
+    assert np.array_equal(R2CY.copy_to_padded_x(me, fu, np.zeros((12, 12, 9), dtype=complex)), orc.pad_axis(fu, 12, 8, 0))
+    assert np.array_equal(R2CX.copy_to_padded_y(me, fu, np.zeros((8, 18, 9), dtype=complex)), orc.pad_axis(fu, 18, 12, 1))
+    assert np.array_equal(R2CY.copy_to_padded_z(me, fu, np.zeros((8, 12, 13), dtype=complex)), orc.pad_z(fu, 13))
+    fp = cplx((12, 18, 13))
+    assert np.allclose(R2CY.copy_from_padded_x(me, fp[:, :12, :9], np.ones((8, 12, 9), dtype=complex)),
+                       orc.trunc_axis(fp[:, :12, :9], 8, 0), atol=0)
+    assert np.allclose(R2CY.copy_from_padded_y(me, fp[:8, :, :9], np.ones((8, 12, 9), dtype=complex)),
+                       orc.trunc_axis(fp[:8, :, :9], 12, 1), atol=0)
+    assert np.array_equal(R2CY.copy_from_padded_z(me, fp[:8, :12], np.zeros((8, 12, 9), dtype=complex)), fp[:8, :12, :9])
+    line = types.SimpleNamespace(N=np.array([8, 16]), Nf=9)
+    f2 = cplx((8, 9))
+    assert np.array_equal(LineR2C.copy_to_padded_x(line, f2, np.zeros((12, 9), dtype=complex)), orc.pad_axis(f2, 12, 8, 0))
+    assert np.array_equal(LineR2C.copy_to_padded_y(line, f2, np.zeros((8, 13), dtype=complex))[:, :9], f2)
+    assert np.array_equal(LineR2C.copy_from_padded_y(line, cplx((8, 13)), np.zeros((8, 9), dtype=complex)).shape, (8, 9))
+    assert _padding.spread is not None
