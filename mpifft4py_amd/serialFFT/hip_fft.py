@@ -6,8 +6,8 @@ backends (mpiFFT4py/serialFFT/numpy_fft.py:25-107, pyfftw_fft.py:26-203):
 `a`/`b` may be numpy arrays (copied to/from HBM) or DeviceArrays of up to three
 dimensions.  Multi-axis transforms are chains of the single-axis kernels.
 `threads`, `planner_effort` and `overwrite_input` are accepted and ignored
-(`a` is never modified).  `dct` of the reference is not provided: no file of the
-reference uses it.
+(`a` is never modified).  `dct` (numpy_fft.py:11-22; no file of the reference calls it) is provided
+for types 2 and 3 through one complex transform of the same length on the device.
 """
 import ctypes
 
@@ -16,7 +16,7 @@ import numpy as np
 from .. import _lib
 from ..device import DeviceArray, is_device_array
 
-__all__ = ['fft', 'ifft', 'fft2', 'ifft2', 'fftn', 'ifftn',
+__all__ = ['dct', 'fft', 'ifft', 'fft2', 'ifft2', 'fftn', 'ifftn',
            'rfft', 'irfft', 'rfft2', 'irfft2', 'rfftn', 'irfftn']
 
 
@@ -160,3 +160,45 @@ def rfftn(a, b=None, axes=(0, 1, 2), overwrite_input=False, threads=1, **kw):
 
 def irfftn(a, b=None, axes=(0, 1, 2), overwrite_input=False, threads=1, **kw):
     return _irfft_axes(a, b, axes)
+
+
+def _dct_real(x, type, axis):
+    """scipy.fftpack.dct(x, type, axis) (unnormalised) of a real host array, type 2 or 3, through one complex
+    transform of the same length on the device (even/odd reordering + a quarter-wave twiddle)."""
+    x = np.moveaxis(np.asarray(x), axis, 0)
+    n = x.shape[0]
+    h = (n + 1) // 2
+    k = np.arange(n).reshape((n,) + (1,) * (x.ndim - 1))
+    ct = np.complex64 if x.dtype == np.float32 else np.complex128
+    if type == 2:
+        v = np.empty(x.shape, dtype=ct)
+        v[:h] = x[0::2]
+        v[h:] = x[1::2][::-1]
+        V = fft(v, axis=0)
+        y = 2 * np.real(V * np.exp(-1j * np.pi * k / (2 * n)))
+    elif type == 3:
+        xr = np.zeros_like(x)
+        xr[1:] = x[1:][::-1]
+        V = ((x - 1j * xr) * np.exp(1j * np.pi * k / (2 * n))).astype(ct)
+        v = np.real(ifft(V, axis=0)) * n
+        y = np.empty(x.shape, dtype=x.dtype)
+        y[0::2] = v[:h]
+        y[1::2] = v[h:][::-1]
+    else:
+        raise NotImplementedError("dct type %r: types 2 and 3 are provided" % (type,))
+    return np.moveaxis(y.astype(x.dtype, copy=False), 0, axis)
+
+
+def dct(a, b=None, type=2, axis=0, **kw):
+    """numpy_fft.py:14-22: real and imaginary parts are transformed separately."""
+    a = a.get() if is_device_array(a) else np.asarray(a)
+    if a.ndim > 3:
+        raise ValueError("at most 3-D arrays are supported")
+    if np.iscomplexobj(a):
+        res = _dct_real(a.real, type, axis) + 1j * _dct_real(a.imag, type, axis)
+    else:
+        res = _dct_real(a, type, axis)
+    if b is None:
+        return res
+    b[...] = res
+    return b

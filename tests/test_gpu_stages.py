@@ -219,3 +219,23 @@ def test_unpack_and_mask_vs_reference_compiled_loops():
         dm = DeviceArray.from_numpy(mask)
         _lib.call("mfft_dealias_filter", d.ptr, dm.ptr, fu.size, _lib.precision_code(prec))
         assert np.array_equal(d.get(), want)
+
+
+@pytest.mark.parametrize("n", [8, 7, 64, 100, 129])
+@pytest.mark.parametrize("type_", [2, 3])
+def test_dct(n, type_):
+    """serialFFT.dct (numpy_fft.py:11-22): scipy.fftpack convention, real and complex input."""
+    from scipy.fftpack import dct as sdct
+    from mpifft4py_amd import dct
+    rng = np.random.default_rng(n)
+    for axis in (0, 1):
+        shape = [5, 6]
+        shape[axis] = n
+        a = rng.random(shape)
+        assert orc.rel_l2(dct(a, type=type_, axis=axis), sdct(a, type=type_, axis=axis)) < 1e-12
+        c = a + 1j * rng.random(shape)
+        b = np.zeros(shape, dtype=complex)
+        assert dct(c, b, type=type_, axis=axis) is b
+        assert orc.rel_l2(b, sdct(c.real, type=type_, axis=axis) + 1j * sdct(c.imag, type=type_, axis=axis)) < 1e-12
+    with pytest.raises(NotImplementedError):
+        dct(np.zeros(8), type=1)
