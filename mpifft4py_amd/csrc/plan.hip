@@ -685,7 +685,8 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
   const bool X = d.decomp == MFFT_PENCIL_X;
   // a group of one rank exchanges nothing: its pack / copy steps are skipped altogether
   const bool zsolo = (X ? P2 : P1) == 1 && !d.drop_nyquist, g2solo = (X ? P1 : P2) == 1;
-  const size_t wb = (size_t)std::max(m * n * Nf, std::max(m * N1 * q, N0 * n * q)) * es;
+  // largest intermediate of this alignment: X: (m, N1, q) after the z exchange; Y: (N0, n, q) after it
+  const size_t wb = (size_t)std::max(m * n * Nf, X ? m * N1 * q : N0 * n * q) * es;
   MFFT_TRY(ensure_work(0, wb));
   MFFT_TRY(ensure_work(1, wb));
   void *W0 = work[0], *W1 = work[1];
@@ -728,7 +729,8 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &mm); }));
     src = mm;
   }
-  const size_t wb = (size_t)std::max(m * n * Nf, std::max(m * N1 * q, N0 * n * q)) * es;
+  // largest intermediate of this alignment: X: (m, N1, q) after the z exchange; Y: (N0, n, q) after it
+  const size_t wb = (size_t)std::max(m * n * Nf, X ? m * N1 * q : N0 * n * q) * es;
   MFFT_TRY(ensure_work(0, wb));
   MFFT_TRY(ensure_work(1, wb));
   void *W0 = work[0], *W1 = work[1];

@@ -20,3 +20,20 @@ def test_random_configurations_match_the_oracle(seed):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0 and "60 cases, 0 failures" in out, out[-3000:]
+
+
+def test_config5_full_size_pencil_c2c():
+    """BASELINE config 5 at its full size, 2048^3 complex64 pencil C2C over 8 ranks (all on this GPU, 275 GB of HBM):
+    Parseval through device-side reductions and the round trip on sampled planes (scripts/config5_full.py).  Falls
+    back to 1024^3 when less than 290 GB of HBM is free."""
+    import ctypes
+    if not have_gpu():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+    n = 2048 if free.value > 290e9 else 1024
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "config5_full.py"), str(n), "8"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "CONFIG5_OK" in out, out[-3000:]
