@@ -1059,7 +1059,11 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
     p->use_graphs = p->P == 1 && e && atoi(e) != 0;
   }
   if (p->nslice > 1) {
-    MFFT_HIP(hipStreamCreateWithFlags(&p->cstream, hipStreamNonBlocking));
+    // The exchange runs on its own stream at the highest priority the device offers: its (RCCL) kernels have to get
+    // onto CUs that the transform kernels of the compute stream would otherwise keep filling block after block.
+    int prio_least = 0, prio_greatest = 0;
+    MFFT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    MFFT_HIP(hipStreamCreateWithPriority(&p->cstream, hipStreamNonBlocking, prio_greatest));
     p->ev_compute.resize(p->nslice);
     p->ev_comm.resize(p->nslice);
     for (int s = 0; s < p->nslice; ++s) {
