@@ -14,6 +14,8 @@ Two P > 1 behaviours of the reference are handled explicitly:
     buffer, which is zero-filled when fetched the second time (line.py:264-266, 297;
     mpibase.py:90-93), so the reference returns zeros.  NOT reproduced: the masked transform is
     returned, as on one rank.
+On one rank the reference indexes the padded rows with (fftfreq(n) * n).astype(int) (line.py:61), which
+truncates e.g. 4.999999999999999 to 4 for n = 24, 28, 36, 48, ...; exact indices are used here.
 """
 import numpy as np
 from numpy.fft import fftfreq, rfftfreq
@@ -50,7 +52,7 @@ class R2C(DistFFTBase):
         self.Nf = int(self.N[1] // 2 + 1)
         self.Npf = int(self.Np[1] // 2 + 1) if self.rank + 1 == P else int(self.Np[1] // 2)
         self.Nfp = int(padsize * self.N[1] / 2 + 1)
-        self.ks = (fftfreq(int(self.N[0])) * self.N[0]).astype(int)
+        self.ks = np.rint(fftfreq(int(self.N[0])) * self.N[0]).astype(int)
         N2 = self.N
         self.N = np.array([1, int(N2[0]), int(N2[1])])        # the 3-D mesh the plan sees
         try:

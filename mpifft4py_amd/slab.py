@@ -185,7 +185,7 @@ class C2C(R2C):
         self.transformed_shape = self.complex_shape
         self.original_local_slice = self.real_local_slice
         self.transformed_local_slice = self.complex_local_slice
-        self.ks = (fftfreq(N[2]) * N[2]).astype(int)
+        self.ks = np.rint(fftfreq(N[2]) * N[2]).astype(int)      # exact (the reference truncates: see oracle._exact_ks)
 
     def global_shape(self, padsize=1.):
         return (int(padsize * self.N[0]), int(padsize * self.N[1]), int(padsize * self.N[2]))

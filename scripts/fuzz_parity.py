@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from gpu_util import L, TOL, cdtype, rdtype, orc, run_ranks
-from mpifft4py_amd import Pencil_R2C, Slab_R2C
+from mpifft4py_amd import Line_R2C, Pencil_C2C, Pencil_R2C, Slab_R2C
 from mpifft4py_amd.slab import C2C as Slab_C2C
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
@@ -23,10 +23,77 @@ def pick(P, need_div, even_quot=False):
     return 64 * need_div
 
 
+def line_case(prec, dealias):
+    """2-D class: forward / inverse (plain, 2/3-rule) and the 3/2-rule pair against the oracle's restatement of line.py."""
+    P = int(rng.choice([1, 2, 4]))
+    N = [pick(P, P), pick(P, 2 * P, True)]
+    if dealias == "3/2-rule":
+        N = [max(n - n % (4 * P), 4 * P) for n in N]
+    rt, ct = rdtype(prec), cdtype(prec)
+    L2 = np.array([2 * np.pi, 3 * np.pi])
+    lay = orc.LineLayout(N, P)
+    A = rng.random(N).astype(rt)
+    us = [np.ascontiguousarray(A[lay.real_slice(r)]) for r in range(P)]
+    want_c = orc.line_r2c_forward(us, N, prec)
+    if dealias == "3/2-rule":
+        want_b = orc.line_r2c_backward_padded(want_c, N, prec)
+        want_c2 = orc.line_r2c_forward_padded(want_b, N, prec)
+    elif dealias == "2/3-rule":
+        want_b = orc.line_r2c_backward([c * orc.line_dealias_mask(N, L2, lay, r) for r, c in enumerate(want_c)], N, prec)
+    else:
+        want_b = orc.line_r2c_backward(want_c, N, prec)
+
+    def body(comm):
+        F = Line_R2C(np.array(N), L2, comm, prec)
+        r = comm.Get_rank()
+        c = F.fft2(us[r], np.zeros(want_c[r].shape, dtype=ct))
+        b = F.ifft2(c, np.zeros(want_b[r].shape, dtype=rt), dealias)
+        c2 = F.fft2(b, np.zeros(want_c[r].shape, dtype=ct), "3/2-rule") if dealias == "3/2-rule" else None
+        return c, b, c2
+    worst = 0.0
+    for r, (c, b, c2) in enumerate(run_ranks(P, body)):
+        worst = max(worst, orc.rel_l2(c, want_c[r]), orc.rel_l2(b, want_b[r]))
+        if c2 is not None:
+            worst = max(worst, orc.rel_l2(c2, want_c2[r]))
+    return "line N=%s P=%d %s dealias=%s" % (N, P, prec, dealias), worst
+
+
+def pencil_c2c_case(prec):
+    P = int(rng.choice([4, 8]))
+    P1P2 = 4 if P == 4 else 8
+    N = [pick(P, P1P2), pick(P, P1P2), pick(P, P1P2)]
+    al = str(rng.choice(["X", "Y"]))
+    ct = cdtype(prec)
+    A = (rng.random(N) + 1j * rng.random(N)).astype(ct)
+    B = np.fft.fftn(A.astype(np.complex128))
+
+    def body(comm):
+        F = Pencil_C2C(np.array(N), L, comm, prec, alignment=al)
+        a = np.ascontiguousarray(A[F.original_local_slice()])
+        c = F.fftn(a, np.zeros(F.transformed_shape(), dtype=ct))
+        b = F.ifftn(c, np.zeros(F.original_shape(), dtype=ct))
+        return orc.rel_l2(c, B[F.transformed_local_slice()]), orc.rel_l2(b, a)
+    worst = max(max(r) for r in run_ranks(P, body))
+    return "pencilc2c%s N=%s P=%d %s" % (al, N, P, prec), worst
+
+
 fails = 0
 t0 = time.time()
 for case in range(ncases):
-    kind = rng.choice(["slab", "slab", "pencilX", "pencilY", "slabc2c"])
+    kind = rng.choice(["slab", "slab", "pencilX", "pencilY", "slabc2c", "line", "pencilc2c"])
+    if kind in ("line", "pencilc2c"):
+        prec = str(rng.choice(["double", "single"]))
+        dealias = rng.choice([None, "3/2-rule", "2/3-rule"])
+        try:
+            tag, worst = line_case(prec, dealias) if kind == "line" else pencil_c2c_case(prec)
+            ok = worst < 4 * TOL[prec]
+            print("%-70s %.2e %s" % (tag, worst, "ok" if ok else "FAIL"))
+            fails += 0 if ok else 1
+        except Exception as e:      # noqa: BLE001
+            fails += 1
+            print("%-70s EXCEPTION %s: %s" % (kind, type(e).__name__, str(e)[:300]))
+            traceback.print_exc(limit=3)
+        continue
     prec = str(rng.choice(["double", "single"]))
     dealias = rng.choice([None, None, "3/2-rule", "2/3-rule"])
     if kind == "slab":
