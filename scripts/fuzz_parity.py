@@ -58,6 +58,31 @@ def line_case(prec, dealias):
     return "line N=%s P=%d %s dealias=%s" % (N, P, prec, dealias), worst
 
 
+def pencil_n_case(prec):
+    """communication='AlltoallN' (pencil.py:410-432): the z-Nyquist column is neither exchanged nor returned."""
+    P = int(rng.choice([4, 8]))
+    P1P2 = 4 if P == 4 else 8
+    N = [pick(P, P1P2), pick(P, P1P2), pick(P, 2 * P1P2, True)]
+    al = str(rng.choice(["X", "Y"]))
+    rt, ct = rdtype(prec), cdtype(prec)
+    A = rng.random(N).astype(rt)
+    lay = orc.PencilNLayout(N, P, None, al)
+    us = orc.scatter_real(A, lay)
+    want_c = orc.pencil_r2c_forward_n(us, N, None, al, prec)
+    want_b = orc.pencil_r2c_backward_n(want_c, N, None, al, prec)
+
+    def body(comm):
+        F = Pencil_R2C(np.array(N), L, comm, prec, communication="AlltoallN", alignment=al)
+        r = comm.Get_rank()
+        c = F.fftn(np.ascontiguousarray(us[r]), np.zeros(want_c[r].shape, dtype=ct))
+        b = F.ifftn(c, np.zeros(want_b[r].shape, dtype=rt))
+        return c, b
+    worst = 0.0
+    for r, (c, b) in enumerate(run_ranks(P, body)):
+        worst = max(worst, orc.rel_l2(c, want_c[r]), orc.rel_l2(b, want_b[r]))
+    return "pencilN%s N=%s P=%d %s" % (al, N, P, prec), worst
+
+
 def pencil_c2c_case(prec):
     P = int(rng.choice([4, 8]))
     P1P2 = 4 if P == 4 else 8
@@ -80,12 +105,13 @@ def pencil_c2c_case(prec):
 fails = 0
 t0 = time.time()
 for case in range(ncases):
-    kind = rng.choice(["slab", "slab", "pencilX", "pencilY", "slabc2c", "line", "pencilc2c"])
-    if kind in ("line", "pencilc2c"):
+    kind = rng.choice(["slab", "slab", "pencilX", "pencilY", "slabc2c", "line", "pencilc2c", "pencilN"])
+    if kind in ("line", "pencilc2c", "pencilN"):
         prec = str(rng.choice(["double", "single"]))
         dealias = rng.choice([None, "3/2-rule", "2/3-rule"])
         try:
-            tag, worst = line_case(prec, dealias) if kind == "line" else pencil_c2c_case(prec)
+            tag, worst = (line_case(prec, dealias) if kind == "line" else
+                          pencil_c2c_case(prec) if kind == "pencilc2c" else pencil_n_case(prec))
             ok = worst < 4 * TOL[prec]
             print("%-70s %.2e %s" % (tag, worst, "ok" if ok else "FAIL"))
             fails += 0 if ok else 1
@@ -122,7 +148,9 @@ for case in range(ncases):
             A = rng.random(N).astype(rt)
         if kind == "slab":
             lay = orc.SlabLayout(N, P)
-            make = lambda comm: Slab_R2C(np.array(N), L, comm, prec)
+            depth = int(rng.choice([0, 1, 2, 4, 8]))          # exchange pipeline depth (0 = default)
+            tag += " pipeline=%d" % depth
+            make = lambda comm: Slab_R2C(np.array(N), L, comm, prec, pipeline=depth)
             fwd, bwd = orc.slab_r2c_forward, orc.slab_r2c_backward
             fwdp, bwdp = orc.slab_r2c_forward_padded, orc.slab_r2c_backward_padded
             extra = ()
