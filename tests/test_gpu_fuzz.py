@@ -37,3 +37,14 @@ def test_config5_full_size_pencil_c2c():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0 and "CONFIG5_OK" in out, out[-3000:]
+
+
+def test_random_serialfft_calls_match_numpy():
+    """Random 1-D / 2-D / 3-D shapes (radix, chirp-z and unit lengths), every serialFFT function, both precisions
+    (scripts/fuzz_stages.py)."""
+    if not have_gpu():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_stages.py"), "200", "5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "200 cases, 0 failures" in out, out[-3000:]
