@@ -783,3 +783,34 @@ def test_c2c_meshes_with_unit_axes(N):
     c = F.fftn(A.copy(), np.zeros(F.transformed_shape(), dtype=complex))
     b = F.ifftn(c, np.zeros(F.original_shape(), dtype=complex))
     assert orc.rel_l2(c, np.fft.fftn(A)) < 1e-12 and orc.rel_l2(b, A) < 1e-12
+
+
+@pytest.mark.parametrize("ps", [2.0, 1.25, 1.75])
+@pytest.mark.parametrize("kind,N,P", [("slab", [16, 32, 24], 1), ("slab", [16, 32, 24], 2), ("slab", [32, 16, 64], 4),
+                                      ("X", [32, 32, 64], 4), ("Y", [32, 32, 64], 4)])
+def test_other_pad_factors(kind, N, P, ps):
+    """`padsize` other than 1.5 (constructor argument of every class, slab.py:68, pencil.py:168): copy-based pad /
+    truncate, padded lengths of any kind (28, 30, 56, ...)."""
+    from mpifft4py_amd import Pencil_R2C, Slab_R2C
+    A = np.random.default_rng(3).random(N)
+    if kind == "slab":
+        lay = orc.SlabLayout(N, P, padsize=ps)
+        fus = orc.slab_r2c_forward(orc.scatter_real(A, lay), N, "double")
+        wb = orc.slab_r2c_backward_padded(fus, N, "double", ps)
+        wc = orc.slab_r2c_forward_padded(wb, N, "double", ps)
+        make = lambda c: Slab_R2C(np.array(N), L, c, "double", padsize=ps)
+    else:
+        lay = orc.PencilLayout(N, P, None, kind)
+        fus = orc.pencil_r2c_forward(orc.scatter_real(A, lay), N, None, kind, "double")
+        wb = orc.pencil_r2c_backward_padded(fus, N, None, kind, "double", ps)
+        wc = orc.pencil_r2c_forward_padded(wb, N, None, kind, "double", ps)
+        make = lambda c: Pencil_R2C(np.array(N), L, c, "double", communication="Alltoallw", alignment=kind, padsize=ps)
+
+    def body(c):
+        F = make(c)
+        r = c.Get_rank()
+        b = F.ifftn(fus[r].copy(), np.zeros(wb[r].shape), "3/2-rule")
+        cc = F.fftn(b, np.zeros(wc[r].shape, dtype=complex), "3/2-rule")
+        return orc.rel_l2(b, wb[r]), orc.rel_l2(cc, wc[r])
+    for e1, e2 in run_ranks(P, body):
+        assert e1 < 1e-10 and e2 < 1e-10
