@@ -100,3 +100,11 @@ def test_bench_multi_rank_prints_one_json_line(world, launcher):
     if world == 4:
         assert d["extras"]["pencil_R2CX"]["grid"] == [2, 2]
         assert d["extras"]["pencil_R2CX"]["roundtrip_rel_l2"] < 1e-10
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_mpi4py_like_communicator_is_wrapped(world):
+    """INTEGRATION.md route A with the caller's own communicator object: the constructors accept anything with
+    Get_rank / Get_size / bcast (an mpi4py communicator) and build the RCCL communicator through it."""
+    rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker_mpi4py_like.py")])
+    assert rc == 0 and "MPI4PY_LIKE_OK %d" % world in out, (out[-2000:], err[-4000:])
