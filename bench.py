@@ -246,6 +246,7 @@ def main():
                        "alg_bytes_per_pair": alg_pair,
                        "whole_path_hbm_GBs_per_gpu": alg_pair / world / (ms * 1e-3) / 1e9,
                        "whole_path_frac_of_8TBs": alg_pair / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "whole_path_frac_of_6.29TBs_copy_ceiling": alg_pair / world / (ms * 1e-3) / 1e9 / 6290.0,
                        "stage_ms": {k_: v[0] / max(v[1], 1) for k_, v in sorted(stages.items())}},
             "roofline": {"bound": "hbm", "kernel": "col_fft (strided-axis c2c, stages *_x/*_y)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
