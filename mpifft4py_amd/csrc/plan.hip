@@ -87,6 +87,7 @@ struct mfft_plan_s {
   // 3/2-rule
   int64_t M0 = 0, M1 = 0, M2 = 0, Mf = 0;
   void* work3 = nullptr;        // y output of the pipelined inverse
+  size_t work3_bytes = 0;
   void* work[3] = {nullptr, nullptr, nullptr};
   size_t work_bytes[3] = {0, 0, 0};
   uint8_t* mask = nullptr;
@@ -97,6 +98,8 @@ struct mfft_plan_s {
   std::vector<GraphEntry> graphs;
   // exchange pipeline (slab, P > 1): kz slices, a communication stream and events
   int nslice = 1;
+  int nbatch = 1;               // pencil X: batches of local x rows pipelined through both exchanges
+  std::vector<hipEvent_t> ev2_compute, ev2_comm;
   hipStream_t cstream = nullptr;
   std::vector<hipEvent_t> ev_compute, ev_comm;
   std::vector<Chunk> kslice;    // (len, start) of each kz slice
@@ -113,6 +116,8 @@ struct mfft_plan_s {
     drop_graphs();
     for (hipEvent_t e : ev_compute) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_comm) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev2_compute) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev2_comm) (void)hipEventDestroy(e);
     if (cstream) (void)hipStreamDestroy(cstream);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -312,6 +317,19 @@ struct mfft_plan_s {
   bool can_fuse_pad() const;
   int slab_forward_padded_fused(const void* u, void* fu);
   int slab_backward_padded_fused(const void* fu, void* u);
+  int pencil_forward_pipelined_x(const void* u, void* fu);
+  int pencil_backward_pipelined_x(const void* src, void* u);
+  int sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sched* out) const;
+  int ensure_work3(size_t bytes) {
+    if (work3 && work3_bytes >= bytes) return 0;
+    if (work3) MFFT_HIP(hipFree(work3));
+    work3 = nullptr;
+    work3_bytes = 0;
+    hipError_t e = hipMalloc(&work3, bytes);
+    if (e != hipSuccess) return set_error(MFFT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    work3_bytes = bytes;
+    return 0;
+  }
   int pencil_forward_padded_fused(const void* u, void* fu);
   int pencil_backward_padded_fused(const void* fu, void* u);
   int pencil_forward(const void* u, void* fu);
@@ -482,10 +500,7 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
   const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
   for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, cb));
   // work[2] may hold the masked copy of the spectrum (src): use a 4th buffer for the y output
-  if (!work3) {
-    hipError_t e = hipMalloc(&work3, cb);
-    if (e != hipSuccess) return set_error(MFFT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", cb, hipGetErrorString(e));
-  }
+  MFFT_TRY(ensure_work3(cb));
   char *A = static_cast<char*>(work[0]), *B = static_cast<char*>(work[1]), *A2 = static_cast<char*>(work3);
   const char* in = static_cast<const char*>(src);
   for (int s = 0; s < nslice; ++s) {
@@ -679,7 +694,181 @@ static int pack_z(mfft_plan_s* p, const void* Z, void* S, int64_t rows, int64_t 
   return 0;
 }
 
+// ---- pencil, X alignment: batches of local x rows pipelined through BOTH exchanges -------------------
+// Everything up to the final x transform (forward) / after the first x transform (inverse) is independent per
+// local x row i, and the blocks a row batch contributes to either exchange are contiguous in the packed layouts,
+// so batch b's exchanges run on the communication stream while batch b+1 is transformed on the compute stream.
+// Sub-schedules of one batch [i0, i0+mb) of the m local rows (bytes):
+int mfft_plan_s::sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sched* o) const {
+  const int64_t m = N1_0, n = N2_1;
+  if (which == 0) {            // z-splitting exchange over group1 (P2 ranks): uneven chunks <-> (m, n, q) blocks
+    const int Pz = (int)group1.size();
+    o->peers = group1;
+    o->sc.resize(Pz); o->sd.resize(Pz); o->rc.resize(Pz); o->rd.resize(Pz);
+    size_t base = 0;
+    for (int l = 0; l < Pz; ++l) {
+      const size_t usz = (size_t)(mb * n * zc[l].len) * es, uoff = base + (size_t)(i0 * n * zc[l].len) * es;
+      const size_t esz = (size_t)(mb * n * q) * es, eoff = (size_t)(l * m * n * q + i0 * n * q) * es;
+      if (forward) { o->sc[l] = usz; o->sd[l] = uoff; o->rc[l] = esz; o->rd[l] = eoff; }
+      else         { o->sc[l] = esz; o->sd[l] = eoff; o->rc[l] = usz; o->rd[l] = uoff; }
+      base += (size_t)(m * n * zc[l].len) * es;
+    }
+    return 0;
+  }
+  // y-chunk exchange over group0 (P1 ranks): P1 blocks (m, N1_1, q) <-> rows of (N0, N1_1, q)
+  const int Pg = (int)group0.size();
+  o->peers = group0;
+  o->sc.assign(Pg, (size_t)(mb * N1_1 * q) * es);
+  o->rc = o->sc;
+  o->sd.resize(Pg); o->rd.resize(Pg);
+  for (int g = 0; g < Pg; ++g) {
+    const size_t blk = (size_t)(g * m * N1_1 * q + i0 * N1_1 * q) * es;      // [g][i][j'][k]
+    const size_t row = (size_t)((g * m + i0) * N1_1 * q) * es;               // x = g*m + i
+    if (forward) { o->sd[g] = blk; o->rd[g] = row; }
+    else         { o->sd[g] = row; o->rd[g] = blk; }
+  }
+  return 0;
+}
+
+// z chunks of rows [r0, r0+nr) of Z (rows_total, nf) <-> the matching sub-blocks of the packed chunk blocks
+static int pack_z_rows(mfft_plan_s* p, const void* Z, void* S, int64_t rows_total, int64_t r0, int64_t nr, int64_t nf,
+                       const std::vector<Chunk>& zc, bool unpack) {
+  size_t base = 0;
+  for (const Chunk& c : zc) {
+    const char* zp = static_cast<const char*>(Z) + (size_t)(r0 * nf + c.start) * p->es;
+    char* sp = static_cast<char*>(S) + base + (size_t)(r0 * c.len) * p->es;
+    if (!unpack) MFFT_TRY(p->box(zp, sp, 1, nr, c.len, 0, nf, 0, c.len));
+    else MFFT_TRY(p->box(sp, const_cast<char*>(zp), 1, nr, c.len, 0, c.len, 0, nf));
+    base += (size_t)(rows_total * c.len) * p->es;
+  }
+  return 0;
+}
+
+int mfft_plan_s::pencil_forward_pipelined_x(const void* u, void* fu) {
+  const int64_t m = N1_0, n = N2_1;
+  const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
+  const bool zsolo = P2 == 1, g2solo = P1 == 1;
+  const size_t wb = (size_t)std::max(m * n * Nf, m * N1 * q) * es;
+  for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
+  char *W0 = static_cast<char*>(work[0]), *W1 = static_cast<char*>(work[1]), *W2 = static_cast<char*>(work[2]);
+  const char* in = static_cast<const char*>(u);
+  char* out = static_cast<char*>(fu);
+  const int B = nbatch;
+  auto rows = [&](int b, int64_t* i0, int64_t* mb) { *i0 = m * b / B; *mb = m * (b + 1) / B - *i0; };
+  // z transform + z-chunk pack of a batch on the compute stream, its exchange on the communication stream
+  for (int b = 0; b < B; ++b) {
+    int64_t i0, mb;
+    rows(b, &i0, &mb);
+    MFFT_TRY(stage("fwd_z", (Rb + Cb) / B, [&] {
+      return z_forward(in + (size_t)(i0 * n * N2) * rs, W0 + (size_t)(i0 * n * Nf) * es, mb * n, N2, Nf);
+    }));
+    if (zsolo) continue;
+    MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z_rows(this, W0, W1, m * n, i0 * n, mb * n, Nf, zc, false); }));
+    MFFT_HIP(hipEventRecord(ev_compute[b], stream));
+    MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[b], 0));
+    MFFT_TRY(stage_on(cstream, "fwd_a2a_1", 0, [&] {
+      Sched sc;
+      MFFT_TRY(sched_rows(0, true, i0, mb, &sc));
+      return run_sched(sc, W1, W2, cstream);
+    }));
+    MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
+  }
+  // y transform of a batch as soon as its z chunks have arrived; W0 is free again (all packs are behind us on
+  // this stream) and takes the P1 blocks (m, N1_1, q) that feed the second exchange
+  const char* ysrc = zsolo ? W0 : W2;
+  char* ydst = g2solo ? out : (zsolo ? W1 : W0);
+  for (int b = 0; b < B; ++b) {
+    int64_t i0, mb;
+    rows(b, &i0, &mb);
+    if (!zsolo) MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
+    MFFT_TRY(stage("fwd_y", 2 * Cb / B, [&] {
+      return col(ysrc + (size_t)(i0 * n * q) * es, ydst + (size_t)(i0 * N1_1 * q) * es, N1, false, mb, q, n * q,
+                 two_level(n, m * n * q, q), N1_1 * q, two_level(N1_1, m * N1_1 * q, q));
+    }));
+    if (g2solo) continue;
+    MFFT_HIP(hipEventRecord(ev2_compute[b], stream));
+    MFFT_HIP(hipStreamWaitEvent(cstream, ev2_compute[b], 0));
+    MFFT_TRY(stage_on(cstream, "fwd_a2a_2", 0, [&] {
+      Sched sc;
+      MFFT_TRY(sched_rows(1, true, i0, mb, &sc));
+      return run_sched(sc, ydst, out, cstream);
+    }));
+    MFFT_HIP(hipEventRecord(ev2_comm[b], cstream));
+  }
+  if (!g2solo) MFFT_HIP(hipStreamWaitEvent(stream, ev2_comm[B - 1], 0));     // in order on the comm stream: all batches
+  MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
+  return 0;
+}
+
+int mfft_plan_s::pencil_backward_pipelined_x(const void* src, void* u) {
+  const int64_t m = N1_0, n = N2_1;
+  const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
+  const bool zsolo = P2 == 1, g2solo = P1 == 1;
+  const size_t wb = (size_t)std::max(m * n * Nf, m * N1 * q) * es;
+  for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, wb));
+  // third buffer: work[2], unless it holds the masked copy of the spectrum (src)
+  const bool src_in_work2 = work[2] != nullptr && src == work[2];
+  if (src_in_work2) MFFT_TRY(ensure_work3(wb));
+  else MFFT_TRY(ensure_work(2, wb));
+  char *W0 = static_cast<char*>(work[0]), *W1 = static_cast<char*>(work[1]);
+  char* W2 = static_cast<char*>(src_in_work2 ? work3 : work[2]);
+  char* out = static_cast<char*>(u);
+  const int B = nbatch;
+  auto rows = [&](int b, int64_t* i0, int64_t* mb) { *i0 = m * b / B; *mb = m * (b + 1) / B - *i0; };
+  MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, W0, N0, true, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
+  if (!g2solo) {
+    MFFT_HIP(hipEventRecord(ev2_compute[0], stream));
+    MFFT_HIP(hipStreamWaitEvent(cstream, ev2_compute[0], 0));
+    for (int b = 0; b < B; ++b) {
+      int64_t i0, mb;
+      rows(b, &i0, &mb);
+      MFFT_TRY(stage_on(cstream, "bwd_a2a_2", 0, [&] {
+        Sched sc;
+        MFFT_TRY(sched_rows(1, false, i0, mb, &sc));
+        return run_sched(sc, W0, W1, cstream);
+      }));
+      MFFT_HIP(hipEventRecord(ev2_comm[b], cstream));
+    }
+  }
+  // y transform of a batch (P1 blocks gathered through the row map) -> P2 blocks (m, n, q) in W2, then its z exchange
+  const char* ysrc = g2solo ? W0 : W1;
+  for (int b = 0; b < B; ++b) {
+    int64_t i0, mb;
+    rows(b, &i0, &mb);
+    if (!g2solo) MFFT_HIP(hipStreamWaitEvent(stream, ev2_comm[b], 0));
+    MFFT_TRY(stage("bwd_y", 2 * Cb / B, [&] {
+      return col(ysrc + (size_t)(i0 * N1_1 * q) * es, W2 + (size_t)(i0 * n * q) * es, N1, true, mb, q, N1_1 * q,
+                 two_level(N1_1, m * N1_1 * q, q), n * q, two_level(n, m * n * q, q));
+    }));
+    if (zsolo) continue;
+    MFFT_HIP(hipEventRecord(ev_compute[b], stream));
+    MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[b], 0));
+    MFFT_TRY(stage_on(cstream, "bwd_a2a_1", 0, [&] {       // all bwd_a2a_2 are ahead of it on this stream: W0 is free
+      Sched sc;
+      MFFT_TRY(sched_rows(0, false, i0, mb, &sc));
+      return run_sched(sc, W2, W0, cstream);
+    }));
+    MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
+  }
+  // z chunks of a batch back into full rows (W1: every y transform that read it is behind us on this stream), c2r
+  for (int b = 0; b < B; ++b) {
+    int64_t i0, mb;
+    rows(b, &i0, &mb);
+    const char* zin = W2 + (size_t)(i0 * n * Nf) * es;
+    if (!zsolo) {
+      MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
+      MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z_rows(this, W1, W0, m * n, i0 * n, mb * n, Nf, zc, true); }));
+      zin = W1 + (size_t)(i0 * n * Nf) * es;
+    }
+    MFFT_TRY(stage("bwd_z", (Rb + Cb) / B, [&] {
+      return z_backward(zin, out + (size_t)(i0 * n * N2) * rs, mb * n, N2, Nf);
+    }));
+  }
+  return 0;
+}
+
 int mfft_plan_s::pencil_forward(const void* u, void* fu) {
+  if (nbatch > 1) return pencil_forward_pipelined_x(u, fu);
   const int64_t m = N1_0, n = N2_1;                 // local real rows in x, y
   const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
   const bool X = d.decomp == MFFT_PENCIL_X;
@@ -729,6 +918,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &mm); }));
     src = mm;
   }
+  if (nbatch > 1) return pencil_backward_pipelined_x(src, u);
   // largest intermediate of this alignment: X: (m, N1, q) after the z exchange; Y: (N0, n, q) after it
   const size_t wb = (size_t)std::max(m * n * Nf, X ? m * N1 * q : N0 * n * q) * es;
   MFFT_TRY(ensure_work(0, wb));
@@ -1028,6 +1218,10 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
     }
     p->q = p->zc[cz].len;
     p->zstart = p->zc[cz].start;
+    // exchange pipeline of the x-aligned pencil: batches of local x rows (`pipeline`, default 4 like the slab's)
+    const int want = desc->pipeline > 0 ? desc->pipeline : 4;
+    if (desc->decomp == MFFT_PENCIL_X && want > 1 && P > 1 && !desc->drop_nyquist && !desc->line2d)
+      p->nbatch = (int)std::min<int64_t>(want, p->N1_0);
   } else {
     return set_error(MFFT_ERR_INVALID, "bad decomposition %d", desc->decomp);
   }
@@ -1058,17 +1252,17 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
     const char* e = getenv("MFFT_GRAPH");
     p->use_graphs = p->P == 1 && e && atoi(e) != 0;
   }
-  if (p->nslice > 1) {
+  const int nev = std::max(p->nslice > 1 ? p->nslice : 0, p->nbatch > 1 ? p->nbatch : 0);
+  if (nev > 0) {
     // The exchange runs on its own stream at the highest priority the device offers: its (RCCL) kernels have to get
     // onto CUs that the transform kernels of the compute stream would otherwise keep filling block after block.
     int prio_least = 0, prio_greatest = 0;
     MFFT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     MFFT_HIP(hipStreamCreateWithPriority(&p->cstream, hipStreamNonBlocking, prio_greatest));
-    p->ev_compute.resize(p->nslice);
-    p->ev_comm.resize(p->nslice);
-    for (int s = 0; s < p->nslice; ++s) {
-      MFFT_HIP(hipEventCreateWithFlags(&p->ev_compute[s], hipEventDisableTiming));
-      MFFT_HIP(hipEventCreateWithFlags(&p->ev_comm[s], hipEventDisableTiming));
+    for (std::vector<hipEvent_t>* v : {&p->ev_compute, &p->ev_comm, &p->ev2_compute, &p->ev2_comm}) {
+      if ((v == &p->ev2_compute || v == &p->ev2_comm) && p->nbatch <= 1) continue;
+      v->resize(nev);
+      for (int s = 0; s < nev; ++s) MFFT_HIP(hipEventCreateWithFlags(&(*v)[s], hipEventDisableTiming));
     }
   }
   *out = p.release();
@@ -1144,7 +1338,7 @@ int mfft_plan_layout(mfft_plan_t p, int64_t rshape[3], int64_t cshape[3], int64_
 
 int mfft_plan_workspace_bytes(mfft_plan_t p, size_t* bytes) {
   if (!p || !bytes) return set_error(MFFT_ERR_INVALID, "null argument");
-  *bytes = p->work_bytes[0] + p->work_bytes[1] + p->work_bytes[2] + (p->work3 ? (size_t)(p->Np0 * p->N1 * p->Nf) * p->es : 0);
+  *bytes = p->work_bytes[0] + p->work_bytes[1] + p->work_bytes[2] + p->work3_bytes;
   return 0;
 }
 

@@ -12,7 +12,9 @@ P = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 N = np.array([n] * 3); L = np.array([2 * np.pi] * 3)
 
 def body(comm):
-    F = Pencil_C2C(N, L, comm, "single", alignment="X")
+    # pipeline=1: the exchange pipeline needs a third work buffer per rank, which 8 ranks on ONE device cannot afford
+    # at 2048^3 (it is for overlapping real exchanges, of which there are none here)
+    F = Pencil_C2C(N, L, comm, "single", alignment="X", pipeline=1 if n >= 2048 else 0)
     r = comm.Get_rank()
     u = DeviceArray.random(F.original_shape(), F.complex, seed=100 + r)
     fu = DeviceArray.empty(F.transformed_shape(), F.complex)

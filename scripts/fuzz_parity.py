@@ -162,7 +162,10 @@ for case in range(ncases):
         else:
             al = kind[-1]
             lay = orc.PencilLayout(N, P, None, al)
-            make = lambda comm: Pencil_R2C(np.array(N), L, comm, prec, communication="Alltoallw", alignment=al)
+            pdepth = int(rng.choice([0, 0, 2, 4, 7]))         # X alignment: opt-in exchange pipeline
+            tag += " pipeline=%d" % pdepth
+            make = lambda comm: Pencil_R2C(np.array(N), L, comm, prec, communication="Alltoallw", alignment=al,
+                                           pipeline=pdepth)
             fwd = lambda us, N_, p: orc.pencil_r2c_forward(us, N_, None, al, p)
             bwd = lambda fs, N_, p: orc.pencil_r2c_backward(fs, N_, None, al, p)
             fwdp = lambda us, N_, p: orc.pencil_r2c_forward_padded(us, N_, None, al, p)

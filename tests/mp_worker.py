@@ -68,6 +68,13 @@ def main():
             assert orc.rel_l2(c, B2[Fp.complex_local_slice()]) < 1e-10, align
             b = Fp.ifftn(c, np.zeros(Fp.real_shape()))
             assert orc.rel_l2(b, A[Fp.real_local_slice()]) < 1e-10
+        # x-aligned pencil with its exchange pipeline (two streams, batches of rows through both exchanges)
+        Fq = Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment="X", pipeline=4)
+        for _ in range(2):
+            c = Fq.fftn(np.ascontiguousarray(A[Fq.real_local_slice()]), np.zeros(Fq.complex_shape(), dtype=complex))
+            b = Fq.ifftn(c, np.zeros(Fq.real_shape()))
+        assert orc.rel_l2(c, B2[Fq.complex_local_slice()]) < 1e-10, "pencil X pipelined"
+        assert orc.rel_l2(b, A[Fq.real_local_slice()]) < 1e-10
     comm.barrier()
     if rank == 0:
         print("MP_OK world=%d" % P)

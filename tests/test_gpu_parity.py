@@ -814,3 +814,39 @@ def test_other_pad_factors(kind, N, P, ps):
         return orc.rel_l2(b, wb[r]), orc.rel_l2(cc, wc[r])
     for e1, e2 in run_ranks(P, body):
         assert e1 < 1e-10 and e2 < 1e-10
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("depth", [2, 3, 4, 16])
+@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2), (16, None)])
+def test_pencil_x_exchange_pipeline(P, P1, depth, prec):
+    """Opt-in exchange pipeline of the x-aligned pencil (batches of local x rows through both exchanges, compute and
+    communication streams): same numbers as the un-pipelined path, R2C plain / 2/3-rule and C2C."""
+    from mpifft4py_amd.pencil import C2CX, R2CX
+    N = [32, 64, 128]
+    rt, ct = rdtype(prec), cdtype(prec)
+    rng = np.random.default_rng(900 + P + depth)
+    A = rng.random(N).astype(rt)
+    Ac = (rng.random(N) + 1j * rng.random(N)).astype(ct)
+
+    def body(comm):
+        res = []
+        for pipe in (1, depth):                               # 1 = no pipeline (0 would be the default depth, 4)
+            F = R2CX(np.array(N), L, comm, prec, P1=P1, communication="Alltoallw", allow_single=True, pipeline=pipe)
+            a = np.ascontiguousarray(A[F.real_local_slice()])
+            c = F.fftn(a, np.zeros(F.complex_shape(), dtype=ct))
+            b = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt))
+            b23 = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt), "2/3-rule")
+            G = C2CX(np.array(N), L, comm, prec, P1=P1, allow_single=True, pipeline=pipe)
+            ac = np.ascontiguousarray(Ac[G.original_local_slice()])
+            cc = G.fftn(ac, np.zeros(G.transformed_shape(), dtype=ct))
+            bc = G.ifftn(cc, np.zeros(G.original_shape(), dtype=ct))
+            res.append((c, b, b23, cc, bc, F.complex_local_slice(), F.real_local_slice(), ac))
+        return res
+    B2 = np.fft.rfftn(A.astype(np.float64))
+    for plain, piped in run_ranks(P, body):
+        for x, y in zip(plain[:5], piped[:5]):
+            assert np.array_equal(x, y)                       # same kernels, same order of operations per element
+        assert orc.rel_l2(piped[0], B2[piped[5]]) < TOL[prec]
+        assert orc.rel_l2(piped[1], A[piped[6]]) < 4 * TOL[prec]
+        assert orc.rel_l2(piped[4], piped[7]) < 4 * TOL[prec]
