@@ -153,12 +153,12 @@ def main():
     L = np.array([2 * np.pi] * 3)
     tuning = None
     if args.decomp == "slab" and world > 1 and args.pipeline == 0:
-        # exchange-pipeline depth (kz slices in flight) measured on this machine's links before the warm-up,
-        # like a planner's MEASURE mode: 2 untimed + 2 timed pairs per candidate, slowest rank counts
+        # exchange pipeline (flavour and depth) measured on this machine's links before the warm-up, like a planner's
+        # MEASURE mode: 2 untimed + 2 timed pairs per candidate, slowest rank counts
         tuning = {}
         try:
             ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
-            for depth in (1, 2, 4, 8):
+            for depth in (1, 2, 4, 8, -2, -4, -8):        # kz slices / (negative) batches of local x rows
                 Ft = Slab_R2C(N, L, comm, args.precision, pipeline=depth)
                 fut = DeviceArray.empty(Ft.complex_shape(), Ft.complex)
                 for it in range(4):

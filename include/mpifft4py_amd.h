@@ -97,8 +97,9 @@ typedef struct {
   int decomp;         /* mfft_decomp */
   int p1;             /* pencil: ranks along the first axis, 0 = Compute_dims default */
   double padsize;     /* 3/2-rule pad factor (1.5) */
-  int pipeline;       /* exchange pipeline depth: slab = kz slices, x-aligned pencil = batches of local x rows, each
-                         exchanged on a second stream while the next one is transformed; 0 = default (4), 1 = off */
+  int pipeline;       /* exchange pipeline: slab: n > 1 = n kz slices, n < -1 = |n| batches of local x rows; x-aligned
+                         pencil: |n| batches of local x rows; each piece is exchanged on a second stream while the
+                         next one is transformed; 0 = default (4), 1 = off */
   int drop_nyquist;   /* pencil 'AlltoallN' mode (pencil.py:410-432, 647-668): the kz = N2/2 column is
                          neither exchanged nor returned; the inverse treats it as zero */
   int line2d;         /* 1: the 2-D class of line.py:41-340, expressed as an x-aligned pencil plan of the mesh

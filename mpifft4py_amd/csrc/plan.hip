@@ -317,6 +317,8 @@ struct mfft_plan_s {
   bool can_fuse_pad() const;
   int slab_forward_padded_fused(const void* u, void* fu);
   int slab_backward_padded_fused(const void* fu, void* u);
+  int slab_forward_rows(const void* u, void* fu);
+  int slab_backward_rows(const void* src, void* u);
   int pencil_forward_pipelined_x(const void* u, void* fu);
   int pencil_backward_pipelined_x(const void* src, void* u);
   int sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sched* out) const;
@@ -402,6 +404,7 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
     MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
     return 0;
   }
+  if (nbatch > 1) return slab_forward_rows(u, fu);
   if (nslice > 1) return slab_forward_pipelined(u, fu);
   const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
   MFFT_TRY(ensure_work(0, cb));
@@ -445,6 +448,7 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A, u, N0 * N1, N2, Nf); }));
     return 0;
   }
+  if (nbatch > 1) return slab_backward_rows(src, u);
   if (nslice > 1) return slab_backward_pipelined(src, u);
   MFFT_TRY(ensure_work(1, cb));
   void* B = work[1];
@@ -526,6 +530,94 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
     }));
   }
   MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A2, u, Np0 * N1, N2, Nf); }));
+  return 0;
+}
+
+// ---- slab, second pipeline flavour (`pipeline` < 0): batches of local x rows -----------------------------
+// z and y transforms of batch b+1 overlap the exchange of batch b; the exchange delivers straight into the output
+// array (its receive layout (N0, Np1, Nf) IS the output layout), where the x transform then runs in place over whole
+// rows.  Compared with the kz slices: the z transform is overlapped instead of the x transform, no strided kz
+// sub-columns, one work buffer less in the forward direction.  Which one is faster depends on the links; bench.py
+// measures both.
+static void slab_row_sched(const mfft_plan_s* p, bool forward, int64_t i0, int64_t mb, Sched* o) {
+  (void)forward;      // both directions move the same blocks: [r][i][j][k] of the packed layout IS row r*Np0+i of (N0, Np1, Nf)
+  const int P = p->P;
+  o->peers = p->world;
+  o->sc.assign(P, (size_t)(mb * p->Np1 * p->Nf) * p->es);
+  o->rc = o->sc;
+  o->sd.resize(P);
+  o->rd.resize(P);
+  for (int r = 0; r < P; ++r) {
+    const size_t blk = (size_t)((r * p->Np0 + i0) * p->Np1 * p->Nf) * p->es;      // [r][i][j][k] == row x = r*Np0 + i
+    o->sd[r] = blk;
+    o->rd[r] = blk;
+  }
+}
+
+int mfft_plan_s::slab_forward_rows(const void* u, void* fu) {
+  const double Cb = (double)(N0 * Np1 * Nf) * es, Rb = (double)(Np0 * N1 * N2) * rs;
+  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, cb));
+  char *A = static_cast<char*>(work[0]), *Bk = static_cast<char*>(work[1]);
+  const char* in = static_cast<const char*>(u);
+  const int B = nbatch;
+  for (int b = 0; b < B; ++b) {
+    const int64_t i0 = Np0 * b / B, mb = Np0 * (b + 1) / B - i0;
+    MFFT_TRY(stage("fwd_z", (Rb + Cb) / B, [&] {
+      return z_forward(in + (size_t)(i0 * N1 * N2) * rs, A + (size_t)(i0 * N1 * Nf) * es, mb * N1, N2, Nf);
+    }));
+    MFFT_TRY(stage("fwd_y", 2 * Cb / B, [&] {
+      return col(A + (size_t)(i0 * N1 * Nf) * es, Bk + (size_t)(i0 * Np1 * Nf) * es, N1, false, mb, Nf, N1 * Nf, plain(Nf),
+                 Np1 * Nf, two_level(Np1, Np0 * Np1 * Nf, Nf));
+    }));
+    MFFT_HIP(hipEventRecord(ev_compute[b], stream));
+    MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[b], 0));
+    MFFT_TRY(stage_on(cstream, "fwd_a2a", 0, [&] {
+      Sched sc;
+      slab_row_sched(this, true, i0, mb, &sc);
+      return run_sched(sc, Bk, fu, cstream);
+    }));
+    MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
+  }
+  MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[B - 1], 0));
+  MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
+  return 0;
+}
+
+int mfft_plan_s::slab_backward_rows(const void* src, void* u) {
+  const double Cb = (double)(N0 * Np1 * Nf) * es, Rb = (double)(Np0 * N1 * N2) * rs;
+  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, cb));
+  const bool src_in_work2 = work[2] != nullptr && src == work[2];     // the masked copy of the spectrum
+  if (src_in_work2) MFFT_TRY(ensure_work3(cb));
+  else MFFT_TRY(ensure_work(2, cb));
+  char *A = static_cast<char*>(work[0]), *Bk = static_cast<char*>(work[1]);
+  char* A2 = static_cast<char*>(src_in_work2 ? work3 : work[2]);
+  char* out = static_cast<char*>(u);
+  const int B = nbatch;
+  MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
+  MFFT_HIP(hipEventRecord(ev_compute[0], stream));
+  MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[0], 0));
+  for (int b = 0; b < B; ++b) {
+    const int64_t i0 = Np0 * b / B, mb = Np0 * (b + 1) / B - i0;
+    MFFT_TRY(stage_on(cstream, "bwd_a2a", 0, [&] {
+      Sched sc;
+      slab_row_sched(this, false, i0, mb, &sc);
+      return run_sched(sc, A, Bk, cstream);
+    }));
+    MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
+  }
+  for (int b = 0; b < B; ++b) {
+    const int64_t i0 = Np0 * b / B, mb = Np0 * (b + 1) / B - i0;
+    MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
+    MFFT_TRY(stage("bwd_y", 2 * Cb / B, [&] {
+      return col(Bk + (size_t)(i0 * Np1 * Nf) * es, A2 + (size_t)(i0 * N1 * Nf) * es, N1, true, mb, Nf, Np1 * Nf,
+                 two_level(Np1, Np0 * Np1 * Nf, Nf), N1 * Nf, plain(Nf));
+    }));
+    MFFT_TRY(stage("bwd_z", (Rb + Cb) / B, [&] {
+      return z_backward(A2 + (size_t)(i0 * N1 * Nf) * es, out + (size_t)(i0 * N1 * N2) * rs, mb * N1, N2, Nf);
+    }));
+  }
   return 0;
 }
 
@@ -1171,7 +1263,9 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
     if (p->N0 % P || p->N1 % P) return set_error(MFFT_ERR_INVALID, "N[0]=%lld and N[1]=%lld must be divisible by the number of ranks %d", (long long)p->N0, (long long)p->N1, P);
     p->Np0 = p->N0 / P;
     p->Np1 = p->N1 / P;
-    if (P > 1) {
+    if (P > 1 && desc->pipeline < 0) {
+      p->nbatch = (int)std::min<int64_t>(-(int64_t)desc->pipeline, p->Np0);      // batches of local x rows
+    } else if (P > 1) {
       // kz slices for the exchange pipeline: boundaries on 16-column (tile) multiples
       const int want = desc->pipeline > 0 ? desc->pipeline : 4;
       const int64_t unit = 16;
@@ -1219,7 +1313,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
     p->q = p->zc[cz].len;
     p->zstart = p->zc[cz].start;
     // exchange pipeline of the x-aligned pencil: batches of local x rows (`pipeline`, default 4 like the slab's)
-    const int want = desc->pipeline > 0 ? desc->pipeline : 4;
+    const int want = desc->pipeline > 0 ? desc->pipeline : desc->pipeline < 0 ? -desc->pipeline : 4;
     if (desc->decomp == MFFT_PENCIL_X && want > 1 && P > 1 && !desc->drop_nyquist && !desc->line2d)
       p->nbatch = (int)std::min<int64_t>(want, p->N1_0);
   } else {

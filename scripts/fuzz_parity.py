@@ -148,7 +148,7 @@ for case in range(ncases):
             A = rng.random(N).astype(rt)
         if kind == "slab":
             lay = orc.SlabLayout(N, P)
-            depth = int(rng.choice([0, 1, 2, 4, 8]))          # exchange pipeline depth (0 = default)
+            depth = int(rng.choice([0, 1, 2, 4, 8, -2, -4, -5]))   # exchange pipeline (0 default, <0 row batches)
             tag += " pipeline=%d" % depth
             make = lambda comm: Slab_R2C(np.array(N), L, comm, prec, pipeline=depth)
             fwd, bwd = orc.slab_r2c_forward, orc.slab_r2c_backward

@@ -31,7 +31,7 @@ def main():
     assert comm.allreduce(float(rank)) == sum(range(P))
     assert comm.bcast({"hello": P} if rank == 0 else None)["hello"] == P
 
-    for pipeline in (1, 4):
+    for pipeline in (1, 4, -4):
         F = Slab_R2C(np.array(N), L, comm, "double", pipeline=pipeline)
         u = DeviceArray.from_numpy(np.ascontiguousarray(A[F.real_local_slice()]))
         fu = DeviceArray.empty(F.complex_shape(), F.complex)

@@ -95,7 +95,7 @@ def test_bench_multi_rank_prints_one_json_line(world, launcher):
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0
     # the exchange-pipeline depth is measured before the warm-up (all four candidates), the best one is used
     tun = d["config"]["exchange_pipeline_tuning_ms_per_pair"]
-    assert sorted(int(k) for k in tun) == [1, 2, 4, 8] and all(v > 0 for v in tun.values())
+    assert sorted(int(k) for k in tun) == [-8, -4, -2, 1, 2, 4, 8] and all(v > 0 for v in tun.values())
     assert d["config"]["exchange_pipeline_depth"] == int(min(tun, key=tun.get))
     if world == 4:
         assert d["extras"]["pencil_R2CX"]["grid"] == [2, 2]

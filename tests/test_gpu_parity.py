@@ -323,10 +323,10 @@ def test_errors_match_the_reference():
         g.free()
 
 
-@pytest.mark.parametrize("pipeline", [1, 2, 4])
+@pytest.mark.parametrize("pipeline", [1, 2, 4, -2, -3, -4, -64])
 def test_slab_exchange_pipeline(pipeline):
-    """The kz-sliced exchange pipeline (compute stream + communication stream) gives
-    the same numbers as the un-pipelined path."""
+    """The exchange pipelines (compute stream + communication stream; positive: kz slices, negative: batches of
+    local x rows) give the same numbers as the un-pipelined path."""
     from mpifft4py_amd import DeviceArray, Slab_R2C
     N = [64, 64, 128]
     P = 4
