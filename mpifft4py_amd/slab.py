@@ -22,6 +22,9 @@ class R2C(DistFFTBase):
         N, L, comm, precision ("single"/"double"),
         communication ('Alltoall' | 'Alltoallw': identical results, both map to
         the RCCL exchange), padsize, threads, planner_effort (accepted, unused).
+    Extension: pipeline -- the exchange of a multi-rank plan is cut into pieces that travel on a second stream
+        while the next piece is transformed: n > 1 = n kz slices, n < -1 = |n| batches of local x rows,
+        0 = default (4 kz slices), 1 = one blocking exchange.
     """
     _kind = _lib.R2C
 
