@@ -8,7 +8,7 @@ N = np.array([n]*3); L = np.array([2*np.pi]*3)
 A = np.random.default_rng(1).random(tuple(N))
 B2 = np.fft.rfftn(A)
 def rel(x, r): return float(np.linalg.norm((x-r).ravel())/np.linalg.norm(r.ravel()))
-for pipeline in (1, 2, 4, 8):
+for pipeline in (1, 2, 4, 8, -2, -4, -8):
     F = Slab_R2C(N, L, comm, "double", pipeline=pipeline)
     u = DeviceArray.from_numpy(np.ascontiguousarray(A[F.real_local_slice()]))
     fu = DeviceArray.empty(F.complex_shape(), F.complex); u2 = DeviceArray.empty(F.real_shape(), F.float)
