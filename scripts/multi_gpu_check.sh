@@ -1,6 +1,6 @@
 #!/bin/bash
 # First thing to run on a node with more than one MI355X (nothing in this round could): the multi-process product
-# path over REAL RCCL / xGMI -- parity of slab (every pipeline flavour) and pencil transforms at 256^3 and 1024^3,
+# path over REAL RCCL / xGMI -- parity of slab (every pipeline flavour) and pencil transforms at 256^3 and 512^3,
 # then the bench at 2, 4 and 8 ranks.  Usage: scripts/multi_gpu_check.sh [max_ranks]
 set -u
 cd "$(dirname "$0")/.."
@@ -9,7 +9,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 PORT=29610
 for P in 2 4 8; do
   [ "$P" -gt "$MAXR" ] && break
-  for n in 256 1024; do
+  for n in 256 512; do
     echo "== parity: $P ranks, $n^3 (slab pipelines 1/2/4/8, pencils X and Y)"
     MP_N=$n timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 \
       --master-port $((PORT++)) scripts/mp_big_check.py 2>&1 | grep -E "BIG_OK|Error|error|assert" | head -5
