@@ -124,6 +124,12 @@ MFFT_API int mfft_plan_workspace_bytes(mfft_plan_t plan, size_t* bytes);
 MFFT_API int mfft_plan_exchange_schedule(const mfft_plan_desc* desc, int nranks, int rank, int which,
                                          int forward, int padded, int max_peers, int* npeers, int* peers,
                                          size_t* scount, size_t* sdisp, size_t* rcount, size_t* rdisp);
+/* The same for ONE piece of the pipelined exchange that `desc->pipeline` selects (slab: kz slice or batch of local
+ * x rows; x-aligned pencil: batch of local x rows of exchange `which`): displacements are relative to the whole send /
+ * receive buffers, *npieces returns how many pieces the exchange has (1 = not pipelined: the whole exchange). */
+MFFT_API int mfft_plan_exchange_pieces(const mfft_plan_desc* desc, int nranks, int rank, int which, int forward,
+                                       int piece, int max_peers, int* npieces, int* npeers, int* peers,
+                                       size_t* scount, size_t* sdisp, size_t* rcount, size_t* rdisp);
 
 /* fftn: slab.py:349-485 / pencil.py:634-883, 1228-1475.  `u` is never written. */
 MFFT_API int mfft_forward(mfft_plan_t plan, const void* u, void* fu, int dealias);

@@ -63,6 +63,9 @@ _SIGNATURES = {
     "mfft_plan_exchange_schedule": ([POINTER(PlanDesc), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),
                                      POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t),
                                      POINTER(c_size_t)], c_int),
+    "mfft_plan_exchange_pieces": ([POINTER(PlanDesc), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),
+                                   POINTER(c_int), POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t),
+                                   POINTER(c_size_t), POINTER(c_size_t)], c_int),
     "mfft_forward": ([c_void_p, c_void_p, c_void_p, c_int], c_int),
     "mfft_backward": ([c_void_p, c_void_p, c_void_p, c_int], c_int),
     "mfft_plan_sync": ([c_void_p], c_int),
@@ -150,6 +153,29 @@ def exchange_schedule(N, nranks, rank, decomp, which=0, forward=True, padded=Fal
     k = n.value
     return dict(peers=list(peers[:k]), scount=list(arrs[0][:k]), sdisp=list(arrs[1][:k]),
                 rcount=list(arrs[2][:k]), rdisp=list(arrs[3][:k]))
+
+
+def exchange_pieces(N, nranks, rank, decomp, which, forward, pipeline, precision="double", kind=R2C, p1=0):
+    """Host-only query of the pipelined exchange selected by `pipeline` (0 = the default): list of piece schedules
+    dict(peers, scount, sdisp, rcount, rdisp), displacements relative to the whole buffers."""
+    d = PlanDesc()
+    for i in range(3):
+        d.n[i] = int(N[i])
+    d.precision = SINGLE if precision == "single" else DOUBLE
+    d.kind, d.decomp, d.p1, d.padsize, d.pipeline = kind, decomp, int(p1 or 0), 1.5, int(pipeline)
+    mx = 64
+    out, piece, total = [], 0, 1
+    while piece < total:
+        n, npieces = c_int(0), c_int(0)
+        peers = (c_int * mx)()
+        arrs = [(c_size_t * mx)() for _ in range(4)]
+        call("mfft_plan_exchange_pieces", ctypes.byref(d), nranks, rank, which, 1 if forward else 0, piece, mx,
+             ctypes.byref(npieces), ctypes.byref(n), peers, *arrs)
+        total, k = npieces.value, n.value
+        out.append(dict(peers=list(peers[:k]), scount=list(arrs[0][:k]), sdisp=list(arrs[1][:k]),
+                        rcount=list(arrs[2][:k]), rdisp=list(arrs[3][:k])))
+        piece += 1
+    return out
 
 
 def device_count():

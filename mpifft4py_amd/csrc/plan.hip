@@ -322,6 +322,9 @@ struct mfft_plan_s {
   int pencil_forward_pipelined_x(const void* u, void* fu);
   int pencil_backward_pipelined_x(const void* src, void* u);
   int sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sched* out) const;
+  // pieces of the pipelined exchanges (host only; the executors and mfft_plan_exchange_pieces share it)
+  int npieces() const { return nbatch > 1 ? nbatch : nslice > 1 ? nslice : 1; }
+  int piece_sched(int which, bool forward, int piece, Sched* out) const;
   int ensure_work3(size_t bytes) {
     if (work3 && work3_bytes >= bytes) return 0;
     if (work3) MFFT_HIP(hipFree(work3));
@@ -390,6 +393,41 @@ int mfft_plan_s::sched(int which, bool forward, bool padded, Sched* o) const {
     return 0;
   }
   return set_error(MFFT_ERR_INVALID, "pencil plans have two exchanges");
+}
+
+// Schedule of ONE piece of a pipelined exchange, displacements relative to the whole send / receive buffers:
+//   slab, kz slices   : slice s of the packed [s][p][i][j][kz_s] layout (equal chunks)
+//   slab, row batches : rows [i0, i0+mb) of every peer block of the packed (P, Np0, Np1, Nf) layout
+//   pencil X          : rows [i0, i0+mb) of the blocks of exchange `which`
+// An un-pipelined plan has one piece: the whole exchange.
+int mfft_plan_s::piece_sched(int which, bool forward, int piece, Sched* o) const {
+  if (piece < 0 || piece >= npieces()) return set_error(MFFT_ERR_INVALID, "piece %d of %d", piece, npieces());
+  if (npieces() == 1) return sched(which, forward, false, o);
+  if (d.decomp == MFFT_SLAB) {
+    if (which != 0) return set_error(MFFT_ERR_INVALID, "slab plans have one exchange");
+    if (nbatch > 1) {
+      const int64_t i0 = Np0 * piece / nbatch, mb = Np0 * (piece + 1) / nbatch - i0;
+      o->peers = world;
+      o->sc.assign(P, (size_t)(mb * Np1 * Nf) * es);
+      o->rc = o->sc;
+      o->sd.resize(P);
+      o->rd.resize(P);
+      // [r][i][j][k] of the packed layout IS row r*Np0 + i of (N0, Np1, Nf): same blocks in both directions
+      for (int r = 0; r < P; ++r) o->sd[r] = o->rd[r] = (size_t)((r * Np0 + i0) * Np1 * Nf) * es;
+      return 0;
+    }
+    const int64_t k0 = kslice[piece].start, kz = kslice[piece].len;
+    const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es, chunk = (size_t)(Np0 * Np1 * kz) * es;
+    o->peers = world;
+    o->sc.assign(P, chunk);
+    o->rc = o->sc;
+    o->sd.resize(P);
+    o->rd.resize(P);
+    for (int r = 0; r < P; ++r) o->sd[r] = o->rd[r] = boff + (size_t)r * chunk;
+    return 0;
+  }
+  const int64_t m = N1_0, i0 = m * piece / nbatch, mb = m * (piece + 1) / nbatch - i0;
+  return sched_rows(which, forward, i0, mb, o);
 }
 
 // ===========================================================================
@@ -484,7 +522,9 @@ int mfft_plan_s::slab_forward_pipelined(const void* u, void* fu) {
     MFFT_HIP(hipEventRecord(ev_compute[s], stream));
     MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[s], 0));
     MFFT_TRY(stage_on(cstream, "fwd_a2a", 0, [&] {
-      return exchange_equal(world, B + boff, Cr + boff, (size_t)(Np0 * Np1 * kz) * es, cstream);
+      Sched sc;
+      MFFT_TRY(piece_sched(0, true, s, &sc));
+      return run_sched(sc, B, Cr, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev_comm[s], cstream));
   }
@@ -516,7 +556,9 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
     MFFT_HIP(hipEventRecord(ev_compute[s], stream));
     MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[s], 0));
     MFFT_TRY(stage_on(cstream, "bwd_a2a", 0, [&] {
-      return exchange_equal(world, A + boff, B + boff, (size_t)(Np0 * Np1 * kz) * es, cstream);
+      Sched sc;
+      MFFT_TRY(piece_sched(0, false, s, &sc));
+      return run_sched(sc, A, B, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev_comm[s], cstream));
   }
@@ -539,21 +581,6 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
 // rows.  Compared with the kz slices: the z transform is overlapped instead of the x transform, no strided kz
 // sub-columns, one work buffer less in the forward direction.  Which one is faster depends on the links; bench.py
 // measures both.
-static void slab_row_sched(const mfft_plan_s* p, bool forward, int64_t i0, int64_t mb, Sched* o) {
-  (void)forward;      // both directions move the same blocks: [r][i][j][k] of the packed layout IS row r*Np0+i of (N0, Np1, Nf)
-  const int P = p->P;
-  o->peers = p->world;
-  o->sc.assign(P, (size_t)(mb * p->Np1 * p->Nf) * p->es);
-  o->rc = o->sc;
-  o->sd.resize(P);
-  o->rd.resize(P);
-  for (int r = 0; r < P; ++r) {
-    const size_t blk = (size_t)((r * p->Np0 + i0) * p->Np1 * p->Nf) * p->es;      // [r][i][j][k] == row x = r*Np0 + i
-    o->sd[r] = blk;
-    o->rd[r] = blk;
-  }
-}
-
 int mfft_plan_s::slab_forward_rows(const void* u, void* fu) {
   const double Cb = (double)(N0 * Np1 * Nf) * es, Rb = (double)(Np0 * N1 * N2) * rs;
   const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
@@ -574,7 +601,7 @@ int mfft_plan_s::slab_forward_rows(const void* u, void* fu) {
     MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[b], 0));
     MFFT_TRY(stage_on(cstream, "fwd_a2a", 0, [&] {
       Sched sc;
-      slab_row_sched(this, true, i0, mb, &sc);
+      MFFT_TRY(piece_sched(0, true, b, &sc));
       return run_sched(sc, Bk, fu, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
@@ -599,10 +626,9 @@ int mfft_plan_s::slab_backward_rows(const void* src, void* u) {
   MFFT_HIP(hipEventRecord(ev_compute[0], stream));
   MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[0], 0));
   for (int b = 0; b < B; ++b) {
-    const int64_t i0 = Np0 * b / B, mb = Np0 * (b + 1) / B - i0;
     MFFT_TRY(stage_on(cstream, "bwd_a2a", 0, [&] {
       Sched sc;
-      slab_row_sched(this, false, i0, mb, &sc);
+      MFFT_TRY(piece_sched(0, false, b, &sc));
       return run_sched(sc, A, Bk, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
@@ -860,7 +886,7 @@ int mfft_plan_s::pencil_forward_pipelined_x(const void* u, void* fu) {
     MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[b], 0));
     MFFT_TRY(stage_on(cstream, "fwd_a2a_1", 0, [&] {
       Sched sc;
-      MFFT_TRY(sched_rows(0, true, i0, mb, &sc));
+      MFFT_TRY(piece_sched(0, true, b, &sc));
       return run_sched(sc, W1, W2, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
@@ -882,7 +908,7 @@ int mfft_plan_s::pencil_forward_pipelined_x(const void* u, void* fu) {
     MFFT_HIP(hipStreamWaitEvent(cstream, ev2_compute[b], 0));
     MFFT_TRY(stage_on(cstream, "fwd_a2a_2", 0, [&] {
       Sched sc;
-      MFFT_TRY(sched_rows(1, true, i0, mb, &sc));
+      MFFT_TRY(piece_sched(1, true, b, &sc));
       return run_sched(sc, ydst, out, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev2_comm[b], cstream));
@@ -916,7 +942,7 @@ int mfft_plan_s::pencil_backward_pipelined_x(const void* src, void* u) {
       rows(b, &i0, &mb);
       MFFT_TRY(stage_on(cstream, "bwd_a2a_2", 0, [&] {
         Sched sc;
-        MFFT_TRY(sched_rows(1, false, i0, mb, &sc));
+        MFFT_TRY(piece_sched(1, false, b, &sc));
         return run_sched(sc, W0, W1, cstream);
       }));
       MFFT_HIP(hipEventRecord(ev2_comm[b], cstream));
@@ -937,7 +963,7 @@ int mfft_plan_s::pencil_backward_pipelined_x(const void* src, void* u) {
     MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[b], 0));
     MFFT_TRY(stage_on(cstream, "bwd_a2a_1", 0, [&] {       // all bwd_a2a_2 are ahead of it on this stream: W0 is free
       Sched sc;
-      MFFT_TRY(sched_rows(0, false, i0, mb, &sc));
+      MFFT_TRY(piece_sched(0, false, b, &sc));
       return run_sched(sc, W2, W0, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
@@ -1375,6 +1401,27 @@ int mfft_plan_exchange_schedule(const mfft_plan_desc* desc, int nranks, int rank
   MFFT_TRY(decomp_init(&p, desc, nranks, rank));
   Sched sc;
   MFFT_TRY(p.sched(which, forward != 0, padded != 0, &sc));
+  *npeers = (int)sc.peers.size();
+  if (*npeers > max_peers) return set_error(MFFT_ERR_INVALID, "schedule has %d peers, room for %d", *npeers, max_peers);
+  for (int i = 0; i < *npeers; ++i) {
+    if (peers) peers[i] = sc.peers[i];
+    if (scount) scount[i] = sc.sc[i];
+    if (sdisp) sdisp[i] = sc.sd[i];
+    if (rcount) rcount[i] = sc.rc[i];
+    if (rdisp) rdisp[i] = sc.rd[i];
+  }
+  return 0;
+}
+
+int mfft_plan_exchange_pieces(const mfft_plan_desc* desc, int nranks, int rank, int which, int forward, int piece,
+                              int max_peers, int* npieces, int* npeers, int* peers, size_t* scount, size_t* sdisp,
+                              size_t* rcount, size_t* rdisp) {
+  if (!desc || !npeers || !npieces) return set_error(MFFT_ERR_INVALID, "null argument");
+  mfft_plan_s p;
+  MFFT_TRY(decomp_init(&p, desc, nranks, rank));
+  *npieces = p.npieces();
+  Sched sc;
+  MFFT_TRY(p.piece_sched(which, forward != 0, piece, &sc));
   *npeers = (int)sc.peers.size();
   if (*npeers > max_peers) return set_error(MFFT_ERR_INVALID, "schedule has %d peers, room for %d", *npeers, max_peers);
   for (int i = 0; i < *npeers; ++i) {

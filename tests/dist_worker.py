@@ -44,6 +44,75 @@ def exchange(rank, sched, send, recv_bytes):
     return recv.view(np.complex128)
 
 
+def exchange_pieces(rank, pieces, send, recv_bytes):
+    """A pipelined exchange, piece by piece into ONE receive buffer (displacements are relative to the whole buffers)."""
+    send = np.ascontiguousarray(send).view(np.uint8).reshape(-1)
+    recv = np.zeros(recv_bytes, dtype=np.uint8)
+    got = 0
+    for sched in pieces:
+        reqs, keep = [], []
+        for i, peer in enumerate(sched["peers"]):
+            sc, sd, rc, rd = (sched[k][i] for k in ("scount", "sdisp", "rcount", "rdisp"))
+            got += rc
+            if peer == rank:
+                recv[rd:rd + rc] = send[sd:sd + sc]
+                continue
+            t_out = torch.from_numpy(send[sd:sd + sc].copy())
+            t_in = torch.from_numpy(recv[rd:rd + rc])
+            keep += [t_out, t_in]
+            reqs.append(dist.isend(t_out, dst=peer))
+            reqs.append(dist.irecv(t_in, src=peer))
+        for r in reqs:
+            r.wait()
+    assert got == recv_bytes, (got, recv_bytes)          # the pieces tile the receive buffer exactly
+    return recv.view(np.complex128)
+
+
+def slab_pipelined(rank, P, N, A, pipeline):
+    """The device path's DEFAULT multi-rank slab transform (kz slices) and its row-batch flavour, with the piece
+    schedules of mfft_plan_exchange_pieces -- the ones the executor hands to RCCL piece by piece."""
+    lay = orc.SlabLayout(N, P)
+    want = orc.slab_r2c_forward(orc.scatter_real(A, lay), N)
+    Np0, Np1, Nf = int(lay.Np[0]), int(lay.Np[1]), lay.Nf
+    u = np.ascontiguousarray(A[lay.real_local_slice(rank)])
+    a = np.fft.rfft2(u, axes=(1, 2))                                      # (Np0, N1, Nf)
+    total = Np0 * N[1] * Nf * ES
+    fwd = _lib.exchange_pieces(N, P, rank, _lib.SLAB, 0, True, pipeline)
+    bwd = _lib.exchange_pieces(N, P, rank, _lib.SLAB, 0, False, pipeline)
+    packed = orc.slab_pack(a, P)                                          # (P, Np0, Np1, Nf)
+    if pipeline < 0:        # row batches: the packed layout itself, pieces = row ranges of every peer block
+        assert len(fwd) == min(-pipeline, Np0)
+        r = exchange_pieces(rank, fwd, packed, total)
+        fu = np.fft.fft(r.reshape(N[0], Np1, Nf), axis=0)
+        assert orc.rel_l2(fu, want[rank]) < 1e-13
+        r = exchange_pieces(rank, bwd, np.fft.ifft(fu, axis=0), total)
+        back = np.fft.irfft2(orc.slab_unpack(r.reshape(P, Np0, Np1, Nf)), s=(N[1], N[2]), axes=(1, 2))
+        assert orc.rel_l2(back, u) < 1e-13
+        return
+    # kz slices: send / receive buffers hold slice after slice, each packed as (P, Np0, Np1, kz_s)
+    kz = [p["scount"][0] // (Np0 * Np1 * ES) for p in fwd]
+    k0 = np.concatenate([[0], np.cumsum(kz)[:-1]]).astype(int)
+    assert sum(kz) == Nf and all(p["sdisp"][0] == P * Np0 * Np1 * int(k) * ES for p, k in zip(fwd, k0))
+    send = np.concatenate([packed[:, :, :, k:k + w].ravel() for k, w in zip(k0, kz)])
+    r = exchange_pieces(rank, fwd, send, total)
+    fu = np.empty((N[0], Np1, Nf), dtype=complex)
+    off = 0
+    for k, w in zip(k0, kz):
+        fu[:, :, k:k + w] = np.fft.fft(r[off:off + N[0] * Np1 * w].reshape(N[0], Np1, w), axis=0)
+        off += N[0] * Np1 * w
+    assert orc.rel_l2(fu, want[rank]) < 1e-13
+    b = np.fft.ifft(fu, axis=0)
+    send = np.concatenate([b[:, :, k:k + w].ravel() for k, w in zip(k0, kz)])
+    r = exchange_pieces(rank, bwd, send, total)
+    t = np.empty((Np0, N[1], Nf), dtype=complex)
+    off = 0
+    for k, w in zip(k0, kz):
+        t[:, :, k:k + w] = orc.slab_unpack(r[off:off + N[0] * Np1 * w].reshape(P, Np0, Np1, w))
+        off += N[0] * Np1 * w
+    back = np.fft.irfft2(t, s=(N[1], N[2]), axes=(1, 2))
+    assert orc.rel_l2(back, u) < 1e-13
+
+
 def slab(rank, P, N, A):
     lay = orc.SlabLayout(N, P)
     want = orc.slab_r2c_forward(orc.scatter_real(A, lay), N)
@@ -63,8 +132,17 @@ def slab(rank, P, N, A):
     assert orc.rel_l2(back, u) < 1e-13
 
 
-def pencil(rank, P, N, A, align, P1=None):
+def pencil(rank, P, N, A, align, P1=None, pipeline=1):
+    """pipeline != 1 (X alignment): every exchange runs piece by piece with the schedules of
+    mfft_plan_exchange_pieces (batches of local x rows), into the same buffers as the un-pipelined exchange."""
     lay = orc.PencilLayout(N, P, P1, align)
+
+    def exchange(rank_, sched, send, recv_bytes, which=None, forward=None):
+        if pipeline == 1 or align != "X":
+            return globals()["exchange"](rank_, sched, send, recv_bytes)
+        pieces = _lib.exchange_pieces(N, P, rank, dec, which, forward, pipeline, p1=P1 or 0)
+        assert len(pieces) == min(pipeline if pipeline > 0 else 4, int(lay.N1[0]))
+        return exchange_pieces(rank_, pieces, send, recv_bytes)
     want = orc.pencil_r2c_forward(orc.scatter_real(A, lay), N, P1, align)
     c0, c1 = lay.ranks(rank)
     m, n, Nf = int(lay.N1[0]), int(lay.N2[1]), lay.Nf
@@ -80,14 +158,14 @@ def pencil(rank, P, N, A, align, P1=None):
     send = np.concatenate([a[:, :, st:st + ln].ravel() for ln, st in zip(lens, starts)])
     q = s0["rcount"][0] // (m * n * ES)
     assert q == lay.complex_shape(rank)[2]
-    r = exchange(rank, s0, send, sum(s0["rcount"]))
+    r = exchange(rank, s0, send, sum(s0["rcount"]), 0, True)
     blocks = r.reshape(len(lens), m, n, q)
     s1 = _lib.exchange_schedule(N, P, rank, dec, 1, True, p1=P1 or 0)
     if align == "X":
         b = np.fft.fft(np.concatenate(list(blocks), axis=1), axis=1)              # (m, N1, q)
         assert s1["peers"] == lay.comm0_members(rank)
         send = np.concatenate([b[:, l * N1_1:(l + 1) * N1_1, :].ravel() for l in range(lay.P1)])
-        r = exchange(rank, s1, send, sum(s1["rcount"]))
+        r = exchange(rank, s1, send, sum(s1["rcount"]), 1, True)
         fu = np.fft.fft(r.reshape(N[0], N1_1, q), axis=0)
     else:
         b = np.fft.fft(np.concatenate(list(blocks), axis=0), axis=0)              # (N0, n, q)
@@ -102,7 +180,7 @@ def pencil(rank, P, N, A, align, P1=None):
     s0b = _lib.exchange_schedule(N, P, rank, dec, 0, False, p1=P1 or 0)
     if align == "X":
         b = np.fft.ifft(fu, axis=0)                                                  # x chunks contiguous
-        r = exchange(rank, s1b, b, sum(s1b["rcount"]))
+        r = exchange(rank, s1b, b, sum(s1b["rcount"]), 1, False)
         blocks = r.reshape(lay.P1, m, N1_1, q)
         b = np.fft.ifft(np.concatenate(list(blocks), axis=1), axis=1)               # (m, N1, q)
         send = np.concatenate([b[:, l * n:(l + 1) * n, :].ravel() for l in range(lay.P2)])
@@ -111,7 +189,7 @@ def pencil(rank, P, N, A, align, P1=None):
         send = np.concatenate([b[:, l * n:(l + 1) * n, :].ravel() for l in range(lay.P2)])
         r = exchange(rank, s1b, send, sum(s1b["rcount"]))
         send = np.fft.ifft(r.reshape(N[0], n, q), axis=0)                            # x chunks contiguous
-    r = exchange(rank, s0b, send, sum(s0b["rcount"]))
+    r = exchange(rank, s0b, send, sum(s0b["rcount"]), 0, False)
     z = np.zeros((m, n, Nf), dtype=complex)
     off = 0
     for ln, st in zip(lens, starts):
@@ -127,9 +205,17 @@ def main():
     N = [16, 32, 64]
     A = np.random.default_rng(2026).random(N)
     slab(rank, P, N, A)
+    Nw = [16, 32, 256]                                     # Nf = 129: the default depth really is 4 kz slices
+    Aw = np.random.default_rng(2027).random(Nw)
+    assert len(_lib.exchange_pieces(Nw, P, rank, _lib.SLAB, 0, True, 0)) == 4
+    for pipeline in (0, 2, 3, -2, -3, -8):                 # default kz slices, other depths, row batches
+        slab_pipelined(rank, P, N, A, pipeline)
+        slab_pipelined(rank, P, Nw, Aw, pipeline)
     if P >= 4:
         for align in ("X", "Y"):
             pencil(rank, P, N, A, align)
+        for pipeline in (0, 2, 3):                         # x-aligned pencil: batches of local x rows
+            pencil(rank, P, N, A, "X", pipeline=pipeline)
         if P == 8:
             for align in ("X", "Y"):
                 pencil(rank, P, N, A, align, P1=2)
