@@ -151,14 +151,115 @@ def main():
     n = args.n
     N = np.array([n, n, n])
     L = np.array([2 * np.pi] * 3)
+    def measure(pipeline):
+        """W warm-up pairs, then exactly K timed pairs bracketed by stream sync + device sync + barrier."""
+        if args.decomp == "slab":
+            F = Slab_R2C(N, L, comm, args.precision, pipeline=pipeline)
+        else:
+            F = Pencil_R2C(N, L, comm, args.precision, communication="Alltoallw", alignment="X",
+                           allow_single=True, pipeline=pipeline)
+        u = DeviceArray.random(F.real_shape(), F.float, seed=1234 + rank)
+        fu = DeviceArray.empty(F.complex_shape(), F.complex)
+        u2 = DeviceArray.empty(F.real_shape(), F.float)
+
+        def sync_all():
+            F.sync()
+            _lib.call("mfft_device_sync")
+            comm.barrier()
+
+        # stage timing is switched on before the warm-up so that its HIP events exist (and the
+        # queue's timestamping is live) before the timed region starts
+        F.enable_timing(args.stage_timing == "on")
+        for _ in range(args.warmup):
+            F.fftn(u, fu)
+            F.ifftn(fu, u2)
+        sync_all()
+        F.reset_timing()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            F.fftn(u, fu)
+            F.ifftn(fu, u2)
+        F.sync()
+        _lib.call("mfft_device_sync")
+        comm.barrier()
+        dt = time.perf_counter() - t0
+        dt = comm.allreduce(dt, op=mcomm.MAX) if world > 1 else dt
+        stages = F.stage_times()
+        # correctness gate on the data of the timed loop (after it, so that no host copy sits
+        # between warm-up and timed region): round trip of the first x-planes
+        k = max(1, min(F.real_shape()[0], 2))
+        a0 = u.leading(0, k).get()
+        b0 = u2.leading(0, k).get()
+        rt_err = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
+        return {"dt": dt, "stages": stages, "rt_err": rt_err, "pipeline": pipeline}
+
+    def headline(mres, tuning):
+        dt, stages, rt_err = mres["dt"], mres["stages"], mres["rt_err"]
+        esz = 8 if args.precision == "double" else 4
+        R = esz * n ** 3
+        C = 2 * esz * n * n * (n // 2 + 1)
+        alg_pair = 2.0 * (R + 5.0 * C)
+        ms = 1e3 * dt / args.steps
+        # dominant kernel family: the strided-axis c2c (stages *_x, *_y)
+        col = [(k_, v) for k_, v in stages.items() if k_.endswith("_x") or k_.endswith("_y")]
+        col_ms = sum(v[0] for _, v in col)
+        col_calls = sum(v[1] for _, v in col)
+        col_bytes = col[0][1][2] if col else 0.0
+        avg_ms = col_ms / max(col_calls, 1)
+        achieved = (col_bytes / (avg_ms * 1e-3)) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(n, args.precision, args.decomp, world)
+        return {
+            "metric": "3D R2C+C2R pairs/sec, %d^3 %s %s" % (n, "fp64" if args.precision == "double" else "fp32", args.decomp),
+            "value": args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64" if args.precision == "double" else "f32",
+            "data": "synthetic",
+            "config": {"workload": "%d^3 %s %s R2C forward+inverse, device-resident, %d rank(s)"
+                                   % (n, "fp64" if args.precision == "double" else "fp32", args.decomp, world),
+                       "roundtrip_rel_l2": rt_err,
+                       "exchange_pipeline_depth": mres["pipeline"] if world > 1 else None,
+                       "exchange_pipeline_tuning_ms_per_pair": tuning,
+                       "alg_bytes_per_pair": alg_pair,
+                       "whole_path_hbm_GBs_per_gpu": alg_pair / world / (ms * 1e-3) / 1e9,
+                       "whole_path_frac_of_8TBs": alg_pair / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "whole_path_frac_of_6.29TBs_copy_ceiling": alg_pair / world / (ms * 1e-3) / 1e9 / 6290.0,
+                       "stage_ms": {k_: v[0] / max(v[1], 1) for k_, v in sorted(stages.items())}},
+            "roofline": {"bound": "hbm", "kernel": "col_fft (strided-axis c2c, stages *_x/*_y)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "alg_bytes_per_launch": col_bytes, "avg_launch_ms": avg_ms},
+        }
+
+    import threading
+
+    def arm_watchdog(seconds, fallback_line, why):
+        """If the work that follows does not finish, rank 0 prints `fallback_line` (a complete, valid measurement
+        taken earlier) and every rank leaves: a number must survive a transport problem in an optional step."""
+        def give_up():
+            if rank == 0 and fallback_line is not None:
+                fallback_line["extras"] = {"note": why}
+                fallback_line.setdefault("cpu_baseline", None)
+                sys.stdout.write(json.dumps(fallback_line) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+        t = threading.Timer(seconds, give_up)
+        t.daemon = True
+        t.start()
+        return t
+
     tuning = None
     if args.decomp == "slab" and world > 1 and args.pipeline == 0:
-        # exchange pipeline (flavour and depth) measured on this machine's links before the warm-up, like a planner's
-        # MEASURE mode: 2 untimed + 2 timed pairs per candidate, slowest rank counts
-        tuning = {}
+        # 1. the plain, blocking exchange: W + K pairs, a complete measurement that is also the fallback line
+        base = measure(1)
+        tuning = {1: 1e3 * base["dt"] / args.steps}
+        fallback = headline(base, {"note": "blocking exchange; the pipelined candidates did not finish"}) if rank == 0 else None
+        dog = arm_watchdog(600.0, fallback, "the pipelined exchange candidates did not finish within 600 s")
+        # 2. exchange pipeline (flavour and depth) measured on this machine's links, like a planner's MEASURE mode:
+        #    2 untimed + 2 timed pairs per candidate, slowest rank counts
         try:
             ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
-            for depth in (1, 2, 4, 8, -2, -4, -8):        # kz slices / (negative) batches of local x rows
+            for depth in (2, 4, 8, -2, -4, -8):           # kz slices / (negative) batches of local x rows
                 Ft = Slab_R2C(N, L, comm, args.precision, pipeline=depth)
                 fut = DeviceArray.empty(Ft.complex_shape(), Ft.complex)
                 for it in range(4):
@@ -173,89 +274,17 @@ def main():
                 tuning[depth] = comm.allreduce((time.perf_counter() - tt) / 2, op=mcomm.MAX) * 1e3
                 del Ft, fut
             del ut
-            args.pipeline = min(tuning, key=tuning.get)
-        except Exception as e:      # noqa: BLE001  - every rank takes the same path: fall back to the default depth
-            sys.stderr.write("pipeline tuning failed (%s: %s); using the default depth\n" % (type(e).__name__, e))
-            tuning = {"error": "%s: %s" % (type(e).__name__, e)}
-            args.pipeline = 4
-    if args.decomp == "slab":
-        F = Slab_R2C(N, L, comm, args.precision, pipeline=args.pipeline)
+            best = min(tuning, key=tuning.get)
+        except Exception as e:      # noqa: BLE001  - every rank takes the same path
+            sys.stderr.write("pipeline tuning failed (%s: %s); keeping the blocking exchange\n" % (type(e).__name__, e))
+            tuning["error"] = "%s: %s" % (type(e).__name__, e)
+            best = 1
+        # 3. the timed region with the best candidate (the first measurement stands if nothing beats it)
+        mres = base if best == 1 else measure(best)
+        dog.cancel()
     else:
-        F = Pencil_R2C(N, L, comm, args.precision, communication="Alltoallw", alignment="X",
-                       allow_single=True, pipeline=args.pipeline)
-    u = DeviceArray.random(F.real_shape(), F.float, seed=1234 + rank)
-    fu = DeviceArray.empty(F.complex_shape(), F.complex)
-    u2 = DeviceArray.empty(F.real_shape(), F.float)
-
-    def sync_all():
-        F.sync()
-        _lib.call("mfft_device_sync")
-        comm.barrier()
-
-    # stage timing is switched on before the warm-up so that its HIP events exist (and the
-    # queue's timestamping is live) before the timed region starts
-    F.enable_timing(args.stage_timing == "on")
-    for _ in range(args.warmup):
-        F.fftn(u, fu)
-        F.ifftn(fu, u2)
-    sync_all()
-    F.reset_timing()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        F.fftn(u, fu)
-        F.ifftn(fu, u2)
-    F.sync()
-    _lib.call("mfft_device_sync")
-    comm.barrier()
-    dt = time.perf_counter() - t0
-    dt = comm.allreduce(dt, op=mcomm.MAX) if world > 1 else dt
-    stages = F.stage_times()
-    # correctness gate on the data of the timed loop (after it, so that no host copy sits
-    # between warm-up and timed region): round trip of the first x-planes
-    k = max(1, min(F.real_shape()[0], 2))
-    a0 = u.leading(0, k).get()
-    b0 = u2.leading(0, k).get()
-    rt_err = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
-
-    def headline():
-        esz = 8 if args.precision == "double" else 4
-        R = esz * n ** 3
-        C = 2 * esz * n * n * (n // 2 + 1)
-        alg_pair = 2.0 * (R + 5.0 * C)
-        ms = 1e3 * dt / args.steps
-        # dominant kernel family: the strided-axis c2c (stages *_x, *_y)
-        col = [(k_, v) for k_, v in stages.items() if k_.endswith("_x") or k_.endswith("_y")]
-        col_ms = sum(v[0] for _, v in col)
-        col_calls = sum(v[1] for _, v in col)
-        col_bytes = col[0][1][2] if col else 0.0
-        avg_ms = col_ms / max(col_calls, 1)
-        achieved = (col_bytes / (avg_ms * 1e-3)) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(n, args.precision, args.decomp, world)
-        out = {
-            "metric": "3D R2C+C2R pairs/sec, %d^3 %s %s" % (n, "fp64" if args.precision == "double" else "fp32", args.decomp),
-            "value": args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64" if args.precision == "double" else "f32",
-            "data": "synthetic",
-            "config": {"workload": "%d^3 %s %s R2C forward+inverse, device-resident, %d rank(s)"
-                                   % (n, "fp64" if args.precision == "double" else "fp32", args.decomp, world),
-                       "roundtrip_rel_l2": rt_err,
-                       "exchange_pipeline_depth": args.pipeline if world > 1 else None,
-                       "exchange_pipeline_tuning_ms_per_pair": tuning,
-                       "alg_bytes_per_pair": alg_pair,
-                       "whole_path_hbm_GBs_per_gpu": alg_pair / world / (ms * 1e-3) / 1e9,
-                       "whole_path_frac_of_8TBs": alg_pair / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "whole_path_frac_of_6.29TBs_copy_ceiling": alg_pair / world / (ms * 1e-3) / 1e9 / 6290.0,
-                       "stage_ms": {k_: v[0] / max(v[1], 1) for k_, v in sorted(stages.items())}},
-            "roofline": {"bound": "hbm", "kernel": "col_fft (strided-axis c2c, stages *_x/*_y)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "alg_bytes_per_launch": col_bytes, "avg_launch_ms": avg_ms},
-        }
-        return out
-
-    out = headline() if rank == 0 else None
+        mres = measure(args.pipeline)
+    out = headline(mres, tuning) if rank == 0 else None
 
     # ---- secondary measurement: the pencil path on the same cube (needs a P1 x P2 grid with
     # even factors, i.e. 4 or 8 ranks, or the degenerate 1 x 1 grid as the 1-GPU denominator)
@@ -264,24 +293,9 @@ def main():
                                                  and world in (1, 4, 8, 16))
     watchdog = None
     if want_pencil and world > 1:
-        # The headline number must survive whatever happens in this secondary measurement: if it has not finished
-        # after 5 minutes (e.g. a transport problem that only shows up in the sub-group exchanges), rank 0 prints
-        # the line without it and every rank leaves.
-        import threading
-
-        def give_up():
-            if rank == 0:
-                out["extras"] = {"pencil_R2CX": {"error": "timed out after 300 s"}}
-                out["cpu_baseline"] = None
-                sys.stdout.write(json.dumps(out) + "\n")
-                sys.stdout.flush()
-            os._exit(0)
-        watchdog = threading.Timer(300.0, give_up)
-        watchdog.daemon = True
-        watchdog.start()
+        watchdog = arm_watchdog(300.0, out, "the pencil measurement did not finish within 300 s")
     if want_pencil:
         try:
-            del F
             Fp = Pencil_R2C(N, L, comm, args.precision, communication="Alltoallw", alignment="X", allow_single=True)
             up = DeviceArray.random(Fp.real_shape(), Fp.float, seed=99 + rank)
             fup = DeviceArray.empty(Fp.complex_shape(), Fp.complex)
