@@ -321,8 +321,6 @@ struct mfft_plan_s {
   int slab_backward_rows(const void* src, void* u);
   int pencil_forward_pipelined_x(const void* u, void* fu);
   int pencil_backward_pipelined_x(const void* src, void* u);
-  bool placed = false;
-  int place_work0(const void* src, size_t cb);
   int sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sched* out) const;
   // pieces of the pipelined exchanges (host only; the executors and mfft_plan_exchange_pieces share it)
   int npieces() const { return nbatch > 1 ? nbatch : nslice > 1 ? nslice : 1; }
@@ -470,54 +468,6 @@ int mfft_plan_s::apply_mask_copy(const void* fu, void** masked_out) {
   return 0;
 }
 
-// Planner-style placement of the work buffer of the one-rank inverse.  Its first pass (x, out of place: spectrum ->
-// work buffer) runs at 3.65 or 3.88 ms at 1024^3 depending on where hipMalloc happened to put the buffer relative to
-// the spectrum (same virtual alignment either way; measured in 6 of 8 placements the slow one).  For buffers of
-// 256 MB and more, up to five candidates are allocated and the pass is timed once on each (stopping as soon as both
-// modes have been seen, i.e. two timings 4 % apart); the fastest stays.
-// MFFT_PLACE=0 switches it off.
-int mfft_plan_s::place_work0(const void* src, size_t cb) {
-  placed = true;
-  static const int enabled = getenv("MFFT_PLACE") ? atoi(getenv("MFFT_PLACE")) : 1;
-  size_t free_b = 0, total_b = 0;
-  if (!enabled || cb < ((size_t)256 << 20)) return 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * cb) return 0;
-  const int NC = free_b >= 7 * cb ? 5 : 3;
-  void* cand[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  float best_ms = 0, worst_ms = 0;
-  int best = -1;
-  hipEvent_t e0, e1;
-  MFFT_HIP(hipEventCreate(&e0));
-  MFFT_HIP(hipEventCreate(&e1));
-  for (int c = 0; c < NC; ++c) {
-    if (hipMalloc(&cand[c], cb) != hipSuccess) { cand[c] = nullptr; (void)hipGetLastError(); break; }
-    float ms = 0;
-    for (int rep = 0; rep < 2; ++rep) {          // first run warms the kernel up, second is timed
-      MFFT_HIP(hipEventRecord(e0, stream));
-      const int rc = col(src, cand[c], N0, true, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf));
-      if (rc != 0) { best = -2; break; }
-      MFFT_HIP(hipEventRecord(e1, stream));
-      MFFT_HIP(hipEventSynchronize(e1));
-      MFFT_HIP(hipEventElapsedTime(&ms, e0, e1));
-    }
-    if (best == -2) break;
-    if (best < 0 || ms < best_ms) { best = c; best_ms = ms; }
-    if (ms > worst_ms) worst_ms = ms;
-    if (worst_ms > 1.04f * best_ms) break;       // both modes seen
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  for (int c = 0; c < 5; ++c)
-    if (cand[c] && c != best) (void)hipFree(cand[c]);
-  if (best >= 0) {
-    if (work[0]) (void)hipFree(work[0]);
-    drop_graphs();
-    work[0] = cand[best];
-    work_bytes[0] = cb;
-  }
-  return 0;
-}
-
 int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
   const double Cb = (double)(N0 * Np1 * Nf) * es;
   const double Rb = (double)(Np0 * N1 * N2) * rs;
@@ -528,7 +478,6 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     src = m;
   }
   const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
-  if (P == 1 && !placed && work_bytes[0] < cb) MFFT_TRY(place_work0(src, cb));
   MFFT_TRY(ensure_work(0, cb));
   void* A = work[0];
   if (P == 1) {
