@@ -186,6 +186,7 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.remap = a.remap;
   P.fold = a.fold ? 1 : 0;
   P.scale = (T)a.scale;
+  P.nblocks = 0;
   const int64_t grid = (int64_t)P.ntile_c * a.nouter;
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large (%lld tiles)", (long long)grid);
@@ -209,17 +210,21 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   auto aligned = [&](const void* p, int64_t outer, const RowSpec& r) {
     return ((uintptr_t)p % 128 == 0) && outer % per_line == 0 && r.lo % per_line == 0 && r.hi % per_line == 0;
   };
-  // (measured at 1024^3: out-of-place x pass 3.87 -> 3.65 ms with NT, in-place x pass 3.62 -> 3.85 ms)
-  static const int nt_mode = getenv("MFFT_NT") ? atoi(getenv("MFFT_NT")) : 1;   // 0 never, 1 out-of-place, 2 always
-  const bool nt = a.allow_nt && nt_mode > 0 && (nt_mode == 2 || a.in != a.out) &&
-                  aligned(a.in, a.in_outer, a.in_rows) && aligned(a.out, a.out_outer, a.out_rows);
+  // Out of place the NT variant is always ahead (1024^3 x pass 3.70 -> 3.63 ms at one workgroup per CU, 3.24 -> 3.19 ms at
+  // two); in place only the kernels that run two workgroups per CU gain from it (3.42 -> 3.35 ms; one per CU: 3.57 -> 3.84 ms)
+  static const int nt_mode = getenv("MFFT_NT") ? atoi(getenv("MFFT_NT")) : 1;   // 0 never, 1 by that rule, 2 always
+  const KernelEntry* ent = nullptr;
+  if (a.allow_nt && nt_mode > 0 && !a.pad && aligned(a.in, a.in_outer, a.in_rows) && aligned(a.out, a.out_outer, a.out_rows)) {
+    ent = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1);
+    if (ent && a.in == a.out && !(ent->nt_inplace || nt_mode == 2)) ent = nullptr;
+  }
   const KernelEntry* e = nullptr;
   if (a.pad) {
     if ((a.pad == 1) != a.inverse) return set_error(MFFT_ERR_INVALID, "pad-on-load is an inverse-transform mode, truncate-on-store a forward one");
     e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0, a.pad);
     if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no fused 3/2-rule kernel for length %d", a.n);
   }
-  if (!e && nt) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1);
+  if (!e && ent) e = ent;
   if (!e) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0);
   void* tw = nullptr;
   if (!e) {   // no radix plan for this length: chirp-z on the next compiled length >= 2n-1

@@ -690,7 +690,7 @@ int main() {
   test_chirpz_all<Spec<160, 4, 4, 5, 2>>();
 #endif
 #if EMU_HAS(1)
-  MFFT_PLANS_B(MFFT_PLAN) MFFT_PLANS_C(MFFT_PLAN) MFFT_COLPLANS_F32_C(MFFT_PLAN)
+  MFFT_PLANS_B(MFFT_PLAN) MFFT_PLANS_C(MFFT_PLAN) MFFT_COLPLANS_F32_C(MFFT_PLAN) MFFT_COLPLANS_F64_B(MFFT_PLAN)
 #endif
 #if EMU_HAS(2)
   MFFT_PLANS_D(MFFT_PLAN) MFFT_PLANS_E(MFFT_PLAN)

@@ -84,6 +84,7 @@ struct ColParams {
   int remap;             // 1: XCD-aware block -> tile mapping
   int fold;              // PAD == 2: 1 = add the Nyquist row N/3 into row 2N/3 before it is stored
   T scale;
+  int nblocks;           // persistent experiment (fft_persist_experiment.h): workgroups launched; unused by ColFft
 };
 
 template <typename T>
@@ -236,13 +237,14 @@ struct XchSplitV {
   }
 };
 
-template <class S, int P, typename T, int VEC, class TwPtr, class Xch>
+// PB0: also synchronise before the FIRST scatter (persistent kernels: the previous tile's last gather)
+template <class S, int P, typename T, int VEC, class TwPtr, class Xch, bool PB0 = false>
 MFFT_D void run_passes_v(cx<T> (&v)[VEC][S::E], int j, TwPtr tw, Xch& xch) {
 #pragma unroll
   for (int i = 0; i < VEC; ++i) pass_compute<S, P, T>(v[i], j, tw);
   if constexpr (P + 1 < S::NP) {
-    xch.template exchange<S, P>(v, j, P > 0);
-    run_passes_v<S, P + 1, T, VEC>(v, j, tw, xch);
+    xch.template exchange<S, P>(v, j, P > 0 || PB0);
+    run_passes_v<S, P + 1, T, VEC, TwPtr, Xch, PB0>(v, j, tw, xch);
   }
 }
 

@@ -1,0 +1,314 @@
+// kbench3.hip -- persistent (register double-buffered) strided-axis kernel against the per-tile one
+// (developer tool, not part of the library).  Interleaved rounds in one process, results compared.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 kbench3.hip -o build/kbench3 && build/kbench3 [filter] [rounds]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+#include "fft_kernels.h"
+#include "fft_persist_experiment.h"
+#include "twiddle.h"
+
+using namespace mfft;
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__);  \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+template <class K, class P>
+__global__ __launch_bounds__(K::THREADS) void kern(P p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
+}
+
+template <typename T>
+struct Variant {
+  std::string name;
+  bool persistent;
+  int cols;
+  std::function<void(const ColParams<T>&, int)> launch;   // (params, grid)
+  std::vector<cx<T>> tw;
+};
+
+template <class K, typename T>
+void launch_k(const ColParams<T>& p, int grid) {
+  static bool attr = false;
+  if (!attr) {
+    if (K::LDS_BYTES > 65536)
+      CK(hipFuncSetAttribute((const void*)kern<K, ColParams<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+    attr = true;
+  }
+  hipLaunchKernelGGL((kern<K, ColParams<T>>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, 0, p);
+}
+
+template <class S, typename T, int COLS, bool TWLDS, bool SPLIT, int VEC, bool NT = false>
+Variant<T> make_tile(const char* plan) {
+  typedef ColFft<S, T, COLS, false, TWLDS, SPLIT, VEC, NT> K;
+  char nm[128];
+  snprintf(nm, sizeof nm, "tile    %s c%d v%d%s%s%s thr%d lds%dK", plan, COLS, VEC, TWLDS ? " twlds" : "", SPLIT ? " split" : "", NT ? " nt" : "", K::THREADS,
+           K::LDS_BYTES / 1024);
+  return Variant<T>{nm, false, COLS, &launch_k<K, T>, build_pass_twiddles<S, T>()};
+}
+template <class S, typename T, int COLS, int VEC>
+Variant<T> make_persist(const char* plan) {
+  typedef ColFftP<S, T, COLS, false, VEC> K;
+  char nm[128];
+  snprintf(nm, sizeof nm, "persist %s c%d v%d thr%d lds%dK", plan, COLS, VEC, K::THREADS, K::LDS_BYTES / 1024);
+  return Variant<T>{nm, true, COLS, &launch_k<K, T>, build_pass_twiddles<S, T>()};
+}
+
+static int g_pgrid = 256;
+
+template <typename T>
+void run_all(std::vector<Variant<T>>& vs, int N, const char* filter, int rounds) {
+  const int NF = N / 2 + 1;
+  const size_t elems = (size_t)N * N * NF;
+  cx<T>*src = nullptr, *buf = nullptr, *ref = nullptr;
+  CK(hipMalloc(&src, elems * sizeof(cx<T>)));
+  CK(hipMalloc(&buf, elems * sizeof(cx<T>)));
+  CK(hipMalloc(&ref, elems * sizeof(cx<T>)));
+  {
+    std::vector<cx<T>> h((size_t)4 * N * NF);
+    for (size_t i = 0; i < h.size(); ++i)
+      h[i] = mk<T>((T)((double)((i * 2654435761u) % 1000) / 1000.0 - 0.5), (T)((double)((i * 40503u) % 977) / 977.0 - 0.5));
+    for (size_t off = 0; off < elems; off += h.size())
+      CK(hipMemcpy(src + off, h.data(), std::min(h.size(), elems - off) * sizeof(cx<T>), hipMemcpyHostToDevice));
+  }
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const double alg_bytes = 2.0 * elems * sizeof(cx<T>);
+  struct Layout { const char* name; bool xdir; bool inplace; };
+  const Layout layouts[] = {{"y inplace", false, true}, {"x inplace", true, true}, {"x outofplace", true, false}};
+  std::vector<cx<T>*> twd(vs.size());
+  for (size_t i = 0; i < vs.size(); ++i) {
+    CK(hipMalloc(&twd[i], vs[i].tw.size() * sizeof(cx<T>)));
+    CK(hipMemcpy(twd[i], vs[i].tw.data(), vs[i].tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+  }
+  std::vector<cx<T>> href(1 << 16), hout(1 << 16);
+  for (const Layout& L : layouts) {
+    printf("== N=%d %s %s\n", N, sizeof(T) == 8 ? "fp64" : "fp32", L.name);
+    std::vector<std::vector<double>> times(vs.size());
+    bool have_ref = false;
+    for (int round = 0; round < rounds; ++round) {
+      for (size_t i = 0; i < vs.size(); ++i) {
+        Variant<T>& v = vs[i];
+        if (filter[0] && !strstr(v.name.c_str(), filter) && i != 0) continue;
+        ColParams<T> P;
+        memset(&P, 0, sizeof P);
+        P.tw = twd[i];
+        P.remap = 1;
+        P.scale = (T)1;
+        if (!L.xdir) {
+          P.in_outer = P.out_outer = (i64)N * NF;
+          P.in_map = P.out_map = make_rowmap(0, NF, N, N);
+          P.ncols = NF;
+          P.nouter = N;
+        } else {
+          P.in_outer = P.out_outer = 0;
+          P.in_map = P.out_map = make_rowmap(0, (i64)N * NF, N, N);
+          P.ncols = N * NF;
+          P.nouter = 1;
+        }
+        P.ntile_c = (P.ncols + v.cols - 1) / v.cols;
+        const int ntiles = P.ntile_c * P.nouter;
+        const int grid = v.persistent ? std::min(g_pgrid, ntiles / 8 * 8 > 0 ? ntiles / 8 * 8 : ntiles) : ntiles;
+        P.nblocks = grid;
+        if (round == 0) {   // correctness: src -> buf (or in place on a copy of src), compare with variant 0
+          CK(hipMemcpy(buf, src, elems * sizeof(cx<T>), hipMemcpyDeviceToDevice));
+          P.in = buf; P.out = buf;
+          v.launch(P, grid);
+          CK(hipDeviceSynchronize());
+          if (!have_ref) {
+            CK(hipMemcpy(ref, buf, elems * sizeof(cx<T>), hipMemcpyDeviceToDevice));
+            have_ref = true;
+          } else {
+            double maxd = 0, maxv = 0;
+            for (size_t off : {(size_t)0, elems / 3, elems / 2, elems - href.size()}) {
+              CK(hipMemcpy(href.data(), ref + off, href.size() * sizeof(cx<T>), hipMemcpyDeviceToHost));
+              CK(hipMemcpy(hout.data(), buf + off, hout.size() * sizeof(cx<T>), hipMemcpyDeviceToHost));
+              for (size_t q = 0; q < href.size(); ++q) {
+                maxd = std::max(maxd, (double)std::fabs(href[q].x - hout[q].x));
+                maxd = std::max(maxd, (double)std::fabs(href[q].y - hout[q].y));
+                maxv = std::max(maxv, (double)std::fabs(href[q].x));
+              }
+            }
+            printf("   check %-44s max|diff| %.3e (max|ref| %.3e)%s\n", v.name.c_str(), maxd, maxv, maxd > 1e-9 * maxv * (sizeof(T) == 8 ? 1 : 1e7) ? "  MISMATCH" : "");
+          }
+        }
+        P.in = L.inplace ? buf : src;
+        P.out = buf;
+        v.launch(P, grid);
+        CK(hipDeviceSynchronize());
+        const int reps = 5;
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) v.launch(P, grid);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        times[i].push_back(ms / reps);
+      }
+    }
+    for (size_t i = 0; i < vs.size(); ++i) {
+      if (times[i].empty()) continue;
+      std::vector<double> t = times[i];
+      std::sort(t.begin(), t.end());
+      printf("   %-48s min %.3f med %.3f max %.3f ms  (%.0f GB/s at median)\n", vs[i].name.c_str(), t.front(), t[t.size() / 2], t.back(),
+             alg_bytes / (t[t.size() / 2] * 1e-3) / 1e9);
+    }
+    fflush(stdout);
+  }
+  for (auto p : twd) CK(hipFree(p));
+  CK(hipFree(src));
+  CK(hipFree(buf));
+  CK(hipFree(ref));
+}
+
+
+// Infinity Cache experiment: the same launch geometry (a section of `np` x-planes for the y pass, or a kz-chunk of
+// `nf` columns for the x pass) either always on the same section (resident in the 256 MiB cache when it fits) or on
+// a different section of a 8.6 GB array every time (served from HBM).
+template <class K, typename T>
+void mall_probe(const char* name, int cols, bool persistent, const std::vector<cx<T>>& twh) {
+  const int N = 1024, NF = 513;
+  const size_t elems = (size_t)N * N * NF;
+  cx<T>* buf = nullptr;
+  CK(hipMalloc(&buf, elems * sizeof(cx<T>)));
+  CK(hipMemset(buf, 0, elems * sizeof(cx<T>)));
+  cx<T>* tw = nullptr;
+  CK(hipMalloc(&tw, twh.size() * sizeof(cx<T>)));
+  CK(hipMemcpy(tw, twh.data(), twh.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  printf("== Infinity Cache probe, %s\n", name);
+  for (int np : {4, 8, 16, 32, 64}) {            // y pass over np planes (np * 8.4 MB)
+    ColParams<T> P;
+    memset(&P, 0, sizeof P);
+    P.tw = tw; P.remap = 1; P.scale = (T)1;
+    P.in_outer = P.out_outer = (i64)N * NF;
+    P.in_map = P.out_map = make_rowmap(0, NF, N, N);
+    P.ncols = NF; P.nouter = np;
+    P.ntile_c = (P.ncols + cols - 1) / cols;
+    const int ntiles = P.ntile_c * P.nouter;
+    const int grid = persistent ? std::min(g_pgrid, ntiles / 8 * 8) : ntiles;
+    P.nblocks = grid;
+    const int nsec = N / np, reps = 64;
+    double ms_hot = 0, ms_cold = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+      for (int r = 0; r < 4; ++r) { P.in = P.out = buf; launch_k<K, T>(P, grid); }
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; ++r) {
+        cx<T>* sec = buf + (mode == 0 ? 0 : (size_t)((r * 37) % nsec) * np * N * NF);
+        P.in = P.out = sec;
+        launch_k<K, T>(P, grid);
+      }
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      (mode == 0 ? ms_hot : ms_cold) = ms / reps;
+    }
+    const double bytes = 2.0 * np * N * NF * sizeof(cx<T>);
+    printf("   y pass, %2d planes (%6.1f MB): same section %.4f ms (%.0f GB/s)   rotating sections %.4f ms (%.0f GB/s)\n", np, bytes / 2e6, ms_hot,
+           bytes / ms_hot / 1e6, ms_cold, bytes / ms_cold / 1e6);
+    fflush(stdout);
+  }
+  for (int nf : {8, 16, 32}) {                   // x pass over a (1024, 1024, nf) array, in place, rows of nf*1024 columns
+    ColParams<T> P;
+    memset(&P, 0, sizeof P);
+    P.tw = tw; P.remap = 1; P.scale = (T)1;
+    P.in_outer = P.out_outer = 0;
+    P.in_map = P.out_map = make_rowmap(0, (i64)N * nf, N, N);
+    P.ncols = N * nf; P.nouter = 1;
+    P.ntile_c = (P.ncols + cols - 1) / cols;
+    const int ntiles = P.ntile_c;
+    const int grid = persistent ? std::min(g_pgrid, ntiles / 8 * 8) : ntiles;
+    P.nblocks = grid;
+    const size_t sec_elems = (size_t)N * N * nf;
+    const int nsec = (int)(elems / sec_elems), reps = 64;
+    double ms_hot = 0, ms_cold = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+      for (int r = 0; r < 4; ++r) { P.in = P.out = buf; launch_k<K, T>(P, grid); }
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; ++r) {
+        cx<T>* sec = buf + (mode == 0 ? 0 : (size_t)((r * 37) % nsec) * sec_elems);
+        P.in = P.out = sec;
+        launch_k<K, T>(P, grid);
+      }
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      (mode == 0 ? ms_hot : ms_cold) = ms / reps;
+    }
+    const double bytes = 2.0 * sec_elems * sizeof(cx<T>);
+    printf("   x pass, nf = %2d (%6.1f MB): same section %.4f ms (%.0f GB/s)   rotating sections %.4f ms (%.0f GB/s)\n", nf, bytes / 2e6, ms_hot,
+           bytes / ms_hot / 1e6, ms_cold, bytes / ms_cold / 1e6);
+    fflush(stdout);
+  }
+  CK(hipFree(tw));
+  CK(hipFree(buf));
+}
+
+int main(int argc, char** argv) {
+  const char* filter = argc > 1 ? argv[1] : "";
+  const int rounds = argc > 2 ? atoi(argv[2]) : 3;
+  if (getenv("KB_PGRID")) g_pgrid = atoi(getenv("KB_PGRID"));
+  typedef Spec<1024, 16, 8, 8> SA;
+  typedef Spec<1024, 16, 16, 4> SC;
+  typedef Spec<512, 8, 8, 8> S512;
+  typedef Spec<512, 16, 8, 4> S512b;
+  if (!filter[0] || strstr("mall", filter)) {
+    mall_probe<ColFft<SA, double, 8, false, false, false, 1>, double>("tile 16x8x8 c8", 8, false, build_pass_twiddles<SA, double>());
+    mall_probe<ColFftP<SA, double, 8, false, 1>, double>("persist 16x8x8 c8", 8, true, build_pass_twiddles<SA, double>());
+    if (filter[0]) return 0;
+  }
+  typedef Spec<1024, 8, 8, 4, 4> SD;
+  typedef Spec<1024, 8, 8, 8, 2> SF;
+  {
+    std::vector<Variant<double>> vs;
+    vs.push_back(make_tile<SA, double, 8, false, false, 1>("16x8x8"));
+    vs.push_back(make_tile<SA, double, 8, false, false, 1, true>("16x8x8"));
+    vs.push_back(make_tile<SA, double, 8, true, true, 1>("16x8x8"));
+    vs.push_back(make_tile<SA, double, 8, true, true, 1, true>("16x8x8"));
+    vs.push_back(make_tile<SD, double, 8, true, true, 1>("8x8x4x4"));
+    vs.push_back(make_tile<SD, double, 8, true, true, 1, true>("8x8x4x4"));
+    vs.push_back(make_tile<SD, double, 8, false, true, 1>("8x8x4x4"));
+    vs.push_back(make_tile<SF, double, 8, true, true, 1>("8x8x8x2"));
+    run_all<double>(vs, 1024, filter, rounds);
+  }
+  {
+    std::vector<Variant<float>> vs;
+    vs.push_back(make_tile<SA, float, 16, false, false, 2>("16x8x8"));
+    vs.push_back(make_tile<SA, float, 16, false, false, 2, true>("16x8x8"));
+    vs.push_back(make_tile<SA, float, 16, true, true, 2>("16x8x8"));
+    vs.push_back(make_tile<SD, float, 16, true, true, 2>("8x8x4x4"));
+    vs.push_back(make_tile<SD, float, 16, true, true, 2, true>("8x8x4x4"));
+    vs.push_back(make_tile<SD, float, 16, true, false, 1>("8x8x4x4"));
+    run_all<float>(vs, 1024, filter, rounds);
+  }
+  {
+    std::vector<Variant<double>> vs;
+    vs.push_back(make_tile<S512, double, 8, true, false, 1>("8x8x8"));
+    vs.push_back(make_tile<S512, double, 8, true, false, 1, true>("8x8x8"));
+    vs.push_back(make_tile<S512, double, 8, true, true, 1>("8x8x8"));
+    vs.push_back(make_tile<Spec<512, 8, 4, 4, 4>, double, 8, true, false, 1>("8x4x4x4"));
+    vs.push_back(make_tile<Spec<512, 8, 4, 4, 4>, double, 8, true, true, 1>("8x4x4x4"));
+    run_all<double>(vs, 512, filter, rounds);
+  }
+  return 0;
+}

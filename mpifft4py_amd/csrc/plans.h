@@ -51,7 +51,15 @@ constexpr bool mfft_has_row_override(int n) {
 // two columns per lane at 1024 threads, which spills).  A length listed here gets its fp32 strided kernels from
 // this list, everything else from its MFFT_PLANS_* entry.
 #define MFFT_COLPLANS_F32_C(X) X(2048, 32, 8, 8) X(4096, 32, 32, 4)
-template <typename T> constexpr bool mfft_has_col_override(int n) { return sizeof(T) == 4 && (n == 2048 || n == 4096); }
+// Strided-kernel override for DOUBLE precision: 1024 runs as 8x8x4x4 (E = 8, 1024 threads, 60 VGPRs) with LDS twiddles and
+// the split re/im exchange, i.e. 80 KB of LDS, so that TWO workgroups share a CU and one's loads and stores overlap the
+// other's passes.  Interleaved A/B at 1024^3 (kbench3, profiles/r02_kbench3_variants.txt): y in place 3.52 -> 3.44 ms,
+// x in place 3.57 -> 3.35 ms (with non-temporal accesses, which only pay in place at two workgroups per CU),
+// x out of place 3.63 -> 3.19 ms.  The same change loses in single precision (1.85 -> 2.4 ms) and is neutral at 512.
+#define MFFT_COLPLANS_F64_B(X) X(1024, 8, 8, 4, 4)
+template <typename T> constexpr bool mfft_has_col_override(int n) {
+  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && n == 1024);
+}
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \

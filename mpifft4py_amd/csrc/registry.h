@@ -23,6 +23,7 @@ struct KernelEntry {
   int prec;         // 0 single, 1 double
   int inv;          // COL/ROW: 1 = inverse
   int nt;           // COL: 1 = non-temporal variant (128-byte aligned rows only)
+  int nt_inplace;   // COL, nt = 1: also faster than the regular variant when the transform is in place
   int pad;          // COL: 1 = zero-padded input (inverse), 2 = truncated output (forward)
   int tile;         // COLS (COL) or ROWS (others)
   int threads;
@@ -61,12 +62,14 @@ template <class S, typename T> constexpr int col_cols() {
   while (S::TPT * (cols / vec) < 64) cols *= 2;      // at least one full wave
   return cols;
 }
+// two workgroups per CU (split exchange + LDS twiddles = 80 KB each): the fp64 1024 = 8x8x4x4 plan, see plans.h
+template <class S, typename T> constexpr bool col_pair() { return sizeof(T) == 8 && S::N == 1024 && S::E == 8; }
 template <class S, typename T> constexpr bool col_split() {
-  return S::NP > 1 && (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) > 131072;
+  return S::NP > 1 && (col_pair<S, T>() || (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) > 131072);
 }
 template <class S, typename T> constexpr bool col_twlds() {
-  return S::NP > 1 && !col_split<S, T>() &&
-         (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) + S::TW * (int)sizeof(cx<T>) <= 65536;
+  return S::NP > 1 && (col_pair<S, T>() || (!col_split<S, T>() &&
+         (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) + S::TW * (int)sizeof(cx<T>) <= 65536));
 }
 template <class S, typename T> constexpr int row_rows() {
   int rows = 256 / S::TPT;
@@ -104,6 +107,7 @@ KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
   e.prec = sizeof(T) == 8 ? 1 : 0;
   e.inv = inv;
   e.nt = 0;
+  e.nt_inplace = 0;
   e.pad = 0;
   e.tile = tile;
   e.threads = K::THREADS;
@@ -134,8 +138,10 @@ void register_col(const char* name) {
   if constexpr (S::N >= 256) {     // aligned-row variants for the large out-of-place passes
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
     reg.back().nt = 1;
+    reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
     reg.back().nt = 1;
+    reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
   }
 }
 
