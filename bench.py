@@ -11,11 +11,61 @@ slab decomposition, RCCL all-to-all over xGMI).  Rank 0 prints one JSON line.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", "--n", dest="n", type=int, default=1024,
+                    help="cube edge (use --size under torch.distributed.run: its parser rejects the abbreviation --n)")
+    ap.add_argument("--decomp", default="slab", choices=["slab", "pencil"])
+    ap.add_argument("--precision", default="double", choices=["double", "single"])
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--rendezvous", default="file", choices=["file", "torch"],
+                    help="how rank 0's RCCL unique id reaches the other ranks (torch = gloo process group)")
+    ap.add_argument("--pencil-extra", default="auto", choices=["auto", "on", "off"],
+                    help="also time the pencil (R2CX) decomposition of the same cube and report it under 'extras'")
+    ap.add_argument("--stage-timing", default="on", choices=["on", "off"],
+                    help="HIP events around every stage inside the timed region (roofline numbers)")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, exactly as
+    `torch.distributed.run --nproc-per-node N` would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relay rank 0's JSON
+    line and leave with the worst exit code.  This process has not touched the GPU (nothing of the package is imported
+    yet) and the ranks are fresh children, not an exec of this one."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    sys.exit(0 if not bad else (bad[0] if bad[0] > 0 else 1))
+
+
+ARGS = parse_args() if __name__ == "__main__" else None
+if ARGS is not None and ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    self_launch(ARGS)
 
 import numpy as np  # noqa: E402
 
@@ -113,31 +163,13 @@ def cpu_baseline(n_full, seconds_budget=30.0):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", "--n", dest="n", type=int, default=1024,
-                    help="cube edge (use --size under torch.distributed.run: its parser rejects the abbreviation --n)")
-    ap.add_argument("--decomp", default="slab", choices=["slab", "pencil"])
-    ap.add_argument("--precision", default="double", choices=["double", "single"])
-    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
-    ap.add_argument("--pipeline", type=int, default=0)
-    ap.add_argument("--rendezvous", default="file", choices=["file", "torch"],
-                    help="how rank 0's RCCL unique id reaches the other ranks (torch = gloo process group)")
-    ap.add_argument("--pencil-extra", default="auto", choices=["auto", "on", "off"],
-                    help="also time the pencil (R2CX) decomposition of the same cube and report it under 'extras'")
-    ap.add_argument("--stage-timing", default="on", choices=["on", "off"],
-                    help="HIP events around every stage inside the timed region (roofline numbers)")
-    args = ap.parse_args()
-
+    args = ARGS if ARGS is not None else parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.stderr.write("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "(one process per GPU)\n" % args.gpus)
-            sys.exit(2)
+        sys.stderr.write("bench.py --gpus %d was started with WORLD_SIZE=%d: the launcher must start one process per "
+                         "GPU (or none: `python bench.py --gpus N` starts its ranks itself)\n" % (args.gpus, world))
+        sys.exit(2)
     # RCCL prints a version banner on stdout at communicator creation; keep stdout for the JSON line
     sys.stdout.flush()
     saved_stdout = os.dup(1)
@@ -235,14 +267,16 @@ def main():
 
     def arm_watchdog(seconds, fallback_line, why):
         """If the work that follows does not finish, rank 0 prints `fallback_line` (a complete, valid measurement
-        taken earlier) and every rank leaves: a number must survive a transport problem in an optional step."""
+        taken earlier, marked "degraded": true) and every rank leaves with exit code 3: the number survives a
+        transport problem in an optional step, but the run does not look green."""
         def give_up():
             if rank == 0 and fallback_line is not None:
                 fallback_line["extras"] = {"note": why}
+                fallback_line["degraded"] = True
                 fallback_line.setdefault("cpu_baseline", None)
                 sys.stdout.write(json.dumps(fallback_line) + "\n")
                 sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)                    # a step that hangs is a failure, whatever was measured before it
         t = threading.Timer(seconds, give_up)
         t.daemon = True
         t.start()
@@ -324,18 +358,28 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
 
+    # correctness gate: a wrong transform must not print a headline number with rc 0
+    tol = 1e-10 if args.precision == "double" else 1e-4
+    rt_all = [mres["rt_err"]] + [v["roundtrip_rel_l2"] for v in extras.values() if "roundtrip_rel_l2" in v]
+    bad = max(comm.allreduce(max(rt_all), op=mcomm.MAX) if world > 1 else max(rt_all), 0.0)
+    failed = not (bad <= tol)              # also catches NaN
     if rank == 0:
         out["extras"] = extras
-        if world == 1 and args.cpu_baseline == "auto":
+        if world == 1 and args.cpu_baseline == "auto" and not failed:
             out["cpu_baseline"] = cpu_baseline(n)
         else:
             out["cpu_baseline"] = None
+        if failed:
+            out["degraded"] = True
+            out["error"] = "round trip rel-L2 %.3e exceeds %.0e: the transform is wrong, the timing means nothing" % (bad, tol)
         print(json.dumps(out))
     if dist is not None:
         try:
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001
             pass
+    if failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -57,7 +57,9 @@ MFFT_API int mfft_device_name(char* buf, size_t buflen);
 MFFT_API int mfft_device_sync(void);
 
 /* ---- device memory (replaces mpibase.py:38-51 empty/zeros and the
- *      work_arrays cache, mpibase.py:53-131, for device-resident buffers) --- */
+ *      work_arrays cache, mpibase.py:53-131, for device-resident buffers) ---
+ * mfft_memset / mfft_memcpy_* wait for ALL work of the current device (the transforms run asynchronously on their
+ * plan's own stream, see mfft_forward) before they touch memory and return when the copy is complete. */
 MFFT_API int mfft_malloc(void** dptr, size_t bytes);
 MFFT_API int mfft_free(void* dptr);
 MFFT_API int mfft_memset(void* dptr, int value, size_t bytes);
@@ -95,7 +97,9 @@ typedef struct {
   int precision;      /* mfft_precision */
   int kind;           /* mfft_kind */
   int decomp;         /* mfft_decomp */
-  int p1;             /* pencil: ranks along the first axis, 0 = Compute_dims default */
+  int p1;             /* pencil: ranks along the first axis, 0 = Compute_dims default.  Any p1 that divides the number
+                         of ranks is accepted (also 1 x P, P x 1 and odd grids); the reference, and the Python classes
+                         by default, insist on even P1 and P2 (pencil.py:204-208) */
   double padsize;     /* 3/2-rule pad factor (1.5) */
   int pipeline;       /* exchange pipeline: slab: n > 1 = n kz slices, n < -1 = |n| batches of local x rows; x-aligned
                          pencil: |n| batches of local x rows; each piece is exchanged on a second stream while the
@@ -131,7 +135,10 @@ MFFT_API int mfft_plan_exchange_pieces(const mfft_plan_desc* desc, int nranks, i
                                        int piece, int max_peers, int* npieces, int* npeers, int* peers,
                                        size_t* scount, size_t* sdisp, size_t* rcount, size_t* rdisp);
 
-/* fftn: slab.py:349-485 / pencil.py:634-883, 1228-1475.  `u` is never written. */
+/* mfft_forward / mfft_backward ENQUEUE the transform on the plan's own (non-blocking) HIP stream and return; calls on
+ * one plan execute in order.  Before the host or another stream reads the result (or reuses the input), call
+ * mfft_plan_sync -- or one of the mfft_memcpy_* helpers, which synchronise the device themselves.
+ * fftn: slab.py:349-485 / pencil.py:634-883, 1228-1475.  `u` is never written. */
 MFFT_API int mfft_forward(mfft_plan_t plan, const void* u, void* fu, int dealias);
 /* ifftn: slab.py:214-346 / pencil.py:386-632, 1001-1224.  `fu` is never written. */
 MFFT_API int mfft_backward(mfft_plan_t plan, const void* fu, void* u, int dealias);

@@ -133,24 +133,66 @@ def get_unique_id():
     return buf.raw
 
 
+_RDV_MAGIC = b"MFFTRDV1"
+
+
+def _rendezvous_path():
+    """Default rendezvous file: a 0700 directory of this user, one name per (MASTER_PORT, launcher pid, run id)."""
+    explicit = os.environ.get("MFFT_RENDEZVOUS_FILE")
+    if explicit:
+        return explicit, False
+    d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mfft-%d" % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise _lib.MfftError("rendezvous directory %s is not private to this user" % d)
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "none").replace(os.sep, "_")
+    return os.path.join(d, "uid_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), run)), True
+
+
+def _publisher_alive(pid, same_parent):
+    """A leftover file of a crashed earlier launch names a dead publisher (or one of another launcher)."""
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return False                       # somebody else's process: not our rank 0
+    if same_parent:
+        try:
+            with open("/proc/%d/stat" % pid) as f:
+                ppid = int(f.read().rsplit(")", 1)[1].split()[1])
+            return ppid == os.getppid()
+        except (OSError, ValueError, IndexError):
+            return False
+    return True
+
+
 def _file_bcast(rank, payload, timeout=300.0):
-    """Single-node rendezvous through a file: rank 0 publishes, the rest poll."""
-    port = os.environ.get("MASTER_PORT", "0")
-    path = os.environ.get("MFFT_RENDEZVOUS_FILE",
-                          os.path.join("/tmp", "mfft_uid_%s_%d" % (port, os.getppid())))
+    """Single-node rendezvous through a file: rank 0 publishes, the rest poll.  The file carries the publisher's pid;
+    readers only accept it while that process is alive (and is a child of the same launcher), so a file left behind by
+    a crashed earlier launch with the same port and parent is never mistaken for this launch's id."""
+    path, same_parent = _rendezvous_path()
     if rank == 0:
+        try:
+            os.unlink(path)                # a leftover of an earlier launch
+        except FileNotFoundError:
+            pass
         tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
-            f.write(payload)
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(_RDV_MAGIC + os.getpid().to_bytes(8, "little") + payload)
         os.replace(tmp, path)
         return payload, path
     t0 = time.time()
+    want = len(_RDV_MAGIC) + 8 + _lib.UNIQUE_ID_BYTES
     while True:
         try:
             with open(path, "rb") as f:
                 data = f.read()
-            if len(data) == _lib.UNIQUE_ID_BYTES:
-                return data, path
+            if len(data) == want and data[:8] == _RDV_MAGIC and \
+                    _publisher_alive(int.from_bytes(data[8:16], "little"), same_parent):
+                return data[16:], path
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:

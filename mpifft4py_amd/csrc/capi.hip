@@ -54,20 +54,30 @@ int mfft_free(void* dptr) {
   if (dptr) MFFT_HIP(hipFree(dptr));
   return 0;
 }
+// The transforms run asynchronously on their plan's own non-blocking stream, which the null stream does not order
+// against.  These helpers therefore wait for ALL work of the device (every plan's streams) before they touch memory,
+// and return when the copy is complete: a copy issued after mfft_forward sees its result, a transform issued after
+// a copy sees the copied data.
 int mfft_memset(void* dptr, int value, size_t bytes) {
+  MFFT_HIP(hipDeviceSynchronize());
   MFFT_HIP(hipMemset(dptr, value, bytes));
+  MFFT_HIP(hipDeviceSynchronize());
   return 0;
 }
 int mfft_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  MFFT_HIP(hipDeviceSynchronize());
   MFFT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return 0;
 }
 int mfft_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  MFFT_HIP(hipDeviceSynchronize());
   MFFT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return 0;
 }
 int mfft_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+  MFFT_HIP(hipDeviceSynchronize());
   MFFT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+  MFFT_HIP(hipDeviceSynchronize());
   return 0;
 }
 int mfft_fill_uniform(void* dptr, size_t count, int precision, uint64_t seed) {

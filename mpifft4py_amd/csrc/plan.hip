@@ -950,6 +950,12 @@ int mfft_plan_s::pencil_backward_pipelined_x(const void* src, void* u) {
   }
   // y transform of a batch (P1 blocks gathered through the row map) -> P2 blocks (m, n, q) in W2, then its z exchange
   const char* ysrc = g2solo ? W0 : W1;
+  // Where the z exchange delivers its chunks.  With a second exchange (P1 > 1) every bwd_a2a_2 is ahead of it on the
+  // communication stream and the y transforms read W1, so W0 is free.  On a 1 x P2 grid there is no second exchange and
+  // the y transforms of LATER batches still read W0 on the compute stream: the chunks go to W1 (unused there) and are
+  // unpacked into W0 once every y transform is behind the unpack on the compute stream.
+  char* zrecv = g2solo ? W1 : W0;
+  char* zfull = g2solo ? W0 : W1;
   for (int b = 0; b < B; ++b) {
     int64_t i0, mb;
     rows(b, &i0, &mb);
@@ -961,22 +967,22 @@ int mfft_plan_s::pencil_backward_pipelined_x(const void* src, void* u) {
     if (zsolo) continue;
     MFFT_HIP(hipEventRecord(ev_compute[b], stream));
     MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[b], 0));
-    MFFT_TRY(stage_on(cstream, "bwd_a2a_1", 0, [&] {       // all bwd_a2a_2 are ahead of it on this stream: W0 is free
+    MFFT_TRY(stage_on(cstream, "bwd_a2a_1", 0, [&] {
       Sched sc;
       MFFT_TRY(piece_sched(0, false, b, &sc));
-      return run_sched(sc, W2, W0, cstream);
+      return run_sched(sc, W2, zrecv, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
   }
-  // z chunks of a batch back into full rows (W1: every y transform that read it is behind us on this stream), c2r
+  // z chunks of a batch back into full rows (zfull: every y transform that read it is behind us on this stream), c2r
   for (int b = 0; b < B; ++b) {
     int64_t i0, mb;
     rows(b, &i0, &mb);
     const char* zin = W2 + (size_t)(i0 * n * Nf) * es;
     if (!zsolo) {
       MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
-      MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z_rows(this, W1, W0, m * n, i0 * n, mb * n, Nf, zc, true); }));
-      zin = W1 + (size_t)(i0 * n * Nf) * es;
+      MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z_rows(this, zfull, zrecv, m * n, i0 * n, mb * n, Nf, zc, true); }));
+      zin = zfull + (size_t)(i0 * n * Nf) * es;
     }
     MFFT_TRY(stage("bwd_z", (Rb + Cb) / B, [&] {
       return z_backward(zin, out + (size_t)(i0 * n * N2) * rs, mb * n, N2, Nf);

@@ -36,7 +36,7 @@ class R2CY(DistFFTBase):
     _kind = _lib.R2C
 
     def __init__(self, N, L, comm, precision, P1=None, communication='Alltoallw', padsize=1.5, threads=1,
-                 planner_effort=None, allow_single=False, pipeline=0):
+                 planner_effort=None, allow_single=False, pipeline=0, allow_odd_grid=False):
         self._init_common(N, L, comm, precision, communication, padsize, threads,
                           planner_effort if planner_effort is not None else default_planner_effort())
         N = self.N
@@ -52,10 +52,13 @@ class R2CY(DistFFTBase):
         else:
             P2 = P // P1
         self.P1, self.P2 = P1, P2
-        if not (P % 2 == 0 or P == 1):
-            raise IOError("Number of cpus must be even")
-        if P > 1 and ((P1 % 2 != 0) or (P2 % 2 != 0)):
-            raise IOError("Number of cpus in each direction must be even power of 2")
+        # the reference's grid rules (pencil.py:202-208); `allow_odd_grid=True` lifts them: the C ABI takes any P1 that
+        # divides P (1 x P and P x 1 grids are what an odd number of GPUs, or one exchange, would use)
+        if not allow_odd_grid:
+            if not (P % 2 == 0 or P == 1):
+                raise IOError("Number of cpus must be even")
+            if P > 1 and ((P1 % 2 != 0) or (P2 % 2 != 0)):
+                raise IOError("Number of cpus in each direction must be even power of 2")
         self.N1 = N // P1
         self.N2 = N // P2
         self.comm0_rank = self.rank % P1
@@ -201,10 +204,10 @@ class R2CX(R2CY):
     _decomp = _lib.PENCIL_X
 
     def __init__(self, N, L, comm, precision, P1=None, communication='Alltoall', padsize=1.5, threads=1,
-                 planner_effort=None, allow_single=False, pipeline=0):
+                 planner_effort=None, allow_single=False, pipeline=0, allow_odd_grid=False):
         R2CY.__init__(self, N, L, comm, precision, P1=P1, communication=communication, padsize=padsize,
                       threads=threads, planner_effort=planner_effort, allow_single=allow_single,
-                      pipeline=pipeline)
+                      pipeline=pipeline, allow_odd_grid=allow_odd_grid)
 
     def complex_shape(self):
         return (int(self.N[0]), int(self.N1[1]), self.N2f)

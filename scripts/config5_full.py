@@ -7,8 +7,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpifft4py_amd import DeviceArray, LocalGroup, Pencil_C2C
 from mpifft4py_amd import spectral
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+import ctypes
+_hip = ctypes.CDLL("libamdhip64.so")
+_free, _total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+_hip.hipMemGetInfo(ctypes.byref(_free), ctypes.byref(_total))
+arg = sys.argv[1] if len(sys.argv) > 1 else "2048"
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+# 2048^3 complex64: four 8.6 GB buffers per rank x 8 ranks = 275 GB.  "auto" = 2048 whenever they fit.
+n = (2048 if _free.value > 280e9 else 1024) if arg == "auto" else int(arg)
+print("CONFIG5_SIZE n=%d free_hbm_gb=%.1f total_hbm_gb=%.1f" % (n, _free.value / 1e9, _total.value / 1e9), flush=True)
 N = np.array([n] * 3); L = np.array([2 * np.pi] * 3)
 
 def body(comm):

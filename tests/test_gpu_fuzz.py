@@ -24,18 +24,24 @@ def test_random_configurations_match_the_oracle(seed):
 
 def test_config5_full_size_pencil_c2c():
     """BASELINE config 5 at its full size, 2048^3 complex64 pencil C2C over 8 ranks (all on this GPU, 275 GB of HBM):
-    Parseval through device-side reductions and the round trip on sampled planes (scripts/config5_full.py).  Falls
-    back to 1024^3 when less than 290 GB of HBM is free."""
+    Parseval through device-side reductions and the round trip on sampled planes (scripts/config5_full.py).  The
+    script runs in a process of its own (this one's HBM pools do not count against it), prints the size it ran and
+    the free HBM it found; on a 288 GB device the size MUST be 2048: nothing shrinks silently."""
     import ctypes
+    import re
     if not have_gpu():
         pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
     hip = ctypes.CDLL("libamdhip64.so")
     free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
     hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
-    n = 2048 if free.value > 290e9 else 1024
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "config5_full.py"), str(n), "8"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "config5_full.py"), "auto", "8"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout.decode()
+    print(out)                                     # shown with -rA / on failure: which size ran, free / total HBM
+    m = re.search(r"CONFIG5_SIZE n=(\d+) free_hbm_gb=([0-9.]+) total_hbm_gb=([0-9.]+)", out)
+    assert m, out[-3000:]
+    if total.value >= 280e9:
+        assert int(m.group(1)) == 2048, "config 5 ran at %s^3 on a %.0f GB device (free %s GB)" % (m.group(1), total.value / 1e9, m.group(2))
     assert p.returncode == 0 and "CONFIG5_OK" in out, out[-3000:]
 
 

@@ -103,6 +103,23 @@ def test_bench_multi_rank_prints_one_json_line(world, launcher):
 
 
 @pytest.mark.parametrize("world", [2, 4])
+def test_bench_starts_its_own_ranks_without_a_launcher(world):
+    """`python bench.py --gpus N` as the driver's 1-GPU command line would look with N > 1: no torch.distributed.run,
+    no RANK / WORLD_SIZE in the environment.  bench.py starts its N ranks itself (fresh child processes) and still
+    prints exactly one JSON line."""
+    env = {k: v for k, v in _env().items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "128", "--steps", "3",
+                        "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    out, err = p.stdout.decode(), p.stderr.decode()
+    assert p.returncode == 0, (out[-2000:], err[-4000:])
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["value"] > 0 and d["config"]["roundtrip_rel_l2"] < 1e-10 and not d.get("degraded")
+
+
+@pytest.mark.parametrize("world", [2, 4])
 def test_mpi4py_like_communicator_is_wrapped(world):
     """INTEGRATION.md route A with the caller's own communicator object: the constructors accept anything with
     Get_rank / Get_size / bcast (an mpi4py communicator) and build the RCCL communicator through it."""

@@ -58,8 +58,9 @@ def test_slab_r2c(P, mode, prec):
 
 @pytest.mark.parametrize("prec", ["double", "single"])
 @pytest.mark.parametrize("align", ["X", "Y"])
+@pytest.mark.parametrize("communication", ["Alltoall", "Alltoallw"])      # 'Alltoall' is the reference factory's default (pencil.py:1479)
 @pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2), (16, None)])
-def test_pencil_r2c(P, P1, align, prec):
+def test_pencil_r2c(P, P1, align, prec, communication):
     from mpifft4py_amd import Pencil_R2C
     rng = np.random.default_rng(200 + P)
     A = rng.random(NREF).astype(rdtype(prec))
@@ -68,7 +69,8 @@ def test_pencil_r2c(P, P1, align, prec):
     want = orc.pencil_r2c_forward(orc.scatter_real(A, lay), NREF, P1, align, prec)
 
     def body(comm):
-        F = Pencil_R2C(np.array(NREF), L, comm, prec, P1=P1, communication="Alltoallw", alignment=align)
+        F = Pencil_R2C(np.array(NREF), L, comm, prec, P1=P1, communication=communication, alignment=align)
+        assert F.communication == communication
         assert (F.P1, F.P2) == (lay.P1, lay.P2)
         assert tuple(F.complex_shape()) == tuple(lay.complex_shape(comm.Get_rank()))
         a = np.ascontiguousarray(A[F.real_local_slice()])
@@ -521,6 +523,32 @@ def test_local_group_does_not_hang_when_one_rank_fails():
     assert time.time() - t0 < 60
 
 
+def test_config2_512_cubed_one_gpu():
+    """BASELINE config 2: 512^3 fp64 slab R2C on one GPU, device-resident (single-GPU kernels, no exchange).  Forward
+    spectrum against the host's pocketfft on the SAME input (rel-L2 <= 1e-10, and the reference's own max-norm
+    criterion tests/test_FFT.py:85), round trip <= 1e-10, input preserved by both transforms."""
+    import os
+    import scipy.fft as sfft
+    from mpifft4py_amd import DeviceArray, SelfComm, Slab_R2C
+    N = np.array([512] * 3)
+    F = Slab_R2C(N, L, SelfComm(0), "double")
+    assert F.num_processes == 1 and tuple(F.real_shape()) == (512, 512, 512) and tuple(F.complex_shape()) == (512, 512, 257)
+    A = np.random.default_rng(512).random(tuple(N))
+    u = DeviceArray.from_numpy(A)
+    fu = DeviceArray.empty(F.complex_shape(), F.complex)
+    u2 = DeviceArray.empty(F.real_shape(), F.float)
+    F.fftn(u, fu)
+    F.sync()
+    c = fu.get()
+    F.ifftn(fu, u2)
+    F.sync()
+    C = sfft.rfftn(A, workers=os.cpu_count())
+    assert orc.rel_l2(c, C) < 1e-10                                           # forward vs pocketfft
+    assert np.abs(c - C).max() / np.abs(C).max() < 1e-8                       # the reference's criterion
+    assert orc.rel_l2(u2.get(), A) < 1e-10                                    # round trip
+    assert np.array_equal(u.get(), A) and np.array_equal(fu.get(), c)        # inputs untouched
+
+
 def test_full_size_1024_cubed():
     """BASELINE workload at full size: 1024^3 fp64, device-resident.  Forward spectrum against
     the host's pocketfft (scipy.fft, all cores) on the SAME input, round trip, input preserved.
@@ -818,10 +846,12 @@ def test_other_pad_factors(kind, N, P, ps):
 
 @pytest.mark.parametrize("prec", ["double", "single"])
 @pytest.mark.parametrize("depth", [2, 3, 4, 16])
-@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2), (16, None)])
+@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2), (16, None), (2, 1), (4, 1), (8, 1), (2, 2), (4, 4)])
 def test_pencil_x_exchange_pipeline(P, P1, depth, prec):
     """Opt-in exchange pipeline of the x-aligned pencil (batches of local x rows through both exchanges, compute and
-    communication streams): same numbers as the un-pipelined path, R2C plain / 2/3-rule and C2C."""
+    communication streams): same numbers as the un-pipelined path, R2C plain / 2/3-rule and C2C.  The 1 x P2, P1 x 1
+    and odd grids are not offered by the reference (pencil.py:204-208) but by the C ABI (any P1 dividing P): on a
+    1 x P2 grid the inverse's z exchange must not deliver into the buffer the y transforms of later batches read."""
     from mpifft4py_amd.pencil import C2CX, R2CX
     N = [32, 64, 128]
     rt, ct = rdtype(prec), cdtype(prec)
@@ -832,12 +862,13 @@ def test_pencil_x_exchange_pipeline(P, P1, depth, prec):
     def body(comm):
         res = []
         for pipe in (1, depth):                               # 1 = no pipeline (0 would be the default depth, 4)
-            F = R2CX(np.array(N), L, comm, prec, P1=P1, communication="Alltoallw", allow_single=True, pipeline=pipe)
+            F = R2CX(np.array(N), L, comm, prec, P1=P1, communication="Alltoallw", allow_single=True, pipeline=pipe,
+                     allow_odd_grid=True)
             a = np.ascontiguousarray(A[F.real_local_slice()])
             c = F.fftn(a, np.zeros(F.complex_shape(), dtype=ct))
             b = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt))
             b23 = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt), "2/3-rule")
-            G = C2CX(np.array(N), L, comm, prec, P1=P1, allow_single=True, pipeline=pipe)
+            G = C2CX(np.array(N), L, comm, prec, P1=P1, allow_single=True, pipeline=pipe, allow_odd_grid=True)
             ac = np.ascontiguousarray(Ac[G.original_local_slice()])
             cc = G.fftn(ac, np.zeros(G.transformed_shape(), dtype=ct))
             bc = G.ifftn(cc, np.zeros(G.original_shape(), dtype=ct))

@@ -1,5 +1,6 @@
 """Host-side numpy helpers the classes carry for API parity with the reference (copy_to_padded / copy_from_padded
 families: slab.py:516-536, 803-825; pencil.py:351-379; line.py:164-175) against the oracle's pad / truncate."""
+import os
 import types
 
 import numpy as np
@@ -68,3 +69,34 @@ def test_pencil_and_line_helpers():
     assert np.array_equal(LineR2C.copy_to_padded_y(line, f2, np.zeros((8, 13), dtype=complex))[:, :9], f2)
     assert np.array_equal(LineR2C.copy_from_padded_y(line, cplx((8, 13)), np.zeros((8, 9), dtype=complex)).shape, (8, 9))
     assert _padding.spread is not None
+
+
+def test_file_rendezvous_ignores_leftovers_of_a_crashed_launch(tmp_path):
+    """The single-node rendezvous file names its publisher: a file left behind by an earlier (dead) rank 0 with the
+    same MASTER_PORT and the same launcher is never accepted; rank 0's fresh id is (mpifft4py_amd/comm.py)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TMPDIR=str(tmp_path), MASTER_PORT="45999", PYTHONPATH=root)
+    env.pop("MFFT_RENDEZVOUS_FILE", None)
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    d = tmp_path / ("mfft-%d" % os.getuid())
+    d.mkdir(mode=0o700)
+    stale = d / ("uid_45999_%d_none" % os.getpid())
+    stale.write_bytes(b"MFFTRDV1" + dead.pid.to_bytes(8, "little") + b"S" * 128)
+    code = ("import sys\nfrom mpifft4py_amd import comm\n"
+            "r = int(sys.argv[1])\n"
+            "got, path = comm._file_bcast(r, (b'F' * 128) if r == 0 else None, timeout=30)\n"
+            "sys.stdout.write(got.decode()[:4])\n"
+            "import time\ntime.sleep(2.0 if r == 0 else 0)\n")
+    reader = subprocess.Popen([sys.executable, "-c", code, "1"], env=env, stdout=subprocess.PIPE)
+    time.sleep(1.0)
+    assert reader.poll() is None, "the reader accepted the leftover file of a dead publisher"
+    writer = subprocess.Popen([sys.executable, "-c", code, "0"], env=env, stdout=subprocess.PIPE)
+    out, _ = reader.communicate(timeout=60)
+    assert reader.returncode == 0 and out == b"FFFF"
+    writer.communicate(timeout=60)
+    assert writer.returncode == 0
