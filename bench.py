@@ -30,6 +30,9 @@ def parse_args():
     ap.add_argument("--precision", default="double", choices=["double", "single"])
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "ipc"],
+                    help="multi-rank exchange: RCCL send/recv kernels, copy-engine pulls through IPC-mapped work buffers "
+                         "(one node), or auto = measure both and use the faster one")
     ap.add_argument("--rendezvous", default="file", choices=["file", "torch"],
                     help="how rank 0's RCCL unique id reaches the other ranks (torch = gloo process group)")
     ap.add_argument("--pencil-extra", default="auto", choices=["auto", "on", "off"],
@@ -76,14 +79,14 @@ from mpifft4py_amd import DeviceArray, Pencil_R2C, Slab_R2C  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def make_comm(world, rendezvous):
+def make_comm(world, rendezvous, transport=None):
     if world == 1:
         return mcomm.SelfComm(int(os.environ.get("LOCAL_RANK", "0")) % max(_lib.device_count(), 1)), None
     bcast, dist = None, None
     if rendezvous == "file":
-        # single node: rank 0 publishes the RCCL unique id in /tmp (keyed by MASTER_PORT and the
+        # single node: rank 0 publishes the unique id in a private directory under /tmp (keyed by MASTER_PORT and the
         # launcher's pid); no second HIP runtime / process group is brought into the workers
-        return mcomm.from_env(None), None
+        return mcomm.from_env(None, transport=transport), None
     try:
         import torch.distributed as dist       # plumbing only: rendezvous for the RCCL id
         dist.init_process_group("gloo")
@@ -95,7 +98,7 @@ def make_comm(world, rendezvous):
     except Exception as e:                      # noqa: BLE001
         sys.stderr.write("torch.distributed unavailable (%s): file rendezvous\n" % e)
         bcast, dist = None, None
-    return mcomm.from_env(bcast), dist
+    return mcomm.from_env(bcast, transport=transport), dist
 
 
 def pmc_traffic(n, precision, decomp, world):
@@ -175,7 +178,8 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        comm, dist = make_comm(world, args.rendezvous)
+        first = None if args.transport == "auto" else args.transport     # auto: $MFFT_TRANSPORT, else rccl
+        comm, dist = make_comm(world, args.rendezvous, first)
     finally:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
@@ -183,7 +187,7 @@ def main():
     n = args.n
     N = np.array([n, n, n])
     L = np.array([2 * np.pi] * 3)
-    def measure(pipeline):
+    def measure(pipeline, comm=comm):
         """W warm-up pairs, then exactly K timed pairs bracketed by stream sync + device sync + barrier."""
         if args.decomp == "slab":
             F = Slab_R2C(N, L, comm, args.precision, pipeline=pipeline)
@@ -224,7 +228,10 @@ def main():
         a0 = u.leading(0, k).get()
         b0 = u2.leading(0, k).get()
         rt_err = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
-        return {"dt": dt, "stages": stages, "rt_err": rt_err, "pipeline": pipeline}
+        return {"dt": dt, "stages": stages, "rt_err": rt_err, "pipeline": pipeline, "transport": comm_name(comm)}
+
+    def comm_name(c):
+        return getattr(c, "transport_name", "rccl" if world > 1 else "none")
 
     def headline(mres, tuning):
         dt, stages, rt_err = mres["dt"], mres["stages"], mres["rt_err"]
@@ -251,6 +258,7 @@ def main():
                                    % (n, "fp64" if args.precision == "double" else "fp32", args.decomp, world),
                        "roundtrip_rel_l2": rt_err,
                        "exchange_pipeline_depth": mres["pipeline"] if world > 1 else None,
+                       "exchange_transport": mres["transport"] if world > 1 else None,
                        "exchange_pipeline_tuning_ms_per_pair": tuning,
                        "alg_bytes_per_pair": alg_pair,
                        "whole_path_hbm_GBs_per_gpu": alg_pair / world / (ms * 1e-3) / 1e9,
@@ -285,36 +293,56 @@ def main():
     tuning = None
     if args.decomp == "slab" and world > 1 and args.pipeline == 0:
         # 1. the plain, blocking exchange: W + K pairs, a complete measurement that is also the fallback line
+        comm.transport_name = first or os.environ.get("MFFT_TRANSPORT", "rccl")
         base = measure(1)
-        tuning = {1: 1e3 * base["dt"] / args.steps}
-        fallback = headline(base, {"note": "blocking exchange; the pipelined candidates did not finish"}) if rank == 0 else None
-        dog = arm_watchdog(600.0, fallback, "the pipelined exchange candidates did not finish within 600 s")
-        # 2. exchange pipeline (flavour and depth) measured on this machine's links, like a planner's MEASURE mode:
-        #    2 untimed + 2 timed pairs per candidate, slowest rank counts
+        tuning = {comm.transport_name: {1: 1e3 * base["dt"] / args.steps}}
+        fallback = headline(base, {"note": "blocking exchange; the other candidates did not finish"}) if rank == 0 else None
+        dog = arm_watchdog(900.0, fallback, "the exchange candidates (transport, pipeline) did not finish within 900 s")
+        # 2. transport x exchange pipeline (flavour and depth) measured on this machine's links, like a planner's MEASURE
+        #    mode: 2 untimed + 2 timed pairs per candidate, slowest rank counts
+        comms = [comm]
+        if args.transport == "auto":
+            other = "ipc" if comm.transport_name != "ipc" else "rccl"
+            try:
+                c2, _ = make_comm(world, "file", other)
+                c2.transport_name = other
+                comms.append(c2)
+            except Exception as e:      # noqa: BLE001
+                sys.stderr.write("transport %s unavailable (%s: %s)\n" % (other, type(e).__name__, e))
+                tuning[other] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # every rank must agree on the candidate list
+            if -comm.allreduce(-float(len(comms)), op=mcomm.MAX) < 2:
+                comms = comms[:1]
+        best = (comm, 1)
+        best_ms = tuning[comm.transport_name][1]
         try:
             ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
-            for depth in (2, 4, 8, -2, -4, -8):           # kz slices / (negative) batches of local x rows
-                Ft = Slab_R2C(N, L, comm, args.precision, pipeline=depth)
-                fut = DeviceArray.empty(Ft.complex_shape(), Ft.complex)
-                for it in range(4):
-                    if it == 2:
-                        Ft.sync()
-                        comm.barrier()
-                        tt = time.perf_counter()
-                    Ft.fftn(ut, fut)
-                    Ft.ifftn(fut, ut)
-                Ft.sync()
-                comm.barrier()
-                tuning[depth] = comm.allreduce((time.perf_counter() - tt) / 2, op=mcomm.MAX) * 1e3
-                del Ft, fut
+            for c in comms:
+                tc = tuning.setdefault(c.transport_name, {})
+                for depth in (1, 2, 4, 8, -2, -4, -8):       # 1: blocking; kz slices / (negative) batches of local x rows
+                    if depth in tc:
+                        continue
+                    Ft = Slab_R2C(N, L, c, args.precision, pipeline=depth)
+                    fut = DeviceArray.empty(Ft.complex_shape(), Ft.complex)
+                    for it in range(4):
+                        if it == 2:
+                            Ft.sync()
+                            c.barrier()
+                            tt = time.perf_counter()
+                        Ft.fftn(ut, fut)
+                        Ft.ifftn(fut, ut)
+                    Ft.sync()
+                    c.barrier()
+                    tc[depth] = c.allreduce((time.perf_counter() - tt) / 2, op=mcomm.MAX) * 1e3
+                    del Ft, fut
+                    if tc[depth] < best_ms:
+                        best, best_ms = (c, depth), tc[depth]
             del ut
-            best = min(tuning, key=tuning.get)
         except Exception as e:      # noqa: BLE001  - every rank takes the same path
-            sys.stderr.write("pipeline tuning failed (%s: %s); keeping the blocking exchange\n" % (type(e).__name__, e))
+            sys.stderr.write("exchange tuning failed (%s: %s); keeping the best candidate so far\n" % (type(e).__name__, e))
             tuning["error"] = "%s: %s" % (type(e).__name__, e)
-            best = 1
         # 3. the timed region with the best candidate (the first measurement stands if nothing beats it)
-        mres = base if best == 1 else measure(best)
+        mres = base if best == (comm, 1) else measure(best[1], best[0])
         dog.cancel()
     else:
         mres = measure(args.pipeline)

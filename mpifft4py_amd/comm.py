@@ -134,6 +134,7 @@ def get_unique_id():
 
 
 _RDV_MAGIC = b"MFFTRDV1"
+_rdv_count = 0          # rendezvous of this process so far: every from_env() of a launch gets a file name of its own
 
 
 def _rendezvous_path():
@@ -147,7 +148,7 @@ def _rendezvous_path():
     if st.st_uid != os.getuid() or (st.st_mode & 0o077):
         raise _lib.MfftError("rendezvous directory %s is not private to this user" % d)
     run = os.environ.get("TORCHELASTIC_RUN_ID", "none").replace(os.sep, "_")
-    return os.path.join(d, "uid_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), run)), True
+    return os.path.join(d, "uid_%s_%d_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), run, _rdv_count)), True
 
 
 def _publisher_alive(pid, same_parent):
@@ -200,11 +201,15 @@ def _file_bcast(rank, payload, timeout=300.0):
         time.sleep(0.02)
 
 
-def from_env(bcast=None):
+def from_env(bcast=None, transport=None):
     """Build the world communicator of a `torch.distributed.run` / mpirun style
     launch from RANK / WORLD_SIZE / LOCAL_RANK.  `bcast(obj_or_None) -> obj`
-    broadcasts rank 0's RCCL unique id (e.g. over a gloo process group); without
-    it a file under /tmp is used (single node)."""
+    broadcasts rank 0's unique id (e.g. over a gloo process group); without
+    it a file under /tmp is used (single node).  `transport`: "rccl" (grouped send/recv over RCCL) or "ipc"
+    (copy-engine pulls through IPC-mapped work buffers, one node); default: $MFFT_TRANSPORT, else rccl.  Rank 0's
+    choice counts: the id it creates names the transport."""
+    global _rdv_count
+    _rdv_count += 1
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -213,7 +218,19 @@ def from_env(bcast=None):
     if world == 1:
         return SelfComm(device)
     _lib.call("mfft_set_device", device)
-    uid = get_unique_id() if rank == 0 else None
+    uid = None
+    if rank == 0:
+        saved = os.environ.get("MFFT_TRANSPORT")
+        if transport is not None:
+            os.environ["MFFT_TRANSPORT"] = transport
+        try:
+            uid = get_unique_id()
+        finally:
+            if transport is not None:
+                if saved is None:
+                    os.environ.pop("MFFT_TRANSPORT", None)
+                else:
+                    os.environ["MFFT_TRANSPORT"] = saved
     path = None
     if bcast is not None:
         uid = bcast(uid)

@@ -45,15 +45,9 @@ int mfft_device_sync(void) {
 int mfft_malloc(void** dptr, size_t bytes) {
   if (!dptr) return set_error(MFFT_ERR_INVALID, "null argument");
   *dptr = nullptr;
-  if (bytes == 0) bytes = 16;
-  hipError_t e = hipMalloc(dptr, bytes);
-  if (e != hipSuccess) return set_error(MFFT_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-  return 0;
+  return dev_alloc(dptr, bytes);      // registered: the buffer may be the source or target of an exchange
 }
-int mfft_free(void* dptr) {
-  if (dptr) MFFT_HIP(hipFree(dptr));
-  return 0;
-}
+int mfft_free(void* dptr) { return dev_free(dptr); }
 // The transforms run asynchronously on their plan's own non-blocking stream, which the null stream does not order
 // against.  These helpers therefore wait for ALL work of the device (every plan's streams) before they touch memory,
 // and return when the copy is complete: a copy issued after mfft_forward sees its result, a transform issued after
@@ -125,6 +119,11 @@ int mfft_comm_abort(mfft_comm_t c) {
   return 0;
 }
 int mfft_comm_destroy(mfft_comm_t c) {
+  if (!c) return 0;
+  if (c->plan_refs > 0) {                  // plans still use it (their work buffers live in it): the last one frees it
+    c->destroy_requested = true;
+    return 0;
+  }
   delete c;
   return 0;
 }

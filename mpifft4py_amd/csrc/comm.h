@@ -1,10 +1,14 @@
 // comm.h -- communicator abstraction behind mfft_comm_t.
 //
 // Replaces the mpi4py communicator the reference receives in its constructors
-// (slab.py:77-81, pencil.py:173-195).  Three transports:
+// (slab.py:77-81, pencil.py:173-195).  Four transports:
 //   SelfComm  : P = 1.
 //   RcclComm  : one process per GPU, RCCL (loaded with dlopen at first use) over
 //               xGMI; the exchange is a grouped ncclSend/ncclRecv all-to-all-v.
+//   IpcComm   : one process per GPU on one node; chunks are pushed into the peers'
+//               IPC-mapped receive buffers by the copy engines, cross-process
+//               ordering through stream memory operations (ipc_comm.hip).  Selected
+//               with MFFT_TRANSPORT=ipc on rank 0 (the unique id names the transport).
 //   LocalComm : P virtual ranks inside ONE process, each driven by its own host
 //               thread, exchanging with peer-to-peer device copies.  Used for
 //               single-process multi-GPU runs and to exercise the full
@@ -20,13 +24,22 @@ struct mfft_comm_s {
   // All-to-all-v inside a sub-group.  `peers` lists the comm ranks of the group
   // (every member passes the same list); chunk i is sent to / received from
   // peers[i].  Counts and displacements are in BYTES.  Enqueued on stream s.
+  // `channel` names the issuing stream's role (0: the plan's compute stream, 1: its
+  // communication stream): exchanges of one channel execute in the order they are issued.
   virtual int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv,
                         const size_t* rcount, const size_t* rdisp, const int* peers, int npeers,
-                        hipStream_t s) = 0;
+                        hipStream_t s, int channel = 0) = 0;
   virtual int barrier() = 0;
   virtual int bcast_host(void* buf, size_t bytes, int root) = 0;
   virtual int allreduce_host(double* vals, int count, int op /*0 sum, 1 max*/) = 0;
   virtual void abort() {}    // wake every rank blocked in a host-side barrier of this group
+  // Plan work buffers (the only buffers an exchange ever SENDS from).  A transport that has to make them reachable
+  // for its peers hands them out itself (IpcComm: an arena of IPC-exported segments); the others use hipMalloc.
+  virtual int work_alloc(void** p, size_t bytes);
+  virtual int work_free(void* p);
+  // plans hold a reference: a communicator destroyed before its plans lives until the last of them is gone
+  int plan_refs = 0;
+  bool destroy_requested = false;
 };
 
 namespace mfft {
@@ -34,4 +47,9 @@ int comm_create_self(mfft_comm_s** out);
 int comm_get_unique_id(void* id128);
 int comm_create_rccl(int nranks, int rank, const void* id128, mfft_comm_s** out);
 int comm_create_local(int nranks, const int* devices, mfft_comm_s** out);
+int comm_create_ipc(int nranks, int rank, const void* id128, mfft_comm_s** out);
+int ipc_make_unique_id(void* id128);
+bool ipc_is_unique_id(const void* id128);
+int dev_alloc(void** p, size_t bytes);    // hipMalloc / hipFree with the library's error reporting
+int dev_free(void* p);
 }  // namespace mfft

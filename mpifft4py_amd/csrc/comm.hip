@@ -10,6 +10,9 @@
 #include "comm.h"
 #include "mfft_internal.h"
 
+int mfft_comm_s::work_alloc(void** p, size_t bytes) { return mfft::dev_alloc(p, bytes); }
+int mfft_comm_s::work_free(void* p) { return mfft::dev_free(p); }
+
 namespace mfft {
 
 // ===========================================================================
@@ -17,7 +20,7 @@ namespace mfft {
 // ===========================================================================
 struct SelfComm : mfft_comm_s {
   int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
-                const size_t* rdisp, const int*, int npeers, hipStream_t s) override {
+                const size_t* rdisp, const int*, int npeers, hipStream_t s, int) override {
     if (npeers != 1) return set_error(MFFT_ERR_INVALID, "self comm: group of %d", npeers);
     if (scount[0] != rcount[0]) return set_error(MFFT_ERR_INVALID, "self comm: count mismatch");
     if (scount[0])
@@ -102,7 +105,7 @@ struct RcclComm : mfft_comm_s {
     if (hstream) (void)hipStreamDestroy(hstream);
   }
   int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
-                const size_t* rdisp, const int* peers, int npeers, hipStream_t s) override {
+                const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int) override {
     const char* sp = static_cast<const char*>(send);
     char* rp = static_cast<char*>(recv);
     // the self chunk never enters RCCL
@@ -158,6 +161,9 @@ struct RcclComm : mfft_comm_s {
 };
 
 int comm_get_unique_id(void* id128) {
+  const char* tr = getenv("MFFT_TRANSPORT");
+  if (tr && strcmp(tr, "ipc") == 0) return ipc_make_unique_id(id128);     // the id itself says which transport the group uses
+  if (tr && *tr && strcmp(tr, "rccl") != 0) return set_error(MFFT_ERR_INVALID, "MFFT_TRANSPORT=%s: expected rccl or ipc", tr);
   RcclApi* api = rccl_api();
   if (!api) return set_error(MFFT_ERR_RCCL, "librccl.so.1 could not be loaded: %s", dlerror());
   ncclUniqueId id;
@@ -168,6 +174,7 @@ int comm_get_unique_id(void* id128) {
 }
 
 int comm_create_rccl(int nranks, int rank, const void* id128, mfft_comm_s** out) {
+  if (ipc_is_unique_id(id128)) return comm_create_ipc(nranks, rank, id128, out);
   RcclApi* api = rccl_api();
   if (!api) return set_error(MFFT_ERR_RCCL, "librccl.so.1 could not be loaded: %s", dlerror());
   if (nranks < 1 || rank < 0 || rank >= nranks) return set_error(MFFT_ERR_INVALID, "bad rank %d of %d", rank, nranks);
@@ -250,7 +257,7 @@ struct LocalComm : mfft_comm_s {
     return 0;
   }
   int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
-                const size_t* rdisp, const int* peers, int npeers, hipStream_t s) override {
+                const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int) override {
     MFFT_TRY(ensure_events());
     LocalShared::Post& me = sh->posts[rank];
     int myidx = -1;

@@ -1,0 +1,454 @@
+// ipc_comm.hip -- IpcComm: one process per GPU on ONE node; every rank PULLS its chunks out of the peers' send
+// buffers with hipMemcpyAsync through IPC-mapped device memory.  No kernel of the transport ever occupies a CU: on
+// xGMI a peer-to-peer copy is an SDMA transfer.
+//
+// Replaces, like RcclComm, the mpi4py collectives of the reference (comm.Alltoall slab.py:406/281, Alltoallw
+// pencil.py:741-750, 1324-1333).  Why a second transport: RCCL's send/recv are kernels, and the FFT kernels keep every
+// CU busy (two 1024-thread workgroups with 80 KB of LDS each), so RCCL's copy kernels queue behind them.  It also runs
+// between processes that share ONE GPU, which RCCL refuses, so the process-per-GPU path is tested for real (no mock)
+// on a single-GPU box.
+//
+// Design, each point decided by a measurement on this pool (csrc/ipc_probe.hip, tests/test_gpu_multiprocess.py):
+//  * Only plan work buffers are ever the SOURCE of an exchange (plan.hip), and they come from an arena this
+//    communicator owns (work_alloc): segments of device memory that are exported once, when they are created, and
+//    live as long as the communicator.  Exporting arbitrary buffers on demand does not survive long runs: after a
+//    process has closed imported mappings (of buffers their owners had freed), hipIpcGetMemHandle of a NEW allocation
+//    fails with "invalid argument" (ROCm 7.2, 4 and 8 processes).  So nothing is exported late, nothing imported is
+//    closed before the communicator goes, and user arrays are never exported at all (they are only ever pulled INTO).
+//  * Cross-process ordering: 32-bit sequence numbers in device memory, written into the PEER's flag array with
+//    hipStreamWriteValue32 and awaited locally with hipStreamWaitValue32(>=): "ready" (sender -> receiver: my send
+//    buffer holds exchange q) and "done" (receiver -> sender: I have pulled my chunk of exchange q).  Everything is
+//    enqueued; the only host-side wait is for the peer's post (where its chunk lies), a few microseconds behind.
+//    Interprocess HIP events would be the textbook tool, and they do work here -- for exactly 32 records: the 33rd
+//    hipStreamWaitEvent on an opened interprocess event returns "invalid argument" (ROCm 7.2, ipc_probe2.hip).
+//    A first version PUSHED chunks into the peers' receive buffers under the same flags: one rank in four then read
+//    stale data after the wait (a remote write behind the reader's L2); a pull is an ordinary local copy command
+//    of the reader's own stream, and the sender's data is released by an event record before its flag is written.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+#include "comm.h"
+#include "mfft_internal.h"
+
+namespace mfft {
+
+// plain device buffers (everything that is not a plan work buffer of an IpcComm)
+int dev_alloc(void** p, size_t bytes) {
+  *p = nullptr;
+  hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+  if (e != hipSuccess) return set_error(MFFT_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  return 0;
+}
+int dev_free(void* p) {
+  if (p) MFFT_HIP(hipFree(p));
+  return 0;
+}
+
+namespace {
+
+constexpr int IPC_MAX_RANKS = 16, IPC_MAX_CH = 2, IPC_MAX_SEG = 64, IPC_SCRATCH = 4096;
+constexpr uint64_t IPC_MAGIC = 0x4D46465449504331ull;   // "MFFTIPC1"
+
+struct IpcSegment {
+  std::atomic<uint32_t> live;
+  uint32_t pad;
+  uint64_t base, size;
+  hipIpcMemHandle_t h;
+};
+constexpr int IPC_RING = 4;
+struct IpcPost {                    // where the receiver finds its chunk of exchange `seq` in the sender's memory
+  std::atomic<uint64_t> seq;
+  uint32_t seg, pad;
+  uint64_t offset, bytes;
+};
+struct IpcPair {                    // one per ordered pair (sender, receiver) and channel
+  IpcPost ring[IPC_RING];
+  std::atomic<uint64_t> consumed;   // last post the receiver has read
+};
+struct IpcRankInfo {
+  int device, pid;
+  hipIpcMemHandle_t flags_h;
+  IpcSegment seg[IPC_MAX_SEG];
+  alignas(64) char scratch[IPC_SCRATCH];
+};
+struct IpcShm {
+  std::atomic<uint64_t> magic;
+  int nranks;
+  std::atomic<uint32_t> attached, detached;
+  std::atomic<uint32_t> bar_count, bar_gen, broken;
+  IpcRankInfo rk[IPC_MAX_RANKS];
+  IpcPair pair[IPC_MAX_RANKS /*sender*/][IPC_MAX_RANKS /*receiver*/][IPC_MAX_CH];
+};
+// device-side flags of one rank (the READER of a flag owns it, so that polling stays local)
+struct IpcFlags {
+  uint32_t ready[IPC_MAX_RANKS][IPC_MAX_CH];   // ready[p]: written by sender p, "my send buffer holds exchange q"
+  uint32_t done[IPC_MAX_RANKS][IPC_MAX_CH];    // done[r]:  written by receiver r, "I have pulled my chunk of exchange q"
+};
+static_assert(std::atomic<uint64_t>::is_always_lock_free && std::atomic<uint32_t>::is_always_lock_free, "shared-memory atomics");
+
+long ipc_timeout_s() {
+  static const long t = getenv("MFFT_LOCAL_TIMEOUT") ? atol(getenv("MFFT_LOCAL_TIMEOUT")) : 180;
+  return t;
+}
+
+struct IpcComm : mfft_comm_s {
+  IpcShm* sh = nullptr;
+  std::string shm_name;
+  bool creator = false;
+  int device = 0;
+  IpcFlags* flags = nullptr;                               // mine (device memory, exported at creation)
+  std::vector<IpcFlags*> peer_flags;                       // IPC mappings of the peers' flags
+  hipEvent_t release_ev[IPC_MAX_CH] = {};                  // plain events: a record releases kernel-written data
+  uint32_t sseq[IPC_MAX_RANKS][IPC_MAX_CH] = {}, rseq[IPC_MAX_RANKS][IPC_MAX_CH] = {};
+  std::map<std::pair<int, uint32_t>, void*> maps;          // (peer, segment) -> mapping, closed with the communicator
+  // arena: first-fit over the segments, 2 MiB granules
+  struct Block { uint64_t off, size; bool used; };
+  struct Seg { char* base; uint64_t size; std::vector<Block> blocks; };
+  std::vector<Seg> segs;
+  hipStream_t last_stream[IPC_MAX_CH] = {};
+  hipEvent_t last_issue[IPC_MAX_CH] = {};
+  bool used_ch[IPC_MAX_CH] = {};
+
+  ~IpcComm() override {
+    (void)hipDeviceSynchronize();
+    if (sh) {
+      // peers may still pull from my segments or wait on my events: leave together (best effort, bounded)
+      sh->detached.fetch_add(1);
+      const auto t0 = std::chrono::steady_clock::now();
+      while (sh->detached.load() < (uint32_t)size && !sh->broken.load() &&
+             std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20))
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    for (auto& m : maps) (void)hipIpcCloseMemHandle(m.second);
+    for (int r = 0; r < (int)peer_flags.size(); ++r)
+      if (peer_flags[r] && r != rank) (void)hipIpcCloseMemHandle(peer_flags[r]);
+    for (int ch = 0; ch < IPC_MAX_CH; ++ch) {
+      if (release_ev[ch]) (void)hipEventDestroy(release_ev[ch]);
+      if (last_issue[ch]) (void)hipEventDestroy(last_issue[ch]);
+    }
+    if (flags) (void)hipFree(flags);
+    for (Seg& s : segs) (void)hipFree(s.base);
+    if (sh) munmap(sh, sizeof(IpcShm));
+    if (creator && !shm_name.empty()) (void)shm_unlink(shm_name.c_str());
+  }
+
+  template <class Pred>
+  int spin(Pred ok, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int n = 0;
+    while (!ok()) {
+      if (sh->broken.load()) return set_error(MFFT_ERR_INTERNAL, "ipc transport: a peer rank failed (%s)", what);
+      if (++n > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+      if ((n & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(ipc_timeout_s())) {
+        sh->broken.store(1);
+        return set_error(MFFT_ERR_INTERNAL, "ipc transport: timed out after %ld s waiting for %s", ipc_timeout_s(), what);
+      }
+    }
+    return 0;
+  }
+
+  int barrier() override {
+    const uint32_t gen = sh->bar_gen.load();
+    if (sh->bar_count.fetch_add(1) + 1 == (uint32_t)size) {
+      sh->bar_count.store(0);
+      sh->bar_gen.fetch_add(1);
+      return 0;
+    }
+    return spin([&] { return sh->bar_gen.load() != gen; }, "a host barrier");
+  }
+  void abort() override {
+    if (sh) sh->broken.store(1);
+  }
+  int bcast_host(void* buf, size_t bytes, int root) override {
+    char* p = static_cast<char*>(buf);
+    for (size_t off = 0; off < bytes; off += IPC_SCRATCH) {
+      const size_t n = std::min<size_t>(IPC_SCRATCH, bytes - off);
+      if (rank == root) memcpy(sh->rk[root].scratch, p + off, n);
+      MFFT_TRY(barrier());
+      if (rank != root) memcpy(p + off, sh->rk[root].scratch, n);
+      MFFT_TRY(barrier());
+    }
+    return 0;
+  }
+  int allreduce_host(double* vals, int count, int op) override {
+    const int per = IPC_SCRATCH / (int)sizeof(double);
+    for (int off = 0; off < count; off += per) {
+      const int n = std::min(per, count - off);
+      memcpy(sh->rk[rank].scratch, vals + off, n * sizeof(double));
+      MFFT_TRY(barrier());
+      std::vector<double> acc(n);
+      for (int i = 0; i < n; ++i) acc[i] = reinterpret_cast<double*>(sh->rk[0].scratch)[i];
+      for (int r = 1; r < size; ++r) {
+        const double* o = reinterpret_cast<const double*>(sh->rk[r].scratch);
+        for (int i = 0; i < n; ++i) acc[i] = op == 1 ? (o[i] > acc[i] ? o[i] : acc[i]) : acc[i] + o[i];
+      }
+      MFFT_TRY(barrier());
+      memcpy(vals + off, acc.data(), n * sizeof(double));
+    }
+    return 0;
+  }
+
+  // ---- arena of exportable work buffers -------------------------------------------------------------------------
+  static constexpr uint64_t GRAN = (uint64_t)2 << 20;
+  int work_alloc(void** p, size_t bytes) override {
+    const uint64_t want = ((bytes ? bytes : 16) + GRAN - 1) / GRAN * GRAN;
+    for (Seg& s : segs)
+      for (size_t i = 0; i < s.blocks.size(); ++i) {
+        Block& b = s.blocks[i];
+        if (b.used || b.size < want) continue;
+        if (b.size > want) {
+          const Block rest{b.off + want, b.size - want, false};
+          b.size = want;
+          s.blocks.insert(s.blocks.begin() + i + 1, rest);
+        }
+        s.blocks[i].used = true;
+        *p = s.base + s.blocks[i].off;
+        return 0;
+      }
+    // a new segment: the request itself (large plans) or 64 MiB that small plans share
+    if ((int)segs.size() >= IPC_MAX_SEG) return set_error(MFFT_ERR_NOMEM, "ipc transport: more than %d work segments", IPC_MAX_SEG);
+    const uint64_t seg_bytes = std::max<uint64_t>(want, (uint64_t)64 << 20);
+    void* base = nullptr;
+    hipError_t e = hipMalloc(&base, seg_bytes);
+    if (e != hipSuccess) return set_error(MFFT_ERR_NOMEM, "hipMalloc(%llu) for a work segment failed: %s", (unsigned long long)seg_bytes, hipGetErrorString(e));
+    IpcSegment& pub = sh->rk[rank].seg[segs.size()];
+    e = hipIpcGetMemHandle(&pub.h, base);
+    if (e != hipSuccess) {
+      (void)hipFree(base);
+      return set_error(MFFT_ERR_HIP, "ipc transport: hipIpcGetMemHandle of a %llu-byte segment failed: %s", (unsigned long long)seg_bytes, hipGetErrorString(e));
+    }
+    pub.base = (uint64_t)(uintptr_t)base;
+    pub.size = seg_bytes;
+    pub.live.store(1, std::memory_order_release);
+    Seg s{static_cast<char*>(base), seg_bytes, {}};
+    s.blocks.push_back(Block{0, want, true});
+    if (seg_bytes > want) s.blocks.push_back(Block{want, seg_bytes - want, false});
+    segs.push_back(std::move(s));
+    *p = base;
+    return 0;
+  }
+  int work_free(void* p) override {
+    if (!p) return 0;
+    for (Seg& s : segs) {
+      if (static_cast<char*>(p) < s.base || static_cast<char*>(p) >= s.base + s.size) continue;
+      const uint64_t off = (uint64_t)(static_cast<char*>(p) - s.base);
+      for (size_t i = 0; i < s.blocks.size(); ++i) {
+        if (s.blocks[i].off != off || !s.blocks[i].used) continue;
+        s.blocks[i].used = false;
+        if (i + 1 < s.blocks.size() && !s.blocks[i + 1].used) {
+          s.blocks[i].size += s.blocks[i + 1].size;
+          s.blocks.erase(s.blocks.begin() + i + 1);
+        }
+        if (i > 0 && !s.blocks[i - 1].used) {
+          s.blocks[i - 1].size += s.blocks[i].size;
+          s.blocks.erase(s.blocks.begin() + i);
+        }
+        return 0;
+      }
+    }
+    return set_error(MFFT_ERR_INVALID, "ipc transport: %p is not a work buffer of this communicator", p);
+  }
+  int locate(const void* p, uint32_t* seg, uint64_t* off) const {
+    for (size_t i = 0; i < segs.size(); ++i)
+      if (static_cast<const char*>(p) >= segs[i].base && static_cast<const char*>(p) < segs[i].base + segs[i].size) {
+        *seg = (uint32_t)i;
+        *off = (uint64_t)(static_cast<const char*>(p) - segs[i].base);
+        return 0;
+      }
+    return set_error(MFFT_ERR_INVALID, "ipc transport: the send buffer %p of an exchange is not a work buffer of this communicator", p);
+  }
+  int remote_base(int peer, uint32_t seg, char** out) {
+    if (seg >= (uint32_t)IPC_MAX_SEG || !sh->rk[peer].seg[seg].live.load(std::memory_order_acquire))
+      return set_error(MFFT_ERR_INTERNAL, "ipc transport: rank %d offers data in a segment it never published", peer);
+    auto key = std::make_pair(peer, seg);
+    auto it = maps.find(key);
+    if (it == maps.end()) {
+      void* ptr = nullptr;
+      MFFT_HIP(hipIpcOpenMemHandle(&ptr, sh->rk[peer].seg[seg].h, hipIpcMemLazyEnablePeerAccess));
+      it = maps.emplace(key, ptr).first;
+    }
+    *out = static_cast<char*>(it->second);
+    return 0;
+  }
+
+  int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
+                const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int channel) override {
+    const int rc = exchange(send, scount, sdisp, recv, rcount, rdisp, peers, npeers, s, channel);
+    if (rc != 0) sh->broken.store(1);      // the peers are (or will be) waiting in a host barrier: let them fail fast
+    return rc;
+  }
+  int exchange(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
+               const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int ch) {
+    if (ch < 0 || ch >= IPC_MAX_CH) return set_error(MFFT_ERR_INVALID, "ipc transport: channel %d", ch);
+    if (npeers > IPC_MAX_RANKS) return set_error(MFFT_ERR_INVALID, "ipc transport: group of %d", npeers);
+    int myidx = -1;
+    for (int i = 0; i < npeers; ++i)
+      if (peers[i] == rank) myidx = i;
+    if (myidx < 0) return set_error(MFFT_ERR_INVALID, "ipc transport: rank %d not in its own group", rank);
+    // exchanges of one channel execute in the order they are issued, also when the channel moves to another stream
+    if (!last_issue[ch]) MFFT_HIP(hipEventCreateWithFlags(&last_issue[ch], hipEventDisableTiming));
+    if (used_ch[ch]) MFFT_HIP(hipStreamWaitEvent(s, last_issue[ch], 0));     // (a no-op on the same stream; a new stream may reuse a dead one's handle)
+    if (!release_ev[ch]) MFFT_HIP(hipEventCreateWithFlags(&release_ev[ch], hipEventDisableTiming));
+    const char* sp = static_cast<const char*>(send);
+    char* rp = static_cast<char*>(recv);
+    // 1. sender role: say where each peer finds its chunk (host), then, on the stream, that the data is there
+    bool any_send = false;
+    for (int i = 0; i < npeers; ++i) any_send = any_send || (peers[i] != rank && scount[i]);
+    uint32_t seg = 0;
+    uint64_t soff = 0;
+    if (any_send) {
+      MFFT_TRY(locate(send, &seg, &soff));
+      MFFT_HIP(hipEventRecord(release_ev[ch], s));         // system-scope release of what the kernels before us wrote
+    }
+    std::vector<uint32_t> qs(npeers, 0);
+    for (int i = 0; i < npeers; ++i) {
+      const int p = peers[i];
+      if (p == rank || !scount[i]) continue;
+      const uint32_t q = ++sseq[p][ch];
+      qs[i] = q;
+      IpcPair& pr = sh->pair[rank][p][ch];
+      if (q > (uint32_t)IPC_RING)
+        MFFT_TRY(spin([&] { return pr.consumed.load(std::memory_order_acquire) + IPC_RING >= q; }, "a peer to read an earlier post"));
+      IpcPost& post = pr.ring[q % IPC_RING];
+      post.seg = seg; post.offset = soff + sdisp[i]; post.bytes = scount[i];
+      post.seq.store(q, std::memory_order_release);
+      MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[p]->ready[rank][ch], q, 0));
+    }
+    // 2. the self chunk
+    if (rcount[myidx]) {
+      if (scount[myidx] != rcount[myidx]) return set_error(MFFT_ERR_INVALID, "ipc transport: self chunk size mismatch");
+      MFFT_HIP(hipMemcpyAsync(rp + rdisp[myidx], sp + sdisp[myidx], rcount[myidx], hipMemcpyDeviceToDevice, s));
+    }
+    // 3. receiver role: pull every chunk out of its sender's segment (starting with the next rank: spreads the links)
+    for (int k = 1; k < npeers; ++k) {
+      const int i = (myidx + k) % npeers, p = peers[i];
+      if (!rcount[i]) continue;
+      const uint32_t q = ++rseq[p][ch];
+      IpcPair& pr = sh->pair[p][rank][ch];
+      IpcPost& post = pr.ring[q % IPC_RING];
+      MFFT_TRY(spin([&] { return post.seq.load(std::memory_order_acquire) == q; }, "a peer to post its send buffer"));
+      const uint32_t pseg = post.seg;
+      const uint64_t off = post.offset, bytes = post.bytes;
+      pr.consumed.store(q, std::memory_order_release);
+      if (bytes != rcount[i])
+        return set_error(MFFT_ERR_INTERNAL, "ipc transport: rank %d expects %zu bytes from %d, which sends %llu", rank, rcount[i], p,
+                         (unsigned long long)bytes);
+      char* rbase = nullptr;
+      MFFT_TRY(remote_base(p, pseg, &rbase));
+      MFFT_HIP(hipStreamWaitValue32(s, &flags->ready[p][ch], q, hipStreamWaitValueGte, 0xFFFFFFFFu));
+      MFFT_HIP(hipMemcpyAsync(rp + rdisp[i], rbase + off, rcount[i], hipMemcpyDeviceToDevice, s));
+      MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[p]->done[rank][ch], q, 0));
+    }
+    // 4. sender role: nobody overwrites its send buffer before all peers have pulled from it
+    for (int i = 0; i < npeers; ++i)
+      if (qs[i]) MFFT_HIP(hipStreamWaitValue32(s, &flags->done[peers[i]][ch], qs[i], hipStreamWaitValueGte, 0xFFFFFFFFu));
+    MFFT_HIP(hipEventRecord(last_issue[ch], s));
+    last_stream[ch] = s;
+    used_ch[ch] = true;
+    return 0;
+  }
+};
+
+std::string ipc_shm_name(const unsigned char* id128) {
+  char nm[64] = "/mfft-";
+  for (int i = 0; i < 16; ++i) snprintf(nm + 6 + 2 * i, 3, "%02x", id128[8 + i]);
+  return nm;
+}
+
+}  // namespace
+
+// a unique id of the IPC transport: magic + random bytes (names the shared-memory segment of the group)
+int ipc_make_unique_id(void* id128) {
+  unsigned char* b = static_cast<unsigned char*>(id128);
+  memset(b, 0, MFFT_UNIQUE_ID_BYTES);
+  memcpy(b, &IPC_MAGIC, 8);
+  int fd = open("/dev/urandom", O_RDONLY);
+  if (fd < 0 || read(fd, b + 8, 16) != 16) {
+    if (fd >= 0) close(fd);
+    return set_error(MFFT_ERR_INTERNAL, "cannot read /dev/urandom");
+  }
+  close(fd);
+  return 0;
+}
+bool ipc_is_unique_id(const void* id128) { return memcmp(id128, &IPC_MAGIC, 8) == 0; }
+
+int comm_create_ipc(int nranks, int rank, const void* id128, mfft_comm_s** out) {
+  if (nranks < 1 || nranks > IPC_MAX_RANKS || rank < 0 || rank >= nranks)
+    return set_error(MFFT_ERR_INVALID, "ipc transport: rank %d of %d (at most %d ranks, one node)", rank, nranks, IPC_MAX_RANKS);
+  std::unique_ptr<IpcComm> c(new IpcComm());
+  c->size = nranks;
+  c->rank = rank;
+  MFFT_HIP(hipGetDevice(&c->device));
+  c->shm_name = ipc_shm_name(static_cast<const unsigned char*>(id128));
+  int fd = -1;
+  if (rank == 0) {
+    (void)shm_unlink(c->shm_name.c_str());
+    fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return set_error(MFFT_ERR_INTERNAL, "shm_open(%s) failed: %s", c->shm_name.c_str(), strerror(errno));
+    c->creator = true;
+    if (ftruncate(fd, sizeof(IpcShm)) != 0) { close(fd); return set_error(MFFT_ERR_INTERNAL, "ftruncate failed: %s", strerror(errno)); }
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcShm)) break;
+        close(fd);
+        fd = -1;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(ipc_timeout_s()))
+        return set_error(MFFT_ERR_INTERNAL, "ipc transport: rank 0 never created %s", c->shm_name.c_str());
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+  }
+  void* m = mmap(nullptr, sizeof(IpcShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return set_error(MFFT_ERR_INTERNAL, "mmap of %s failed: %s", c->shm_name.c_str(), strerror(errno));
+  c->sh = static_cast<IpcShm*>(m);
+  IpcShm* sh = c->sh;
+  if (rank == 0) {
+    sh->nranks = nranks;                                // the segment is zero-filled by ftruncate
+    sh->magic.store(IPC_MAGIC, std::memory_order_release);
+  } else {
+    MFFT_TRY(c->spin([&] { return sh->magic.load(std::memory_order_acquire) == IPC_MAGIC; }, "rank 0 to initialise the segment"));
+    if (sh->nranks != nranks) return set_error(MFFT_ERR_INVALID, "ipc transport: rank 0 says %d ranks, this rank %d", sh->nranks, nranks);
+  }
+  int can = 0;
+  (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
+  if (!can) return set_error(MFFT_ERR_UNSUPPORTED, "ipc transport: this device has no stream memory operations");
+  // my flags: zeroed, exported (the first and only export besides the work segments)
+  MFFT_HIP(hipMalloc(reinterpret_cast<void**>(&c->flags), (size_t)2 << 20));
+  MFFT_HIP(hipMemset(c->flags, 0, sizeof(IpcFlags)));
+  MFFT_HIP(hipDeviceSynchronize());
+  MFFT_HIP(hipIpcGetMemHandle(&sh->rk[rank].flags_h, c->flags));
+  sh->rk[rank].device = c->device;
+  sh->rk[rank].pid = (int)getpid();
+  sh->attached.fetch_add(1);
+  MFFT_TRY(c->spin([&] { return sh->attached.load() >= (uint32_t)nranks; }, "every rank to attach"));
+  c->peer_flags.assign(nranks, nullptr);
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) { c->peer_flags[r] = c->flags; continue; }
+    void* p = nullptr;
+    MFFT_HIP(hipIpcOpenMemHandle(&p, sh->rk[r].flags_h, hipIpcMemLazyEnablePeerAccess));
+    c->peer_flags[r] = static_cast<IpcFlags*>(p);
+  }
+  MFFT_TRY(c->barrier());
+  if (rank == 0) {                                      // everybody holds a mapping: the name can go
+    (void)shm_unlink(c->shm_name.c_str());
+    c->creator = false;
+  }
+  *out = c.release();
+  return 0;
+}
+
+}  // namespace mfft

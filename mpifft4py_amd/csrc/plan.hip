@@ -106,9 +106,9 @@ struct mfft_plan_s {
 
   ~mfft_plan_s() {
     for (void* w : work)
-      if (w) (void)hipFree(w);
+      if (w) (void)wfree(w);
     if (mask) (void)hipFree(mask);
-    if (work3) (void)hipFree(work3);
+    if (work3) (void)wfree(work3);
     for (auto& t : timers) {
       for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
       for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -122,6 +122,9 @@ struct mfft_plan_s {
     if (stream) (void)hipStreamDestroy(stream);
   }
 
+  int walloc(void** p, size_t bytes) { return comm ? comm->work_alloc(p, bytes) : dev_alloc(p, bytes); }
+  int wfree(void* p) { return comm ? comm->work_free(p) : dev_free(p); }
+
   void drop_graphs() {
     for (auto& g : graphs)
       if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -131,11 +134,10 @@ struct mfft_plan_s {
   int ensure_work(int i, size_t bytes) {
     if (work_bytes[i] >= bytes) return 0;
     drop_graphs();               // captured sequences hold the old buffer address
-    if (work[i]) MFFT_HIP(hipFree(work[i]));
+    if (work[i]) MFFT_TRY(wfree(work[i]));
     work[i] = nullptr;
     work_bytes[i] = 0;
-    hipError_t e = hipMalloc(&work[i], bytes);
-    if (e != hipSuccess) return set_error(MFFT_ERR_NOMEM, "hipMalloc(%zu) for work buffer %d failed: %s", bytes, i, hipGetErrorString(e));
+    MFFT_TRY(walloc(&work[i], bytes));         // from the communicator: work buffers are what exchanges send from
     work_bytes[i] = bytes;
     return 0;
   }
@@ -240,7 +242,7 @@ struct mfft_plan_s {
   int exchange(const std::vector<int>& grp, const void* send, const std::vector<size_t>& sc, const std::vector<size_t>& sd,
                void* recv, const std::vector<size_t>& rc, const std::vector<size_t>& rd, hipStream_t on = nullptr) {
     return comm->alltoallv(send, sc.data(), sd.data(), recv, rc.data(), rd.data(), grp.data(), (int)grp.size(),
-                           on ? on : stream);
+                           on ? on : stream, on && on != stream ? 1 : 0);
   }
   int exchange_equal(const std::vector<int>& grp, const void* send, void* recv, size_t chunk_bytes, hipStream_t on = nullptr) {
     const int n = (int)grp.size();
@@ -301,7 +303,7 @@ struct mfft_plan_s {
   int sched(int which, bool forward, bool padded, Sched* out) const;
   int run_sched(const Sched& sc, const void* send, void* recv, hipStream_t on = nullptr) {
     return comm->alltoallv(send, sc.sc.data(), sc.sd.data(), recv, sc.rc.data(), sc.rd.data(), sc.peers.data(),
-                           (int)sc.peers.size(), on ? on : stream);
+                           (int)sc.peers.size(), on ? on : stream, on && on != stream ? 1 : 0);
   }
   int xchg(int which, bool forward, bool padded, const void* send, void* recv) {
     Sched sc;
@@ -327,11 +329,10 @@ struct mfft_plan_s {
   int piece_sched(int which, bool forward, int piece, Sched* out) const;
   int ensure_work3(size_t bytes) {
     if (work3 && work3_bytes >= bytes) return 0;
-    if (work3) MFFT_HIP(hipFree(work3));
+    if (work3) MFFT_TRY(wfree(work3));
     work3 = nullptr;
     work3_bytes = 0;
-    hipError_t e = hipMalloc(&work3, bytes);
-    if (e != hipSuccess) return set_error(MFFT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    MFFT_TRY(walloc(&work3, bytes));
     work3_bytes = bytes;
     return 0;
   }
@@ -1368,6 +1369,11 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
   std::unique_ptr<mfft_plan_s> p(new mfft_plan_s());
   p->comm = comm;
   MFFT_TRY(decomp_init(p.get(), desc, comm->size, comm->rank));
+  comm->plan_refs++;                       // released by mfft_plan_destroy / the error path below
+  struct Unref {
+    mfft_comm_s* c; bool armed;
+    ~Unref() { if (armed) c->plan_refs--; }
+  } unref{comm, true};
   MFFT_HIP(hipGetDevice(&p->dev));
   MFFT_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   {
@@ -1391,6 +1397,7 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
       for (int s = 0; s < nev; ++s) MFFT_HIP(hipEventCreateWithFlags(&(*v)[s], hipEventDisableTiming));
     }
   }
+  unref.armed = false;
   *out = p.release();
   return 0;
 }
@@ -1443,7 +1450,9 @@ int mfft_plan_exchange_pieces(const mfft_plan_desc* desc, int nranks, int rank, 
 int mfft_plan_destroy(mfft_plan_t plan) {
   if (!plan) return 0;
   (void)hipStreamSynchronize(plan->stream);
-  delete plan;
+  mfft_comm_s* c = plan->comm;
+  delete plan;                             // returns its work buffers to the communicator
+  if (c && --c->plan_refs == 0 && c->destroy_requested) delete c;
   return 0;
 }
 

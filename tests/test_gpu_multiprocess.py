@@ -1,9 +1,12 @@
 """GPU: the process-per-GPU product path with 2, 4 and 8 PROCESSES launched by
 torch.distributed.run -- exactly as the benchmark driver launches bench.py -- on the single
-GPU of the box.  Real RCCL refuses two ranks on one device, so librccl is replaced behind
-the same dlsym'd entry points by tests/mock_rccl (shared-memory mailboxes); everything
-above the wire (rendezvous, DistComm, RcclComm.alltoallv, plans, pipeline, bench.py's
-rank-0 JSON line) is the shipped code."""
+GPU of the box, over two transports:
+  * "ipc":  the shipped IpcComm (csrc/ipc_comm.hip): IPC-mapped receive buffers, copy-engine pushes, stream memory
+            operations between the processes.  Nothing is mocked: this IS the product's wire, it just runs with all
+            ranks on one device.
+  * "mock": RcclComm.  Real RCCL refuses two ranks on one device, so librccl is replaced behind the same dlsym'd entry
+            points by tests/mock_rccl (shared-memory mailboxes); everything above the wire (rendezvous, DistComm,
+            RcclComm.alltoallv, plans, pipeline, bench.py's rank-0 JSON line) is the shipped code."""
 import json
 import os
 import socket
@@ -38,25 +41,34 @@ def _free_port():
     return p
 
 
-def _env():
-    return dict(os.environ, MFFT_RCCL_LIB=MOCK, MOCK_RCCL_SLOT_KB="2048", OMP_NUM_THREADS="1")
+def _env(transport="mock"):
+    env = {k: v for k, v in os.environ.items() if k not in ("MFFT_TRANSPORT", "MFFT_RCCL_LIB")}
+    env["OMP_NUM_THREADS"] = "1"
+    if transport == "ipc":
+        env["MFFT_TRANSPORT"] = "ipc"
+    else:
+        env.update(MFFT_RCCL_LIB=MOCK, MOCK_RCCL_SLOT_KB="2048")
+    return env
 
 
-def _torchrun(nproc, script_args, timeout=900):
+TRANSPORTS = ["ipc", "mock"]
+
+
+def _torchrun(nproc, script_args, timeout=900, transport="mock"):
     """The driver's launch line (python -m torch.distributed.run ...)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
-    p = subprocess.run(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
+    p = subprocess.run(cmd, env=_env(transport), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
     return p.returncode, p.stdout.decode(), p.stderr.decode()
 
 
-def _spawn(nproc, script_args, timeout=600):
+def _spawn(nproc, script_args, timeout=600, transport="mock"):
     """Same environment contract (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) without the launcher's
     own start-up cost: one python process per rank started directly."""
     port = _free_port()
     procs = []
     for r in range(nproc):
-        env = dict(_env(), RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+        env = dict(_env(transport), RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable] + script_args, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, cwd=ROOT))
@@ -74,42 +86,55 @@ def _spawn(nproc, script_args, timeout=600):
     return rc, "".join(outs), "\n".join(errs)
 
 
+@pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_process_per_rank_parity(world):
-    rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker.py")])
+def test_process_per_rank_parity(world, transport):
+    rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker.py")], transport=transport)
     assert rc == 0, (out[-2000:], err[-4000:])
     assert "MP_OK world=%d" % world in out
 
 
+@pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("world,launcher", [(2, "torchrun"), (4, "spawn"), (8, "spawn")])
-def test_bench_multi_rank_prints_one_json_line(world, launcher):
+def test_bench_multi_rank_prints_one_json_line(world, launcher, transport):
     run = _torchrun if launcher == "torchrun" else _spawn
-    rc, out, err = run(world, [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "128",
-                               "--steps", "3", "--warmup", "1", "--cpu-baseline", "off"])
+    # "mock": --transport auto, i.e. the (mocked) RCCL path first and the IPC transport as the second candidate, the
+    # way the driver's multi-GPU run goes; "ipc": the IPC transport alone (real RCCL would refuse the shared GPU)
+    rc, out, err = run(world, [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "128", "--steps", "3",
+                               "--warmup", "1", "--cpu-baseline", "off", "--transport", "ipc" if transport == "ipc" else "auto"],
+                       transport=transport)
     assert rc == 0, (out[-2000:], err[-4000:])
     lines = [l for l in out.splitlines() if l.strip()]
     assert len(lines) == 1, out                      # exactly one line on stdout, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "strong"
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "strong" and not d.get("degraded")
     assert d["config"]["roundtrip_rel_l2"] < 1e-10
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0
-    # the exchange-pipeline depth is measured before the warm-up (all four candidates), the best one is used
+    # transport x exchange-pipeline flavour are measured before the timed region, the best candidate is used
     tun = d["config"]["exchange_pipeline_tuning_ms_per_pair"]
-    assert sorted(int(k) for k in tun) == [-8, -4, -2, 1, 2, 4, 8] and all(v > 0 for v in tun.values())
-    assert d["config"]["exchange_pipeline_depth"] == int(min(tun, key=tun.get))
+    assert sorted(tun) == (["ipc"] if transport == "ipc" else ["ipc", "rccl"]), tun
+    best = None
+    for name, per in tun.items():
+        assert sorted(int(k) for k in per) == [-8, -4, -2, 1, 2, 4, 8] and all(v > 0 for v in per.values()), tun
+        for k, v in per.items():
+            if best is None or v < best[0]:
+                best = (v, name, int(k))
+    assert (d["config"]["exchange_transport"], d["config"]["exchange_pipeline_depth"]) == best[1:]
     if world == 4:
         assert d["extras"]["pencil_R2CX"]["grid"] == [2, 2]
         assert d["extras"]["pencil_R2CX"]["roundtrip_rel_l2"] < 1e-10
 
 
+@pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("world", [2, 4])
-def test_bench_starts_its_own_ranks_without_a_launcher(world):
+def test_bench_starts_its_own_ranks_without_a_launcher(world, transport):
     """`python bench.py --gpus N` as the driver's 1-GPU command line would look with N > 1: no torch.distributed.run,
     no RANK / WORLD_SIZE in the environment.  bench.py starts its N ranks itself (fresh child processes) and still
     prints exactly one JSON line."""
-    env = {k: v for k, v in _env().items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env = {k: v for k, v in _env(transport).items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "128", "--steps", "3",
-                        "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off"], env=env, stdout=subprocess.PIPE,
+                        "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off", "--transport",
+                        "ipc" if transport == "ipc" else "auto"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
     out, err = p.stdout.decode(), p.stderr.decode()
     assert p.returncode == 0, (out[-2000:], err[-4000:])

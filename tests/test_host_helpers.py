@@ -85,7 +85,7 @@ def test_file_rendezvous_ignores_leftovers_of_a_crashed_launch(tmp_path):
     dead.wait()
     d = tmp_path / ("mfft-%d" % os.getuid())
     d.mkdir(mode=0o700)
-    stale = d / ("uid_45999_%d_none" % os.getpid())
+    stale = d / ("uid_45999_%d_none_0" % os.getpid())
     stale.write_bytes(b"MFFTRDV1" + dead.pid.to_bytes(8, "little") + b"S" * 128)
     code = ("import sys\nfrom mpifft4py_amd import comm\n"
             "r = int(sys.argv[1])\n"
