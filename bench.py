@@ -101,15 +101,35 @@ def make_comm(world, rendezvous, transport=None):
     return mcomm.from_env(bcast, transport=transport), dist
 
 
+def launched_col_kernel(n, precision):
+    """The strided-axis kernel the library runs for length n: (plan as "8x8x4x4", tile, full registry name)."""
+    import ctypes
+    import re
+    buf = ctypes.create_string_buffer(256)
+    try:
+        _lib.call("mfft_kernel_name", 0, n, 1 if precision == "double" else 0, 0, 0, buf, 256)
+    except Exception:  # noqa: BLE001
+        return None
+    name = buf.value.decode()
+    m = re.search(r"n%d\(([\d, ]+)\).* tile=(\d+)" % n, name)
+    if not m:
+        return None
+    return m.group(1).replace(", ", "x"), int(m.group(2)), name
+
+
 def pmc_traffic(n, precision, decomp, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_traffic.json, written by scripts/summarize_profiles.py from separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None if no profile matches."""
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  Only a profile of EXACTLY the kernel that has just
+    been timed counts -- same length, radix plan, precision and tile, as the registry reports it
+    (mfft_kernel_name) -- so a profile cannot outlive a kernel change; None otherwise."""
     import glob
     if world != 1 or decomp != "slab":
         return None, None
-    want = "ColFft n=%d" % n
-    tname = "double" if precision == "double" else "float"
+    k = launched_col_kernel(n, precision)
+    if k is None:
+        return None, "no radix kernel for this length"
+    want = "ColFft n=%dx%s %s tile=%d " % (n, k[0], "double" if precision == "double" else "float", k[1])
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             prof = json.load(open(path))
@@ -117,11 +137,10 @@ def pmc_traffic(n, precision, decomp, world):
             continue
         if ("%d^3" % n) not in prof.get("workload", ""):
             continue
-        vals = [v["hbm_bytes_per_launch"] for k, v in prof["kernels"].items()
-                if k.startswith(want + "x") and (" %s " % tname) in k]
+        vals = [v["hbm_bytes_per_launch"] for key, v in prof["kernels"].items() if key.startswith(want)]
         if vals:
-            return sum(vals) / len(vals), os.path.basename(path)
-    return None, None
+            return sum(vals) / len(vals), "%s (kernel %s)" % (os.path.basename(path), k[2])
+    return None, "no committed PMC profile of '%s'" % want.strip()
 
 
 def cpu_baseline(n_full, seconds_budget=30.0):

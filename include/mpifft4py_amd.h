@@ -171,6 +171,12 @@ MFFT_API int mfft_dealias_filter(void* fu, const uint8_t* mask_dev, size_t count
 /* 1 if a transform of length n along an axis is supported: radix plans for 2^a <= 4096, 3*2^a <= 3072,
  * 5*2^a <= 2560, 9*2^a <= 2304, 25*2^a <= 1600 (real: twice that), chirp-z kernels for every other length up to 2048 */
 MFFT_API int mfft_length_supported(int64_t n, int real_transform);
+/* Which compiled kernel a strided-axis (family 0), contiguous-axis c2c (1), r2c (2) or c2r (3) transform of length n
+ * runs: "<plan name> tile=<columns or rows> threads=<n> lds=<bytes>[ nt]", e.g.
+ * "cols n1024(8, 8, 4, 4)double tile=8 threads=1024 lds=81792".  Device-free.  bench.py uses it to check that a
+ * committed rocprof profile belongs to the kernel it has just timed.  Returns MFFT_ERR_UNSUPPORTED for lengths that
+ * go through the chirp-z kernels. */
+MFFT_API int mfft_kernel_name(int family, int64_t n, int precision, int inverse, int nt, char* buf, size_t buflen);
 
 /* ---- element-wise pieces of a pseudo-spectral Navier-Stokes step on device-resident
  * fields (what the reference demo does with numpy on the host,

@@ -80,6 +80,7 @@ _SIGNATURES = {
     "mfft_slab_unpack": ([c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int], c_int),
     "mfft_dealias_filter": ([c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_length_supported": ([c_int64, c_int], c_int),
+    "mfft_kernel_name": ([c_int, c_int64, c_int, c_int, c_int, c_void_p, c_size_t], c_int),
     "mfft_ew_cross": ([c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_ew_curl_hat": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int], c_int),
     "mfft_ew_ns_rhs": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_double, c_int], c_int),

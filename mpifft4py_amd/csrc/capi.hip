@@ -131,6 +131,14 @@ int mfft_comm_destroy(mfft_comm_t c) {
 // ---- stage level ------------------------------------------------------------------
 int mfft_length_supported(int64_t n, int real_transform) { return length_supported(n, real_transform != 0) ? 1 : 0; }
 
+int mfft_kernel_name(int family, int64_t n, int precision, int inverse, int nt, char* buf, size_t buflen) {
+  if (!buf || buflen == 0 || family < FAM_COL || family > FAM_C2R) return set_error(MFFT_ERR_INVALID, "bad argument");
+  const KernelEntry* e = find_kernel(family, (int)n, precision, family == FAM_C2R ? 1 : (inverse ? 1 : 0), nt ? 1 : 0);
+  if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no radix kernel of family %d for length %lld", family, (long long)n);
+  snprintf(buf, buflen, "%s tile=%d threads=%d lds=%d%s", e->name, e->tile, e->threads, e->lds_bytes, e->nt ? " nt" : "");
+  return 0;
+}
+
 int mfft_c2c_axis(const void* in, void* out, const int64_t shape[3], int axis, int inverse, int precision) {
   if (!in || !out || !shape) return set_error(MFFT_ERR_INVALID, "null argument");
   const int64_t s0 = shape[0], s1 = shape[1], s2 = shape[2];

@@ -256,6 +256,10 @@ static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStr
   P.out_stride = a.out_stride;
   P.nrows = a.nrows;
   P.scale = (T)a.scale;
+  if constexpr (std::is_same<PT, RowParams<T>>::value) {
+    P.zs = a.zs.nchunk ? make_zsplit(a.zs.q, a.zs.nchunk, a.zs.last_len, a.zs.rows_total) : ZSplit{1, 1, 0, 0, 0};
+    P.row0 = a.zs.row0;
+  }
   const int64_t grid = (a.nrows + e->tile - 1) / e->tile;
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large");
@@ -264,7 +268,20 @@ static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStr
   return 0;
 }
 
+bool zsplit_supported(int64_t n, int prec, bool real_transform) {
+  if (n < 2 || n > 65536) return false;
+  if (real_transform) return find_kernel(FAM_R2C, (int)n, prec, 0, 0, 4) && find_kernel(FAM_C2R, (int)n, prec, 1, 0, 4);
+  return find_kernel(FAM_ROW, (int)n, prec, 0, 0, 4) && find_kernel(FAM_ROW, (int)n, prec, 1, 0, 4);
+}
+
 int launch_row(const RowArgs& a, hipStream_t s) {
+  if (a.zs.nchunk) {
+    const KernelEntry* ec = find_kernel(FAM_ROW, a.n, a.prec, a.inverse ? 1 : 0, 0, 4);
+    if (!ec) return set_error(MFFT_ERR_UNSUPPORTED, "no z-chunked row kernel of length %d", a.n);
+    void* twc = nullptr;
+    MFFT_TRY(prepare_kernel(ec, &twc));
+    return a.prec == MFFT_DOUBLE ? launch_row_t<double>(ec, a, twc, s) : launch_row_t<float>(ec, a, twc, s);
+  }
   const KernelEntry* e = find_kernel(FAM_ROW, a.n, a.prec, a.inverse ? 1 : 0);
   void* tw = nullptr;
   if (!e) {
@@ -298,6 +315,10 @@ static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void
   P.nrows = a.nrows;
   P.valid = a.valid > 0 ? a.valid : a.n / 2 + 1;
   P.scale = (T)a.scale;
+  if constexpr (std::is_same<PT, RealParams<T>>::value) {
+    P.zs = a.zs.nchunk ? make_zsplit(a.zs.q, a.zs.nchunk, a.zs.last_len, a.zs.rows_total) : ZSplit{1, 1, 0, 0, 0};
+    P.row0 = a.zs.row0;
+  }
   const int64_t grid = (a.nrows + e->tile - 1) / e->tile;
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large");
@@ -307,6 +328,15 @@ static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void
 }
 
 static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
+  if (a.zs.nchunk) {
+    const KernelEntry* ec = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, 4);
+    const int64_t real_stride_c = fam == FAM_R2C ? a.in_stride : a.out_stride;
+    if (!ec || real_stride_c % 2 != 0) return set_error(MFFT_ERR_UNSUPPORTED, "no z-chunked real kernel of length %d", a.n);
+    void *twc = nullptr, *rtwc = nullptr;
+    MFFT_TRY(prepare_kernel(ec, &twc));
+    MFFT_TRY(real_twiddles(a.n, a.prec, &rtwc));
+    return a.prec == MFFT_DOUBLE ? launch_real_t<double>(ec, a, twc, rtwc, s) : launch_real_t<float>(ec, a, twc, rtwc, s);
+  }
   const bool limited = a.valid > 0 && a.valid < a.n / 2 + 1;
   const KernelEntry* e = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, limited ? 3 : 0);
   if (!e && limited) return set_error(MFFT_ERR_UNSUPPORTED, "no column-limited real kernel of length %d", a.n);

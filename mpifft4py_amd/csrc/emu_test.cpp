@@ -339,6 +339,32 @@ static void test_row() {
   char name[64];
   snprintf(name, sizeof name, "row r%d %s%s", ROWS, INV ? "inv" : "fwd", TWLDS ? " twlds" : "");
   report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
+  // z-chunked side (pencil C2C): forward stores into / inverse loads out of nch equal blocks (rows_total, q)
+  if (N % 4 == 0 && N >= 8) {
+    const int nch = 4, q = N / nch, rows_total = nrows + 2, row0 = 1;
+    const ZSplit zs = make_zsplit(q, nch, q, rows_total);
+    std::vector<cx<T>> blocks((size_t)rows_total * N, mk<T>((T)3, (T)3)), out2((size_t)nrows * pout);
+    typedef RowFft<S, T, ROWS, INV, TWLDS, true> K;
+    RowParams<T> Pc{in.data(), out2.data(), tw.data(), pin, pout, nrows, INV ? (T)(1.0 / N) : (T)1, zs, row0};
+    if (INV) {       // scatter the plain input rows into the blocks, transform out of them
+      for (int r = 0; r < nrows; ++r)
+        for (int k = 0; k < N; ++k) blocks[(size_t)(k / q) * rows_total * q + (size_t)(row0 + r) * q + k % q] = in[(size_t)r * pin + k];
+      Pc.in = blocks.data();
+    } else {
+      Pc.out = blocks.data();
+    }
+    emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(Pc, b, t, lds); });
+    long double nn = 0, dd = 0;
+    for (int r = 0; r < nrows; ++r)
+      for (int k = 0; k < N; ++k) {
+        const cx<T> e = out[(size_t)r * pout + k];
+        const cx<T> g = INV ? out2[(size_t)r * pout + k] : blocks[(size_t)(k / q) * rows_total * q + (size_t)(row0 + r) * q + k % q];
+        nn += (g.x - e.x) * (g.x - e.x) + (g.y - e.y) * (g.y - e.y);
+        dd += e.x * e.x + e.y * e.y;
+      }
+    snprintf(name, sizeof name, "row r%d %s z-chunked", ROWS, INV ? "inv" : "fwd");
+    report(name, N, pname<T>(), (double)sqrtl(nn / dd), 1e-30 + (double)0);   // same arithmetic, other addresses: identical
+  }
 }
 
 template <class S, typename T, int ROWS, bool TWLDS>
@@ -439,6 +465,55 @@ static void test_real() {
     }
     snprintf(name, sizeof name, "c2r valid<M+1 r%d", ROWS);
     report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
+  }
+  // z-chunked complex side (fused pencil pack / unpack): the M + 1 bins of a row go to nch blocks (rows_total, len_l);
+  // `drop`: the last block has no room for the Nyquist bin (the 'AlltoallN' mode), which then reads back as zero
+  if (M >= 4 && M % 2 == 0) {
+    for (int drop = 0; drop < 2; ++drop) {
+      const int nch = 2, q = M / nch, last = q + (drop ? 0 : 1), rows_total = nrows + 3, row0 = 2;
+      const ZSplit zs = make_zsplit(q, nch, last, rows_total);
+      std::vector<cx<T>> blocks((size_t)rows_total * (q * (nch - 1) + last), mk<T>((T)7, (T)7));
+      {
+        typedef R2CFft<S, T, ROWS, TWLDS, false, true> K;
+        RealParams<T> P{in.data(), blocks.data(), tw.data(), rtw.data(), pin, 0, nrows, M + 1, (T)1, zs, row0};
+        emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+      }
+      long double nn = 0, dd = 0;
+      for (int r = 0; r < nrows; ++r)
+        for (int k = 0; k <= M - drop; ++k) {
+          const int l = std::min(k / q, nch - 1), len = l == nch - 1 ? last : q;
+          cx<T> g = blocks[(size_t)l * rows_total * q + (size_t)(row0 + r) * len + (k - l * q)], e = out[(size_t)r * pout + k];
+          if (k == 0 || k == M) e.y = 0;
+          nn += (g.x - e.x) * (g.x - e.x) + (g.y - e.y) * (g.y - e.y);
+          dd += e.x * e.x + e.y * e.y;
+        }
+      snprintf(name, sizeof name, "r2c z-chunked%s r%d", drop ? " drop" : "", ROWS);
+      report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
+      std::vector<T> b3((size_t)nrows * pin, (T)0);
+      {
+        typedef C2RFft<S, T, ROWS, TWLDS, false, true> K;
+        RealParams<T> P{blocks.data(), b3.data(), tw.data(), rtw.data(), 0, pin, nrows, M + 1, (T)(1.0 / N), zs, row0};
+        emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+      }
+      nn = dd = 0;
+      for (int r = 0; r < nrows; ++r) {
+        lvec X(N);
+        for (int k = 0; k < N; ++k) { X[k].x = 0; X[k].y = 0; }
+        for (int k = 0; k <= M - drop; ++k) {
+          const cx<T> z = out[(size_t)r * pout + k];
+          X[k].x = z.x; X[k].y = (k == 0 || k == M) ? 0 : z.y;
+          if (k > 0 && k < M) { X[N - k].x = z.x; X[N - k].y = -z.y; }
+        }
+        lvec x = naive_dft(X, +1);
+        for (int i = 0; i < N; ++i) {
+          long double e = x[i].x / N, g = b3[(size_t)r * pin + i];
+          nn += (g - e) * (g - e);
+          dd += e * e;
+        }
+      }
+      snprintf(name, sizeof name, "c2r z-chunked%s r%d", drop ? " drop" : "", ROWS);
+      report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
+    }
   }
 }
 

@@ -71,6 +71,35 @@ MFFT_HD i64 row_off(const RowMap& m, unsigned r) {
   return (i64)q * m.hi + (i64)rem * m.lo;
 }
 
+// Complex side of a contiguous-axis kernel split into z chunks (pencil decompositions): the pack / unpack copies
+// around the z-splitting exchange -- the Alltoallw sub-array types of the reference, pencil.py:218-246, 971-999 --
+// fused into the kernel's own stores / loads.  Position k of row r lives in block l = min(k / q, nchunk - 1), a
+// (rows_total, len_l) array with len_l = q except for the last block (last_len: q + 1 with the Nyquist column).
+struct ZSplit {
+  unsigned q, magic;     // chunk length, floor(2^32 / q) + 1
+  int nchunk;            // 0: plain rows
+  int last_len;
+  i64 block;             // elements between the starts of consecutive blocks: rows_total * q
+};
+inline ZSplit make_zsplit(i64 q, int nchunk, i64 last_len, i64 rows_total) {
+  ZSplit z;
+  z.q = (unsigned)q;
+  z.magic = (unsigned)(0x100000000ull / (unsigned long long)q + 1ull);
+  z.nchunk = nchunk;
+  z.last_len = (int)last_len;
+  z.block = rows_total * q;
+  return z;
+}
+// element offset of (row, k); *ok = the position exists (the last chunk may drop the Nyquist column)
+MFFT_HD i64 zsplit_off(const ZSplit& z, i64 row, int k, bool* ok) {
+  int l = (int)fastdiv((unsigned)k, z.magic);
+  if (l >= z.nchunk) l = z.nchunk - 1;
+  const int kk = k - l * (int)z.q;
+  const int len = l == z.nchunk - 1 ? z.last_len : (int)z.q;
+  *ok = kk < len;
+  return (i64)l * z.block + row * (i64)len + kk;
+}
+
 template <typename T>
 struct ColParams {
   const cx<T>* in;
@@ -95,6 +124,8 @@ struct RowParams {
   i64 in_stride, out_stride;   // row strides in complex elements
   i64 nrows;
   T scale;
+  ZSplit zs;                   // CHUNK kernels: the chunked side (output of a forward, input of an inverse transform)
+  i64 row0;                    // first row of this launch inside the chunk blocks
 };
 
 template <typename T>
@@ -108,6 +139,8 @@ struct RealParams {            // r2c: in = real rows, out = complex rows; c2r t
   int valid;                   // complex columns that exist in memory (N/2+1 normally; fewer for the
                                // 3/2-rule: r2c stores only the first `valid`, c2r reads the rest as 0)
   T scale;
+  ZSplit zs;                   // CHUNK kernels: the complex side is split into z chunks
+  i64 row0;                    // first row of this launch inside the chunk blocks
 };
 
 // position -> padded LDS slot for row-major (lane-along-row) exchange buffers:
@@ -412,7 +445,8 @@ struct ColFft {
 // ---------------------------------------------------------------------------
 // contiguous-axis c2c
 // ---------------------------------------------------------------------------
-template <class S, typename T, int ROWS, bool INV, bool TWLDS>
+// CHUNK: the output (forward) / input (inverse) rows are split into z chunks (ZSplit), see above.
+template <class S, typename T, int ROWS, bool INV, bool TWLDS, bool CHUNK = false>
 struct RowFft {
   static constexpr int THREADS = S::TPT * ROWS;
   static constexpr int PD = S::R(0);
@@ -433,10 +467,17 @@ struct RowFft {
     const cx<T>* ip = P.in + (active ? row : P.nrows - 1) * P.in_stride;
     cx<T>* op = P.out + row * P.out_stride;
 
+    const i64 crow = P.row0 + (active ? row : P.nrows - 1);     // CHUNK: row inside the chunk blocks
     cx<T> v[S::E];
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
-      const cx<T> x = ip[j + k * S::TPT];
+      cx<T> x;
+      if constexpr (CHUNK && INV) {          // every position of a complex row exists: the load stays unconditional
+        bool ok;
+        x = P.in[zsplit_off(P.zs, crow, j + k * S::TPT, &ok)];
+      } else {
+        x = ip[j + k * S::TPT];
+      }
       v[k] = INV ? swapri(x) : x;
     }
     if constexpr (TWLDS && S::NP > 1) {
@@ -451,7 +492,14 @@ struct RowFft {
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {
         cx<T> x = scale(v[k], P.scale);
-        op[j + k * S::TPT] = INV ? swapri(x) : x;
+        x = INV ? swapri(x) : x;
+        if constexpr (CHUNK && !INV) {
+          bool ok;
+          const i64 o = zsplit_off(P.zs, crow, j + k * S::TPT, &ok);
+          if (ok) P.out[o] = x;
+        } else {
+          op[j + k * S::TPT] = x;
+        }
       }
     }
   }
@@ -463,7 +511,7 @@ struct RowFft {
 // LIMIT: only the first P.valid complex columns exist in memory (3/2-rule): r2c does not
 // store the others, c2r reads them as zeros.  A template flag so that the regular kernels keep
 // unconditional loads (a runtime test costs the c2r kernel 7 % at 1024^3).
-template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false>
+template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false>
 struct R2CFft {
   static constexpr int M = S::N;
   static constexpr int THREADS = S::TPT * ROWS;
@@ -499,15 +547,24 @@ struct R2CFft {
     // split post-pass: X[k] = E[k] + w_k O[k],  E = (Z[k] + conj Z[M-k])/2,
     // O = -i (Z[k] - conj Z[M-k])/2,  w_k = exp(-2 pi i k / N)
     const T half = (T)0.5;
+    auto put = [&](int pos, cx<T> val) {
+      if constexpr (CHUNK) {
+        bool ok;
+        const i64 o = zsplit_off(P.zs, P.row0 + row, pos, &ok);
+        if (ok) static_cast<cx<T>*>(P.out)[o] = val;
+      } else {
+        op[pos] = val;
+      }
+    };
     auto emit = [&](int pos, cx<T> zk, cx<T> zpartner) {
       if (pos == 0) {
-        op[0] = mk<T>((zk.x + zk.y) * P.scale, (T)0);
-        if (!LIMIT || M < P.valid) op[M] = mk<T>((zk.x - zk.y) * P.scale, (T)0);
+        put(0, mk<T>((zk.x + zk.y) * P.scale, (T)0));
+        if (!LIMIT || M < P.valid) put(M, mk<T>((zk.x - zk.y) * P.scale, (T)0));
       } else if (!LIMIT || pos < P.valid) {
         const cx<T> zm = conj(zpartner);
         const cx<T> e = scale(zk + zm, half);
         const cx<T> o = mul_mi(scale(zk - zm, half));
-        op[pos] = scale(e + P.rtw[pos] * o, P.scale);
+        put(pos, scale(e + P.rtw[pos] * o, P.scale));
       }
     };
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -548,7 +605,7 @@ struct R2CFft {
 // half-complex -> real along the contiguous axis.  S describes M = N/2.
 // out = irfft(in) * N * scale   (scale = 1/N gives numpy's irfft)
 // ---------------------------------------------------------------------------
-template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false>
+template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false>
 struct C2RFft {
   static constexpr int M = S::N;
   static constexpr int THREADS = S::TPT * ROWS;
@@ -569,6 +626,19 @@ struct C2RFft {
     const cx<T>* ip = static_cast<const cx<T>*>(P.in) + (active ? row : P.nrows - 1) * P.in_stride;
     cx<T>* op = reinterpret_cast<cx<T>*>(static_cast<T*>(P.out) + row * P.out_stride);
 
+    // bin `pos` of this row; CHUNK: out of its z chunk, a position the last chunk does not hold (dropped Nyquist
+    // column) reads as zero -- the load itself stays unconditional (clamped offset + select), see RowFft
+    const i64 crow = P.row0 + (active ? row : P.nrows - 1);
+    auto bin = [&](int pos) -> cx<T> {
+      if constexpr (CHUNK) {
+        bool ok;
+        const i64 o = zsplit_off(P.zs, crow, pos, &ok);
+        const cx<T> x = static_cast<const cx<T>*>(P.in)[ok ? o : (i64)0];
+        return ok ? x : mk<T>((T)0, (T)0);
+      } else {
+        return ip[pos];
+      }
+    };
     // pre-pass: Z[k] = (X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])
     // (twice the textbook value; the factor is folded into the normalisation)
     cx<T> v[S::E];
@@ -591,13 +661,13 @@ struct C2RFft {
         const int pos = j + k * S::TPT;
         if constexpr (LIMIT) {
           v[k] = mk<T>((T)0, (T)0);
-          if (pos < P.valid) v[k] = ip[pos];
+          if (pos < P.valid) v[k] = bin(pos);
         } else {
-          v[k] = ip[pos];
+          v[k] = bin(pos);
         }
       }
       cx<T> carry = mk<T>((T)0, (T)0);
-      if (j == 0 && (!LIMIT || M < P.valid)) carry = ip[M];
+      if (j == 0 && (!LIMIT || M < P.valid)) carry = bin(M);
 #if defined(__HIP_DEVICE_COMPILE__)
       const int src = (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));     // lane of thread TPT-j (mod TPT) of this row
       auto prepass = [&](cx<T> xk, cx<T> pm, int pos) {
@@ -632,11 +702,11 @@ struct C2RFft {
         {
           cx<T> xk, xm;
           if constexpr (LIMIT) {
-            xk = pos < P.valid ? ip[pos] : mk<T>((T)0, (T)0);
-            xm = (M - pos) < P.valid ? conj(ip[M - pos]) : mk<T>((T)0, (T)0);
+            xk = pos < P.valid ? bin(pos) : mk<T>((T)0, (T)0);
+            xm = (M - pos) < P.valid ? conj(bin(M - pos)) : mk<T>((T)0, (T)0);
           } else {
-            xk = ip[pos];
-            xm = conj(ip[M - pos]);
+            xk = bin(pos);
+            xm = conj(bin(M - pos));
           }
           if (pos == 0) {            // imaginary parts of the k=0 and k=N/2 bins are ignored
             xk.y = (T)0;

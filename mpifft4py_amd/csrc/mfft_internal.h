@@ -52,6 +52,14 @@ struct ColArgs {
 };
 int launch_col(const ColArgs& a, hipStream_t s);
 
+// complex side of a contiguous-axis transform split into z chunks (fft_kernels.h, ZSplit): the pack / unpack of the
+// pencils' z-splitting exchange fused into the transform.  nchunk = 0: plain rows.
+struct ZSplitArgs {
+  int nchunk = 0;
+  int64_t q = 0, last_len = 0;       // chunk length; length of the last chunk
+  int64_t rows_total = 0, row0 = 0;  // rows of every chunk block; first row of this launch inside them
+};
+
 struct RowArgs {
   const void* in = nullptr;
   void* out = nullptr;
@@ -60,6 +68,7 @@ struct RowArgs {
   bool inverse = false;
   int64_t in_stride = 0, out_stride = 0, nrows = 0;
   double scale = 1.0;
+  ZSplitArgs zs;         // forward: of `out`, inverse: of `in`
 };
 int launch_row(const RowArgs& a, hipStream_t s);
 
@@ -71,6 +80,7 @@ struct RealArgs {
   int64_t in_stride = 0, out_stride = 0, nrows = 0;   // in elements of the respective types
   double scale = 1.0;
   int valid = 0;         // complex columns present in memory (0 = all n/2+1)
+  ZSplitArgs zs;         // of the complex side
 };
 int launch_r2c(const RealArgs& a, hipStream_t s);
 int launch_c2r(const RealArgs& a, hipStream_t s);
@@ -96,6 +106,7 @@ int launch_scale(void* data, size_t count_real, double scale, int prec, hipStrea
 int launch_fill_uniform(void* data, size_t count, int prec, uint64_t seed, hipStream_t s);
 
 bool length_supported(int64_t n, bool real_transform);
+bool zsplit_supported(int64_t n, int prec, bool real_transform);   // radix kernels with fused z-chunk pack exist for n
 hipStream_t plan_stream(mfft_plan_t plan);   // the plan's compute stream (nullptr plan -> default stream)
 
 }  // namespace mfft

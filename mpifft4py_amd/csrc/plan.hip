@@ -220,6 +220,38 @@ struct mfft_plan_s {
     if (r2c) return c2r_rows(in, out, nrows, nz, nzf, nz, 1.0 / (double)nz);
     return c2c_rows(in, out, nrows, nz, nzf, nz, true, 1.0 / (double)nz);
   }
+  // z stage with the z-chunk pack / unpack of the pencils fused in (fft_kernels.h, ZSplit): rows [row0, row0 + nrows)
+  // of the Pz blocks (rows_total, len_l) that the z-splitting exchange sends / has received
+  bool zfuse = false;
+  ZSplitArgs zsplit(int64_t rows_total, int64_t row0) const {
+    ZSplitArgs z;
+    z.nchunk = (int)zc.size(); z.q = zc[0].len; z.last_len = zc.back().len; z.rows_total = rows_total; z.row0 = row0;
+    return z;
+  }
+  int z_forward_chunked(const void* in, void* blocks, int64_t nrows, int64_t row0, int64_t rows_total) {
+    if (r2c) {
+      RealArgs a;
+      a.in = in; a.out = blocks; a.n = (int)N2; a.prec = prec; a.in_stride = N2; a.out_stride = Nf; a.nrows = nrows; a.scale = 1.0;
+      a.zs = zsplit(rows_total, row0);
+      return launch_r2c(a, stream);
+    }
+    RowArgs a;
+    a.in = in; a.out = blocks; a.n = (int)N2; a.prec = prec; a.inverse = false; a.in_stride = N2; a.out_stride = Nf; a.nrows = nrows;
+    a.scale = 1.0; a.zs = zsplit(rows_total, row0);
+    return launch_row(a, stream);
+  }
+  int z_backward_chunked(const void* blocks, void* out, int64_t nrows, int64_t row0, int64_t rows_total) {
+    if (r2c) {
+      RealArgs a;
+      a.in = blocks; a.out = out; a.n = (int)N2; a.prec = prec; a.in_stride = Nf; a.out_stride = N2; a.nrows = nrows;
+      a.scale = 1.0 / (double)N2; a.zs = zsplit(rows_total, row0);
+      return launch_c2r(a, stream);
+    }
+    RowArgs a;
+    a.in = blocks; a.out = out; a.n = (int)N2; a.prec = prec; a.inverse = true; a.in_stride = Nf; a.out_stride = N2; a.nrows = nrows;
+    a.scale = 1.0 / (double)N2; a.zs = zsplit(rows_total, row0);
+    return launch_row(a, stream);
+  }
   int col(const void* in, void* out, int64_t n, bool inv, int64_t nouter, int64_t ncols, int64_t in_outer, RowSpec in_rows,
           int64_t out_outer, RowSpec out_rows, double scale = 0.0) {
     ColArgs a;
@@ -878,11 +910,17 @@ int mfft_plan_s::pencil_forward_pipelined_x(const void* u, void* fu) {
   for (int b = 0; b < B; ++b) {
     int64_t i0, mb;
     rows(b, &i0, &mb);
-    MFFT_TRY(stage("fwd_z", (Rb + Cb) / B, [&] {
-      return z_forward(in + (size_t)(i0 * n * N2) * rs, W0 + (size_t)(i0 * n * Nf) * es, mb * n, N2, Nf);
-    }));
-    if (zsolo) continue;
-    MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z_rows(this, W0, W1, m * n, i0 * n, mb * n, Nf, zc, false); }));
+    if (!zsolo && zfuse) {          // the z transform writes the batch's rows of the send blocks itself
+      MFFT_TRY(stage("fwd_z", (Rb + Cb) / B, [&] {
+        return z_forward_chunked(in + (size_t)(i0 * n * N2) * rs, W1, mb * n, i0 * n, m * n);
+      }));
+    } else {
+      MFFT_TRY(stage("fwd_z", (Rb + Cb) / B, [&] {
+        return z_forward(in + (size_t)(i0 * n * N2) * rs, W0 + (size_t)(i0 * n * Nf) * es, mb * n, N2, Nf);
+      }));
+      if (zsolo) continue;
+      MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z_rows(this, W0, W1, m * n, i0 * n, mb * n, Nf, zc, false); }));
+    }
     MFFT_HIP(hipEventRecord(ev_compute[b], stream));
     MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[b], 0));
     MFFT_TRY(stage_on(cstream, "fwd_a2a_1", 0, [&] {
@@ -982,6 +1020,12 @@ int mfft_plan_s::pencil_backward_pipelined_x(const void* src, void* u) {
     const char* zin = W2 + (size_t)(i0 * n * Nf) * es;
     if (!zsolo) {
       MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
+      if (zfuse) {                    // the z transform reads the batch's rows out of the received blocks itself
+        MFFT_TRY(stage("bwd_z", (Rb + Cb) / B, [&] {
+          return z_backward_chunked(zrecv, out + (size_t)(i0 * n * N2) * rs, mb * n, i0 * n, m * n);
+        }));
+        continue;
+      }
       MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z_rows(this, zfull, zrecv, m * n, i0 * n, mb * n, Nf, zc, true); }));
       zin = zfull + (size_t)(i0 * n * Nf) * es;
     }
@@ -1004,10 +1048,15 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
   MFFT_TRY(ensure_work(0, wb));
   MFFT_TRY(ensure_work(1, wb));
   void *W0 = work[0], *W1 = work[1];
-  MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, W0, m * n, N2, Nf); }));
-  if (!zsolo) {
-    MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, m * n, Nf, zc, false); }));
+  if (!zsolo && zfuse) {            // z transform straight into the Pz send blocks (pencil.py:218-246 fused)
+    MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward_chunked(u, W1, m * n, 0, m * n); }));
     MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, false, W1, W0); }));
+  } else {
+    MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, W0, m * n, N2, Nf); }));
+    if (!zsolo) {
+      MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, m * n, Nf, zc, false); }));
+      MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, false, W1, W0); }));
+    }
   }
   if (X) {
     // W0 = P2 blocks (m, n, q) -> y transform (gathers y through two-level rows) -> P1 blocks (m, N1_1, q)
@@ -1076,6 +1125,10 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
   if (!zsolo) {
     void* other = cur == W0 ? W1 : W0;
     MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, false, cur, other); }));
+    if (zfuse) {      // the z transform reads the received Pz blocks itself (a dropped Nyquist column reads as zero)
+      MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward_chunked(other, u, m * n, 0, m * n); }));
+      return 0;
+    }
     MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z(this, cur, other, m * n, Nf, zc, true); }));
   }
   if (d.drop_nyquist)   // the neglected Nyquist column counts as zero (pencil.py:430, 1045)
@@ -1345,6 +1398,11 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
     }
     p->q = p->zc[cz].len;
     p->zstart = p->zc[cz].start;
+    // z-chunk pack / unpack fused into the z transform when a radix kernel with chunked stores / loads exists
+    // (MFFT_NO_ZFUSE: the copy-based path, kept for A/B runs and for the lengths that go through chirp-z)
+    p->zfuse = !desc->line2d && getenv("MFFT_NO_ZFUSE") == nullptr &&
+               zsplit_supported(p->N2, p->prec, p->r2c) &&
+               (!p->r2c || p->N2 % 2 == 0) && p->zc[0].len < 65536;
     // exchange pipeline of the x-aligned pencil: batches of local x rows (`pipeline`, default 4 like the slab's)
     const int want = desc->pipeline > 0 ? desc->pipeline : desc->pipeline < 0 ? -desc->pipeline : 4;
     if (desc->decomp == MFFT_PENCIL_X && want > 1 && P > 1 && !desc->drop_nyquist && !desc->line2d)

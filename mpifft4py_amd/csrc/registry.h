@@ -24,7 +24,8 @@ struct KernelEntry {
   int inv;          // COL/ROW: 1 = inverse
   int nt;           // COL: 1 = non-temporal variant (128-byte aligned rows only)
   int nt_inplace;   // COL, nt = 1: also faster than the regular variant when the transform is in place
-  int pad;          // COL: 1 = zero-padded input (inverse), 2 = truncated output (forward)
+  int pad;          // COL: 1 = zero-padded input (inverse), 2 = truncated output (forward); ROW / R2C / C2R: 3 = column-limited
+                    // (3/2-rule), 4 = complex side split into z chunks (fused pencil pack / unpack)
   int tile;         // COLS (COL) or ROWS (others)
   int threads;
   int lds_bytes;
@@ -154,6 +155,15 @@ void register_rows(const char* name) {
   reg.push_back(make_entry<RowFft<S, T, R, true, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
   reg.push_back(make_entry<R2CFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
   reg.push_back(make_entry<C2RFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
+  // pencil decompositions: the z-chunk pack / unpack fused into the stores / loads (pad = 4)
+  reg.push_back(make_entry<RowFft<S, T, R, false, RT, true>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
+  reg.back().pad = 4;
+  reg.push_back(make_entry<RowFft<S, T, R, true, RT, true>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
+  reg.back().pad = 4;
+  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, true>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+  reg.back().pad = 4;
+  reg.push_back(make_entry<C2RFft<S, T, R, RT, false, true>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
+  reg.back().pad = 4;
   if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
     reg.push_back(make_entry<R2CFft<S, T, R, RT, true>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
     reg.back().pad = 3;
