@@ -98,7 +98,7 @@ struct mfft_plan_s {
   std::vector<GraphEntry> graphs;
   // exchange pipeline (slab, P > 1): kz slices, a communication stream and events
   int nslice = 1;
-  int nbatch = 1;               // pencil X: batches of local x rows pipelined through both exchanges
+  int nbatch = 1;               // pencils: batches of rows pipelined through the exchanges (X: both together, Y: one after the other)
   std::vector<hipEvent_t> ev2_compute, ev2_comm;
   hipStream_t cstream = nullptr;
   std::vector<hipEvent_t> ev_compute, ev_comm;
@@ -355,6 +355,8 @@ struct mfft_plan_s {
   int slab_backward_rows(const void* src, void* u);
   int pencil_forward_pipelined_x(const void* u, void* fu);
   int pencil_backward_pipelined_x(const void* src, void* u);
+  int pencil_forward_pipelined_y(const void* u, void* fu);
+  int pencil_backward_pipelined_y(const void* src, void* u);
   int sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sched* out) const;
   // pieces of the pipelined exchanges (host only; the executors and mfft_plan_exchange_pieces share it)
   int npieces() const { return nbatch > 1 ? nbatch : nslice > 1 ? nslice : 1; }
@@ -459,7 +461,10 @@ int mfft_plan_s::piece_sched(int which, bool forward, int piece, Sched* o) const
     for (int r = 0; r < P; ++r) o->sd[r] = o->rd[r] = boff + (size_t)r * chunk;
     return 0;
   }
-  const int64_t m = N1_0, i0 = m * piece / nbatch, mb = m * (piece + 1) / nbatch - i0;
+  // X: both exchanges in batches of the m local x rows; Y: the z-splitting exchange in batches of the m local x rows,
+  // the x-chunk exchange in batches of the N2_0 rows a rank owns after it
+  const int64_t m = (d.decomp == MFFT_PENCIL_Y && which == 1) ? N2_0 : N1_0;
+  const int64_t i0 = m * piece / nbatch, mb = m * (piece + 1) / nbatch - i0;
   return sched_rows(which, forward, i0, mb, o);
 }
 
@@ -852,9 +857,11 @@ static int pack_z(mfft_plan_s* p, const void* Z, void* S, int64_t rows, int64_t 
 // Sub-schedules of one batch [i0, i0+mb) of the m local rows (bytes):
 int mfft_plan_s::sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sched* o) const {
   const int64_t m = N1_0, n = N2_1;
-  if (which == 0) {            // z-splitting exchange over group1 (P2 ranks): uneven chunks <-> (m, n, q) blocks
-    const int Pz = (int)group1.size();
-    o->peers = group1;
+  const bool X = d.decomp == MFFT_PENCIL_X;
+  if (which == 0) {            // z-splitting exchange (X: group1, Y: group0): uneven chunks <-> (m, n, q) blocks, rows [i0, i0+mb) of m
+    const std::vector<int>& gz = X ? group1 : group0;
+    const int Pz = (int)gz.size();
+    o->peers = gz;
     o->sc.resize(Pz); o->sd.resize(Pz); o->rc.resize(Pz); o->rd.resize(Pz);
     size_t base = 0;
     for (int l = 0; l < Pz; ++l) {
@@ -866,7 +873,18 @@ int mfft_plan_s::sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sch
     }
     return 0;
   }
-  // y-chunk exchange over group0 (P1 ranks): P1 blocks (m, N1_1, q) <-> rows of (N0, N1_1, q)
+  if (!X) {
+    // Y alignment, x-chunk exchange over group1 (P2 ranks): rows [i0, i0+mb) of the N2_0 rows of every block
+    // [c][x'][j][k] (N2_0, n, q); the send block c is rows c*N2_0.. of (N0, n, q), the receive block c' the same shape
+    const int Pg = (int)group1.size();
+    o->peers = group1;
+    o->sc.assign(Pg, (size_t)(mb * n * q) * es);
+    o->rc = o->sc;
+    o->sd.resize(Pg); o->rd.resize(Pg);
+    for (int g = 0; g < Pg; ++g) o->sd[g] = o->rd[g] = (size_t)((g * N2_0 + i0) * n * q) * es;
+    return 0;
+  }
+  // X alignment, y-chunk exchange over group0 (P1 ranks): P1 blocks (m, N1_1, q) <-> rows of (N0, N1_1, q)
   const int Pg = (int)group0.size();
   o->peers = group0;
   o->sc.assign(Pg, (size_t)(mb * N1_1 * q) * es);
@@ -1036,8 +1054,108 @@ int mfft_plan_s::pencil_backward_pipelined_x(const void* src, void* u) {
   return 0;
 }
 
+// ---- pencil, Y alignment: exchange pipeline in two halves ------------------------------------------------------
+// (pencil.py:730-754 forward, 483-507 inverse).  The x transform between the two exchanges needs every row of both,
+// so the pipeline is cut there: the z stage runs in batches of the local x rows, each batch's z-splitting exchange on
+// the communication stream while the next batch is transformed (the z transform writes the send blocks itself: zfuse);
+// after the x transform the x-chunk exchange goes out in batches of the rows a rank owns afterwards, and the y
+// transform of a batch starts as soon as that batch has landed.  Compute order z0 z1 .. x y0 y1 ..; only z0, the x
+// transform and the last y batch are not overlapped.  Needs P1 > 1, P2 > 1 and the fused z-chunk kernels.
+int mfft_plan_s::pencil_forward_pipelined_y(const void* u, void* fu) {
+  const int64_t m = N1_0, n = N2_1;
+  const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
+  const size_t wb = (size_t)std::max(m * n * Nf, N0 * n * q) * es;
+  for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, wb));
+  char *W0 = static_cast<char*>(work[0]), *W1 = static_cast<char*>(work[1]);
+  const char* in = static_cast<const char*>(u);
+  char* out = static_cast<char*>(fu);
+  const int B = nbatch;
+  for (int b = 0; b < B; ++b) {
+    const int64_t i0 = m * b / B, mb = m * (b + 1) / B - i0;
+    MFFT_TRY(stage("fwd_z", (Rb + Cb) / B, [&] {
+      return z_forward_chunked(in + (size_t)(i0 * n * N2) * rs, W1, mb * n, i0 * n, m * n);
+    }));
+    MFFT_HIP(hipEventRecord(ev_compute[b], stream));
+    MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[b], 0));
+    MFFT_TRY(stage_on(cstream, "fwd_a2a_1", 0, [&] {
+      Sched sc;
+      MFFT_TRY(piece_sched(0, true, b, &sc));
+      return run_sched(sc, W1, W0, cstream);
+    }));
+    MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
+  }
+  MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[B - 1], 0));                    // in order on the comm stream: all batches
+  MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, W0, N0, false, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+  MFFT_HIP(hipEventRecord(ev2_compute[0], stream));
+  MFFT_HIP(hipStreamWaitEvent(cstream, ev2_compute[0], 0));
+  for (int b = 0; b < B; ++b) {
+    MFFT_TRY(stage_on(cstream, "fwd_a2a_2", 0, [&] {
+      Sched sc;
+      MFFT_TRY(piece_sched(1, true, b, &sc));
+      return run_sched(sc, W0, W1, cstream);                                  // W1: every z exchange read it long ago
+    }));
+    MFFT_HIP(hipEventRecord(ev2_comm[b], cstream));
+  }
+  for (int b = 0; b < B; ++b) {
+    const int64_t x0 = N2_0 * b / B, xb = N2_0 * (b + 1) / B - x0;
+    MFFT_HIP(hipStreamWaitEvent(stream, ev2_comm[b], 0));
+    MFFT_TRY(stage("fwd_y", 2 * Cb / B, [&] {
+      return col(W1 + (size_t)(x0 * n * q) * es, out + (size_t)(x0 * N1 * q) * es, N1, false, xb, q, n * q,
+                 two_level(n, N2_0 * n * q, q), N1 * q, plain(q));
+    }));
+  }
+  return 0;
+}
+
+int mfft_plan_s::pencil_backward_pipelined_y(const void* src, void* u) {
+  const int64_t m = N1_0, n = N2_1;
+  const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
+  const size_t wb = (size_t)std::max(m * n * Nf, N0 * n * q) * es;
+  for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, wb));
+  char *W0 = static_cast<char*>(work[0]), *W1 = static_cast<char*>(work[1]);
+  const char* in = static_cast<const char*>(src);
+  char* out = static_cast<char*>(u);
+  const int B = nbatch;
+  // y transform of a batch of my rows (written as P2 blocks (N2_0, n, q)), its x-chunk exchange behind it
+  for (int b = 0; b < B; ++b) {
+    const int64_t x0 = N2_0 * b / B, xb = N2_0 * (b + 1) / B - x0;
+    MFFT_TRY(stage("bwd_y", 2 * Cb / B, [&] {
+      return col(in + (size_t)(x0 * N1 * q) * es, W0 + (size_t)(x0 * n * q) * es, N1, true, xb, q, N1 * q, plain(q), n * q,
+                 two_level(n, N2_0 * n * q, q));
+    }));
+    MFFT_HIP(hipEventRecord(ev2_compute[b], stream));
+    MFFT_HIP(hipStreamWaitEvent(cstream, ev2_compute[b], 0));
+    MFFT_TRY(stage_on(cstream, "bwd_a2a_2", 0, [&] {
+      Sched sc;
+      MFFT_TRY(piece_sched(1, false, b, &sc));
+      return run_sched(sc, W0, W1, cstream);
+    }));
+    MFFT_HIP(hipEventRecord(ev2_comm[b], cstream));
+  }
+  MFFT_HIP(hipStreamWaitEvent(stream, ev2_comm[B - 1], 0));
+  MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(W1, W1, N0, true, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+  MFFT_HIP(hipEventRecord(ev_compute[0], stream));
+  MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[0], 0));
+  for (int b = 0; b < B; ++b) {
+    MFFT_TRY(stage_on(cstream, "bwd_a2a_1", 0, [&] {
+      Sched sc;
+      MFFT_TRY(piece_sched(0, false, b, &sc));
+      return run_sched(sc, W1, W0, cstream);                                  // W0: every x-chunk exchange has read it
+    }));
+    MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
+  }
+  for (int b = 0; b < B; ++b) {
+    const int64_t i0 = m * b / B, mb = m * (b + 1) / B - i0;
+    MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
+    MFFT_TRY(stage("bwd_z", (Rb + Cb) / B, [&] {
+      return z_backward_chunked(W0, out + (size_t)(i0 * n * N2) * rs, mb * n, i0 * n, m * n);
+    }));
+  }
+  return 0;
+}
+
 int mfft_plan_s::pencil_forward(const void* u, void* fu) {
-  if (nbatch > 1) return pencil_forward_pipelined_x(u, fu);
+  if (nbatch > 1) return d.decomp == MFFT_PENCIL_X ? pencil_forward_pipelined_x(u, fu) : pencil_forward_pipelined_y(u, fu);
   const int64_t m = N1_0, n = N2_1;                 // local real rows in x, y
   const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
   const bool X = d.decomp == MFFT_PENCIL_X;
@@ -1092,7 +1210,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &mm); }));
     src = mm;
   }
-  if (nbatch > 1) return pencil_backward_pipelined_x(src, u);
+  if (nbatch > 1) return d.decomp == MFFT_PENCIL_X ? pencil_backward_pipelined_x(src, u) : pencil_backward_pipelined_y(src, u);
   // largest intermediate of this alignment: X: (m, N1, q) after the z exchange; Y: (N0, n, q) after it
   const size_t wb = (size_t)std::max(m * n * Nf, X ? m * N1 * q : N0 * n * q) * es;
   MFFT_TRY(ensure_work(0, wb));
@@ -1407,6 +1525,9 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
     const int want = desc->pipeline > 0 ? desc->pipeline : desc->pipeline < 0 ? -desc->pipeline : 4;
     if (desc->decomp == MFFT_PENCIL_X && want > 1 && P > 1 && !desc->drop_nyquist && !desc->line2d)
       p->nbatch = (int)std::min<int64_t>(want, p->N1_0);
+    // ... and of the y-aligned one (pencil_forward_pipelined_y): two halves around the x transform
+    if (desc->decomp == MFFT_PENCIL_Y && want > 1 && P1 > 1 && P2 > 1 && p->zfuse && !desc->drop_nyquist)
+      p->nbatch = (int)std::min<int64_t>(want, std::min(p->N1_0, p->N2_0));
   } else {
     return set_error(MFFT_ERR_INVALID, "bad decomposition %d", desc->decomp);
   }

@@ -133,15 +133,17 @@ def slab(rank, P, N, A):
 
 
 def pencil(rank, P, N, A, align, P1=None, pipeline=1):
-    """pipeline != 1 (X alignment): every exchange runs piece by piece with the schedules of
-    mfft_plan_exchange_pieces (batches of local x rows), into the same buffers as the un-pipelined exchange."""
+    """pipeline != 1: every exchange runs piece by piece with the schedules of mfft_plan_exchange_pieces (X: batches
+    of local x rows through both exchanges; Y: batches of local x rows in the z-splitting exchange, batches of the
+    rows owned afterwards in the x-chunk exchange), into the same buffers as the un-pipelined exchange."""
     lay = orc.PencilLayout(N, P, P1, align)
 
     def exchange(rank_, sched, send, recv_bytes, which=None, forward=None):
-        if pipeline == 1 or align != "X":
+        if pipeline == 1:
             return globals()["exchange"](rank_, sched, send, recv_bytes)
         pieces = _lib.exchange_pieces(N, P, rank, dec, which, forward, pipeline, p1=P1 or 0)
-        assert len(pieces) == min(pipeline if pipeline > 0 else 4, int(lay.N1[0]))
+        depth = pipeline if pipeline > 0 else 4
+        assert len(pieces) == (min(depth, int(lay.N1[0])) if align == "X" else min(depth, int(lay.N1[0]), int(lay.N2[0])))
         return exchange_pieces(rank_, pieces, send, recv_bytes)
     want = orc.pencil_r2c_forward(orc.scatter_real(A, lay), N, P1, align)
     c0, c1 = lay.ranks(rank)
@@ -170,7 +172,7 @@ def pencil(rank, P, N, A, align, P1=None, pipeline=1):
     else:
         b = np.fft.fft(np.concatenate(list(blocks), axis=0), axis=0)              # (N0, n, q)
         assert s1["peers"] == lay.comm1_members(rank)
-        r = exchange(rank, s1, b, sum(s1["rcount"]))
+        r = exchange(rank, s1, b, sum(s1["rcount"]), 1, True)
         blocks = r.reshape(lay.P2, N2_0, n, q)
         fu = np.fft.fft(np.concatenate(list(blocks), axis=1), axis=1)              # (N2_0, N1, q)
     assert fu.shape == lay.complex_shape(rank)
@@ -187,7 +189,7 @@ def pencil(rank, P, N, A, align, P1=None, pipeline=1):
     else:
         b = np.fft.ifft(fu, axis=1)                                                  # (N2_0, N1, q)
         send = np.concatenate([b[:, l * n:(l + 1) * n, :].ravel() for l in range(lay.P2)])
-        r = exchange(rank, s1b, send, sum(s1b["rcount"]))
+        r = exchange(rank, s1b, send, sum(s1b["rcount"]), 1, False)
         send = np.fft.ifft(r.reshape(N[0], n, q), axis=0)                            # x chunks contiguous
     r = exchange(rank, s0b, send, sum(s0b["rcount"]), 0, False)
     z = np.zeros((m, n, Nf), dtype=complex)
@@ -214,8 +216,9 @@ def main():
     if P >= 4:
         for align in ("X", "Y"):
             pencil(rank, P, N, A, align)
-        for pipeline in (0, 2, 3):                         # x-aligned pencil: batches of local x rows
+        for pipeline in (0, 2, 3):                         # the pencils' exchange pipelines, piece by piece
             pencil(rank, P, N, A, "X", pipeline=pipeline)
+            pencil(rank, P, N, A, "Y", pipeline=pipeline)
         if P == 8:
             for align in ("X", "Y"):
                 pencil(rank, P, N, A, align, P1=2)

@@ -846,6 +846,46 @@ def test_other_pad_factors(kind, N, P, ps):
 
 @pytest.mark.parametrize("prec", ["double", "single"])
 @pytest.mark.parametrize("depth", [2, 3, 4, 16])
+@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2), (16, None)])
+def test_pencil_y_exchange_pipeline(P, P1, depth, prec):
+    """Exchange pipeline of the y-aligned pencil (the reference class's default alignment; pencil.py:730-754, 483-507):
+    z stage and z-splitting exchange in batches of local x rows, then the x transform, then the x-chunk exchange and the
+    y transform in batches of the rows owned afterwards.  Same numbers as the un-pipelined path, R2C plain / 2/3-rule
+    and C2C; the default depth (pipeline=0) is pipelined too."""
+    from mpifft4py_amd.pencil import C2CY, R2CY
+    N = [32, 64, 128]
+    rt, ct = rdtype(prec), cdtype(prec)
+    rng = np.random.default_rng(950 + P + depth)
+    A = rng.random(N).astype(rt)
+    Ac = (rng.random(N) + 1j * rng.random(N)).astype(ct)
+
+    def body(comm):
+        res = []
+        for pipe in (1, depth, 0):
+            F = R2CY(np.array(N), L, comm, prec, P1=P1, communication="Alltoallw", pipeline=pipe)
+            a = np.ascontiguousarray(A[F.real_local_slice()])
+            c = F.fftn(a, np.zeros(F.complex_shape(), dtype=ct))
+            b = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt))
+            b23 = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt), "2/3-rule")
+            G = C2CY(np.array(N), L, comm, prec, P1=P1, pipeline=pipe)
+            ac = np.ascontiguousarray(Ac[G.original_local_slice()])
+            cc = G.fftn(ac, np.zeros(G.transformed_shape(), dtype=ct))
+            bc = G.ifftn(cc, np.zeros(G.original_shape(), dtype=ct))
+            res.append((c, b, b23, cc, bc, F.complex_local_slice(), F.real_local_slice(), ac,
+                        sorted(k for k in F.stage_times())))
+        return res
+    B2 = np.fft.rfftn(A.astype(np.float64))
+    for plain, piped, dflt in run_ranks(P, body):
+        for other in (piped, dflt):
+            for x, y in zip(plain[:5], other[:5]):
+                assert np.array_equal(x, y)                   # same kernels, same order of operations per element
+        assert orc.rel_l2(piped[0], B2[piped[5]]) < TOL[prec]
+        assert orc.rel_l2(piped[1], A[piped[6]]) < 4 * TOL[prec]
+        assert orc.rel_l2(piped[4], piped[7]) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("depth", [2, 3, 4, 16])
 @pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2), (16, None), (2, 1), (4, 1), (8, 1), (2, 2), (4, 4)])
 def test_pencil_x_exchange_pipeline(P, P1, depth, prec):
     """Opt-in exchange pipeline of the x-aligned pencil (batches of local x rows through both exchanges, compute and
