@@ -43,7 +43,35 @@ def pmc(dirname):
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 
 
+def sq_counters(tag, dirs, out_dir):
+    """Per-kernel averages of the SQ / GRBM counters of one or more --pmc passes -> <tag>_pmc_sq_counters.json"""
+    res = collections.defaultdict(dict)
+    for d in dirs:
+        f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+        agg = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            agg[(short(row["Kernel_Name"]), row["Counter_Name"])].append(float(row["Counter_Value"]))
+        for (k, c), v in agg.items():
+            res[k][c] = sum(v) / len(v)
+    for k, c in res.items():
+        if c.get("SQ_WAVE_CYCLES"):
+            for name in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+                if name in c:
+                    c[name + "_share_of_wave_cycles"] = c[name] / c["SQ_WAVE_CYCLES"]
+        if c.get("SQ_WAVES"):
+            for name in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
+                if name in c:
+                    c[name + "_per_wave"] = c[name] / c["SQ_WAVES"]
+    with open(os.path.join(out_dir, "%s_pmc_sq_counters.json" % tag), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    return res
+
+
 def main():
+    if sys.argv[1] == "sq":
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+        print(json.dumps(sq_counters(sys.argv[2], sys.argv[3:], out_dir), indent=1, sort_keys=True))
+        return
     tag, trace_dir, fetch_dir, write_dir, workload = sys.argv[1:6]
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     stats = glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
@@ -61,7 +89,12 @@ def main():
             "FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write[k], "dispatches_sampled": nf[k],
             "hbm_bytes_per_launch": (2.0 * fetch[k] + write[k]) * 1024.0,
             "avg_ms_kernel_trace": kern.get(k, {}).get("avg_ms"),
+            "calls_kernel_trace": kern.get(k, {}).get("calls"),
         }
+        ms = kern.get(k, {}).get("avg_ms")
+        if ms:      # HBM GB/s of the kernel: counter bytes per launch over its average duration in the kernel trace
+            res["kernels"][k]["hbm_GBs"] = res["kernels"][k]["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9
+            res["kernels"][k]["frac_of_8TBs"] = res["kernels"][k]["hbm_GBs"] / 8000.0
     with open(os.path.join(out_dir, "%s_pmc_traffic.json" % tag), "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
