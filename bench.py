@@ -326,6 +326,7 @@ def main():
             try:
                 c2, _ = make_comm(world, "file", other)
                 c2.transport_name = other
+                c2.selftest(1 << 20, 20000)      # a verified 1 MB-per-peer exchange, at most 20 s: never trust an untried wire
                 comms.append(c2)
             except Exception as e:      # noqa: BLE001
                 sys.stderr.write("transport %s unavailable (%s: %s)\n" % (other, type(e).__name__, e))

@@ -81,6 +81,10 @@ MFFT_API int mfft_comm_create_local(int nranks, const int* devices, mfft_comm_t*
 MFFT_API int mfft_comm_size(mfft_comm_t comm, int* size);
 MFFT_API int mfft_comm_rank(mfft_comm_t comm, int* rank);
 MFFT_API int mfft_comm_barrier(mfft_comm_t comm);
+/* One small all-to-all of a known byte pattern over all ranks (collective), verified on the host, waiting at most
+ * timeout_ms for the device: 0 = the transport moves data correctly here.  A hung IPC exchange is released from the
+ * host and reported as an error instead of blocking forever. */
+MFFT_API int mfft_comm_selftest(mfft_comm_t comm, size_t bytes_per_peer, int timeout_ms);
 /* host-buffer helpers for tests/demos (tests/test_FFT.py:77-78 Bcast; demo:103 reduce) */
 MFFT_API int mfft_comm_bcast_host(mfft_comm_t comm, void* buf_host, size_t bytes, int root);
 MFFT_API int mfft_comm_allreduce_sum_host(mfft_comm_t comm, double* vals_host, int count);

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "mfft_comm_size": ([c_void_p, POINTER(c_int)], c_int),
     "mfft_comm_rank": ([c_void_p, POINTER(c_int)], c_int),
     "mfft_comm_barrier": ([c_void_p], c_int),
+    "mfft_comm_selftest": ([c_void_p, c_size_t, c_int], c_int),
     "mfft_comm_bcast_host": ([c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_comm_allreduce_sum_host": ([c_void_p, POINTER(c_double), c_int], c_int),
     "mfft_comm_allreduce_max_host": ([c_void_p, POINTER(c_double), c_int], c_int),

@@ -44,6 +44,10 @@ class _CommBase(object):
     def Get_rank(self):
         return self._rank
 
+    def selftest(self, bytes_per_peer=1 << 20, timeout_ms=20000):
+        """Collective: one small verified all-to-all; raises if the transport does not move data correctly here."""
+        _lib.call("mfft_comm_selftest", self._handle, bytes_per_peer, timeout_ms)
+
     def barrier(self):
         _lib.call("mfft_comm_barrier", self._handle)
 

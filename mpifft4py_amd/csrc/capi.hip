@@ -114,6 +114,10 @@ int mfft_comm_allreduce_sum_host(mfft_comm_t c, double* v, int n) {
 int mfft_comm_allreduce_max_host(mfft_comm_t c, double* v, int n) {
   return c ? c->allreduce_host(v, n, 1) : set_error(MFFT_ERR_INVALID, "null comm");
 }
+int mfft_comm_selftest(mfft_comm_t c, size_t bytes_per_peer, int timeout_ms) {
+  if (!c || timeout_ms <= 0) return set_error(MFFT_ERR_INVALID, "bad argument");
+  return c->selftest(bytes_per_peer ? bytes_per_peer : 4096, timeout_ms);
+}
 int mfft_comm_abort(mfft_comm_t c) {
   if (c) c->abort();
   return 0;

@@ -37,6 +37,11 @@ struct mfft_comm_s {
   // for its peers hands them out itself (IpcComm: an arena of IPC-exported segments); the others use hipMalloc.
   virtual int work_alloc(void** p, size_t bytes);
   virtual int work_free(void* p);
+  // One small all-to-all over all ranks with a known pattern, checked on the host; waits at most timeout_ms for the
+  // GPU side (a transport whose device-side waits can be released from the host does so: `rescue`).  Lets a caller
+  // try a transport on a machine it has never run on without risking a hang (bench.py --transport auto).
+  int selftest(size_t bytes_per_peer, int timeout_ms);
+  virtual void rescue() {}
   // plans hold a reference: a communicator destroyed before its plans lives until the last of them is gone
   int plan_refs = 0;
   bool destroy_requested = false;

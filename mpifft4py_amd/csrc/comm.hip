@@ -2,6 +2,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <chrono>
+#include <thread>
+#include <vector>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +14,55 @@
 
 int mfft_comm_s::work_alloc(void** p, size_t bytes) { return mfft::dev_alloc(p, bytes); }
 int mfft_comm_s::work_free(void* p) { return mfft::dev_free(p); }
+
+int mfft_comm_s::selftest(size_t bytes_per_peer, int timeout_ms) {
+  using namespace mfft;
+  const size_t n = (bytes_per_peer + 15) / 16 * 16, total = n * (size_t)size;
+  void *snd = nullptr, *rcv = nullptr;
+  MFFT_TRY(work_alloc(&snd, total));
+  if (int rc = work_alloc(&rcv, total)) { (void)work_free(snd); return rc; }
+  hipStream_t st = nullptr;
+  int rc = 0;
+  auto fail = [&](int code, const char* what) { rc = set_error(code, "transport self-test: %s", what); };
+  std::vector<unsigned char> h(total), back(total, 0);
+  for (int p = 0; p < size; ++p)                       // chunk for peer p: bytes depend on (sender, receiver, offset)
+    for (size_t i = 0; i < n; ++i) h[(size_t)p * n + i] = (unsigned char)(rank * 31 + p * 7 + i * 13 + (i >> 8));
+  std::vector<size_t> cnt(size, n), dsp(size);
+  std::vector<int> peers(size);
+  for (int p = 0; p < size; ++p) { dsp[p] = (size_t)p * n; peers[p] = p; }
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) fail(MFFT_ERR_HIP, "no stream");
+  if (!rc && hipMemcpyAsync(snd, h.data(), total, hipMemcpyHostToDevice, st) != hipSuccess) fail(MFFT_ERR_HIP, "upload failed");
+  if (!rc && hipMemsetAsync(rcv, 0, total, st) != hipSuccess) fail(MFFT_ERR_HIP, "memset failed");
+  if (!rc) rc = alltoallv(snd, cnt.data(), dsp.data(), rcv, cnt.data(), dsp.data(), peers.data(), size, st, 0);
+  if (!rc) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    while ((q = hipStreamQuery(st)) == hipErrorNotReady) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) {
+        rescue();                                      // release what can be released, then report
+        fail(MFFT_ERR_INTERNAL, "the exchange did not complete in time");
+        break;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    if (!rc && q != hipSuccess) fail(MFFT_ERR_HIP, hipGetErrorString(q));
+    (void)hipGetLastError();
+  }
+  if (st) (void)hipStreamSynchronize(st);
+  if (!rc && hipMemcpy(back.data(), rcv, total, hipMemcpyDeviceToHost) != hipSuccess) fail(MFFT_ERR_HIP, "download failed");
+  if (!rc)
+    for (int p = 0; p < size && !rc; ++p)              // what peer p sent to me
+      for (size_t i = 0; i < n; ++i)
+        if (back[(size_t)p * n + i] != (unsigned char)(p * 31 + rank * 7 + i * 13 + (i >> 8))) {
+          rc = set_error(MFFT_ERR_INTERNAL, "transport self-test: rank %d received wrong data from rank %d at byte %zu", rank, p, i);
+          break;
+        }
+  if (st) (void)hipStreamDestroy(st);
+  (void)work_free(snd);
+  (void)work_free(rcv);
+  if (rc) abort();                                     // peers blocked in a host-side wait of this transport fail fast
+  return rc;
+}
 
 namespace mfft {
 

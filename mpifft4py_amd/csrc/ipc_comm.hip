@@ -168,6 +168,12 @@ struct IpcComm : mfft_comm_s {
   void abort() override {
     if (sh) sh->broken.store(1);
   }
+  // release every device-side wait of THIS rank (the flags are in my own memory): a hung exchange then runs to its
+  // end with whatever data there is, and the communicator is marked broken
+  void rescue() override {
+    if (sh) sh->broken.store(1);
+    if (flags) (void)hipMemset(flags, 0xFF, sizeof(IpcFlags));
+  }
   int bcast_host(void* buf, size_t bytes, int root) override {
     char* p = static_cast<char*>(buf);
     for (size_t off = 0; off < bytes; off += IPC_SCRATCH) {

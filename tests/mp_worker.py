@@ -30,6 +30,7 @@ def main():
     assert np.array_equal(x, np.arange(5.0))
     assert comm.allreduce(float(rank)) == sum(range(P))
     assert comm.bcast({"hello": P} if rank == 0 else None)["hello"] == P
+    comm.selftest(1 << 18, 30000)           # verified all-to-all of a byte pattern through the transport under test
 
     for pipeline in (1, 4, -4):
         F = Slab_R2C(np.array(N), L, comm, "double", pipeline=pipeline)
