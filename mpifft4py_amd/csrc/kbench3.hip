@@ -279,6 +279,34 @@ int main(int argc, char** argv) {
   }
   typedef Spec<1024, 8, 8, 4, 4> SD;
   typedef Spec<1024, 8, 8, 8, 2> SF;
+  if (filter[0] && strstr("sizes", filter)) {       // other lengths whose whole-complex exchange leaves one workgroup per CU
+    {
+      typedef Spec<768, 8, 8, 4, 3> S768;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S768, double, 8, false, false, 1>("8x8x4x3"));
+      vs.push_back(make_tile<S768, double, 8, true, true, 1>("8x8x4x3"));
+      vs.push_back(make_tile<S768, double, 8, false, true, 1>("8x8x4x3"));
+      vs.push_back(make_tile<Spec<768, 4, 4, 4, 4, 3>, double, 8, true, true, 1>("4x4x4x4x3"));
+      run_all<double>(vs, 768, "", rounds);
+    }
+    {
+      typedef Spec<800, 5, 5, 4, 4, 2> S800;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S800, double, 8, false, false, 1>("5x5x4x4x2"));
+      vs.push_back(make_tile<S800, double, 8, true, true, 1>("5x5x4x4x2"));
+      vs.push_back(make_tile<S800, double, 8, false, true, 1>("5x5x4x4x2"));
+      run_all<double>(vs, 800, "", rounds);
+    }
+    {
+      typedef Spec<1536, 8, 8, 8, 3> S1536;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S1536, double, 8, false, true, 1>("8x8x8x3"));
+      vs.push_back(make_tile<Spec<1536, 4, 4, 4, 4, 3, 2>, double, 8, false, true, 1>("4x4x4x4x3x2"));
+      vs.push_back(make_tile<Spec<1536, 8, 8, 4, 3, 2>, double, 8, false, true, 1>("8x8x4x3x2"));
+      run_all<double>(vs, 1536, "", rounds);
+    }
+    return 0;
+  }
   {
     std::vector<Variant<double>> vs;
     vs.push_back(make_tile<SA, double, 8, false, false, 1>("16x8x8"));

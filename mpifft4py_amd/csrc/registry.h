@@ -63,8 +63,19 @@ template <class S, typename T> constexpr int col_cols() {
   while (S::TPT * (cols / vec) < 64) cols *= 2;      // at least one full wave
   return cols;
 }
-// two workgroups per CU (split exchange + LDS twiddles = 80 KB each): the fp64 1024 = 8x8x4x4 plan, see plans.h
-template <class S, typename T> constexpr bool col_pair() { return sizeof(T) == 8 && S::N == 1024 && S::E == 8; }
+// Two (or three) workgroups per CU instead of one: in double precision, when the whole-complex exchange buffer of a
+// 128-byte tile takes between 80 and 128 KiB of the CU's 160 KiB, the kernel uses the split re/im exchange and LDS
+// twiddles, so that one workgroup's loads and stores overlap another's passes.  Measured with kbench3 (interleaved A/B,
+// profiles/r02_kbench3_variants.txt): 1024 (as 8x8x4x4, see plans.h) y 3.52 -> 3.44, x 3.57 -> 3.35, x out of place
+// 3.63 -> 3.19 ms; 768 (8x8x4x3) 1.69 -> 1.39, 1.62 -> 1.40, 1.76 -> 1.36 ms; 800 (5x5x4x4x2) 2.40 -> 2.07, 2.42 ->
+// 1.90, 2.45 -> 1.87 ms.  Not in single precision (1024: 1.85 -> 2.1-2.8 ms) and not 1024 as 16x8x8 (y 3.52 -> 3.68 ms).
+template <class S, typename T> constexpr long long col_full_bytes() {
+  return (long long)S::N * col_cols<S, T>() * (long long)sizeof(cx<T>);
+}
+template <class S, typename T> constexpr bool col_pair() {
+  return sizeof(T) == 8 && S::NP > 1 && col_full_bytes<S, T>() > 81920 && col_full_bytes<S, T>() <= 131072 &&
+         (S::N != 1024 || S::E == 8);
+}
 template <class S, typename T> constexpr bool col_split() {
   return S::NP > 1 && (col_pair<S, T>() || (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) > 131072);
 }
