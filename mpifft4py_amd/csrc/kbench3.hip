@@ -279,6 +279,20 @@ int main(int argc, char** argv) {
   }
   typedef Spec<1024, 8, 8, 4, 4> SD;
   typedef Spec<1024, 8, 8, 8, 2> SF;
+  if (filter[0] && strstr("f32", filter)) {        // single precision, 1024: is there a two-workgroup form that wins?
+    std::vector<Variant<float>> vs;
+    vs.push_back(make_tile<SA, float, 16, false, false, 2>("16x8x8"));
+    vs.push_back(make_tile<SA, float, 16, false, false, 2, true>("16x8x8"));
+    vs.push_back(make_tile<SA, float, 16, true, true, 1>("16x8x8"));
+    vs.push_back(make_tile<SA, float, 16, true, true, 1, true>("16x8x8"));
+    vs.push_back(make_tile<SA, float, 16, false, false, 1>("16x8x8"));
+    vs.push_back(make_tile<Spec<1024, 32, 32>, float, 16, true, true, 1>("32x32"));
+    vs.push_back(make_tile<Spec<1024, 32, 32>, float, 16, true, false, 1>("32x32"));
+    vs.push_back(make_tile<Spec<1024, 32, 32>, float, 16, true, false, 2>("32x32"));
+    vs.push_back(make_tile<SC, float, 16, false, false, 2>("16x16x4"));
+    run_all<float>(vs, 1024, "", rounds);
+    return 0;
+  }
   if (filter[0] && strstr("sizes", filter)) {       // other lengths whose whole-complex exchange leaves one workgroup per CU
     {
       typedef Spec<768, 8, 8, 4, 3> S768;

@@ -50,9 +50,25 @@ const KernelEntry* find_chirpz(int family, int n, int prec, int inv);
 // only while a thread holds at most 32 complex values and the workgroup stays at 512 threads (2^a <= 1024: +5..17 %);
 // measured with kbench2 (profiles/r01_kbench2_long_and_fp32.txt): VEC = 1 is ahead for the E = 20/24/40 plans
 // (640: +20 %, 1280: 2x, 768: +5 %, 1536: +12 %) and for 2048 / 4096, where VEC = 2 needs 1024 threads and spills.
+// Two (or three) workgroups per CU instead of one: when the whole-complex exchange buffer of a 128-byte tile takes
+// between 80 and 128 KiB of the CU's 160 KiB (640 < N <= 1024), the kernel uses the split re/im exchange and LDS
+// twiddles (and one column per lane), so that one workgroup's loads and stores overlap another's passes.  Measured with
+// kbench3 (interleaved A/B, profiles/r02_kbench3_variants.txt), y in place / x in place / x out of place, ms:
+//   fp64 1024 as 8x8x4x4 (plans.h)  3.52 -> 3.44   3.57 -> 3.35   3.63 -> 3.19      (as 16x8x8: y 3.52 -> 3.68, rejected)
+//   fp64  768 (8x8x4x3)             1.69 -> 1.39   1.62 -> 1.40   1.76 -> 1.36
+//   fp64  800 (5x5x4x4x2)           2.40 -> 2.07   2.42 -> 1.90   2.45 -> 1.87
+//   fp32 1024 (16x8x8, 1024 thr.)   1.95 -> 1.74   1.82 -> 1.76   1.86 -> 1.63      (two columns per lane + split: 2.1 - 2.8)
+// Non-temporal accesses help these kernels in double precision (in place too) and hurt in single (8 bytes per lane).
+template <class S, typename T> constexpr bool col_pair() {
+  constexpr long long tile = (long long)S::N * 128;
+  constexpr int lanes = 128 / (int)sizeof(cx<T>);
+  return S::NP > 1 && tile > 81920 && tile <= 131072 && S::TPT * lanes <= 1024 &&
+         (S::N != 1024 || sizeof(T) == 4 || S::E == 8);
+}
 template <class S, typename T> constexpr int col_vec() {
   constexpr int lanes16 = 16 / (int)sizeof(cx<T>) > 0 ? 16 / (int)sizeof(cx<T>) : 1;   // columns in 16 bytes
   constexpr int full = 128 / (int)sizeof(cx<T>);                                         // columns in a 128-byte tile
+  if (col_pair<S, T>()) return 1;
   return (lanes16 > 1 && S::E * lanes16 <= 32 && S::TPT * (full / lanes16) <= 512) ? lanes16 : 1;
 }
 template <class S, typename T> constexpr int col_cols() {
@@ -62,19 +78,6 @@ template <class S, typename T> constexpr int col_cols() {
   while (cols > vec && (long long)S::N * cols * (int)sizeof(T) > 131072) cols /= 2;   // even split must fit
   while (S::TPT * (cols / vec) < 64) cols *= 2;      // at least one full wave
   return cols;
-}
-// Two (or three) workgroups per CU instead of one: in double precision, when the whole-complex exchange buffer of a
-// 128-byte tile takes between 80 and 128 KiB of the CU's 160 KiB, the kernel uses the split re/im exchange and LDS
-// twiddles, so that one workgroup's loads and stores overlap another's passes.  Measured with kbench3 (interleaved A/B,
-// profiles/r02_kbench3_variants.txt): 1024 (as 8x8x4x4, see plans.h) y 3.52 -> 3.44, x 3.57 -> 3.35, x out of place
-// 3.63 -> 3.19 ms; 768 (8x8x4x3) 1.69 -> 1.39, 1.62 -> 1.40, 1.76 -> 1.36 ms; 800 (5x5x4x4x2) 2.40 -> 2.07, 2.42 ->
-// 1.90, 2.45 -> 1.87 ms.  Not in single precision (1024: 1.85 -> 2.1-2.8 ms) and not 1024 as 16x8x8 (y 3.52 -> 3.68 ms).
-template <class S, typename T> constexpr long long col_full_bytes() {
-  return (long long)S::N * col_cols<S, T>() * (long long)sizeof(cx<T>);
-}
-template <class S, typename T> constexpr bool col_pair() {
-  return sizeof(T) == 8 && S::NP > 1 && col_full_bytes<S, T>() > 81920 && col_full_bytes<S, T>() <= 131072 &&
-         (S::N != 1024 || S::E == 8);
 }
 template <class S, typename T> constexpr bool col_split() {
   return S::NP > 1 && (col_pair<S, T>() || (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) > 131072);
@@ -147,7 +150,7 @@ void register_col(const char* name) {
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, false, 2>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
     reg.back().pad = 2;
   }
-  if constexpr (S::N >= 256) {     // aligned-row variants for the large out-of-place passes
+  if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {     // aligned-row (non-temporal) variants
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
     reg.back().nt = 1;
     reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
