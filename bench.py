@@ -338,6 +338,10 @@ def main():
         best_ms = tuning[comm.transport_name][1]
         try:
             ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
+            ksample = max(1, min(n // world, 2))
+            u_ref = ut.leading(0, ksample).get()              # the candidates transform ut back into itself: it must stay what it was
+            tol_c = 1e-9 if args.precision == "double" else 1e-3
+            rejected = tuning.setdefault("rejected", {})
             for c in comms:
                 tc = tuning.setdefault(c.transport_name, {})
                 for depth in (1, 2, 4, 8, -2, -4, -8):       # 1: blocking; kz slices / (negative) batches of local x rows
@@ -355,10 +359,19 @@ def main():
                     Ft.sync()
                     c.barrier()
                     tc[depth] = c.allreduce((time.perf_counter() - tt) / 2, op=mcomm.MAX) * 1e3
+                    # a candidate only counts if it still computes the right thing on THIS machine's wire
+                    err = float(np.linalg.norm((ut.leading(0, ksample).get() - u_ref).ravel()) / np.linalg.norm(u_ref.ravel()))
+                    err = comm.allreduce(err if err == err else 1e30, op=mcomm.MAX)
                     del Ft, fut
+                    if not err <= tol_c:
+                        rejected["%s:%d" % (c.transport_name, depth)] = err
+                        ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
+                        continue
                     if tc[depth] < best_ms:
                         best, best_ms = (c, depth), tc[depth]
             del ut
+            if not rejected:
+                del tuning["rejected"]
         except Exception as e:      # noqa: BLE001  - every rank takes the same path
             sys.stderr.write("exchange tuning failed (%s: %s); keeping the best candidate so far\n" % (type(e).__name__, e))
             tuning["error"] = "%s: %s" % (type(e).__name__, e)

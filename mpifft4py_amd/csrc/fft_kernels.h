@@ -110,7 +110,7 @@ struct ColParams {
   int ncols;             // contiguous columns per outer batch
   int ntile_c;           // ceil(ncols / COLS)
   int nouter;
-  int remap;             // 1: XCD-aware block -> tile mapping
+  int remap;             // 1: XCD-aware block -> tile mapping, 2: the same with skewed entry points (power-of-two tile ranges)
   int fold;              // PAD == 2: 1 = add the Nyquist row N/3 into row 2N/3 before it is stored
   T scale;
   int nblocks;           // persistent experiment (fft_persist_experiment.h): workgroups launched; unused by ColFft
@@ -290,6 +290,17 @@ MFFT_HD int xcd_remap(int b, int nblocks) {
   const int x = b & 7, i = b >> 3;
   return x * q + (x < r ? x : r) + i;
 }
+// The same with XCD x entering its range 64*x tiles later (and wrapping around).  When the tile range is a power of two
+// (C2C arrays: rows a power of two apart), the eight ranges start a power of two apart as well, so the eight windows
+// of tiles in flight would sit on the SAME memory channels; shifted by 8 KB each they cover eight different sets.
+MFFT_HD int xcd_remap_skew(int b, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int x = b & 7, i = b >> 3;
+  const int cnt = q + (x < r ? 1 : 0);
+  int k = i + 64 * x;
+  if (cnt > 0) k %= cnt;
+  return x * q + (x < r ? x : r) + k;
+}
 
 // stage the twiddle table into LDS (cooperatively), returns pointer to it
 template <class S, typename T>
@@ -359,7 +370,8 @@ struct ColFft {
 
   static MFFT_D void body(const ColParams<T>& P, int bid_raw, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
-    const int bid = P.remap ? xcd_remap(bid_raw, P.ntile_c * P.nouter) : bid_raw;
+    const int bid = P.remap == 2 ? xcd_remap_skew(bid_raw, P.ntile_c * P.nouter)
+                  : P.remap    ? xcd_remap(bid_raw, P.ntile_c * P.nouter) : bid_raw;
     const int outer = bid / P.ntile_c;
     const int tc = bid - outer * P.ntile_c;
     const int c = tid % CG;

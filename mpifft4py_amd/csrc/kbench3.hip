@@ -68,10 +68,11 @@ Variant<T> make_persist(const char* plan) {
 }
 
 static int g_pgrid = 256;
+static int g_nf_override = 0, g_remap = 1;
 
 template <typename T>
 void run_all(std::vector<Variant<T>>& vs, int N, const char* filter, int rounds) {
-  const int NF = N / 2 + 1;
+  const int NF = g_nf_override ? g_nf_override : N / 2 + 1;
   const size_t elems = (size_t)N * N * NF;
   cx<T>*src = nullptr, *buf = nullptr, *ref = nullptr;
   CK(hipMalloc(&src, elems * sizeof(cx<T>)));
@@ -107,7 +108,7 @@ void run_all(std::vector<Variant<T>>& vs, int N, const char* filter, int rounds)
         ColParams<T> P;
         memset(&P, 0, sizeof P);
         P.tw = twd[i];
-        P.remap = 1;
+        P.remap = g_remap;
         P.scale = (T)1;
         if (!L.xdir) {
           P.in_outer = P.out_outer = (i64)N * NF;
@@ -279,6 +280,84 @@ int main(int argc, char** argv) {
   }
   typedef Spec<1024, 8, 8, 4, 4> SD;
   typedef Spec<1024, 8, 8, 8, 2> SF;
+  if (filter[0] && strstr("pitch520", filter)) {   // aligned intermediates for the y pass: what do the three passes of an inverse cost then?
+    typedef double T;
+    const int N = 1024, NF = 513, PF = 520;
+    cx<T>*fu = nullptr, *W = nullptr;
+    CK(hipMalloc(&fu, (size_t)N * N * NF * sizeof(cx<T>)));
+    CK(hipMalloc(&W, (size_t)N * N * PF * sizeof(cx<T>)));
+    CK(hipMemset(fu, 0, (size_t)N * N * NF * sizeof(cx<T>)));
+    CK(hipMemset(W, 0, (size_t)N * N * PF * sizeof(cx<T>)));
+    auto twh = build_pass_twiddles<SD, T>();
+    cx<T>* tw = nullptr;
+    CK(hipMalloc(&tw, twh.size() * sizeof(cx<T>)));
+    CK(hipMemcpy(tw, twh.data(), twh.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto timeit = [&](const char* name, std::function<void()> f) {
+      for (int i = 0; i < 3; ++i) f();
+      CK(hipDeviceSynchronize());
+      std::vector<double> t;
+      for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; ++i) f();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        t.push_back(ms / 5);
+      }
+      std::sort(t.begin(), t.end());
+      printf("   %-70s min %.3f med %.3f ms\n", name, t.front(), t[2]);
+    };
+    auto params = [&](const cx<T>* in, cx<T>* out, i64 in_outer, i64 out_outer, i64 in_lo, i64 out_lo, int ncols, int nouter) {
+      ColParams<T> P;
+      memset(&P, 0, sizeof P);
+      P.in = in; P.out = out; P.tw = tw; P.remap = 1; P.scale = 1;
+      P.in_outer = in_outer; P.out_outer = out_outer;
+      P.in_map = make_rowmap(0, in_lo, N, N); P.out_map = make_rowmap(0, out_lo, N, N);
+      P.ncols = ncols; P.nouter = nouter; P.ntile_c = (ncols + 7) / 8;
+      return P;
+    };
+    typedef ColFft<SD, T, 8, false, true, true, 1, false> K;
+    typedef ColFft<SD, T, 8, false, true, true, 1, true> KNT;
+    {
+      ColParams<T> P = params(fu, fu, (i64)N * NF, (i64)N * NF, NF, NF, NF, N);
+      timeit("y in place, pitch 513 (today)", [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
+      P = params(W, W, (i64)N * PF, (i64)N * PF, PF, PF, NF, N);
+      timeit("y in place, pitch 520, nt", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      timeit("y in place, pitch 520", [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
+      P = params(fu, W, 0, 0, (i64)N * NF, (i64)N * NF, N * NF, 1);
+      timeit("x out of place, flattened, both pitch 513, nt (today's inverse x)", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      P = params(fu, W, NF, PF, (i64)N * NF, (i64)N * PF, NF, N);      // per (y, kz tile): in pitch 513 (misaligned), out pitch 520 (aligned)
+      timeit("x out of place, fu(513) -> W(520), tiles per y row", [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
+      P = params(W, fu, PF, NF, (i64)N * PF, (i64)N * NF, NF, N);      // the forward direction with the same tiling: aligned loads, misaligned stores
+      timeit("x out of place, W(520) -> fu(513), tiles per y row (partial-line stores)", [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
+      P = params(fu, fu, 0, 0, (i64)N * NF, (i64)N * NF, N * NF, 1);
+      timeit("x in place, flattened, pitch 513, nt (today's forward x)", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+    }
+    return 0;
+  }
+  if (filter[0] && strstr("pow2", filter)) {       // C2C arrays: row pitch and plane stride are powers of two
+    std::vector<Variant<double>> vs;
+    vs.push_back(make_tile<SD, double, 8, true, true, 1, true>("8x8x4x4"));
+    vs.push_back(make_tile<SD, double, 8, true, true, 1, false>("8x8x4x4"));
+    g_nf_override = 1024;
+    for (int remap : {1, 2}) {
+      g_remap = remap;
+      printf("#### remap mode %d\n", remap);
+      run_all<double>(vs, 1024, "", rounds);
+    }
+    std::vector<Variant<float>> vf;
+    vf.push_back(make_tile<SA, float, 16, true, true, 1>("16x8x8"));
+    for (int remap : {1, 2}) {
+      g_remap = remap;
+      printf("#### remap mode %d\n", remap);
+      run_all<float>(vf, 1024, "", rounds);
+    }
+    return 0;
+  }
   if (filter[0] && strstr("f32", filter)) {        // single precision, 1024: is there a two-workgroup form that wins?
     std::vector<Variant<float>> vs;
     vs.push_back(make_tile<SA, float, 16, false, false, 2>("16x8x8"));
