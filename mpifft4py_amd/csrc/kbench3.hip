@@ -339,6 +339,127 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (filter[0] && strstr("padplane", filter)) {   // C2C 1024^3: what a padded plane stride / row pitch of the intermediate buys
+    typedef double T;
+    const int N = 1024;
+    const i64 PL0 = (i64)N * N;
+    std::vector<i64> pads = {0, 8, 64, 264, 520, 8 * 1024 + 8};
+    if (getenv("KB_PADSWEEP") || getenv("KB_STRIDESWEEP")) pads.clear();
+    const i64 PITCH2 = N + 8;
+    cx<T>*A = nullptr, *W = nullptr;
+    const size_t wel = (size_t)N * (size_t)(N * PITCH2 + 16384) + 4096;
+    CK(hipMalloc(&A, wel * sizeof(cx<T>)));
+    CK(hipMalloc(&W, wel * sizeof(cx<T>)));
+    CK(hipMemset(A, 0, wel * sizeof(cx<T>)));
+    CK(hipMemset(W, 0, wel * sizeof(cx<T>)));
+    auto twh = build_pass_twiddles<SD, T>();
+    cx<T>* tw = nullptr;
+    CK(hipMalloc(&tw, twh.size() * sizeof(cx<T>)));
+    CK(hipMemcpy(tw, twh.data(), twh.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto timeit = [&](const char* name, std::function<void()> f) {
+      for (int i = 0; i < 3; ++i) f();
+      CK(hipDeviceSynchronize());
+      std::vector<double> t;
+      for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; ++i) f();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        t.push_back(ms / 5);
+      }
+      std::sort(t.begin(), t.end());
+      printf("   %-84s min %.3f med %.3f ms  (%.0f GB/s)\n", name, t.front(), t[2], 2.0 * N * N * N * 16 / t[2] / 1e6);
+      fflush(stdout);
+    };
+    auto params = [&](const cx<T>* in, cx<T>* out, i64 in_outer, i64 out_outer, i64 in_lo, i64 out_lo, i64 ncols, int nouter) {
+      ColParams<T> P;
+      memset(&P, 0, sizeof P);
+      P.in = in; P.out = out; P.tw = tw; P.remap = 1; P.scale = 1;
+      P.in_outer = in_outer; P.out_outer = out_outer;
+      P.in_map = make_rowmap(0, in_lo, N, N); P.out_map = make_rowmap(0, out_lo, N, N);
+      P.ncols = ncols; P.nouter = nouter; P.ntile_c = (int)((ncols + 7) / 8);
+      return P;
+    };
+    typedef ColFft<SD, T, 8, false, true, true, 1, false> K;
+    typedef ColFft<SD, T, 8, false, true, true, 1, true> KNT;
+    char nm[160];
+    for (i64 pad : pads) {
+      const i64 PL = PL0 + pad;
+      ColParams<T> P = params(A, A, 0, 0, PL, PL, PL0, 1);
+      snprintf(nm, sizeof nm, "x in place, flattened columns, plane stride N*N+%lld, nt", (long long)pad);
+      timeit(nm, [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      snprintf(nm, sizeof nm, "x in place, flattened columns, plane stride N*N+%lld", (long long)pad);
+      timeit(nm, [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
+      P = params(A, W, 0, 0, PL, PL0, PL0, 1);
+      snprintf(nm, sizeof nm, "x out of place, padded (+%lld) -> power of two, nt", (long long)pad);
+      timeit(nm, [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      P = params(A, W, 0, 0, PL0, PL, PL0, 1);
+      snprintf(nm, sizeof nm, "x out of place, power of two -> padded (+%lld), nt", (long long)pad);
+      timeit(nm, [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      P = params(A, A, PL, PL, N, N, N, N);
+      snprintf(nm, sizeof nm, "y in place, pitch N, plane stride N*N+%lld, nt", (long long)pad);
+      timeit(nm, [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+    }
+    {
+      const i64 PL = (i64)N * PITCH2;
+      ColParams<T> P = params(A, A, PL, PL, PITCH2, PITCH2, N, N);
+      timeit("y in place, pitch N+8, nt", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      P = params(A, A, PITCH2, PITCH2, PL, PL, N, N);
+      timeit("x in place, tiles per y row, pitch N+8, nt", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      P = params(A, W, PITCH2, N, PL, PL0, N, N);
+      timeit("x out of place, pitch N+8 -> power of two, tiles per y row, nt", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      P = params(W, A, N, PITCH2, PL0, PL, N, N);
+      timeit("x out of place, power of two -> pitch N+8, tiles per y row, nt", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+    }
+    if (getenv("KB_STRIDESWEEP")) {   // from which power-of-two row stride on does the x pass suffer?  plane = 2^k bytes
+      for (int k = 13; k <= 24; ++k) {
+        const i64 plane = ((i64)1 << k) / 16, nouter = PL0 / plane;
+        for (i64 pad : {(i64)0, (i64)8}) {
+          ColParams<T> P = params(A, W, (i64)N * (plane + pad), (i64)N * plane, plane + pad, plane, plane, (int)nouter);
+          snprintf(nm, sizeof nm, "x out of place, row stride 2^%d B + %lld B -> 2^%d B, %lld batches, nt", k, (long long)pad * 16, k, (long long)nouter);
+          timeit(nm, [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+        }
+      }
+      return 0;
+    }
+    if (getenv("KB_PADSWEEP")) {
+      for (int m : {1, 2, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 27, 31, 33, 37, 41, 47, 63, 65, 127, 129, 255, 257}) {
+        const i64 pad = 8 * m, PL = PL0 + pad;
+        ColParams<T> P = params(A, W, 0, 0, PL, PL0, PL0, 1);
+        snprintf(nm, sizeof nm, "x out of place, padded (+%d lines of 128 B) -> power of two, nt", m);
+        timeit(nm, [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      }
+      return 0;
+    }
+    {   // the R2C arrays (513 columns): the plane stride 1024 * 513 * 16 B still has 14 zero low bits
+      const i64 NF = 513, PLR = (i64)N * NF;
+      printf("   -- R2C layout, 513 columns (times for 0.5 of the C2C volume)\n");
+      for (i64 pad : {(i64)0, (i64)8, (i64)520}) {
+        const i64 PL = PLR + pad;
+        ColParams<T> P = params(A, A, 0, 0, PL, PL, PLR, 1);
+        snprintf(nm, sizeof nm, "r2c x in place, flattened, plane stride 1024*513+%lld, nt", (long long)pad);
+        timeit(nm, [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+        P = params(A, W, 0, 0, PL, PLR, PLR, 1);
+        snprintf(nm, sizeof nm, "r2c x out of place, padded (+%lld) -> exact, nt", (long long)pad);
+        timeit(nm, [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+        P = params(A, W, 0, 0, PLR, PL, PLR, 1);
+        snprintf(nm, sizeof nm, "r2c x out of place, exact -> padded (+%lld), nt", (long long)pad);
+        timeit(nm, [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+        P = params(A, A, PL, PL, NF, NF, NF, N);
+        snprintf(nm, sizeof nm, "r2c y in place, plane stride +%lld", (long long)pad);
+        timeit(nm, [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
+        P = params(A, W, PLR, PL, NF, NF, NF, N);
+        snprintf(nm, sizeof nm, "r2c y out of place, exact -> plane stride +%lld", (long long)pad);
+        timeit(nm, [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
+      }
+    }
+    return 0;
+  }
   if (filter[0] && strstr("pow2", filter)) {       // C2C arrays: row pitch and plane stride are powers of two
     std::vector<Variant<double>> vs;
     vs.push_back(make_tile<SD, double, 8, true, true, 1, true>("8x8x4x4"));
