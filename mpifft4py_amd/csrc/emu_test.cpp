@@ -310,9 +310,9 @@ template <class S> struct PadTests<S, true> {
   }
 };
 
-template <class S, typename T, int ROWS, bool INV, bool TWLDS>
+template <class S, typename T, int ROWS, bool INV, bool TWLDS, bool SPLIT = false>
 static void test_row() {
-  typedef RowFft<S, T, ROWS, INV, TWLDS> K;
+  typedef RowFft<S, T, ROWS, INV, TWLDS, false, SPLIT> K;
   const int N = S::N;
   const int nrows = ROWS * 2 + 1;
   std::mt19937_64 rng(99 + N);
@@ -337,14 +337,14 @@ static void test_row() {
     }
   }
   char name[64];
-  snprintf(name, sizeof name, "row r%d %s%s", ROWS, INV ? "inv" : "fwd", TWLDS ? " twlds" : "");
+  snprintf(name, sizeof name, "row r%d %s%s%s", ROWS, INV ? "inv" : "fwd", TWLDS ? " twlds" : "", SPLIT ? " split" : "");
   report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
   // z-chunked side (pencil C2C): forward stores into / inverse loads out of nch equal blocks (rows_total, q)
   if (N % 4 == 0 && N >= 8) {
     const int nch = 4, q = N / nch, rows_total = nrows + 2, row0 = 1;
     const ZSplit zs = make_zsplit(q, nch, q, rows_total);
     std::vector<cx<T>> blocks((size_t)rows_total * N, mk<T>((T)3, (T)3)), out2((size_t)nrows * pout);
-    typedef RowFft<S, T, ROWS, INV, TWLDS, true> K;
+    typedef RowFft<S, T, ROWS, INV, TWLDS, true, SPLIT> K;
     RowParams<T> Pc{in.data(), out2.data(), tw.data(), pin, pout, nrows, INV ? (T)(1.0 / N) : (T)1, zs, row0};
     if (INV) {       // scatter the plain input rows into the blocks, transform out of them
       for (int r = 0; r < nrows; ++r)
@@ -367,7 +367,7 @@ static void test_row() {
   }
 }
 
-template <class S, typename T, int ROWS, bool TWLDS>
+template <class S, typename T, int ROWS, bool TWLDS, bool SPLIT = false>
 static void test_real() {
   const int M = S::N, N = 2 * M;
   const int nrows = ROWS + 2;
@@ -380,7 +380,7 @@ static void test_real() {
   auto tw = build_pass_twiddles<S, T>();
   auto rtw = build_real_twiddles<T>(N);
   {
-    typedef R2CFft<S, T, ROWS, TWLDS> K;
+    typedef R2CFft<S, T, ROWS, TWLDS, false, false, SPLIT> K;
     RealParams<T> P{in.data(), out.data(), tw.data(), rtw.data(), pin, pout, nrows, M + 1, (T)1};
     emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
@@ -397,7 +397,7 @@ static void test_real() {
     }
   }
   char name[64];
-  snprintf(name, sizeof name, "r2c r%d%s", ROWS, TWLDS ? " twlds" : "");
+  snprintf(name, sizeof name, "r2c r%d%s%s", ROWS, TWLDS ? " twlds" : "", SPLIT ? " split" : "");
   report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
   // c2r of (the r2c result with garbage imaginary parts in bins 0 and M) must return the input
   std::vector<T> back((size_t)nrows * pin, (T)0);
@@ -406,7 +406,7 @@ static void test_real() {
     out[(size_t)r * pout + M].y = (T)-2.25;
   }
   {
-    typedef C2RFft<S, T, ROWS, TWLDS> K;
+    typedef C2RFft<S, T, ROWS, TWLDS, false, false, SPLIT> K;
     RealParams<T> P{out.data(), back.data(), tw.data(), rtw.data(), pout, pin, nrows, M + 1, (T)(1.0 / N)};
     emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
@@ -418,14 +418,14 @@ static void test_real() {
       num += d * d;
       den += (long double)in[(size_t)r * pin + i] * in[(size_t)r * pin + i];
     }
-  snprintf(name, sizeof name, "c2r(r2c) r%d%s", ROWS, TWLDS ? " twlds" : "");
+  snprintf(name, sizeof name, "c2r(r2c) r%d%s%s", ROWS, TWLDS ? " twlds" : "", SPLIT ? " split" : "");
   report(name, N, pname<T>(), (double)sqrtl(num / den), 4 * tol_of<T>());
   // 3/2-rule column handling: r2c keeps only the first `valid` bins, c2r treats the missing ones as zero
   if (M >= 4) {
     const int valid = M / 2 + 1;
     std::vector<cx<T>> part((size_t)nrows * valid, mk<T>((T)9, (T)9));
     {
-      typedef R2CFft<S, T, ROWS, TWLDS, true> K;
+      typedef R2CFft<S, T, ROWS, TWLDS, true, false, SPLIT> K;
       RealParams<T> P{in.data(), part.data(), tw.data(), rtw.data(), pin, valid, nrows, valid, (T)1};
       emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                  [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
@@ -442,7 +442,7 @@ static void test_real() {
     report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
     std::vector<T> b2((size_t)nrows * pin, (T)0);
     {
-      typedef C2RFft<S, T, ROWS, TWLDS, true> K;
+      typedef C2RFft<S, T, ROWS, TWLDS, true, false, SPLIT> K;
       RealParams<T> P{part.data(), b2.data(), tw.data(), rtw.data(), valid, pin, nrows, valid, (T)(1.0 / N)};
       emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                  [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
@@ -474,7 +474,7 @@ static void test_real() {
       const ZSplit zs = make_zsplit(q, nch, last, rows_total);
       std::vector<cx<T>> blocks((size_t)rows_total * (q * (nch - 1) + last), mk<T>((T)7, (T)7));
       {
-        typedef R2CFft<S, T, ROWS, TWLDS, false, true> K;
+        typedef R2CFft<S, T, ROWS, TWLDS, false, true, SPLIT> K;
         RealParams<T> P{in.data(), blocks.data(), tw.data(), rtw.data(), pin, 0, nrows, M + 1, (T)1, zs, row0};
         emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
       }
@@ -491,7 +491,7 @@ static void test_real() {
       report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
       std::vector<T> b3((size_t)nrows * pin, (T)0);
       {
-        typedef C2RFft<S, T, ROWS, TWLDS, false, true> K;
+        typedef C2RFft<S, T, ROWS, TWLDS, false, true, SPLIT> K;
         RealParams<T> P{blocks.data(), b3.data(), tw.data(), rtw.data(), 0, pin, nrows, M + 1, (T)(1.0 / N), zs, row0};
         emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
       }
@@ -731,6 +731,11 @@ template <class S> static void test_spec_all() {
   test_row<S, float, 3, false, false>();
   test_real<S, double, 2, true>();
   test_real<S, float, 3, false>();
+  if constexpr (S::NP > 1 && (S::E >= 12 || S::N == 64)) {   // split re/im exchange of the contiguous-axis kernels (registry.h row_split)
+    test_row<S, double, 2, false, false, true>();
+    test_row<S, double, 2, true, false, true>();
+    test_real<S, double, 2, false, true>();
+  }
   PadTests<S>::run();
 }
 

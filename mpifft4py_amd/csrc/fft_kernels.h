@@ -454,24 +454,36 @@ struct ColFft {
   }
 };
 
+// exchange policy of the contiguous-axis kernels: whole complex values, or (SPLIT) real and imaginary parts one after the
+// other through half the LDS -- twice the rows per CU for the plans with many values per thread
+template <bool SPLIT, typename T, class Slot> struct RowXch {
+  typedef XchFull<T, Slot> type;
+  typedef cx<T> elem;
+};
+template <typename T, class Slot> struct RowXch<true, T, Slot> {
+  typedef XchSplit<T, Slot> type;
+  typedef T elem;
+};
+
 // ---------------------------------------------------------------------------
 // contiguous-axis c2c
 // ---------------------------------------------------------------------------
 // CHUNK: the output (forward) / input (inverse) rows are split into z chunks (ZSplit), see above.
-template <class S, typename T, int ROWS, bool INV, bool TWLDS, bool CHUNK = false>
+template <class S, typename T, int ROWS, bool INV, bool TWLDS, bool CHUNK = false, bool SPLIT = false>
 struct RowFft {
+  typedef typename RowXch<SPLIT, T, PadSlot<S::R(0)>>::elem XE;
   static constexpr int THREADS = S::TPT * ROWS;
   static constexpr int PD = S::R(0);
   static constexpr int PLEN = padded_len<S::N, PD>();
   static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
-  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(PLEN * ROWS * sizeof(cx<T>)) : 0;
+  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(PLEN * ROWS * sizeof(XE)) : 0;
   static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
 
   static MFFT_D void body(const RowParams<T>& P, int bid, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
     const int rl = tid / S::TPT;
     const int j = tid % S::TPT;
-    cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES) + rl * PLEN;
+    XE* xch = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;
     // rows past the end re-read the last row (and store nothing): unconditional loads let the
@@ -496,7 +508,7 @@ struct RowFft {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
     }
-    XchFull<T, PadSlot<PD>> xc{xch, PadSlot<PD>{}};
+    typename RowXch<SPLIT, T, PadSlot<PD>>::type xc{xch, PadSlot<PD>{}};
     if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xc);
     else run_passes<S, 0, T>(v, j, P.tw, xc);
 
@@ -523,21 +535,22 @@ struct RowFft {
 // LIMIT: only the first P.valid complex columns exist in memory (3/2-rule): r2c does not
 // store the others, c2r reads them as zeros.  A template flag so that the regular kernels keep
 // unconditional loads (a runtime test costs the c2r kernel 7 % at 1024^3).
-template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false>
+template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false, bool SPLIT = false>
 struct R2CFft {
+  typedef typename RowXch<SPLIT, T, PadSlot<S::R(0)>>::elem XE;
   static constexpr int M = S::N;
   static constexpr int THREADS = S::TPT * ROWS;
   static constexpr int PD = S::R(0);
   static constexpr int PLEN = padded_len<M, PD>();
   static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
-  static constexpr int XCH_BYTES = (int)(PLEN * ROWS * sizeof(cx<T>));
+  static constexpr int XCH_BYTES = (int)(PLEN * ROWS * sizeof(XE));
   static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
 
   static MFFT_D void body(const RealParams<T>& P, int bid, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
     const int rl = tid / S::TPT;
     const int j = tid % S::TPT;
-    cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES) + rl * PLEN;
+    XE* xch = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;
     // a row of N reals read as N/2 complex (x[2n], x[2n+1])
@@ -552,7 +565,7 @@ struct R2CFft {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
     }
-    XchFull<T, PadSlot<PD>> xc{xch, PadSlot<PD>{}};
+    typename RowXch<SPLIT, T, PadSlot<PD>>::type xc{xch, PadSlot<PD>{}};
     if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xc);
     else run_passes<S, 0, T>(v, j, P.tw, xc);
 
@@ -597,6 +610,31 @@ struct R2CFft {
         if (active) emit(j + k * S::TPT, v[k], pm);
       }
 #endif
+    } else if constexpr (SPLIT) {
+      // the mirrored partners through the half-size buffer: real parts, then imaginary parts
+      cx<T> pm[S::E];
+      if constexpr (S::NP > 1) MFFT_BARRIER();
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) xch[padpos<PD>(j + k * S::TPT)] = v[k].x;
+      MFFT_BARRIER();
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const int pos = j + k * S::TPT;
+        pm[k].x = xch[padpos<PD>(pos == 0 ? 0 : M - pos)];
+      }
+      MFFT_BARRIER();
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) xch[padpos<PD>(j + k * S::TPT)] = v[k].y;
+      MFFT_BARRIER();
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const int pos = j + k * S::TPT;
+        pm[k].y = xch[padpos<PD>(pos == 0 ? 0 : M - pos)];
+      }
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) emit(j + k * S::TPT, v[k], pm[k]);
+      }
     } else {
       if constexpr (S::NP > 1) MFFT_BARRIER();
 #pragma unroll
@@ -617,21 +655,22 @@ struct R2CFft {
 // half-complex -> real along the contiguous axis.  S describes M = N/2.
 // out = irfft(in) * N * scale   (scale = 1/N gives numpy's irfft)
 // ---------------------------------------------------------------------------
-template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false>
+template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false, bool SPLIT = false>
 struct C2RFft {
+  typedef typename RowXch<SPLIT, T, PadSlot<S::R(0)>>::elem XE;
   static constexpr int M = S::N;
   static constexpr int THREADS = S::TPT * ROWS;
   static constexpr int PD = S::R(0);
   static constexpr int PLEN = padded_len<M, PD>();
   static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
-  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(PLEN * ROWS * sizeof(cx<T>)) : 0;
+  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(PLEN * ROWS * sizeof(XE)) : 0;
   static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
 
   static MFFT_D void body(const RealParams<T>& P, int bid, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
     const int rl = tid / S::TPT;
     const int j = tid % S::TPT;
-    cx<T>* xch = reinterpret_cast<cx<T>*>(lds + TW_BYTES) + rl * PLEN;
+    XE* xch = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;
     // rows past the end re-read the last row (unconditional loads: see RowFft) and store nothing
@@ -736,7 +775,7 @@ struct C2RFft {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
     }
-    XchFull<T, PadSlot<PD>> xc{xch, PadSlot<PD>{}};
+    typename RowXch<SPLIT, T, PadSlot<PD>>::type xc{xch, PadSlot<PD>{}};
     if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xc);
     else run_passes<S, 0, T>(v, j, P.tw, xc);
 

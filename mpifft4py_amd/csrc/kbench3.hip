@@ -31,6 +31,13 @@ __global__ __launch_bounds__(K::THREADS) void kern(P p) {
   K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
 }
 
+// the same with a register cap that lets WGS workgroups share a CU (waves per SIMD = WGS * THREADS / 256)
+template <class K, class P, int WGS>
+__global__ __launch_bounds__(K::THREADS, WGS * K::THREADS / 256) void kern_occ(P p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
+}
+
 template <typename T>
 struct Variant {
   std::string name;
@@ -49,6 +56,28 @@ void launch_k(const ColParams<T>& p, int grid) {
     attr = true;
   }
   hipLaunchKernelGGL((kern<K, ColParams<T>>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, 0, p);
+}
+
+template <class K, typename T, int WGS>
+void launch_k_occ(const ColParams<T>& p, int grid) {
+  static bool attr = false;
+  if (!attr) {
+    if (K::LDS_BYTES > 65536)
+      CK(hipFuncSetAttribute((const void*)kern_occ<K, ColParams<T>, WGS>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern_occ<K, ColParams<T>, WGS>, K::THREADS, K::LDS_BYTES));
+    printf("   (occupancy of the %d-workgroup build: %d per CU)\n", WGS, occ);
+    attr = true;
+  }
+  hipLaunchKernelGGL((kern_occ<K, ColParams<T>, WGS>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, 0, p);
+}
+template <class S, typename T, int COLS, bool TWLDS, bool SPLIT, int VEC, bool NT, int WGS>
+Variant<T> make_tile_occ(const char* plan) {
+  typedef ColFft<S, T, COLS, false, TWLDS, SPLIT, VEC, NT> K;
+  char nm[128];
+  snprintf(nm, sizeof nm, "tile    %s c%d v%d%s%s%s thr%d lds%dK wgs%d", plan, COLS, VEC, TWLDS ? " twlds" : "", SPLIT ? " split" : "", NT ? " nt" : "", K::THREADS,
+           K::LDS_BYTES / 1024, WGS);
+  return Variant<T>{nm, false, COLS, &launch_k_occ<K, T, WGS>, build_pass_twiddles<S, T>()};
 }
 
 template <class S, typename T, int COLS, bool TWLDS, bool SPLIT, int VEC, bool NT = false>
@@ -491,6 +520,98 @@ int main(int argc, char** argv) {
     vs.push_back(make_tile<Spec<1024, 32, 32>, float, 16, true, false, 2>("32x32"));
     vs.push_back(make_tile<SC, float, 16, false, false, 2>("16x16x4"));
     run_all<float>(vs, 1024, "", rounds);
+    return 0;
+  }
+  if (filter[0] && strstr("small", filter)) {       // 384 / 640 / 576: fewer values per thread, more threads per CU?
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<384, 8, 8, 3, 2>, double, 8, true, false, 1>("8x8x3x2"));
+      vs.push_back(make_tile<Spec<384, 4, 4, 4, 3, 2>, double, 8, true, false, 1>("4x4x4x3x2"));
+      vs.push_back(make_tile_occ<Spec<384, 4, 4, 4, 3, 2>, double, 8, true, false, 1, false, 3>("4x4x4x3x2"));
+      vs.push_back(make_tile_occ<Spec<384, 4, 4, 4, 3, 2>, double, 8, true, true, 1, false, 4>("4x4x4x3x2"));
+      vs.push_back(make_tile<Spec<384, 8, 4, 4, 3>, double, 8, true, false, 1>("8x4x4x3"));
+      run_all<double>(vs, 384, "", rounds);
+    }
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<640, 8, 4, 4, 5>, double, 8, false, false, 1>("8x4x4x5"));
+      vs.push_back(make_tile<Spec<640, 4, 4, 4, 5, 2>, double, 8, false, false, 1>("4x4x4x5x2"));
+      vs.push_back(make_tile_occ<Spec<640, 4, 4, 4, 5, 2>, double, 8, true, true, 1, false, 3>("4x4x4x5x2"));
+      vs.push_back(make_tile_occ<Spec<640, 8, 4, 4, 5>, double, 8, true, true, 1, false, 3>("8x4x4x5"));
+      vs.push_back(make_tile_occ<Spec<640, 4, 4, 4, 5, 2>, double, 8, false, false, 1, false, 2>("4x4x4x5x2"));
+      run_all<double>(vs, 640, "", rounds);
+    }
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<576, 8, 8, 3, 3>, double, 8, false, false, 1>("8x8x3x3"));
+      vs.push_back(make_tile_occ<Spec<576, 4, 4, 4, 3, 3>, double, 8, false, false, 1, false, 2>("4x4x4x3x3"));
+      vs.push_back(make_tile_occ<Spec<576, 4, 4, 4, 3, 3>, double, 8, true, true, 1, false, 3>("4x4x4x3x3"));
+      run_all<double>(vs, 576, "", rounds);
+    }
+    return 0;
+  }
+  if (filter[0] && strstr("occ", filter)) {         // 1152 with 12 values per thread and a register cap for two workgroups per CU
+    std::vector<Variant<double>> vs;
+    vs.push_back(make_tile<Spec<1152, 8, 8, 3, 3, 2>, double, 8, false, true, 1>("8x8x3x3x2"));
+    vs.push_back(make_tile_occ<Spec<1152, 4, 4, 4, 3, 3, 2>, double, 8, false, true, 1, false, 2>("4x4x4x3x3x2"));
+    vs.push_back(make_tile_occ<Spec<1152, 8, 8, 3, 3, 2>, double, 8, false, true, 1, false, 2>("8x8x3x3x2"));
+    vs.push_back(make_tile_occ<Spec<1152, 4, 4, 4, 3, 3, 2>, double, 8, false, true, 1, true, 2>("4x4x4x3x3x2"));
+    run_all<double>(vs, 1152, "", rounds);
+    std::vector<Variant<double>> v2;
+    v2.push_back(make_tile<Spec<1280, 8, 8, 4, 5>, double, 8, false, true, 1>("8x8x4x5"));
+    v2.push_back(make_tile_occ<Spec<1280, 4, 4, 4, 4, 5>, double, 8, false, true, 1, false, 2>("4x4x4x4x5"));
+    v2.push_back(make_tile_occ<Spec<1280, 8, 8, 4, 5>, double, 8, false, true, 1, false, 2>("8x8x4x5"));
+    run_all<double>(v2, 1280, "", rounds);
+    return 0;
+  }
+  if (filter[0] && strstr("twl", filter)) {         // LDS twiddles at the long lengths with their present plans
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, false, true, 1>("8x8x8x3"));
+      vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, true, true, 1>("8x8x8x3"));
+      vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, true, true, 1, true>("8x8x8x3"));
+      run_all<double>(vs, 1536, "", rounds);
+    }
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<1152, 8, 8, 3, 3, 2>, double, 8, false, true, 1>("8x8x3x3x2"));
+      vs.push_back(make_tile<Spec<1152, 8, 8, 3, 3, 2>, double, 8, true, true, 1>("8x8x3x3x2"));
+      vs.push_back(make_tile<Spec<1152, 8, 8, 3, 3, 2>, double, 8, true, true, 1, true>("8x8x3x3x2"));
+      run_all<double>(vs, 1152, "", rounds);
+    }
+    return 0;
+  }
+  if (filter[0] && strstr("long", filter)) {        // lengths above 1024 in double precision: threads per CU against values per thread
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<1152, 8, 8, 3, 3, 2>, double, 8, false, true, 1>("8x8x3x3x2"));
+      vs.push_back(make_tile<Spec<1152, 8, 8, 3, 3, 2>, double, 8, false, true, 1, true>("8x8x3x3x2"));
+      vs.push_back(make_tile<Spec<1152, 4, 4, 4, 3, 3, 2>, double, 8, false, true, 1>("4x4x4x3x3x2"));
+      vs.push_back(make_tile<Spec<1152, 4, 4, 4, 3, 3, 2>, double, 8, false, true, 1, true>("4x4x4x3x3x2"));
+      vs.push_back(make_tile<Spec<1152, 4, 4, 4, 3, 3, 2>, double, 8, true, true, 1>("4x4x4x3x3x2"));
+      vs.push_back(make_tile<Spec<1152, 4, 4, 4, 3, 3, 2>, double, 8, true, true, 1, true>("4x4x4x3x3x2"));
+      run_all<double>(vs, 1152, "", rounds);
+    }
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<1280, 8, 8, 4, 5>, double, 8, false, true, 1>("8x8x4x5"));
+      vs.push_back(make_tile<Spec<1280, 8, 8, 4, 5>, double, 8, false, true, 1, true>("8x8x4x5"));
+      vs.push_back(make_tile<Spec<1280, 4, 4, 4, 4, 5>, double, 8, false, true, 1>("4x4x4x4x5"));
+      vs.push_back(make_tile<Spec<1280, 4, 4, 4, 4, 5>, double, 8, false, true, 1, true>("4x4x4x4x5"));
+      vs.push_back(make_tile<Spec<1280, 4, 4, 4, 4, 5>, double, 8, true, true, 1>("4x4x4x4x5"));
+      vs.push_back(make_tile<Spec<1280, 4, 4, 4, 4, 5>, double, 8, true, true, 1, true>("4x4x4x4x5"));
+      run_all<double>(vs, 1280, "", rounds);
+    }
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, false, true, 1>("8x8x8x3"));
+      vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, false, true, 1, true>("8x8x8x3"));
+      vs.push_back(make_tile<Spec<1536, 4, 4, 4, 4, 3, 2>, double, 8, false, true, 1>("4x4x4x4x3x2"));
+      vs.push_back(make_tile<Spec<1536, 4, 4, 4, 4, 3, 2>, double, 8, false, true, 1, true>("4x4x4x4x3x2"));
+      vs.push_back(make_tile<Spec<1536, 4, 4, 4, 4, 3, 2>, double, 8, true, true, 1>("4x4x4x4x3x2"));
+      vs.push_back(make_tile<Spec<1536, 4, 4, 4, 4, 3, 2>, double, 8, true, true, 1, true>("4x4x4x4x3x2"));
+      run_all<double>(vs, 1536, "", rounds);
+    }
     return 0;
   }
   if (filter[0] && strstr("sizes", filter)) {       // other lengths whose whole-complex exchange leaves one workgroup per CU

@@ -115,6 +115,27 @@ __global__ __launch_bounds__(1024 / E * COLS) void k_tile(ColParams<double> P) {
   }
 }
 
+// ---- 4b. the same for other lengths: NR rows per tile, E values per thread (occupancy as the launch allows) ------
+template <int NR, int COLS, int E, int NT>
+__global__ __launch_bounds__(NR / E * COLS) void k_tile_n(ColParams<double> P) {
+  constexpr int TPT = NR / E;
+  const int bid = P.remap ? xcd_remap((int)blockIdx.x, P.ntile_c * P.nouter) : (int)blockIdx.x;
+  const int outer = bid / P.ntile_c, tc = bid - outer * P.ntile_c;
+  const int c = threadIdx.x % COLS, j = threadIdx.x / COLS, col = tc * COLS + c;
+  if (col >= P.ncols) return;
+  const d2* ip = reinterpret_cast<const d2*>(P.in + (i64)outer * P.in_outer + col);
+  d2* op = reinterpret_cast<d2*>(P.out + (i64)outer * P.out_outer + col);
+  d2 v[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) v[k] = ld<NT>(ip + row_off(P.in_map, (unsigned)(j + k * TPT)));
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    d2 x = v[k];
+    x.x += 1.0;
+    st<NT>(op + row_off(P.out_map, (unsigned)(j + k * TPT)), x);
+  }
+}
+
 // ---- 5. stamped diagnostic build of the strided FFT (shares of a workgroup's life; never quote its run time) --
 struct Stamp { unsigned long long t[8]; unsigned xcc, cu; };
 __device__ __forceinline__ unsigned long long stamp_now() {
@@ -296,6 +317,31 @@ static void run_tile(const char* tag, cx<double>* in, cx<double>* out, int pitch
   report(nm, ms, bytes);
 }
 
+template <int NR, int COLS, int E, int NT>
+static void run_tile_n(cx<double>* in, cx<double>* out, bool xdir, int lds_bytes) {
+  const int N = NR, NF = NR / 2 + 1;
+  char nm[160];
+  snprintf(nm, sizeof nm, "tile N=%d c%d e%d nt%d %s %s lds%dK", NR, COLS, E, NT, xdir ? "x" : "y", in == out ? "inplace" : "outofplace", lds_bytes / 1024);
+  ColParams<double> P;
+  memset(&P, 0, sizeof P);
+  P.in = in; P.out = out; P.tw = nullptr; P.remap = 1; P.scale = 1.0;
+  if (!xdir) {
+    P.in_outer = P.out_outer = (i64)N * NF;
+    P.in_map = P.out_map = make_rowmap(0, NF, N, N);
+    P.ncols = NF; P.nouter = N;
+  } else {
+    P.in_outer = P.out_outer = 0;
+    P.in_map = P.out_map = make_rowmap(0, (i64)N * NF, N, N);
+    P.ncols = N * NF; P.nouter = 1;
+  }
+  P.ntile_c = (P.ncols + COLS - 1) / COLS;
+  const int grid = P.ntile_c * P.nouter;
+  if (lds_bytes > 65536)
+    CK(hipFuncSetAttribute((const void*)k_tile_n<NR, COLS, E, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  const double ms = time_ms([&] { hipLaunchKernelGGL((k_tile_n<NR, COLS, E, NT>), dim3(grid), dim3(NR / E * COLS), lds_bytes, 0, P); });
+  report(nm, ms, 2.0 * N * N * 16.0 * NF);
+}
+
 template <class S, int COLS, bool SPLIT>
 static void run_stamped(const char* plan, cx<double>* buf, bool xdir) {
   const int N = 1024, NF = 513, pitch = 513;
@@ -441,6 +487,34 @@ static void run_pstamped(const char* plan, cx<double>* buf, bool xdir) {
 
 int main(int argc, char** argv) {
   g_filter = argc > 1 ? argv[1] : "";
+  if (argc > 1 && !strcmp(argv[1], "tilelong")) {   // the bare tile pattern at the lengths above 1024 (dynamic LDS only limits occupancy)
+    const size_t el = (size_t)1536 * 1536 * 769;
+    cx<double>*a = nullptr, *b = nullptr;
+    CK(hipMalloc(&a, el * sizeof(cx<double>)));
+    CK(hipMalloc(&b, el * sizeof(cx<double>)));
+    CK(hipMemset(a, 0, el * sizeof(cx<double>)));
+    CK(hipMemset(b, 0, el * sizeof(cx<double>)));
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int x = 0; x < 2; ++x) {
+      run_tile_n<1024, 8, 8, 0>(a, a, x, 80 << 10);
+      run_tile_n<1024, 8, 8, 0>(a, a, x, 0);
+      run_tile_n<1152, 8, 24, 0>(a, a, x, 72 << 10);
+      run_tile_n<1152, 8, 24, 0>(a, a, x, 0);
+      run_tile_n<1152, 8, 12, 0>(a, a, x, 72 << 10);
+      run_tile_n<1152, 8, 12, 0>(a, a, x, 0);
+      run_tile_n<1152, 8, 24, 0>(a, b, x, 72 << 10);
+      run_tile_n<1280, 8, 40, 0>(a, a, x, 80 << 10);
+      run_tile_n<1280, 8, 20, 0>(a, a, x, 80 << 10);
+      run_tile_n<1280, 8, 20, 0>(a, a, x, 0);
+      run_tile_n<1536, 8, 24, 0>(a, a, x, 96 << 10);
+      run_tile_n<1536, 8, 24, 0>(a, a, x, 48 << 10);
+      run_tile_n<1536, 8, 12, 0>(a, a, x, 96 << 10);
+      run_tile_n<1536, 8, 12, 0>(a, a, x, 0);
+      run_tile_n<1536, 8, 24, 0>(a, b, x, 96 << 10);
+    }
+    return 0;
+  }
   const int N = 1024;
   const size_t elems = (size_t)N * N * 584;             // complex128 elements per buffer (9.8 GB)
   const size_t n = (size_t)N * N * 513;                 // elements moved by the linear copies (8.6 GB each way)

@@ -57,8 +57,15 @@ constexpr bool mfft_has_row_override(int n) {
 // x in place 3.57 -> 3.35 ms (with non-temporal accesses, which only pay in place at two workgroups per CU),
 // x out of place 3.63 -> 3.19 ms.  The same change loses in single precision (1.85 -> 2.4 ms) and is neutral at 512.
 #define MFFT_COLPLANS_F64_B(X) X(1024, 8, 8, 4, 4)
+// 384 and 1152 in double precision: 12 instead of 24 values per thread, i.e. twice the threads per CU (384: 3 workgroups of
+// 256 instead of 128 threads; 1152: 768 threads and, with the register cap of registry.h col_wgs, two workgroups per CU
+// instead of one).  kbench3 `small` / `occ` (profiles/r02_kbench3_long_lengths.txt), y in place / x in place / x out of
+// place, ms:  384: 0.231 -> 0.184, 0.217 -> 0.186, 0.245 -> 0.191;  1152: 6.72 -> 5.64, 7.14 -> 5.45, 7.36 -> 5.44.
+// The same exchange of plans is neutral at 576, 640, 1280 and loses at 1536 (1024 threads, one workgroup either way).
+#define MFFT_COLPLANS_F64_E(X) X(384, 4, 4, 4, 3, 2)
+#define MFFT_COLPLANS_F64_I(X) X(1152, 4, 4, 4, 3, 3, 2)
 template <typename T> constexpr bool mfft_has_col_override(int n) {
-  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && n == 1024);
+  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && (n == 1024 || n == 384 || n == 1152));
 }
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \

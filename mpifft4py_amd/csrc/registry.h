@@ -86,14 +86,32 @@ template <class S, typename T> constexpr bool col_twlds() {
   return S::NP > 1 && (col_pair<S, T>() || (!col_split<S, T>() &&
          (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) + S::TW * (int)sizeof(cx<T>) <= 65536));
 }
-template <class S, typename T> constexpr int row_rows() {
+// Contiguous-axis kernels keep one exchange buffer per row, so the rows a CU holds at once (its threads in flight) are
+// set by LDS.  The plans with 12 or 20 values per thread (3- and 5-smooth lengths >= 384) in double precision had 6 - 10
+// rows = 380 - 500 threads per CU; they drop the LDS copy of the twiddles (it is per workgroup) and exchange real and
+// imaginary parts one after the other (half the buffer).  z stages (r2c / c2r) of the R2C pair, ms, before -> without
+// LDS twiddles -> with the split exchange as well: 1152^3 5.49/6.04 -> 5.02/4.96; 1280^3 8.60/10.03 -> 7.05/7.24;
+// 1536^3 12.43/12.18 -> 11.38/10.76 (profiles/r02_row_kernels_long_lengths.txt).
+template <class S, typename T> constexpr bool row_lean() { return sizeof(T) == 8 && S::E >= 12 && S::N >= 384; }
+template <class S, typename T, bool C2R = false> constexpr bool row_split() {
+  return S::NP > 1 && row_lean<S, T>() && !(C2R && S::E >= 20);   // the c2r kernels of the E = 20 plans lose with it (1280: 7.2 -> 8.3 ms)
+}
+template <class S, typename T, bool SPLIT> constexpr int row_rows_n() {
   int rows = 256 / S::TPT;
   if (rows < 1) rows = 1;
-  const long long per_row = (long long)(S::N + S::N / S::R(0) + 1) * (int)sizeof(cx<T>);
+  const long long per_row = (long long)(S::N + S::N / S::R(0) + 1) * (int)(SPLIT ? sizeof(T) : sizeof(cx<T>));
   while (rows > 1 && per_row * rows > 40960 && S::TPT * (rows / 2) >= 64) rows /= 2;   // never below one wave
   return rows;
 }
-template <class S, typename T> constexpr bool row_twlds() { return S::NP > 1; }
+template <class S, typename T, bool C2R = false> constexpr int row_rows() { return row_rows_n<S, T, row_split<S, T, C2R>()>(); }
+template <class S, typename T> constexpr bool row_twlds() { return S::NP > 1 && !row_lean<S, T>(); }
+
+// Workgroups per CU the strided kernel's REGISTER allocation must leave room for (0: whatever the compiler takes).
+// 1152 in double precision runs 768 threads with ~88 VGPRs: one register more than two workgroups per CU allow
+// (6 waves per SIMD x 85); capped, both fit (LDS 2 x 72 KiB) and one's loads overlap the other's passes.
+template <class S, typename T> constexpr int col_wgs() {
+  return (sizeof(T) == 8 && S::N == 1152 && S::E == 12) ? 2 : 0;
+}
 
 // ---- generic __global__ wrapper + launch thunks ------------------------------
 template <class K, class P>
@@ -101,11 +119,19 @@ __global__ __launch_bounds__(K::THREADS) void mfft_kern(P p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
 }
+// the same with a register cap: WGS workgroups per CU = WGS * THREADS / 256 waves per SIMD
+template <class K, class P, int WGS>
+__global__ __launch_bounds__(K::THREADS, WGS * K::THREADS / 256) void mfft_kern_occ(P p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
+}
 
-template <class K, class P>
+template <class K, class P, int WGS = 0>
 void launch_thunk(const void* params, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((mfft_kern<K, P>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, s,
-                     *static_cast<const P*>(params));
+  if constexpr (WGS > 1)
+    hipLaunchKernelGGL((mfft_kern_occ<K, P, WGS>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, s, *static_cast<const P*>(params));
+  else
+    hipLaunchKernelGGL((mfft_kern<K, P>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, s, *static_cast<const P*>(params));
 }
 
 template <class S, typename T>
@@ -114,7 +140,7 @@ void tw_thunk(void* dst) {
   memcpy(dst, v.data(), v.size() * sizeof(cx<T>));
 }
 
-template <class K, class P, class S, typename T>
+template <class K, class P, class S, typename T, int WGS = 0>
 KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
   KernelEntry e;
   e.family = family;
@@ -129,8 +155,9 @@ KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
   e.lds_bytes = K::LDS_BYTES;
   e.tw_count = S::TW;
   e.build_tw = &tw_thunk<S, T>;
-  e.launch = &launch_thunk<K, P>;
-  e.func = reinterpret_cast<const void*>(&mfft_kern<K, P>);
+  e.launch = &launch_thunk<K, P, WGS>;
+  if constexpr (WGS > 1) e.func = reinterpret_cast<const void*>(&mfft_kern_occ<K, P, WGS>);
+  else e.func = reinterpret_cast<const void*>(&mfft_kern<K, P>);
   e.name = name;
   return e;
 }
@@ -142,19 +169,20 @@ void register_col(const char* name) {
   constexpr bool CT = col_twlds<S, T>();
   constexpr bool CS = col_split<S, T>();
   constexpr int CV = col_vec<S, T>();
-  reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
-  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+  constexpr int W = col_wgs<S, T>();
+  reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
+  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
   if constexpr (S::E % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: pad-on-load (inverse) / truncate-on-store (forward)
-    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 1>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 1>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
     reg.back().pad = 1;
-    reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, false, 2>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
+    reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, false, 2>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
     reg.back().pad = 2;
   }
   if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {     // aligned-row (non-temporal) variants
-    reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name));
+    reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
     reg.back().nt = 1;
     reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
-    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name));
+    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
     reg.back().nt = 1;
     reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
   }
@@ -165,23 +193,26 @@ void register_rows(const char* name) {
   auto& reg = kernel_registry();
   constexpr int R = row_rows<S, T>();
   constexpr bool RT = row_twlds<S, T>();
-  reg.push_back(make_entry<RowFft<S, T, R, false, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
-  reg.push_back(make_entry<RowFft<S, T, R, true, RT>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
-  reg.push_back(make_entry<R2CFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
-  reg.push_back(make_entry<C2RFft<S, T, R, RT>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
+  constexpr bool SP = row_split<S, T>();
+  constexpr int RC = row_rows<S, T, true>();      // the c2r kernels may differ
+  constexpr bool SC = row_split<S, T, true>();
+  reg.push_back(make_entry<RowFft<S, T, R, false, RT, false, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
+  reg.push_back(make_entry<RowFft<S, T, R, true, RT, false, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
+  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, false, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RT, false, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
   // pencil decompositions: the z-chunk pack / unpack fused into the stores / loads (pad = 4)
-  reg.push_back(make_entry<RowFft<S, T, R, false, RT, true>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
+  reg.push_back(make_entry<RowFft<S, T, R, false, RT, true, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<RowFft<S, T, R, true, RT, true>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
+  reg.push_back(make_entry<RowFft<S, T, R, true, RT, true, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, true>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, true, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<C2RFft<S, T, R, RT, false, true>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RT, false, true, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
   reg.back().pad = 4;
   if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
-    reg.push_back(make_entry<R2CFft<S, T, R, RT, true>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+    reg.push_back(make_entry<R2CFft<S, T, R, RT, true, false, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
     reg.back().pad = 3;
-    reg.push_back(make_entry<C2RFft<S, T, R, RT, true>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, R, name));
+    reg.push_back(make_entry<C2RFft<S, T, RC, RT, true, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 3;
   }
 }
@@ -215,7 +246,7 @@ template <class S, typename T>
 void register_rows_z(const char* name) {
   if constexpr (S::N >= 16) {
     auto& reg = kernel_registry();
-    constexpr int R = row_rows<S, T>();
+    constexpr int R = row_rows_n<S, T, false>();     // the chirp-z kernels exchange whole complex values
     reg.push_back(make_entry<RowFftZ<S, T, R, 0, false>, RowParamsZ<T>, S, T>(FAM_ROWZ, S::N, 0, R, name));
     reg.push_back(make_entry<RowFftZ<S, T, R, 0, true>, RowParamsZ<T>, S, T>(FAM_ROWZ, S::N, 1, R, name));
     reg.push_back(make_entry<RowFftZ<S, T, R, 1, false>, RealParamsZ<T>, S, T>(FAM_R2CZ, S::N, 0, R, name));

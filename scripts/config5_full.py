@@ -26,6 +26,12 @@ def body(comm):
     u = DeviceArray.random(F.original_shape(), F.complex, seed=100 + r)
     fu = DeviceArray.empty(F.transformed_shape(), F.complex)
     F.fftn(u, fu); F.sync(); comm.barrier()
+    if os.environ.get("CONFIG5_STAGES"):          # per-stage event times of one more pair (not the timed one)
+        F.enable_timing(True)
+        F.fftn(u, fu); F.ifftn(fu, u); F.sync(); comm.barrier()
+        if r == 0:
+            print("stages (rank 0, ms): " + " ".join("%s=%.2f" % (k, v[0] / max(v[1], 1)) for k, v in sorted(F.stage_times().items())), flush=True)
+        F.enable_timing(False)
     e_u = spectral.sumsq(F, u)            # sum |u|^2 over this rank (device reduction)
     t0 = time.perf_counter()
     F.fftn(u, fu)
