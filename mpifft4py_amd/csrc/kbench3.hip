@@ -522,6 +522,43 @@ int main(int argc, char** argv) {
     run_all<float>(vs, 1024, "", rounds);
     return 0;
   }
+  if (filter[0] && strstr("half", filter)) {        // 64-byte tiles and more workgroups per CU where a 128-byte tile leaves one
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, false, true, 1>("8x8x8x3"));
+      vs.push_back(make_tile_occ<Spec<1536, 8, 8, 8, 3>, double, 4, false, true, 1, false, 3>("8x8x8x3"));
+      vs.push_back(make_tile_occ<Spec<1536, 8, 8, 8, 3>, double, 4, false, true, 1, false, 2>("8x8x8x3"));
+      vs.push_back(make_tile_occ<Spec<1536, 8, 8, 8, 3>, double, 4, false, false, 1, false, 1>("8x8x8x3"));
+      run_all<double>(vs, 1536, "", rounds);
+    }
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<2048, 16, 16, 8>, double, 8, false, true, 1>("16x16x8"));
+      vs.push_back(make_tile_occ<Spec<2048, 16, 16, 8>, double, 4, false, true, 1, false, 2>("16x16x8"));
+      vs.push_back(make_tile_occ<Spec<2048, 16, 16, 8>, double, 4, false, false, 1, false, 1>("16x16x8"));
+      run_all<double>(vs, 2048, "", rounds);
+    }
+    return 0;
+  }
+  if (filter[0] && strstr("f32long", filter)) {     // single precision at 1152 / 1280 / 1536: register caps, fewer values per thread
+    {
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<Spec<1152, 8, 8, 3, 3, 2>, float, 16, false, true, 1>("8x8x3x3x2"));
+      vs.push_back(make_tile_occ<Spec<1152, 8, 8, 3, 3, 2>, float, 16, false, true, 1, false, 2>("8x8x3x3x2"));
+      vs.push_back(make_tile_occ<Spec<1152, 8, 8, 3, 3, 2>, float, 16, false, true, 1, true, 2>("8x8x3x3x2"));
+      vs.push_back(make_tile_occ<Spec<1152, 4, 4, 4, 3, 3, 2>, float, 8, false, true, 1, false, 2>("4x4x4x3x3x2"));
+      run_all<float>(vs, 1152, "", rounds);
+    }
+    {
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, float, 16, false, true, 1>("8x8x8x3"));
+      vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, float, 16, false, true, 1, true>("8x8x8x3"));
+      vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, float, 16, true, true, 1>("8x8x8x3"));
+      vs.push_back(make_tile_occ<Spec<1536, 8, 8, 8, 3>, float, 8, false, true, 1, false, 3>("8x8x8x3"));
+      run_all<float>(vs, 1536, "", rounds);
+    }
+    return 0;
+  }
   if (filter[0] && strstr("small", filter)) {       // 384 / 640 / 576: fewer values per thread, more threads per CU?
     {
       std::vector<Variant<double>> vs;

@@ -92,6 +92,7 @@ template <class S, typename T> constexpr bool col_twlds() {
 // imaginary parts one after the other (half the buffer).  z stages (r2c / c2r) of the R2C pair, ms, before -> without
 // LDS twiddles -> with the split exchange as well: 1152^3 5.49/6.04 -> 5.02/4.96; 1280^3 8.60/10.03 -> 7.05/7.24;
 // 1536^3 12.43/12.18 -> 11.38/10.76 (profiles/r02_row_kernels_long_lengths.txt).
+// (single precision: measured worse -- 1152^3 z stages 2.71 / 2.74 -> 2.95 / 3.58 ms, 1536^3 6.4 / 5.7 -> 6.9 / 6.3)
 template <class S, typename T> constexpr bool row_lean() { return sizeof(T) == 8 && S::E >= 12 && S::N >= 384; }
 template <class S, typename T, bool C2R = false> constexpr bool row_split() {
   return S::NP > 1 && row_lean<S, T>() && !(C2R && S::E >= 20);   // the c2r kernels of the E = 20 plans lose with it (1280: 7.2 -> 8.3 ms)
@@ -109,8 +110,12 @@ template <class S, typename T> constexpr bool row_twlds() { return S::NP > 1 && 
 // Workgroups per CU the strided kernel's REGISTER allocation must leave room for (0: whatever the compiler takes).
 // 1152 in double precision runs 768 threads with ~88 VGPRs: one register more than two workgroups per CU allow
 // (6 waves per SIMD x 85); capped, both fit (LDS 2 x 72 KiB) and one's loads overlap the other's passes.
+// Single precision (kbench3 f32long, profiles/r02_kbench3_long_lengths.txt): 1152 (8x8x3x3x2, 768 threads) with the cap
+// for two workgroups 3.7 - 3.9 -> 2.9 - 3.0 ms per pass; 1536 as 64-byte tiles (8 columns, 512 threads, 48 KiB) with the
+// cap for three 7.9 - 8.7 -> 7.3 - 7.8 ms (the same tiling changes nothing in double precision).
 template <class S, typename T> constexpr int col_wgs() {
-  return (sizeof(T) == 8 && S::N == 1152 && S::E == 12) ? 2 : 0;
+  if (sizeof(T) == 8) return (S::N == 1152 && S::E == 12) ? 2 : 0;
+  return (S::N == 1152 && S::E == 24) ? 2 : (S::N == 1536 && S::E == 24) ? 3 : 0;
 }
 
 // ---- generic __global__ wrapper + launch thunks ------------------------------
@@ -165,11 +170,11 @@ KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
 template <class S, typename T>
 void register_col(const char* name) {
   auto& reg = kernel_registry();
-  constexpr int C = col_cols<S, T>();
-  constexpr bool CT = col_twlds<S, T>();
-  constexpr bool CS = col_split<S, T>();
-  constexpr int CV = col_vec<S, T>();
   constexpr int W = col_wgs<S, T>();
+  constexpr int C = (sizeof(T) == 4 && S::N == 1536 && W == 3) ? 8 : col_cols<S, T>();      // see col_wgs
+  constexpr bool CT = col_twlds<S, T>();
+  constexpr bool CS = col_split<S, T>() || (W > 1 && (long long)S::N * C * (int)sizeof(cx<T>) * W > 163840);
+  constexpr int CV = col_vec<S, T>();
   reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
   reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
   if constexpr (S::E % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: pad-on-load (inverse) / truncate-on-store (forward)
