@@ -781,6 +781,9 @@ int main() {
 #if EMU_HAS(4)
   MFFT_PLANS_H(MFFT_PLAN) MFFT_PLANS_I(MFFT_PLAN) MFFT_PLANS_J(MFFT_PLAN)
 #endif
+#if EMU_HAS(6)
+  MFFT_PLANS_K(MFFT_PLAN)
+#endif
 #if EMU_HAS(5)
   MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN)
 #endif

@@ -1559,7 +1559,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   // every transform length must have a kernel
   auto need = [&](int64_t n, bool real) -> int {
     if (n == 1 && !real) return 0;
-    if (!length_supported(n, real)) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %lld%s has no kernel (2^a, 3*2^a, 5*2^a up to 4096; any other length up to 2048)", (long long)n, real ? " (real)" : "");
+    if (!length_supported(n, real)) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %lld%s has no kernel (radix plans: 2^a <= 4096, 3*2^a, 5*2^a, 9*2^a, 25*2^a, 125*2^a; any other length up to 2048)", (long long)n, real ? " (real)" : "");
     return 0;
   };
   MFFT_TRY(need(p->N0, false));

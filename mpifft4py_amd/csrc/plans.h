@@ -6,7 +6,8 @@
 // Lengths covered: 2^a (2..4096), 3*2^a (6..3072), 5*2^a (10..2560): these are
 // what the reference's power-of-two meshes and their 3/2-rule padded
 // counterparts (slab.py:75-76, 487-489) produce; 9*2^a (18..2304) are the 3/2-rule
-// images of the 3*2^a meshes, 25*2^a (50..1600) round off the 5-smooth sizes.  Every
+// images of the 3*2^a meshes, 25*2^a (50..1600) and 125*2^a (250..2000: 1000^3 is a mesh people run) round off the
+// 5-smooth sizes.  Every
 // other length goes through the chirp-z kernels (fft_chirpz.h).  The groups only exist
 // so the instantiations can be compiled in parallel translation units.
 #pragma once
@@ -21,6 +22,7 @@
 #define MFFT_PLANS_H(X) X(18, 3, 3, 2) X(36, 4, 3, 3) X(72, 8, 3, 3) X(144, 8, 3, 3, 2) X(288, 8, 4, 3, 3) X(576, 8, 8, 3, 3)
 #define MFFT_PLANS_I(X) X(1152, 8, 8, 3, 3, 2) X(2304, 8, 8, 4, 3, 3)
 #define MFFT_PLANS_J(X) X(50, 5, 5, 2) X(100, 5, 5, 4) X(200, 5, 5, 4, 2) X(400, 5, 5, 4, 4) X(800, 5, 5, 4, 4, 2) X(1600, 5, 5, 4, 4, 4)
+#define MFFT_PLANS_K(X) X(250, 5, 5, 5, 2) X(500, 5, 5, 5, 4) X(1000, 5, 5, 5, 4, 2) X(2000, 5, 5, 5, 4, 4)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -34,6 +36,7 @@
 #define MFFT_ROWPLANS_H(X) X(144, 4, 4, 3, 3) X(288, 4, 4, 3, 3, 2) X(576, 4, 4, 4, 3, 3)
 #define MFFT_ROWPLANS_I(X) X(1152, 4, 4, 4, 3, 3, 2) X(2304, 4, 4, 4, 4, 3, 3)
 #define MFFT_ROWPLANS_J(X)
+#define MFFT_ROWPLANS_K(X)
 #define MFFT_ROWPLANS_A(X)
 #define MFFT_ROWPLANS_B(X)
 #define MFFT_ROWPLANS_C(X)
@@ -70,4 +73,4 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
-  MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X)
+  MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X)
