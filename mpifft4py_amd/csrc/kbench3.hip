@@ -522,6 +522,27 @@ int main(int argc, char** argv) {
     run_all<float>(vs, 1024, "", rounds);
     return 0;
   }
+  if (filter[0] && strstr("h1536", filter)) {       // 1536 fp64: 12 values per thread on 64-byte tiles, three workgroups per CU
+    std::vector<Variant<double>> vs;
+    vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, false, true, 1>("8x8x8x3"));
+    vs.push_back(make_tile_occ<Spec<1536, 4, 4, 4, 4, 3, 2>, double, 4, false, true, 1, false, 3>("4x4x4x4x3x2"));
+    vs.push_back(make_tile_occ<Spec<1536, 4, 4, 4, 4, 3, 2>, double, 4, false, true, 1, false, 2>("4x4x4x4x3x2"));
+    vs.push_back(make_tile_occ<Spec<1536, 4, 4, 4, 4, 3, 2>, double, 4, true, true, 1, false, 2>("4x4x4x4x3x2"));
+    vs.push_back(make_tile_occ<Spec<1536, 8, 4, 4, 4, 3>, double, 4, false, true, 1, false, 3>("8x4x4x4x3"));
+    run_all<double>(vs, 1536, "", rounds);
+    return 0;
+  }
+  if (filter[0] && strstr("f32k2", filter)) {       // single precision 2048: 64-byte tiles, two workgroups per CU
+    std::vector<Variant<float>> vs;
+    vs.push_back(make_tile<Spec<2048, 32, 8, 8>, float, 16, false, true, 1>("32x8x8"));
+    vs.push_back(make_tile<Spec<2048, 32, 8, 8>, float, 16, false, true, 1, true>("32x8x8"));
+    vs.push_back(make_tile_occ<Spec<2048, 32, 8, 8>, float, 8, false, true, 1, false, 2>("32x8x8"));
+    vs.push_back(make_tile_occ<Spec<2048, 32, 8, 8>, float, 8, false, true, 1, true, 2>("32x8x8"));
+    vs.push_back(make_tile_occ<Spec<2048, 16, 16, 8>, float, 8, false, true, 1, false, 2>("16x16x8"));
+    vs.push_back(make_tile_occ<Spec<2048, 16, 16, 8>, float, 16, false, true, 2, false, 1>("16x16x8"));
+    run_all<float>(vs, 2048, "", rounds);
+    return 0;
+  }
   if (filter[0] && strstr("half", filter)) {        // 64-byte tiles and more workgroups per CU where a 128-byte tile leaves one
     {
       std::vector<Variant<double>> vs;

@@ -194,6 +194,31 @@ def test_padded_generic_data(decomp, P, prec, fused, monkeypatch):
         assert orc.rel_l2(a, want_a[r]) < 4 * TOL[prec], (r, "backward")
 
 
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("N", [[768, 8, 8], [8, 768, 8], [8, 8, 768], [1024, 8, 8], [8, 1024, 8], [8, 8, 1024], [256, 8, 8]])
+def test_padded_long_axes(N, prec):
+    """3/2-rule with one LONG axis: the pad-on-load / truncate-on-store builds of the 1152- and 1536-point strided
+    kernels (12 values per thread, register caps, 64-byte tiles in single precision: registry.h col_wgs) and the
+    column-limited real kernels of those lengths, which the small meshes of the other tests never reach."""
+    from mpifft4py_amd import Slab_R2C
+    rt, ct = rdtype(prec), cdtype(prec)
+    rng = np.random.default_rng(sum(N) + 17)
+    Ap = rng.random([int(1.5 * n) for n in N]).astype(rt)
+    Cr = (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5 + 1j * (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5)).astype(ct)
+    lay = orc.SlabLayout(N, 1)
+    want_c = orc.slab_r2c_forward_padded(orc.scatter_real(Ap, lay, 1.5), N, prec)
+    want_a = orc.slab_r2c_backward_padded(orc.scatter_complex(Cr, lay), N, prec)
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, prec)
+        cp = F.fftn(Ap.copy(), np.zeros(F.complex_shape(), dtype=ct), dealias="3/2-rule")
+        a = F.ifftn(Cr.copy(), np.zeros(F.real_shape_padded(), dtype=rt), dealias="3/2-rule")
+        return cp, a
+    for cp, a in run_ranks(1, body):
+        assert orc.rel_l2(cp, want_c[0]) < 4 * TOL[prec], "forward"
+        assert orc.rel_l2(a, want_a[0]) < 4 * TOL[prec], "backward"
+
+
 @pytest.mark.parametrize("decomp", ["slab", "pencilX", "pencilY"])
 def test_two_thirds_rule(decomp):
     """ifftn(dealias='2/3-rule') == ifftn of the masked spectrum (slab.py:237-245)."""
