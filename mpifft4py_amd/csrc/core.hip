@@ -187,6 +187,7 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.fold = a.fold ? 1 : 0;
   P.scale = (T)a.scale;
   P.nblocks = 0;
+  P.mask = a.mask;
   const int64_t grid = (int64_t)P.ntile_c * a.nouter;
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large (%lld tiles)", (long long)grid);
@@ -219,6 +220,16 @@ int launch_col(const ColArgs& a, hipStream_t s) {
     if (ent && a.in == a.out && !(ent->nt_inplace || nt_mode == 2)) ent = nullptr;
   }
   const KernelEntry* e = nullptr;
+  if (a.mask) {
+    if (!a.inverse || a.pad) return set_error(MFFT_ERR_INVALID, "a dealias mask is applied by inverse, un-padded transforms only");
+    if (ent) {      // the same alignment rule picks the non-temporal build
+      e = find_kernel(FAM_COL, a.n, a.prec, 1, 1, 5);
+      if (e && a.in == a.out && !(e->nt_inplace || nt_mode == 2)) e = nullptr;
+    }
+    if (!e) e = find_kernel(FAM_COL, a.n, a.prec, 1, 0, 5);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no masked-load kernel for length %d", a.n);
+    ent = nullptr;
+  }
   if (a.pad) {
     if ((a.pad == 1) != a.inverse) return set_error(MFFT_ERR_INVALID, "pad-on-load is an inverse-transform mode, truncate-on-store a forward one");
     e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0, a.pad);
@@ -267,6 +278,8 @@ static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStr
   MFFT_HIP(hipGetLastError());
   return 0;
 }
+
+bool mask_fusable(int64_t n, int prec) { return n >= 2 && n < 65536 && find_kernel(FAM_COL, (int)n, prec, 1, 0, 5) != nullptr; }
 
 bool zsplit_supported(int64_t n, int prec, bool real_transform) {
   if (n < 2 || n > 65536) return false;

@@ -300,6 +300,45 @@ static void test_col_pad() {
   }
 }
 
+// 2/3-rule: the masked-load build (PAD == 3) against the plain inverse kernel on a pre-masked copy of the input
+template <class S, typename T, int COLS, int VEC>
+static void test_col_mask() {
+  typedef ColFft<S, T, COLS, true, false, false, VEC, false, 3> KM;
+  typedef ColFft<S, T, COLS, true, false, false, VEC> K0;
+  const int N = S::N, ncols = COLS * 2 + 3, nouter = 2, pin = ncols + 1;
+  std::mt19937_64 rng(77 + N);
+  std::uniform_real_distribution<double> U(-1, 1);
+  std::vector<cx<T>> in((size_t)nouter * N * pin), pre(in.size()), out1(in.size(), mk<T>((T)5, (T)5)), out0(in.size(), mk<T>((T)5, (T)5));
+  std::vector<unsigned char> mask(in.size());
+  for (size_t i = 0; i < in.size(); ++i) {
+    in[i] = mk<T>((T)U(rng), (T)U(rng));
+    mask[i] = (unsigned char)((rng() % 3) != 0);
+    pre[i] = mask[i] ? in[i] : mk<T>((T)0, (T)0);
+  }
+  auto tw = build_pass_twiddles<S, T>();
+  ColParams<T> P;
+  memset(&P, 0, sizeof P);
+  P.tw = tw.data();
+  P.in_outer = P.out_outer = (i64)N * pin;
+  P.in_map = P.out_map = make_rowmap(0, pin, N, N);
+  P.ncols = ncols; P.ntile_c = (ncols + COLS - 1) / COLS; P.nouter = nouter; P.remap = 1; P.scale = (T)(1.0 / N);
+  P.in = in.data(); P.out = out1.data(); P.mask = mask.data();
+  emu_launch(P.ntile_c * nouter, KM::THREADS, KM::LDS_BYTES, [&](int b, int t, char* lds) { KM::body(P, b, t, lds); });
+  P.in = pre.data(); P.out = out0.data(); P.mask = nullptr;
+  emu_launch(P.ntile_c * nouter, K0::THREADS, K0::LDS_BYTES, [&](int b, int t, char* lds) { K0::body(P, b, t, lds); });
+  long double num = 0, den = 0;
+  for (int o = 0; o < nouter; ++o)
+    for (int r = 0; r < N; ++r)
+      for (int c = 0; c < ncols; ++c) {
+        const size_t i = (size_t)o * N * pin + (size_t)r * pin + c;
+        num += (out1[i].x - out0[i].x) * (out1[i].x - out0[i].x) + (out1[i].y - out0[i].y) * (out1[i].y - out0[i].y);
+        den += out0[i].x * out0[i].x + out0[i].y * out0[i].y;
+      }
+  char name[64];
+  snprintf(name, sizeof name, "col c%d v%d inv masked load", COLS, VEC);
+  report(name, N, pname<T>(), (double)sqrtl(num / den), 1e-30);     // same arithmetic on the same values: identical
+}
+
 template <class S, bool HAS3 = (S::E % 3 == 0 && S::N >= 6)> struct PadTests {
   static void run() {}
 };
@@ -731,6 +770,8 @@ template <class S> static void test_spec_all() {
   test_row<S, float, 3, false, false>();
   test_real<S, double, 2, true>();
   test_real<S, float, 3, false>();
+  test_col_mask<S, double, 4, 1>();
+  test_col_mask<S, float, 8, 2>();
   if constexpr (S::NP > 1 && (S::E >= 12 || S::N == 64)) {   // split re/im exchange of the contiguous-axis kernels (registry.h row_split)
     test_row<S, double, 2, false, false, true>();
     test_row<S, double, 2, true, false, true>();

@@ -114,6 +114,7 @@ struct ColParams {
   int fold;              // PAD == 2: 1 = add the Nyquist row N/3 into row 2N/3 before it is stored
   T scale;
   int nblocks;           // persistent experiment (fft_persist_experiment.h): workgroups launched; unused by ColFft
+  const unsigned char* mask;   // PAD == 3: one byte per element of `in` (same offsets); 0 = the element reads as zero
 };
 
 template <typename T>
@@ -319,6 +320,8 @@ MFFT_D void stage_twiddles(cx<T>* lds_tw, const cx<T>* gtw, int tid, int nthread
 // for N = 3n/2 (so E is a multiple of 3 and the regions are whole register ranges):
 //   PAD == 1: the input has n = 2N/3 physical rows; logical rows [N/3, 2N/3) are zeros
 //             (copy_to_padded: low half to the front, high half to the back)
+//   PAD == 3: (any plan) the 2/3-rule instead: `fu * dealias` (slab.py:237-245) fused into the load of the first
+//             inverse pass -- one mask byte per element, no masked copy of the spectrum
 //   PAD == 2: only logical rows [0, N/3) and [2N/3, N) are stored, to n physical rows
 //             (copy_from_padded); with P.fold the Nyquist rows N/3 and 2N/3, which sit in the
 //             same thread (j = 0), are summed as `fu[n/2:] += fp[-n/2:]` does.
@@ -326,7 +329,7 @@ template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = fals
           int PAD = 0>
 struct ColFft {
   static_assert(COLS % VEC == 0, "VEC must divide COLS");
-  static_assert(PAD == 0 || S::E % 3 == 0, "pad/truncate fusion needs a radix-3 plan");
+  static_assert(PAD == 0 || PAD == 3 || S::E % 3 == 0, "pad/truncate fusion needs a radix-3 plan");
   static constexpr int KLO = S::E / 3, KHI = 2 * (S::E / 3);     // register ranges of the three row regions
   static constexpr int NSKIP = S::N / 3;
   static constexpr int CG = COLS / VEC;            // lanes along the contiguous axis
@@ -404,6 +407,14 @@ struct ColFft {
           cx<T> x = mk<T>((T)0, (T)0);
           if (i < nact) x = src[i];
           v[i][k] = INV ? swapri(x) : x;
+        }
+      }
+      if constexpr (PAD == 3) {                    // 2/3-rule: the dealias mask applied while the spectrum is read
+        const unsigned char* mp = P.mask + (src - P.in);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const unsigned char keep = i < nact ? mp[i] : (unsigned char)0;
+          if (!keep) v[i][k] = mk<T>((T)0, (T)0);
         }
       }
     }

@@ -49,8 +49,11 @@ struct ColArgs {
   bool allow_nt = true;  // use the non-temporal variant when the layout is 128-byte aligned
   int pad = 0;           // 1: input has 2n/3 physical rows (zero band skipped); 2: output truncated to 2n/3 rows
   bool fold = false;     // pad == 2: sum the two Nyquist rows (R2C convention)
+  const uint8_t* mask = nullptr;   // inverse transforms: one byte per element of `in` (same element offsets), 0 = reads as zero
+                                   // (the 2/3-rule `fu * dealias` of slab.py:237-245 without a masked copy of the spectrum)
 };
 int launch_col(const ColArgs& a, hipStream_t s);
+bool mask_fusable(int64_t n, int prec);   // a strided inverse kernel of length n that applies a mask on load exists
 
 // complex side of a contiguous-axis transform split into z chunks (fft_kernels.h, ZSplit): the pack / unpack of the
 // pencils' z-splitting exchange fused into the transform.  nchunk = 0: plain rows.

@@ -258,7 +258,22 @@ struct mfft_plan_s {
     a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.inverse = inv; a.nouter = nouter; a.ncols = ncols;
     a.in_outer = in_outer; a.out_outer = out_outer; a.in_rows = in_rows; a.out_rows = out_rows;
     a.scale = scale != 0.0 ? scale : (inv ? 1.0 / (double)n : 1.0);
+    // 2/3-rule (fuse_mask below): a pass that reads the caller's spectrum applies the dealias mask while it loads
+    if (mask_src && in >= mask_src && static_cast<const char*>(in) < static_cast<const char*>(mask_src) + mask_count * es)
+      a.mask = mask + (static_cast<const char*>(in) - static_cast<const char*>(mask_src)) / es;
     return launch_col(a, stream);
+  }
+  // `fu * dealias` of the reference's ifftn (slab.py:237-245, pencil.py:455-462) without the masked copy: when the first
+  // inverse pass (length first_len, reading fu) has a masked-load kernel, remember fu and let col() hand the mask down.
+  // Returns false when the copy is needed after all (chirp-z lengths, unit axes, MFFT_NO_MASK_FUSION=1).
+  const void* mask_src = nullptr;
+  int fuse_mask(const void* fu, int64_t first_len, bool* fused) {
+    const size_t cnt = (size_t)local_complex_count();
+    if (!mask || mask_count != cnt) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask of %zu entries was set", cnt);
+    const bool off = getenv("MFFT_NO_MASK_FUSION") && atoi(getenv("MFFT_NO_MASK_FUSION")) != 0;
+    *fused = !off && first_len >= 2 && mask_fusable(first_len, prec);
+    mask_src = *fused ? fu : nullptr;
+    return 0;
   }
   int col_pad(const void* in, void* out, int64_t n, bool inv, int pad, bool fold, int64_t nouter, int64_t ncols,
               int64_t in_outer, RowSpec in_rows, int64_t out_outer, RowSpec out_rows, double scale) {
@@ -525,10 +540,18 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
   const double Cb = (double)(N0 * Np1 * Nf) * es;
   const double Rb = (double)(Np0 * N1 * N2) * rs;
   const void* src = fu;
+  struct MaskScope {            // the mask belongs to this call only
+    mfft_plan_s* p;
+    ~MaskScope() { p->mask_src = nullptr; }
+  } mask_scope{this};
   if (masked) {
-    void* m = nullptr;
-    MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &m); }));
-    src = m;
+    bool fused = false;
+    MFFT_TRY(fuse_mask(fu, (P == 1 && !r2c && plane_pad(N1 * Nf)) ? N1 : N0, &fused));
+    if (!fused) {
+      void* m = nullptr;
+      MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &m); }));
+      src = m;
+    }
   }
   const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
   if (const int64_t xpad = (P == 1 && !r2c) ? plane_pad(N1 * Nf) : 0) {
@@ -1230,10 +1253,18 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
   const bool X = d.decomp == MFFT_PENCIL_X;
   const bool zsolo = (X ? P2 : P1) == 1 && !d.drop_nyquist, g2solo = (X ? P1 : P2) == 1;
   const void* src = fu;
+  struct MaskScope {
+    mfft_plan_s* p;
+    ~MaskScope() { p->mask_src = nullptr; }
+  } mask_scope{this};
   if (masked) {
-    void* mm = nullptr;
-    MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &mm); }));
-    src = mm;
+    bool fused = false;
+    MFFT_TRY(fuse_mask(fu, X ? N0 : N1, &fused));
+    if (!fused) {
+      void* mm = nullptr;
+      MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &mm); }));
+      src = mm;
+    }
   }
   if (nbatch > 1) return d.decomp == MFFT_PENCIL_X ? pencil_backward_pipelined_x(src, u) : pencil_backward_pipelined_y(src, u);
   // largest intermediate of this alignment: X: (m, N1, q) after the z exchange; Y: (N0, n, q) after it

@@ -183,6 +183,15 @@ void register_col(const char* name) {
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, false, 2>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
     reg.back().pad = 2;
   }
+  // 2/3-rule: inverse transform with the dealias mask applied on load (pad = 5)
+  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 3>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
+  reg.back().pad = 5;
+  if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {
+    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 3>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
+    reg.back().pad = 5;
+    reg.back().nt = 1;
+    reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
+  }
   if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {     // aligned-row (non-temporal) variants
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
     reg.back().nt = 1;

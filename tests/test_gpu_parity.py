@@ -219,6 +219,49 @@ def test_padded_long_axes(N, prec):
         assert orc.rel_l2(a, want_a[0]) < 4 * TOL[prec], "backward"
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("decomp,P,pipeline", [("slab", 1, 0), ("slab", 2, 1), ("slab", 4, 2), ("slab", 4, -2), ("pencilX", 4, 1),
+                                               ("pencilX", 8, 2), ("pencilY", 4, 1), ("pencilY", 8, 2), ("c2c", 1, 0), ("c2c", 2, 1)])
+def test_two_thirds_rule_mask_on_load(decomp, P, pipeline, prec, fused, monkeypatch):
+    """The dealias mask applied by the first inverse pass while it reads the spectrum (ColFft PAD == 3, plan.hip
+    fuse_mask) against the masked-copy path (MFFT_NO_MASK_FUSION=1) and against ifftn(fu * mask): blocking and
+    pipelined exchanges (the kz-slice and row-batch pipelines read the caller's array at offsets), both precisions, the
+    C2C class (on one GPU its inverse starts with the y pass).  The mask here is a random one: nothing in the kernels
+    assumes the 2/3-rule's shape."""
+    from mpifft4py_amd import Pencil_R2C, Slab_C2C, Slab_R2C
+    if not fused:
+        monkeypatch.setenv("MFFT_NO_MASK_FUSION", "1")
+    N = [64, 64, 64] if decomp == "c2c" else NREF      # 64^3 complex128: power-of-two planes, the y-first route
+    rng = np.random.default_rng(640 + P)
+    ct = cdtype(prec)
+    if decomp == "c2c":
+        C = (rng.random(N) - 0.5 + 1j * (rng.random(N) - 0.5)).astype(ct)
+        M = (rng.random(N) < 0.6).astype(np.uint8)
+    else:
+        C = np.fft.rfftn(rng.random(N)).astype(ct)
+        M = (rng.random(C.shape) < 0.6).astype(np.uint8)
+
+    def body(comm):
+        if decomp == "slab":
+            F = Slab_R2C(np.array(N), L, comm, prec, pipeline=pipeline)
+        elif decomp == "c2c":
+            F = Slab_C2C(np.array(N), L, comm, prec, pipeline=pipeline)
+        else:
+            F = Pencil_R2C(np.array(N), L, comm, prec, communication="Alltoallw", alignment=decomp[-1], pipeline=pipeline)
+        sl = F.transformed_local_slice() if decomp == "c2c" else F.complex_local_slice()
+        out_shape, out_t = (F.original_shape(), F.complex) if decomp == "c2c" else (F.real_shape(), F.float)
+        F.dealias = np.ascontiguousarray(M[sl])          # the attribute the reference computes lazily (slab.py:237-240)
+        c = np.ascontiguousarray(C[sl])
+        c_in = c.copy()
+        u = F.ifftn(c, np.zeros(out_shape, dtype=out_t), dealias="2/3-rule")
+        assert np.array_equal(c, c_in)          # input spectrum untouched
+        u_ref = F.ifftn((c * M[sl]).astype(ct), np.zeros(out_shape, dtype=out_t))
+        return u, u_ref
+    for u, u_ref in run_ranks(P, body):
+        assert np.array_equal(u, u_ref)         # same kernels, same values: bit-identical
+
+
 @pytest.mark.parametrize("decomp", ["slab", "pencilX", "pencilY"])
 def test_two_thirds_rule(decomp):
     """ifftn(dealias='2/3-rule') == ifftn of the masked spectrum (slab.py:237-245)."""
