@@ -188,6 +188,8 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.scale = (T)a.scale;
   P.nblocks = 0;
   P.mask = a.mask;
+  P.b_row_lo = a.band.row_lo; P.b_row_hi = a.band.row_hi; P.b_coff = a.band.c_off; P.b_cper = a.band.c_per;
+  P.b_clim = a.band.c_lim; P.b_goff = a.band.g_off; P.b_gstep = a.band.g_step; P.b_glo = a.band.g_lo; P.b_ghi = a.band.g_hi;
   const int64_t grid = (int64_t)P.ntile_c * a.nouter;
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large (%lld tiles)", (long long)grid);
@@ -220,13 +222,14 @@ int launch_col(const ColArgs& a, hipStream_t s) {
     if (ent && a.in == a.out && !(ent->nt_inplace || nt_mode == 2)) ent = nullptr;
   }
   const KernelEntry* e = nullptr;
-  if (a.mask) {
-    if (!a.inverse || a.pad) return set_error(MFFT_ERR_INVALID, "a dealias mask is applied by inverse, un-padded transforms only");
+  if (a.mask || a.band.on) {
+    const int code = a.band.on ? 6 : 5;
+    if (!a.inverse || a.pad || (a.mask && a.band.on)) return set_error(MFFT_ERR_INVALID, "a dealias mask is applied by inverse, un-padded transforms only");
     if (ent) {      // the same alignment rule picks the non-temporal build
-      e = find_kernel(FAM_COL, a.n, a.prec, 1, 1, 5);
+      e = find_kernel(FAM_COL, a.n, a.prec, 1, 1, code);
       if (e && a.in == a.out && !(e->nt_inplace || nt_mode == 2)) e = nullptr;
     }
-    if (!e) e = find_kernel(FAM_COL, a.n, a.prec, 1, 0, 5);
+    if (!e) e = find_kernel(FAM_COL, a.n, a.prec, 1, 0, code);
     if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no masked-load kernel for length %d", a.n);
     ent = nullptr;
   }
@@ -279,6 +282,8 @@ static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStr
   return 0;
 }
 
+bool c2r_limit_supported(int64_t n, int prec) { return n >= 4 && n < 65536 && find_kernel(FAM_C2R, (int)n, prec, 1, 0, 3) != nullptr; }
+bool band_fusable(int64_t n, int prec) { return n >= 2 && n < 65536 && find_kernel(FAM_COL, (int)n, prec, 1, 0, 6) != nullptr; }
 bool mask_fusable(int64_t n, int prec) { return n >= 2 && n < 65536 && find_kernel(FAM_COL, (int)n, prec, 1, 0, 5) != nullptr; }
 
 bool zsplit_supported(int64_t n, int prec, bool real_transform) {

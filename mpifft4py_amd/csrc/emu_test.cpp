@@ -339,6 +339,62 @@ static void test_col_mask() {
   report(name, N, pname<T>(), (double)sqrtl(num / den), 1e-30);     // same arithmetic on the same values: identical
 }
 
+// pruned 2/3-rule pass (PAD == 4): removed rows read as zero, tiles without a kept column untouched, kept columns
+// identical to the plain inverse kernel on an input whose removed rows were zeroed
+template <class S, typename T, int COLS, int VEC>
+static void test_col_band() {
+  typedef ColFft<S, T, COLS, true, false, false, VEC, false, 4> KB;
+  typedef ColFft<S, T, COLS, true, false, false, VEC> K0;
+  const int N = S::N, ncols = COLS * 3 + 1, nouter = 2, pin = ncols + 1;
+  if (N < 3) return;
+  std::mt19937_64 rng(177 + N);
+  std::uniform_real_distribution<double> U(-1, 1);
+  const cx<T> sentinel = mk<T>((T)5, (T)5);
+  std::vector<cx<T>> in((size_t)nouter * N * pin), pre(in.size()), out1(in.size(), sentinel), out0(in.size(), sentinel);
+  const int row_lo = N / 3 > 0 ? N / 3 : 1, row_hi = (2 * N) / 3 > row_lo ? (2 * N) / 3 : row_lo;
+  for (int o = 0; o < nouter; ++o)
+    for (int r = 0; r < N; ++r)
+      for (int c = 0; c < pin; ++c) {
+        const size_t i = (size_t)o * N * pin + (size_t)r * pin + c;
+        in[i] = mk<T>((T)U(rng), (T)U(rng));
+        pre[i] = (r >= row_lo && r < row_hi) ? mk<T>((T)0, (T)0) : in[i];
+      }
+  auto tw = build_pass_twiddles<S, T>();
+  ColParams<T> P;
+  memset(&P, 0, sizeof P);
+  P.tw = tw.data();
+  P.in_outer = P.out_outer = (i64)N * pin;
+  P.in_map = P.out_map = make_rowmap(0, pin, N, N);
+  P.ncols = ncols; P.ntile_c = (ncols + COLS - 1) / COLS; P.nouter = nouter; P.remap = 1; P.scale = (T)(1.0 / N);
+  P.b_row_lo = row_lo; P.b_row_hi = row_hi; P.b_coff = 2; P.b_cper = 5; P.b_clim = 3; P.b_goff = 1; P.b_gstep = 2; P.b_glo = 3; P.b_ghi = 5;
+  P.in = in.data(); P.out = out1.data();
+  emu_launch(P.ntile_c * nouter, KB::THREADS, KB::LDS_BYTES, [&](int b, int t, char* lds) { KB::body(P, b, t, lds); });
+  P.in = pre.data(); P.out = out0.data();
+  emu_launch(P.ntile_c * nouter, K0::THREADS, K0::LDS_BYTES, [&](int b, int t, char* lds) { K0::body(P, b, t, lds); });
+  long double num = 0, den = 0;
+  int bad = 0, skipped = 0, kept = 0;
+  for (int o = 0; o < nouter; ++o)
+    for (int c = 0; c < ncols; ++c) {
+      const int t = 2 + c, z = t % 5, y = 1 + t / 5 + o * 2;
+      const bool keep = z < 3 && (y < 3 || y >= 5);
+      kept += keep;
+      for (int r = 0; r < N; ++r) {
+        const size_t i = (size_t)o * N * pin + (size_t)r * pin + c;
+        const bool untouched = out1[i].x == sentinel.x && out1[i].y == sentinel.y;
+        if (untouched) {
+          if (keep) ++bad;               // a kept column must have been transformed
+          ++skipped;
+          continue;
+        }
+        num += (out1[i].x - out0[i].x) * (out1[i].x - out0[i].x) + (out1[i].y - out0[i].y) * (out1[i].y - out0[i].y);
+        den += out0[i].x * out0[i].x + out0[i].y * out0[i].y;
+      }
+    }
+  char name[64];
+  snprintf(name, sizeof name, "col c%d v%d inv pruned (kept %d, skipped %d)", COLS, VEC, kept, skipped / N);
+  report(name, N, pname<T>(), bad || kept == 0 ? 1.0 : (double)sqrtl(num / (den > 0 ? den : 1)), 1e-30);
+}
+
 template <class S, bool HAS3 = (S::E % 3 == 0 && S::N >= 6)> struct PadTests {
   static void run() {}
 };
@@ -772,6 +828,8 @@ template <class S> static void test_spec_all() {
   test_real<S, float, 3, false>();
   test_col_mask<S, double, 4, 1>();
   test_col_mask<S, float, 8, 2>();
+  test_col_band<S, double, 4, 1>();
+  test_col_band<S, float, 8, 2>();
   if constexpr (S::NP > 1 && (S::E >= 12 || S::N == 64)) {   // split re/im exchange of the contiguous-axis kernels (registry.h row_split)
     test_row<S, double, 2, false, false, true>();
     test_row<S, double, 2, true, false, true>();

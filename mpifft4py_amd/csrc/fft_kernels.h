@@ -115,6 +115,10 @@ struct ColParams {
   T scale;
   int nblocks;           // persistent experiment (fft_persist_experiment.h): workgroups launched; unused by ColFft
   const unsigned char* mask;   // PAD == 3: one byte per element of `in` (same offsets); 0 = the element reads as zero
+  // PAD == 4 (pruned 2/3-rule pass): rows [b_row_lo, b_row_hi) read as zero without being loaded; column j of outer
+  // batch o has z = (b_coff + j) % b_cper and y = b_goff + (b_coff + j) / b_cper + o * b_gstep and is KEPT iff
+  // z < b_clim and (y < b_glo or y >= b_ghi); tiles without a kept column do nothing at all
+  int b_row_lo, b_row_hi, b_coff, b_cper, b_clim, b_goff, b_gstep, b_glo, b_ghi;
 };
 
 template <typename T>
@@ -322,6 +326,8 @@ MFFT_D void stage_twiddles(cx<T>* lds_tw, const cx<T>* gtw, int tid, int nthread
 //             (copy_to_padded: low half to the front, high half to the back)
 //   PAD == 3: (any plan) the 2/3-rule instead: `fu * dealias` (slab.py:237-245) fused into the load of the first
 //             inverse pass -- one mask byte per element, no masked copy of the spectrum
+//   PAD == 4: (any plan) the 2/3-rule when the mask is the product of three 1-D band conditions (what
+//             get_dealias_filter builds): removed rows are not loaded, tiles of removed columns are not processed
 //   PAD == 2: only logical rows [0, N/3) and [2N/3, N) are stored, to n physical rows
 //             (copy_from_padded); with P.fold the Nyquist rows N/3 and 2N/3, which sit in the
 //             same thread (j = 0), are summed as `fu[n/2:] += fp[-n/2:]` does.
@@ -329,7 +335,7 @@ template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = fals
           int PAD = 0>
 struct ColFft {
   static_assert(COLS % VEC == 0, "VEC must divide COLS");
-  static_assert(PAD == 0 || PAD == 3 || S::E % 3 == 0, "pad/truncate fusion needs a radix-3 plan");
+  static_assert(PAD == 0 || PAD == 3 || PAD == 4 || S::E % 3 == 0, "pad/truncate fusion needs a radix-3 plan");
   static constexpr int KLO = S::E / 3, KHI = 2 * (S::E / 3);     // register ranges of the three row regions
   static constexpr int NSKIP = S::N / 3;
   static constexpr int CG = COLS / VEC;            // lanes along the contiguous axis
@@ -383,6 +389,16 @@ struct ColFft {
     const int nact = P.ncols - col;                // columns of this thread inside the array (may be <= 0)
     const cx<T>* ip = P.in + (i64)outer * P.in_outer + col;
     cx<T>* op = P.out + (i64)outer * P.out_outer + col;
+    if constexpr (PAD == 4) {                      // nothing downstream reads the columns the mask removes
+      int t = P.b_coff + tc * COLS;
+      int z = t % P.b_cper, y = P.b_goff + t / P.b_cper + outer * P.b_gstep;
+      bool any = false;
+      for (int i = 0; i < COLS && tc * COLS + i < P.ncols; ++i) {
+        any = any || (z < P.b_clim && (y < P.b_glo || y >= P.b_ghi));
+        if (++z == P.b_cper) { z = 0; ++y; }
+      }
+      if (!any) return;                            // the same for every thread of the workgroup
+    }
 
     cx<T> v[VEC][S::E];
 #pragma unroll
@@ -397,6 +413,13 @@ struct ColFft {
         if (k >= KHI) r -= NSKIP;
       }
       const cx<T>* src = ip + row_off(P.in_map, r);
+      bool zero_row = false;
+      if constexpr (PAD == 4) {                    // a removed row: re-read row 0 (a cache hit) and drop the value -- no branch
+                                                   // (skipping the load of a register whose rows are all removed, a workgroup-
+                                                   // uniform branch, was measured: 1024^3 x pass 1.84 -> 2.03 ms, fp32 1.51 -> 2.05)
+        zero_row = (int)r >= P.b_row_lo && (int)r < P.b_row_hi;
+        if (zero_row) src = ip + row_off(P.in_map, 0u);
+      }
       if (nact >= VEC) {
         const GPack g = load_pack(src);
 #pragma unroll
@@ -407,6 +430,12 @@ struct ColFft {
           cx<T> x = mk<T>((T)0, (T)0);
           if (i < nact) x = src[i];
           v[i][k] = INV ? swapri(x) : x;
+        }
+      }
+      if constexpr (PAD == 4) {
+        if (zero_row) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i][k] = mk<T>((T)0, (T)0);
         }
       }
       if constexpr (PAD == 3) {                    // 2/3-rule: the dealias mask applied while the spectrum is read

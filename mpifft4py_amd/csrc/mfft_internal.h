@@ -51,7 +51,15 @@ struct ColArgs {
   bool fold = false;     // pad == 2: sum the two Nyquist rows (R2C convention)
   const uint8_t* mask = nullptr;   // inverse transforms: one byte per element of `in` (same element offsets), 0 = reads as zero
                                    // (the 2/3-rule `fu * dealias` of slab.py:237-245 without a masked copy of the spectrum)
+  // inverse transforms, 2/3-rule mask of band form (fft_kernels.h ColParams b_*): rows [row_lo, row_hi) are zero and
+  // not loaded, tiles whose columns are all removed are skipped
+  struct Band {
+    bool on = false;
+    int row_lo = 0, row_hi = 0, c_off = 0, c_per = 1 << 30, c_lim = 1 << 30, g_off = 0, g_step = 0, g_lo = 1 << 30, g_hi = 1 << 30;
+  } band;
 };
+bool c2r_limit_supported(int64_t n, int prec);   // a c2r kernel of real length n that reads only the first `valid` bins exists
+bool band_fusable(int64_t n, int prec);   // a pruned (band) strided inverse kernel of length n exists
 int launch_col(const ColArgs& a, hipStream_t s);
 bool mask_fusable(int64_t n, int prec);   // a strided inverse kernel of length n that applies a mask on load exists
 

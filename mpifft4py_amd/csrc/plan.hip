@@ -266,6 +266,55 @@ struct mfft_plan_s {
   // `fu * dealias` of the reference's ifftn (slab.py:237-245, pencil.py:455-462) without the masked copy: when the first
   // inverse pass (length first_len, reading fu) has a masked-load kernel, remember fu and let col() hand the mask down.
   // Returns false when the copy is needed after all (chirp-z lengths, unit axes, MFFT_NO_MASK_FUSION=1).
+  // The 2/3-rule's own mask (get_dealias_filter: three 1-D conditions |k| < kmax) recognised when it is set: x and y
+  // keep [0, a) and [b, N), z keeps [0, a2).  One GPU, real data: the inverse then never loads the removed rows, skips
+  // the tiles of removed columns and reads a2 bins per z row (pruned passes).
+  bool band_ok = false;
+  int ba0 = 0, bb0 = 0, ba1 = 0, bb1 = 0, ba2 = 0;
+  int col_band(const void* in, void* out, int64_t n, int64_t nouter, int64_t ncols, int64_t in_outer, RowSpec in_rows,
+               int64_t out_outer, RowSpec out_rows, const ColArgs::Band& b) {
+    ColArgs a;
+    a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.inverse = true; a.nouter = nouter; a.ncols = ncols;
+    a.in_outer = in_outer; a.out_outer = out_outer; a.in_rows = in_rows; a.out_rows = out_rows;
+    a.scale = 1.0 / (double)n;
+    a.band = b;
+    a.band.on = true;
+    return launch_col(a, stream);
+  }
+  void detect_band(const uint8_t* m) {
+    band_ok = false;
+    if (!(d.decomp == MFFT_SLAB && P == 1 && r2c) || N0 < 2 || N1 < 2 || N2 < 4 || N2 % 2 != 0) return;
+    if (!band_fusable(N0, prec) || !band_fusable(N1, prec) || !c2r_limit_supported(N2, prec)) return;
+    std::vector<uint8_t> m0(N0, 0), m1(N1, 0), m2(Nf, 0);
+    for (int64_t i = 0; i < N0; ++i)
+      for (int64_t j = 0; j < N1; ++j) {
+        const uint8_t* row = m + (i * N1 + j) * Nf;
+        uint8_t any = 0;
+        for (int64_t k = 0; k < Nf; ++k) { any |= row[k]; m2[k] |= row[k]; }
+        m0[i] |= any; m1[j] |= any;
+      }
+    for (auto* v : {&m0, &m1, &m2}) for (auto& x : *v) x = x ? 1 : 0;
+    for (int64_t i = 0; i < N0; ++i)          // the mask must BE the product of the three (values other than 0 / 1 are weights, not a filter)
+      for (int64_t j = 0; j < N1; ++j) {
+        const uint8_t* row = m + (i * N1 + j) * Nf;
+        const uint8_t ij = m0[i] & m1[j];
+        for (int64_t k = 0; k < Nf; ++k) if (row[k] != (uint8_t)(ij & m2[k])) return;
+      }
+    auto middle = [](const std::vector<uint8_t>& v, int* a, int* b) {   // zeros form one run [a, b) with a >= 1?  (none: a = b = size)
+      const int n = (int)v.size();
+      int lo = 0;
+      while (lo < n && v[lo]) ++lo;
+      int hi = lo;
+      while (hi < n && !v[hi]) ++hi;
+      for (int i = hi; i < n; ++i) if (!v[i]) return false;
+      *a = lo; *b = hi;
+      return lo >= 1;
+    };
+    int a2 = 0, b2 = 0;
+    if (!middle(m0, &ba0, &bb0) || !middle(m1, &ba1, &bb1) || !middle(m2, &a2, &b2) || b2 != (int)Nf) return;
+    ba2 = a2;
+    band_ok = true;
+  }
   const void* mask_src = nullptr;
   int fuse_mask(const void* fu, int64_t first_len, bool* fused) {
     const size_t cnt = (size_t)local_complex_count();
@@ -544,6 +593,23 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     mfft_plan_s* p;
     ~MaskScope() { p->mask_src = nullptr; }
   } mask_scope{this};
+  if (masked && P == 1 && band_ok && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
+    if (!mask || mask_count != (size_t)local_complex_count()) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask was set");
+    MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nf) * es));
+    void* Aw = work[0];
+    const double keep0 = 1.0 - (double)(bb0 - ba0) / (double)N0, keep1 = 1.0 - (double)(bb1 - ba1) / (double)N1, keep2 = (double)ba2 / (double)Nf;
+    ColArgs::Band bx, by;
+    bx.row_lo = ba0; bx.row_hi = bb0; bx.c_off = 0; bx.c_per = (int)Nf; bx.c_lim = ba2; bx.g_off = 0; bx.g_step = 0; bx.g_lo = ba1; bx.g_hi = bb1;
+    by.row_lo = ba1; by.row_hi = bb1; by.c_lim = ba2;        // columns = kz of one x plane; no second index
+    MFFT_TRY(stage("bwd_x", Cb * keep1 * keep2 * (keep0 + 1.0), [&] {
+      return col_band(fu, Aw, N0, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf), bx);
+    }));
+    MFFT_TRY(stage("bwd_y", Cb * keep2 * (keep1 + 1.0), [&] {
+      return col_band(Aw, Aw, N1, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf), by);
+    }));
+    MFFT_TRY(stage("bwd_z", Rb + Cb * keep2, [&] { return c2r_rows(Aw, u, N0 * N1, N2, Nf, N2, 1.0 / (double)N2, ba2); }));
+    return 0;
+  }
   if (masked) {
     bool fused = false;
     MFFT_TRY(fuse_mask(fu, (P == 1 && !r2c && plane_pad(N1 * Nf)) ? N1 : N0, &fused));
@@ -1825,6 +1891,7 @@ int mfft_plan_set_dealias_mask(mfft_plan_t p, const uint8_t* mask_host, size_t c
   MFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p->mask), count));
   MFFT_HIP(hipMemcpy(p->mask, mask_host, count, hipMemcpyHostToDevice));
   p->mask_count = count;
+  p->detect_band(mask_host);
   return 0;
 }
 

@@ -192,6 +192,15 @@ void register_col(const char* name) {
     reg.back().nt = 1;
     reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
   }
+  // pruned 2/3-rule passes (pad = 6)
+  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 4>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
+  reg.back().pad = 6;
+  if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {
+    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 4>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
+    reg.back().pad = 6;
+    reg.back().nt = 1;
+    reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
+  }
   if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {     // aligned-row (non-temporal) variants
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
     reg.back().nt = 1;
@@ -226,6 +235,8 @@ void register_rows(const char* name) {
   if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
     reg.push_back(make_entry<R2CFft<S, T, R, RT, true, false, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
     reg.back().pad = 3;
+  }
+  if constexpr (S::N >= 4) {                    // column-limited c2r: 3/2-rule lengths and the pruned 2/3-rule (any length)
     reg.push_back(make_entry<C2RFft<S, T, RC, RT, true, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 3;
   }

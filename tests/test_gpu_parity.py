@@ -262,6 +262,36 @@ def test_two_thirds_rule_mask_on_load(decomp, P, pipeline, prec, fused, monkeypa
         assert np.array_equal(u, u_ref)         # same kernels, same values: bit-identical
 
 
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("N", [[32, 32, 32], [48, 20, 36], [64, 128, 256], [16, 24, 10], [100, 36, 50], [8, 8, 8], [12, 6, 4]])
+def test_two_thirds_rule_pruned(N, prec, monkeypatch):
+    """One GPU, real data, the reference's own dealias filter (three 1-D band conditions): the inverse does not load
+    the removed rows, skips the tiles of removed columns and reads only the kept bins of every z row (plan.hip
+    detect_band, ColFft PAD == 4).  Against ifftn(fu * dealias) through the plain kernels and against the same call
+    with MFFT_NO_PRUNE=1 (the general masked-load path); the input spectrum stays untouched."""
+    from mpifft4py_amd import Slab_R2C
+    rng = np.random.default_rng(sum(N) + 23)
+    ct, rt = cdtype(prec), rdtype(prec)
+    C = (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5 + 1j * (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5)).astype(ct)
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, prec)
+        mask = np.broadcast_to(F.get_dealias_filter(), F.complex_shape())
+        c = C.copy()
+        u = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt), dealias="2/3-rule")
+        assert np.array_equal(c, C)
+        u_ref = F.ifftn((C * mask).astype(ct), np.zeros(F.real_shape(), dtype=rt))
+        monkeypatch.setenv("MFFT_NO_PRUNE", "1")
+        u_gen = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt), dealias="2/3-rule")
+        monkeypatch.delenv("MFFT_NO_PRUNE")
+        return u, u_ref, u_gen, mask
+    for u, u_ref, u_gen, mask in run_ranks(1, body):
+        assert 0 < mask.sum() < mask.size
+        assert np.array_equal(u_gen, u_ref)
+        # a different build of the same kernels (the compiler may contract other multiply-adds): round-off apart at most
+        assert orc.rel_l2(u, u_ref) < 0.05 * TOL[prec], orc.rel_l2(u, u_ref)
+
+
 @pytest.mark.parametrize("decomp", ["slab", "pencilX", "pencilY"])
 def test_two_thirds_rule(decomp):
     """ifftn(dealias='2/3-rule') == ifftn of the masked spectrum (slab.py:237-245)."""
