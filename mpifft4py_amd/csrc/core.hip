@@ -190,7 +190,9 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.mask = a.mask;
   P.b_row_lo = a.band.row_lo; P.b_row_hi = a.band.row_hi; P.b_coff = a.band.c_off; P.b_cper = a.band.c_per;
   P.b_clim = a.band.c_lim; P.b_goff = a.band.g_off; P.b_gstep = a.band.g_step; P.b_glo = a.band.g_lo; P.b_ghi = a.band.g_hi;
-  const int64_t grid = (int64_t)P.ntile_c * a.nouter;
+  P.tile_list = a.band.on ? a.band.tile_list : nullptr;
+  P.ntiles_listed = a.band.ntiles_listed;
+  const int64_t grid = P.tile_list ? (int64_t)P.ntiles_listed : (int64_t)P.ntile_c * a.nouter;
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large (%lld tiles)", (long long)grid);
   e->launch(&P, (int)grid, s);
@@ -282,6 +284,10 @@ static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStr
   return 0;
 }
 
+int col_tile_width(int64_t n, int prec, bool inverse, int pad_code) {
+  const KernelEntry* e = find_kernel(FAM_COL, (int)n, prec, inverse ? 1 : 0, 0, pad_code);
+  return e ? e->tile : 0;
+}
 bool c2r_limit_supported(int64_t n, int prec) { return n >= 4 && n < 65536 && find_kernel(FAM_C2R, (int)n, prec, 1, 0, 3) != nullptr; }
 bool band_fusable(int64_t n, int prec) { return n >= 2 && n < 65536 && find_kernel(FAM_COL, (int)n, prec, 1, 0, 6) != nullptr; }
 bool mask_fusable(int64_t n, int prec) { return n >= 2 && n < 65536 && find_kernel(FAM_COL, (int)n, prec, 1, 0, 5) != nullptr; }

@@ -119,6 +119,8 @@ struct ColParams {
   // batch o has z = (b_coff + j) % b_cper and y = b_goff + (b_coff + j) / b_cper + o * b_gstep and is KEPT iff
   // z < b_clim and (y < b_glo or y >= b_ghi); tiles without a kept column do nothing at all
   int b_row_lo, b_row_hi, b_coff, b_cper, b_clim, b_goff, b_gstep, b_glo, b_ghi;
+  const int* tile_list;  // PAD == 4: the tiles that hold a kept column (the launch has one workgroup per entry); null: all tiles
+  int ntiles_listed;
 };
 
 template <typename T>
@@ -379,8 +381,14 @@ struct ColFft {
 
   static MFFT_D void body(const ColParams<T>& P, int bid_raw, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
-    const int bid = P.remap == 2 ? xcd_remap_skew(bid_raw, P.ntile_c * P.nouter)
-                  : P.remap    ? xcd_remap(bid_raw, P.ntile_c * P.nouter) : bid_raw;
+    int bid;
+    if constexpr (PAD == 4) {                      // neighbours in the list are neighbours in memory: the same XCD-aware order
+      if (P.tile_list) bid = P.tile_list[P.remap ? xcd_remap(bid_raw, P.ntiles_listed) : bid_raw];
+      else bid = P.remap ? xcd_remap(bid_raw, P.ntile_c * P.nouter) : bid_raw;
+    } else {
+      bid = P.remap == 2 ? xcd_remap_skew(bid_raw, P.ntile_c * P.nouter)
+          : P.remap    ? xcd_remap(bid_raw, P.ntile_c * P.nouter) : bid_raw;
+    }
     const int outer = bid / P.ntile_c;
     const int tc = bid - outer * P.ntile_c;
     const int c = tid % CG;

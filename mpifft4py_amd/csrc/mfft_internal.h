@@ -56,10 +56,13 @@ struct ColArgs {
   struct Band {
     bool on = false;
     int row_lo = 0, row_hi = 0, c_off = 0, c_per = 1 << 30, c_lim = 1 << 30, g_off = 0, g_step = 0, g_lo = 1 << 30, g_hi = 1 << 30;
+    const int* tile_list = nullptr;     // device array of the tiles with a kept column (tile = outer * ntile_c + tc), or null
+    int ntiles_listed = 0;
   } band;
 };
 bool c2r_limit_supported(int64_t n, int prec);   // a c2r kernel of real length n that reads only the first `valid` bins exists
-bool band_fusable(int64_t n, int prec);   // a pruned (band) strided inverse kernel of length n exists
+bool band_fusable(int64_t n, int prec);
+int col_tile_width(int64_t n, int prec, bool inverse, int pad_code);   // columns per tile of the strided kernel that would run   // a pruned (band) strided inverse kernel of length n exists
 int launch_col(const ColArgs& a, hipStream_t s);
 bool mask_fusable(int64_t n, int prec);   // a strided inverse kernel of length n that applies a mask on load exists
 

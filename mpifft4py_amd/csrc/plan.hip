@@ -108,6 +108,7 @@ struct mfft_plan_s {
     for (void* w : work)
       if (w) (void)wfree(w);
     if (mask) (void)hipFree(mask);
+    if (band_tiles) (void)hipFree(band_tiles);
     if (work3) (void)wfree(work3);
     for (auto& t : timers) {
       for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -313,8 +314,28 @@ struct mfft_plan_s {
     int a2 = 0, b2 = 0;
     if (!middle(m0, &ba0, &bb0) || !middle(m1, &ba1, &bb1) || !middle(m2, &a2, &b2) || b2 != (int)Nf) return;
     ba2 = a2;
+    // x pass: tiles of the flattened (ky, kz) columns that hold a kept column, in memory order
+    const int w = col_tile_width(N0, prec, true, 6);
+    if (w <= 0) return;
+    std::vector<int> list;
+    const int64_t ncols = N1 * Nf, ntile = (ncols + w - 1) / w;
+    for (int64_t t = 0; t < ntile; ++t) {
+      bool any = false;
+      for (int64_t c = t * w; c < std::min(ncols, (t + 1) * w) && !any; ++c) any = m1[c / Nf] && m2[c % Nf];
+      if (any) list.push_back((int)t);
+    }
+    if (band_tiles) (void)hipFree(band_tiles);
+    band_tiles = nullptr;
+    band_ntiles = (int)list.size();
+    if (list.empty() || hipMalloc(reinterpret_cast<void**>(&band_tiles), list.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(band_tiles, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
     band_ok = true;
   }
+  int* band_tiles = nullptr;
+  int band_ntiles = 0;
   const void* mask_src = nullptr;
   int fuse_mask(const void* fu, int64_t first_len, bool* fused) {
     const size_t cnt = (size_t)local_complex_count();
@@ -600,12 +621,13 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     const double keep0 = 1.0 - (double)(bb0 - ba0) / (double)N0, keep1 = 1.0 - (double)(bb1 - ba1) / (double)N1, keep2 = (double)ba2 / (double)Nf;
     ColArgs::Band bx, by;
     bx.row_lo = ba0; bx.row_hi = bb0; bx.c_off = 0; bx.c_per = (int)Nf; bx.c_lim = ba2; bx.g_off = 0; bx.g_step = 0; bx.g_lo = ba1; bx.g_hi = bb1;
-    by.row_lo = ba1; by.row_hi = bb1; by.c_lim = ba2;        // columns = kz of one x plane; no second index
+    bx.tile_list = band_tiles; bx.ntiles_listed = band_ntiles;
+    by.row_lo = ba1; by.row_hi = bb1; by.c_lim = ba2;        // columns = kz of one x plane: only the first a2 are launched
     MFFT_TRY(stage("bwd_x", Cb * keep1 * keep2 * (keep0 + 1.0), [&] {
       return col_band(fu, Aw, N0, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf), bx);
     }));
     MFFT_TRY(stage("bwd_y", Cb * keep2 * (keep1 + 1.0), [&] {
-      return col_band(Aw, Aw, N1, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf), by);
+      return col_band(Aw, Aw, N1, N0, ba2, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf), by);
     }));
     MFFT_TRY(stage("bwd_z", Rb + Cb * keep2, [&] { return c2r_rows(Aw, u, N0 * N1, N2, Nf, N2, 1.0 / (double)N2, ba2); }));
     return 0;
