@@ -149,8 +149,11 @@ MFFT_API int mfft_backward(mfft_plan_t plan, const void* fu, void* u, int dealia
 /* block the host until everything the plan enqueued has finished */
 MFFT_API int mfft_plan_sync(mfft_plan_t plan);
 
-/* 2/3-rule mask (slab.py:191-197; applied by cython/maths.pyx:9-19): uint8 per
- * local complex element, device-resident */
+/* 2/3-rule mask (slab.py:191-197; applied by cython/maths.pyx:9-19): uint8 per local complex element, copied from
+ * the host array.  mfft_backward(..., MFFT_DEALIAS_2_3) transforms `fu * mask` without writing fu: the first inverse
+ * pass applies the mask while it loads.  A mask of the form get_dealias_filter builds (the product of three 1-D band
+ * conditions) is recognised here and lets slab R2C plans run pruned passes and, over P ranks, a smaller exchange; the
+ * ranks agree on that with a host all-reduce, so for plans over more than one rank this call is COLLECTIVE. */
 MFFT_API int mfft_plan_set_dealias_mask(mfft_plan_t plan, const uint8_t* mask_host, size_t count);
 
 /* per-stage timing with HIP events on the plan's own streams (bench roofline) */

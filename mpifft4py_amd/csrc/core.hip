@@ -192,6 +192,7 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.b_clim = a.band.c_lim; P.b_goff = a.band.g_off; P.b_gstep = a.band.g_step; P.b_glo = a.band.g_lo; P.b_ghi = a.band.g_hi;
   P.tile_list = a.band.on ? a.band.tile_list : nullptr;
   P.ntiles_listed = a.band.ntiles_listed;
+  P.b_gzero = a.band.on && a.band.g_zero ? 1 : 0;
   const int64_t grid = P.tile_list ? (int64_t)P.ntiles_listed : (int64_t)P.ntile_c * a.nouter;
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large (%lld tiles)", (long long)grid);

@@ -121,6 +121,8 @@ struct ColParams {
   int b_row_lo, b_row_hi, b_coff, b_cper, b_clim, b_goff, b_gstep, b_glo, b_ghi;
   const int* tile_list;  // PAD == 4: the tiles that hold a kept column (the launch has one workgroup per entry); null: all tiles
   int ntiles_listed;
+  int b_gzero;           // PAD == 4: columns of a removed y are not skipped but read as zeros and WRITTEN (the transform of
+                         // zeros): for outputs that somebody reads whole, e.g. a chunk that goes through an exchange
 };
 
 template <typename T>
@@ -402,10 +404,18 @@ struct ColFft {
       int z = t % P.b_cper, y = P.b_goff + t / P.b_cper + outer * P.b_gstep;
       bool any = false;
       for (int i = 0; i < COLS && tc * COLS + i < P.ncols; ++i) {
-        any = any || (z < P.b_clim && (y < P.b_glo || y >= P.b_ghi));
+        any = any || (z < P.b_clim && (P.b_gzero || y < P.b_glo || y >= P.b_ghi));
         if (++z == P.b_cper) { z = 0; ++y; }
       }
       if (!any) return;                            // the same for every thread of the workgroup
+    }
+    bool zero_col = false;                         // b_gzero: this thread's column(s) belong to a removed y
+    if constexpr (PAD == 4) {
+      if (P.b_gzero) {
+        const int t = P.b_coff + col;
+        const int y = P.b_goff + t / P.b_cper + outer * P.b_gstep;
+        zero_col = !(y < P.b_glo || y >= P.b_ghi);
+      }
     }
 
     cx<T> v[VEC][S::E];
@@ -425,7 +435,7 @@ struct ColFft {
       if constexpr (PAD == 4) {                    // a removed row: re-read row 0 (a cache hit) and drop the value -- no branch
                                                    // (skipping the load of a register whose rows are all removed, a workgroup-
                                                    // uniform branch, was measured: 1024^3 x pass 1.84 -> 2.03 ms, fp32 1.51 -> 2.05)
-        zero_row = (int)r >= P.b_row_lo && (int)r < P.b_row_hi;
+        zero_row = zero_col || ((int)r >= P.b_row_lo && (int)r < P.b_row_hi);
         if (zero_row) src = ip + row_off(P.in_map, 0u);
       }
       if (nact >= VEC) {

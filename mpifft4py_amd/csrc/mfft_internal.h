@@ -58,6 +58,7 @@ struct ColArgs {
     int row_lo = 0, row_hi = 0, c_off = 0, c_per = 1 << 30, c_lim = 1 << 30, g_off = 0, g_step = 0, g_lo = 1 << 30, g_hi = 1 << 30;
     const int* tile_list = nullptr;     // device array of the tiles with a kept column (tile = outer * ntile_c + tc), or null
     int ntiles_listed = 0;
+    bool g_zero = false;                // columns of a removed y are transformed as zeros and written instead of skipped
   } band;
 };
 bool c2r_limit_supported(int64_t n, int prec);   // a c2r kernel of real length n that reads only the first `valid` bins exists

@@ -284,24 +284,54 @@ struct mfft_plan_s {
   }
   void detect_band(const uint8_t* m) {
     band_ok = false;
-    if (!(d.decomp == MFFT_SLAB && P == 1 && r2c) || N0 < 2 || N1 < 2 || N2 < 4 || N2 % 2 != 0) return;
-    if (!band_fusable(N0, prec) || !band_fusable(N1, prec) || !c2r_limit_supported(N2, prec)) return;
-    std::vector<uint8_t> m0(N0, 0), m1(N1, 0), m2(Nf, 0);
+    // every rank must take the same route (the pruned exchange has other counts): agree on the outcome below
+    int ok = 0, a0 = 0, b0 = 0, a1 = 0, b1 = 0, a2 = 0;
+    std::vector<int> list;
+    if (d.decomp == MFFT_SLAB && r2c && N0 >= 2 && N1 >= 2 && N2 >= 4 && N2 % 2 == 0 && band_fusable(N0, prec) &&
+        band_fusable(N1, prec) && c2r_limit_supported(N2, prec))
+      ok = analyse_band(m, &a0, &b0, &a1, &b1, &a2, &list) ? 1 : 0;
+    if (P > 1) {
+      double v[7] = {(double)ok, (double)a0, -(double)a0, (double)b0, -(double)b0, (double)a2, -(double)a2};
+      if (ok == 0) for (int i = 1; i < 7; ++i) v[i] = 0;
+      double ok_min = -(double)ok;
+      if (comm->allreduce_host(v, 7, 1) != 0 || comm->allreduce_host(&ok_min, 1, 1) != 0) return;
+      if (ok_min != -1.0 || v[1] != -v[2] || v[3] != -v[4] || v[5] != -v[6]) return;      // somebody disagrees or has another mask
+    } else if (!ok) {
+      return;
+    }
+    ba0 = a0; bb0 = b0; ba1 = a1; bb1 = b1; ba2 = a2;
+    if (P == 1) {
+      if (a1 < 1) return;                      // the y pass redirects removed rows to row 0, which must be a kept one
+      if (band_tiles) (void)hipFree(band_tiles);
+      band_tiles = nullptr;
+      band_ntiles = (int)list.size();
+      if (list.empty() || hipMalloc(reinterpret_cast<void**>(&band_tiles), list.size() * sizeof(int)) != hipSuccess ||
+          hipMemcpy(band_tiles, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+      }
+    }
+    band_ok = true;
+  }
+  // local mask (N0, Np1, Nf) == m0[kx] & m1[ky] & m2[kz] with the zeros of m0 and m1 one run each and those of m2 a tail?
+  bool analyse_band(const uint8_t* m, int* a0, int* b0, int* a1, int* b1, int* a2, std::vector<int>* list) const {
+    const int64_t n1 = Np1;
+    std::vector<uint8_t> m0(N0, 0), m1(n1, 0), m2(Nf, 0);
     for (int64_t i = 0; i < N0; ++i)
-      for (int64_t j = 0; j < N1; ++j) {
-        const uint8_t* row = m + (i * N1 + j) * Nf;
+      for (int64_t j = 0; j < n1; ++j) {
+        const uint8_t* row = m + (i * n1 + j) * Nf;
         uint8_t any = 0;
         for (int64_t k = 0; k < Nf; ++k) { any |= row[k]; m2[k] |= row[k]; }
         m0[i] |= any; m1[j] |= any;
       }
     for (auto* v : {&m0, &m1, &m2}) for (auto& x : *v) x = x ? 1 : 0;
     for (int64_t i = 0; i < N0; ++i)          // the mask must BE the product of the three (values other than 0 / 1 are weights, not a filter)
-      for (int64_t j = 0; j < N1; ++j) {
-        const uint8_t* row = m + (i * N1 + j) * Nf;
+      for (int64_t j = 0; j < n1; ++j) {
+        const uint8_t* row = m + (i * n1 + j) * Nf;
         const uint8_t ij = m0[i] & m1[j];
-        for (int64_t k = 0; k < Nf; ++k) if (row[k] != (uint8_t)(ij & m2[k])) return;
+        for (int64_t k = 0; k < Nf; ++k) if (row[k] != (uint8_t)(ij & m2[k])) return false;
       }
-    auto middle = [](const std::vector<uint8_t>& v, int* a, int* b) {   // zeros form one run [a, b) with a >= 1?  (none: a = b = size)
+    auto run = [](const std::vector<uint8_t>& v, int* a, int* b) {   // zeros form one run [a, b) (none: a = b = first index after the ones)
       const int n = (int)v.size();
       int lo = 0;
       while (lo < n && v[lo]) ++lo;
@@ -309,30 +339,22 @@ struct mfft_plan_s {
       while (hi < n && !v[hi]) ++hi;
       for (int i = hi; i < n; ++i) if (!v[i]) return false;
       *a = lo; *b = hi;
-      return lo >= 1;
+      return true;
     };
-    int a2 = 0, b2 = 0;
-    if (!middle(m0, &ba0, &bb0) || !middle(m1, &ba1, &bb1) || !middle(m2, &a2, &b2) || b2 != (int)Nf) return;
-    ba2 = a2;
-    // x pass: tiles of the flattened (ky, kz) columns that hold a kept column, in memory order
-    const int w = col_tile_width(N0, prec, true, 6);
-    if (w <= 0) return;
-    std::vector<int> list;
-    const int64_t ncols = N1 * Nf, ntile = (ncols + w - 1) / w;
-    for (int64_t t = 0; t < ntile; ++t) {
-      bool any = false;
-      for (int64_t c = t * w; c < std::min(ncols, (t + 1) * w) && !any; ++c) any = m1[c / Nf] && m2[c % Nf];
-      if (any) list.push_back((int)t);
+    int z0 = 0, z1 = 0;
+    if (!run(m0, a0, b0) || *a0 < 1 || !run(m1, a1, b1) || !run(m2, &z0, &z1) || z1 != (int)Nf || z0 < 1) return false;
+    *a2 = z0;
+    if (P == 1) {      // x pass: tiles of the flattened (ky, kz) columns that hold a kept column, in memory order
+      const int w = col_tile_width(N0, prec, true, 6);
+      if (w <= 0) return false;
+      const int64_t ncols = n1 * Nf, ntile = (ncols + w - 1) / w;
+      for (int64_t t = 0; t < ntile; ++t) {
+        bool any = false;
+        for (int64_t c = t * w; c < std::min(ncols, (t + 1) * w) && !any; ++c) any = m1[c / Nf] && m2[c % Nf];
+        if (any) list->push_back((int)t);
+      }
     }
-    if (band_tiles) (void)hipFree(band_tiles);
-    band_tiles = nullptr;
-    band_ntiles = (int)list.size();
-    if (list.empty() || hipMalloc(reinterpret_cast<void**>(&band_tiles), list.size() * sizeof(int)) != hipSuccess ||
-        hipMemcpy(band_tiles, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-      (void)hipGetLastError();
-      return;
-    }
-    band_ok = true;
+    return true;
   }
   int* band_tiles = nullptr;
   int band_ntiles = 0;
@@ -630,6 +652,30 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
       return col_band(Aw, Aw, N1, N0, ba2, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf), by);
     }));
     MFFT_TRY(stage("bwd_z", Rb + Cb * keep2, [&] { return c2r_rows(Aw, u, N0 * N1, N2, Nf, N2, 1.0 / (double)N2, ba2); }));
+    return 0;
+  }
+  if (masked && P > 1 && band_ok && nbatch <= 1 && nslice <= 1 && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
+    // pruned inverse over P ranks (blocking exchange): the x pass reads the kept kx rows and writes (N0, Np1, a2) -- the
+    // kept kz bins only, zeros for the ky this rank's mask removes --, so the exchange carries a2 / Nf of the bytes; the y
+    // pass and c2r work on rows of a2 bins
+    if (!mask || mask_count != (size_t)local_complex_count()) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask was set");
+    const int64_t a2 = ba2, per_line = (int64_t)(128 / es);
+    const int64_t ap = (a2 + per_line - 1) / per_line * per_line;      // rows of the compact layout start on cache lines
+    const size_t cbp = (size_t)(Np0 * N1 * ap) * es;
+    MFFT_TRY(ensure_work(0, cbp));
+    MFFT_TRY(ensure_work(1, cbp));
+    void *Aw = work[0], *Bw = work[1];
+    const double keep0 = 1.0 - (double)(bb0 - ba0) / (double)N0, keep2 = (double)a2 / (double)Nf;
+    ColArgs::Band bx;
+    bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = true;
+    MFFT_TRY(stage("bwd_x", Cb * keep2 * (keep0 + 1.0), [&] {
+      return col_band(fu, Aw, N0, Np1, a2, Nf, plain(Np1 * Nf), ap, plain(Np1 * ap), bx);
+    }));
+    MFFT_TRY(stage("bwd_a2a", 0, [&] { return exchange_equal(world, Aw, Bw, (size_t)(Np0 * Np1 * ap) * es); }));
+    MFFT_TRY(stage("bwd_y", 2 * Cb * keep2, [&] {
+      return col(Bw, Aw, N1, true, Np0, a2, Np1 * ap, two_level(Np1, Np0 * Np1 * ap, ap), N1 * ap, plain(ap));
+    }));
+    MFFT_TRY(stage("bwd_z", Rb + Cb * keep2, [&] { return c2r_rows(Aw, u, Np0 * N1, N2, ap, N2, 1.0 / (double)N2, (int)a2); }));
     return 0;
   }
   if (masked) {

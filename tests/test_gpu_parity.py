@@ -263,33 +263,44 @@ def test_two_thirds_rule_mask_on_load(decomp, P, pipeline, prec, fused, monkeypa
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("P", [1, 2, 4])
 @pytest.mark.parametrize("N", [[32, 32, 32], [48, 20, 36], [64, 128, 256], [16, 24, 10], [100, 36, 50], [8, 8, 8], [12, 6, 4]])
-def test_two_thirds_rule_pruned(N, prec, monkeypatch):
-    """One GPU, real data, the reference's own dealias filter (three 1-D band conditions): the inverse does not load
-    the removed rows, skips the tiles of removed columns and reads only the kept bins of every z row (plan.hip
-    detect_band, ColFft PAD == 4).  Against ifftn(fu * dealias) through the plain kernels and against the same call
-    with MFFT_NO_PRUNE=1 (the general masked-load path); the input spectrum stays untouched."""
+def test_two_thirds_rule_pruned(N, P, prec, monkeypatch):
+    """Real data, the reference's own dealias filter (three 1-D band conditions).  One GPU: the inverse does not load
+    the removed rows, skips the tiles of removed columns and reads only the kept bins of every z row; P ranks: the x pass
+    writes the kept kz bins only (zeros for removed ky), the exchange carries a2 / Nf of the bytes (plan.hip detect_band,
+    ColFft PAD == 4).  Against ifftn(fu * dealias) through the plain kernels and against the same call with
+    MFFT_NO_PRUNE=1 (the general masked-load path); the input spectrum stays untouched."""
     from mpifft4py_amd import Slab_R2C
+    if N[0] % P or N[1] % P:
+        pytest.skip("mesh does not divide")
     rng = np.random.default_rng(sum(N) + 23)
     ct, rt = cdtype(prec), rdtype(prec)
     C = (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5 + 1j * (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5)).astype(ct)
 
     def body(comm):
-        F = Slab_R2C(np.array(N), L, comm, prec)
+        F = Slab_R2C(np.array(N), L, comm, prec, pipeline=1)
         mask = np.broadcast_to(F.get_dealias_filter(), F.complex_shape())
-        c = C.copy()
+        c0 = np.ascontiguousarray(C[F.complex_local_slice()])
+        c = c0.copy()
         u = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt), dealias="2/3-rule")
-        assert np.array_equal(c, C)
-        u_ref = F.ifftn((C * mask).astype(ct), np.zeros(F.real_shape(), dtype=rt))
-        monkeypatch.setenv("MFFT_NO_PRUNE", "1")
+        assert np.array_equal(c, c0)
+        u_ref = F.ifftn((c0 * mask).astype(ct), np.zeros(F.real_shape(), dtype=rt))
+        os.environ["MFFT_NO_PRUNE"] = "1"        # read at every call; all ranks of this process switch together
+        comm.barrier()
         u_gen = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt), dealias="2/3-rule")
-        monkeypatch.delenv("MFFT_NO_PRUNE")
+        comm.barrier()
+        os.environ.pop("MFFT_NO_PRUNE", None)
         return u, u_ref, u_gen, mask
-    for u, u_ref, u_gen, mask in run_ranks(1, body):
-        assert 0 < mask.sum() < mask.size
+    try:
+        res = run_ranks(P, body)
+    finally:
+        os.environ.pop("MFFT_NO_PRUNE", None)
+    for u, u_ref, u_gen, mask in res:
         assert np.array_equal(u_gen, u_ref)
         # a different build of the same kernels (the compiler may contract other multiply-adds): round-off apart at most
         assert orc.rel_l2(u, u_ref) < 0.05 * TOL[prec], orc.rel_l2(u, u_ref)
+    assert 0 < sum(int(r[3].sum()) for r in res) < C.size
 
 
 @pytest.mark.parametrize("decomp", ["slab", "pencilX", "pencilY"])
