@@ -429,6 +429,41 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
 
+    # ---- secondary measurement (one GPU): the dealiased transforms of the same class on the same cube -- the inverse
+    # with the 2/3-rule (slab.py:237-245; here pruned passes) and the 3/2-rule ifftn + fftn pair (slab.py:247-346, 453-485)
+    if world == 1 and args.decomp == "slab" and args.pencil_extra != "off":
+        try:
+            Fd = Slab_R2C(N, L, comm, args.precision)
+            fud = DeviceArray.random(Fd.complex_shape(), Fd.complex, seed=5)
+            ud = DeviceArray.empty(Fd.real_shape(), Fd.float)
+
+            def timed(fn, reps=5):
+                for _ in range(2):
+                    fn()
+                Fd.sync()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                Fd.sync()
+                return 1e3 * (time.perf_counter() - t0) / reps
+            timed(lambda: Fd.ifftn(fud, ud), 3)          # first use of the plan: work buffers, kernel attributes
+            d_extra = {"ifftn_ms": timed(lambda: Fd.ifftn(fud, ud)),
+                       "ifftn_two_thirds_rule_ms": timed(lambda: Fd.ifftn(fud, ud, "2/3-rule"))}
+            del ud
+            if 3 * n % 2 == 0 and 27 * n ** 3 * (8 if args.precision == "double" else 4) < 0.3 * 288e9 * 8:
+                upd = DeviceArray.empty(Fd.real_shape_padded(), Fd.float)
+                fud2 = DeviceArray.empty(Fd.complex_shape(), Fd.complex)
+
+                def padded_pair():
+                    Fd.ifftn(fud, upd, "3/2-rule")
+                    Fd.fftn(upd, fud2, "3/2-rule")
+                d_extra["three_halves_rule_ifftn_fftn_pair_ms"] = timed(padded_pair, 3)
+                del upd, fud2
+            extras["dealias"] = d_extra
+            del Fd, fud
+        except Exception as e:      # noqa: BLE001  - the headline (slab) line must survive
+            extras["dealias"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # correctness gate: a wrong transform must not print a headline number with rc 0
     tol = 1e-10 if args.precision == "double" else 1e-4
     rt_all = [mres["rt_err"]] + [v["roundtrip_rel_l2"] for v in extras.values() if "roundtrip_rel_l2" in v]
