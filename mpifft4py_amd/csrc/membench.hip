@@ -497,6 +497,10 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     for (int x = 0; x < 2; ++x) {
+      run_tile_n<512, 8, 8, 0>(a, a, x, 72 << 10);
+      run_tile_n<512, 8, 8, 0>(a, a, x, 40 << 10);
+      run_tile_n<512, 8, 8, 0>(a, b, x, 40 << 10);
+      run_tile_n<512, 8, 4, 0>(a, a, x, 72 << 10);
       run_tile_n<1024, 8, 8, 0>(a, a, x, 80 << 10);
       run_tile_n<1024, 8, 8, 0>(a, a, x, 0);
       run_tile_n<1152, 8, 24, 0>(a, a, x, 72 << 10);
