@@ -522,6 +522,25 @@ int main(int argc, char** argv) {
     run_all<float>(vs, 1024, "", rounds);
     return 0;
   }
+  if (filter[0] && strstr("n800", filter)) {        // 800 / 640 / 1600: three workgroups per CU without LDS twiddles?
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<800, 5, 5, 4, 4, 2>, double, 8, true, true, 1>("5x5x4x4x2"));
+      vs.push_back(make_tile_occ<Spec<800, 5, 5, 4, 4, 2>, double, 8, false, true, 1, false, 3>("5x5x4x4x2"));
+      vs.push_back(make_tile_occ<Spec<800, 5, 5, 4, 4, 2>, double, 8, true, true, 1, false, 2>("5x5x4x4x2"));
+      vs.push_back(make_tile_occ<Spec<800, 5, 4, 5, 4, 2>, double, 8, true, true, 1, false, 2>("5x4x5x4x2"));
+      vs.push_back(make_tile_occ<Spec<800, 4, 4, 5, 5, 2>, double, 8, true, true, 1, false, 2>("4x4x5x5x2"));
+      run_all<double>(vs, 800, "", rounds);
+    }
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<1600, 5, 5, 4, 4, 4>, double, 8, false, true, 1>("5x5x4x4x4"));
+      vs.push_back(make_tile<Spec<1600, 5, 5, 4, 4, 4>, double, 8, false, true, 1, true>("5x5x4x4x4"));
+      vs.push_back(make_tile<Spec<1600, 8, 8, 5, 5>, double, 8, false, true, 1>("8x8x5x5"));
+      run_all<double>(vs, 1600, "", rounds);
+    }
+    return 0;
+  }
   if (filter[0] && strstr("h1536", filter)) {       // 1536 fp64: 12 values per thread on 64-byte tiles, three workgroups per CU
     std::vector<Variant<double>> vs;
     vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, false, true, 1>("8x8x8x3"));
