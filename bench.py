@@ -137,7 +137,7 @@ def pmc_traffic(n, precision, decomp, world):
             continue
         if ("%d^3" % n) not in prof.get("workload", ""):
             continue
-        vals = [v["hbm_bytes_per_launch"] for key, v in prof["kernels"].items() if key.startswith(want)]
+        vals = [v["hbm_bytes_per_launch"] for key, v in prof["kernels"].items() if key.startswith(want) and " pad" not in key]
         if vals:
             return sum(vals) / len(vals), "%s (kernel %s)" % (os.path.basename(path), k[2])
     return None, "no committed PMC profile of '%s'" % want.strip()

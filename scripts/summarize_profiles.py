@@ -26,12 +26,20 @@ def short(name):
     extra = ""
     if fam in ("ColFft", "RowFft"):
         extra = " inv" if flag == "true" else " fwd"
-    if fam == "ColFft":
-        tail = [t.strip() for t in rest.split(",") if t.strip()]      # TWLDS, SPLIT, VEC, NT, PAD
+    tail = [t.strip() for t in rest.split(",") if t.strip()]
+    if fam == "ColFft":                                               # TWLDS, SPLIT, VEC, NT, PAD
         if len(tail) >= 4 and tail[3] == "true":
             extra += " nt"
         if len(tail) >= 5 and tail[4] != "0":
             extra += " pad%s" % tail[4]
+    elif fam in ("R2CFft", "C2RFft"):                                 # (TWLDS), LIMIT, CHUNK, SPLIT
+        for i, nm in enumerate(("limit", "chunk", "split")):
+            if len(tail) > i and tail[i] == "true":
+                extra += " " + nm
+    elif fam == "RowFft":                                             # (INV), TWLDS, CHUNK, SPLIT
+        for i, nm in ((1, "chunk"), (2, "split")):
+            if len(tail) > i and tail[i] == "true":
+                extra += " " + nm
     return "%s n=%s %s tile=%s%s" % (fam, spec.replace(", ", "x"), prec, tile, extra)
 
 
