@@ -458,7 +458,7 @@ struct mfft_plan_s {
   int slab_forward(const void* u, void* fu);
   int slab_backward(const void* fu, void* u, bool masked);
   int slab_forward_pipelined(const void* u, void* fu);
-  int slab_backward_pipelined(const void* src, void* u);
+  int slab_backward_pipelined(const void* src, void* u, bool pruned = false);
   int slab_forward_padded(const void* u, void* fu);
   int slab_backward_padded(const void* fu, void* u);
   bool can_fuse_pad() const;
@@ -654,6 +654,10 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_z", Rb + Cb * keep2, [&] { return c2r_rows(Aw, u, N0 * N1, N2, Nf, N2, 1.0 / (double)N2, ba2); }));
     return 0;
   }
+  if (masked && P > 1 && band_ok && nbatch <= 1 && nslice > 1 && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
+    if (!mask || mask_count != (size_t)local_complex_count()) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask was set");
+    return slab_backward_pipelined(fu, u, true);      // the kz-slice exchange pipeline, pruned
+  }
   if (masked && P > 1 && band_ok && nbatch <= 1 && nslice <= 1 && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
     // pruned inverse over P ranks (blocking exchange): the x pass reads the kept kx rows and writes (N0, Np1, a2) -- the
     // kept kz bins only, zeros for the ky this rank's mask removes --, so the exchange carries a2 / Nf of the bytes; the y
@@ -759,8 +763,14 @@ int mfft_plan_s::slab_forward_pipelined(const void* u, void* fu) {
   return 0;
 }
 
-int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
+// pruned (2/3-rule, band mask): slices that start at or beyond the a2 kept kz bins are not transformed or exchanged at
+// all (every rank knows a2), the x pass does not load the removed kx rows and writes zeros for the ky its rank's mask
+// removes, c2r reads a2 bins per row.
+int mfft_plan_s::slab_backward_pipelined(const void* src, void* u, bool pruned) {
   const double Cb = (double)(N0 * Np1 * Nf) * es, Rb = (double)(Np0 * N1 * N2) * rs;
+  ColArgs::Band bx;
+  bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = true;
+  auto kept = [&](int s) { return !pruned || kslice[s].start < ba2; };
   const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
   for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, cb));
   // work[2] may hold the masked copy of the spectrum (src): use a 4th buffer for the y output
@@ -768,9 +778,11 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
   char *A = static_cast<char*>(work[0]), *B = static_cast<char*>(work[1]), *A2 = static_cast<char*>(work3);
   const char* in = static_cast<const char*>(src);
   for (int s = 0; s < nslice; ++s) {
+    if (!kept(s)) continue;
     const int64_t k0 = kslice[s].start, kz = kslice[s].len;
     const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es;
     MFFT_TRY(stage("bwd_x", 2 * Cb / nslice, [&] {
+      if (pruned) return col_band(in + (size_t)k0 * es, A + boff, N0, Np1, kz, Nf, plain(Np1 * Nf), kz, plain(Np1 * kz), bx);
       return col(in + (size_t)k0 * es, A + boff, N0, true, Np1, kz, Nf, plain(Np1 * Nf), kz, plain(Np1 * kz));
     }));
     MFFT_HIP(hipEventRecord(ev_compute[s], stream));
@@ -783,6 +795,7 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
     MFFT_HIP(hipEventRecord(ev_comm[s], cstream));
   }
   for (int s = 0; s < nslice; ++s) {
+    if (!kept(s)) continue;
     const int64_t k0 = kslice[s].start, kz = kslice[s].len;
     const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es;
     MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[s], 0));
@@ -790,6 +803,12 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u) {
       return col(B + boff, A2 + (size_t)k0 * es, N1, true, Np0, kz, Np1 * kz, two_level(Np1, Np0 * Np1 * kz, kz),
                  N1 * Nf, plain(Nf));
     }));
+  }
+  if (pruned) {
+    MFFT_TRY(stage("bwd_z", Rb + Cb * (double)ba2 / (double)Nf, [&] {
+      return c2r_rows(A2, u, Np0 * N1, N2, Nf, N2, 1.0 / (double)N2, ba2);
+    }));
+    return 0;
   }
   MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A2, u, Np0 * N1, N2, Nf); }));
   return 0;
