@@ -658,6 +658,34 @@ def test_config2_512_cubed_one_gpu():
     assert np.array_equal(u.get(), A) and np.array_equal(fu.get(), c)        # inputs untouched
 
 
+@pytest.mark.parametrize("N", [[500, 500, 500], [384, 384, 384], [1000, 250, 200], [96, 1152, 320], [320, 96, 2304]])
+def test_round2_plans_against_pocketfft(N):
+    """The lengths whose kernels changed in round 2 -- the 125*2^a plans (250 / 500 / 1000 / real 2000), 384 and 1152 with
+    12 values per thread, the row kernels without LDS twiddles and with the split exchange (real 2304 = 1152 complex,
+    640-complex rows of 1280 are in the stage tests) -- at sizes where whole workgroups and ragged tiles both occur,
+    device-resident, against the host's pocketfft on the same input; plus the pruned 2/3-rule inverse against
+    irfftn(C * dealias)."""
+    import os
+    import scipy.fft as sfft
+    from mpifft4py_amd import DeviceArray, SelfComm, Slab_R2C
+    F = Slab_R2C(np.array(N), L, SelfComm(0), "double")
+    A = np.random.default_rng(sum(N)).random(tuple(N))
+    u = DeviceArray.from_numpy(A)
+    fu = DeviceArray.empty(F.complex_shape(), F.complex)
+    u2 = DeviceArray.empty(F.real_shape(), F.float)
+    u3 = DeviceArray.empty(F.real_shape(), F.float)
+    F.fftn(u, fu)
+    F.ifftn(fu, u2)
+    F.ifftn(fu, u3, dealias="2/3-rule")
+    F.sync()
+    C = sfft.rfftn(A, workers=os.cpu_count())
+    assert orc.rel_l2(fu.get(), C) < 1e-10
+    assert orc.rel_l2(u2.get(), A) < 1e-10
+    mask = np.broadcast_to(F.get_dealias_filter(), F.complex_shape())
+    want = sfft.irfftn(C * mask, s=tuple(N), workers=os.cpu_count())
+    assert orc.rel_l2(u3.get(), want) < 1e-10
+
+
 def test_full_size_1024_cubed():
     """BASELINE workload at full size: 1024^3 fp64, device-resident.  Forward spectrum against
     the host's pocketfft (scipy.fft, all cores) on the SAME input, round trip, input preserved.
