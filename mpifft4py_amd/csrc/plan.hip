@@ -465,7 +465,7 @@ struct mfft_plan_s {
   int slab_forward_padded_fused(const void* u, void* fu);
   int slab_backward_padded_fused(const void* fu, void* u);
   int slab_forward_rows(const void* u, void* fu);
-  int slab_backward_rows(const void* src, void* u);
+  int slab_backward_rows(const void* src, void* u, bool pruned = false);
   int pencil_forward_pipelined_x(const void* u, void* fu);
   int pencil_backward_pipelined_x(const void* src, void* u);
   int pencil_forward_pipelined_y(const void* u, void* fu);
@@ -654,9 +654,10 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_z", Rb + Cb * keep2, [&] { return c2r_rows(Aw, u, N0 * N1, N2, Nf, N2, 1.0 / (double)N2, ba2); }));
     return 0;
   }
-  if (masked && P > 1 && band_ok && nbatch <= 1 && nslice > 1 && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
+  if (masked && P > 1 && band_ok && (nbatch > 1 || nslice > 1) && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
     if (!mask || mask_count != (size_t)local_complex_count()) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask was set");
-    return slab_backward_pipelined(fu, u, true);      // the kz-slice exchange pipeline, pruned
+    return nbatch > 1 ? slab_backward_rows(fu, u, true)          // the row-batch exchange pipeline, pruned
+                      : slab_backward_pipelined(fu, u, true);    // the kz-slice exchange pipeline, pruned
   }
   if (masked && P > 1 && band_ok && nbatch <= 1 && nslice <= 1 && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
     // pruned inverse over P ranks (blocking exchange): the x pass reads the kept kx rows and writes (N0, Np1, a2) -- the
@@ -850,9 +851,13 @@ int mfft_plan_s::slab_forward_rows(const void* u, void* fu) {
   return 0;
 }
 
-int mfft_plan_s::slab_backward_rows(const void* src, void* u) {
+int mfft_plan_s::slab_backward_rows(const void* src, void* u, bool pruned) {
   const double Cb = (double)(N0 * Np1 * Nf) * es, Rb = (double)(Np0 * N1 * N2) * rs;
-  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  // pruned (2/3-rule, band mask): every array between the x pass and c2r holds rows of `w` = a2 (padded to a cache line)
+  // kept kz bins instead of Nf, the exchange pieces shrink with them; see slab_backward
+  const int64_t per_line = (int64_t)(128 / es);
+  const int64_t w = pruned ? ((int64_t)ba2 + per_line - 1) / per_line * per_line : Nf, nz = pruned ? (int64_t)ba2 : Nf;
+  const size_t cb = (size_t)(Np0 * N1 * w) * es;
   for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, cb));
   const bool src_in_work2 = work[2] != nullptr && src == work[2];     // the masked copy of the spectrum
   if (src_in_work2) MFFT_TRY(ensure_work3(cb));
@@ -861,13 +866,30 @@ int mfft_plan_s::slab_backward_rows(const void* src, void* u) {
   char* A2 = static_cast<char*>(src_in_work2 ? work3 : work[2]);
   char* out = static_cast<char*>(u);
   const int B = nbatch;
-  MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
+  MFFT_TRY(stage("bwd_x", 2 * Cb, [&] {
+    if (pruned) {
+      ColArgs::Band bx;
+      bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = true;
+      return col_band(src, A, N0, Np1, nz, Nf, plain(Np1 * Nf), w, plain(Np1 * w), bx);
+    }
+    return col(src, A, N0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf));
+  }));
   MFFT_HIP(hipEventRecord(ev_compute[0], stream));
   MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[0], 0));
   for (int b = 0; b < B; ++b) {
     MFFT_TRY(stage_on(cstream, "bwd_a2a", 0, [&] {
       Sched sc;
-      MFFT_TRY(piece_sched(0, false, b, &sc));
+      if (pruned) {      // the same blocks as piece_sched's, with rows of w bins
+        const int64_t i0 = Np0 * b / B, mb = Np0 * (b + 1) / B - i0;
+        sc.peers = world;
+        sc.sc.assign(P, (size_t)(mb * Np1 * w) * es);
+        sc.rc = sc.sc;
+        sc.sd.resize(P);
+        sc.rd.resize(P);
+        for (int r = 0; r < P; ++r) sc.sd[r] = sc.rd[r] = (size_t)((r * Np0 + i0) * Np1 * w) * es;
+      } else {
+        MFFT_TRY(piece_sched(0, false, b, &sc));
+      }
       return run_sched(sc, A, Bk, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
@@ -876,10 +898,12 @@ int mfft_plan_s::slab_backward_rows(const void* src, void* u) {
     const int64_t i0 = Np0 * b / B, mb = Np0 * (b + 1) / B - i0;
     MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
     MFFT_TRY(stage("bwd_y", 2 * Cb / B, [&] {
-      return col(Bk + (size_t)(i0 * Np1 * Nf) * es, A2 + (size_t)(i0 * N1 * Nf) * es, N1, true, mb, Nf, Np1 * Nf,
-                 two_level(Np1, Np0 * Np1 * Nf, Nf), N1 * Nf, plain(Nf));
+      return col(Bk + (size_t)(i0 * Np1 * w) * es, A2 + (size_t)(i0 * N1 * w) * es, N1, true, mb, nz, Np1 * w,
+                 two_level(Np1, Np0 * Np1 * w, w), N1 * w, plain(w));
     }));
     MFFT_TRY(stage("bwd_z", (Rb + Cb) / B, [&] {
+      if (pruned)
+        return c2r_rows(A2 + (size_t)(i0 * N1 * w) * es, out + (size_t)(i0 * N1 * N2) * rs, mb * N1, N2, w, N2, 1.0 / (double)N2, ba2);
       return z_backward(A2 + (size_t)(i0 * N1 * Nf) * es, out + (size_t)(i0 * N1 * N2) * rs, mb * N1, N2, Nf);
     }));
   }

@@ -263,7 +263,7 @@ def test_two_thirds_rule_mask_on_load(decomp, P, pipeline, prec, fused, monkeypa
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("P,pipeline", [(1, 1), (2, 1), (4, 1), (2, 0), (4, 2), (4, 3), (2, -2)])
+@pytest.mark.parametrize("P,pipeline", [(1, 1), (2, 1), (4, 1), (2, 0), (4, 2), (4, 3), (2, -2), (4, -3)])
 @pytest.mark.parametrize("N", [[32, 32, 32], [48, 20, 36], [64, 128, 256], [16, 24, 10], [100, 36, 50], [8, 8, 8], [12, 6, 4], [32, 16, 512]])
 def test_two_thirds_rule_pruned(N, P, pipeline, prec, monkeypatch):
     """Real data, the reference's own dealias filter (three 1-D band conditions).  One GPU: the inverse does not load
@@ -279,7 +279,7 @@ def test_two_thirds_rule_pruned(N, P, pipeline, prec, monkeypatch):
     C = (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5 + 1j * (rng.random((N[0], N[1], N[2] // 2 + 1)) - 0.5)).astype(ct)
 
     def body(comm):
-        F = Slab_R2C(np.array(N), L, comm, prec, pipeline=pipeline)     # 1 blocking, 0 / > 1 kz slices (pruned too), < 0 row batches (mask on load)
+        F = Slab_R2C(np.array(N), L, comm, prec, pipeline=pipeline)     # 1 blocking, 0 / > 1 kz slices, < 0 row batches: all pruned
         mask = np.broadcast_to(F.get_dealias_filter(), F.complex_shape())
         c0 = np.ascontiguousarray(C[F.complex_local_slice()])
         c = c0.copy()
