@@ -314,9 +314,9 @@ int main(int argc, char** argv) {
     const int N = 1024, NF = 513, PF = 520;
     cx<T>*fu = nullptr, *W = nullptr;
     CK(hipMalloc(&fu, (size_t)N * N * NF * sizeof(cx<T>)));
-    CK(hipMalloc(&W, (size_t)N * N * PF * sizeof(cx<T>)));
+    CK(hipMalloc(&W, (size_t)N * (N * PF + 8) * sizeof(cx<T>)));
     CK(hipMemset(fu, 0, (size_t)N * N * NF * sizeof(cx<T>)));
-    CK(hipMemset(W, 0, (size_t)N * N * PF * sizeof(cx<T>)));
+    CK(hipMemset(W, 0, (size_t)N * (N * PF + 8) * sizeof(cx<T>)));
     auto twh = build_pass_twiddles<SD, T>();
     cx<T>* tw = nullptr;
     CK(hipMalloc(&tw, twh.size() * sizeof(cx<T>)));
@@ -365,6 +365,17 @@ int main(int argc, char** argv) {
       timeit("x out of place, W(520) -> fu(513), tiles per y row (partial-line stores)", [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
       P = params(fu, fu, 0, 0, (i64)N * NF, (i64)N * NF, N * NF, 1);
       timeit("x in place, flattened, pitch 513, nt (today's forward x)", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      // the same with planes of the padded array one cache line further apart: a plane of 1024 x 520 x 16 B is a multiple
+      // of 2^17 B, the worst row stride for the x pass (profiles/r02_power_of_two_stride.txt)
+      const i64 PLW = (i64)N * PF + 8;
+      P = params(W, W, PLW, PLW, PF, PF, NF, N);
+      timeit("y in place, pitch 520, planes +128 B, nt", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
+      P = params(fu, W, NF, PF, (i64)N * NF, PLW, NF, N);
+      timeit("x out of place, fu(513) -> W(520, planes +128 B), tiles per y row", [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
+      P = params(W, fu, PF, NF, PLW, (i64)N * NF, NF, N);
+      timeit("x out of place, W(520, planes +128 B) -> fu(513), tiles per y row", [&] { launch_k<K, T>(P, P.ntile_c * P.nouter); });
+      P = params(W, W, 0, 0, PLW, PLW, N * PF, 1);
+      timeit("x in place in W(520, planes +128 B), flattened (pad columns transformed too), nt", [&] { launch_k<KNT, T>(P, P.ntile_c * P.nouter); });
     }
     return 0;
   }
