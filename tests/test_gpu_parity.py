@@ -303,6 +303,38 @@ def test_two_thirds_rule_pruned(N, P, pipeline, prec, monkeypatch):
     assert 0 < sum(int(r[3].sum()) for r in res) < C.size
 
 
+@pytest.mark.parametrize("P", [1, 2])
+@pytest.mark.parametrize("kind", ["ones", "zeros", "kx_band_only", "one_mode", "checker"])
+def test_two_thirds_rule_edge_masks(kind, P):
+    """Masks at the edges of what detect_band accepts: nothing removed (band form with empty bands), everything removed,
+    a band along x only, a single kept mode, a mask that is no product of 1-D conditions -- all must equal ifftn(fu * mask)
+    bit for bit or to round-off whichever route they take."""
+    from mpifft4py_amd import Slab_R2C
+    N = [32, 24, 40]
+    C = np.fft.rfftn(np.random.default_rng(77).random(N))
+    M = np.ones(C.shape, dtype=np.uint8)
+    if kind == "zeros":
+        M[:] = 0
+    elif kind == "kx_band_only":
+        M[10:20] = 0
+    elif kind == "one_mode":
+        M[:] = 0
+        M[0, 0, 0] = 1
+    elif kind == "checker":
+        M = ((np.indices(C.shape).sum(axis=0) % 3) != 0).astype(np.uint8)
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, "double", pipeline=1)
+        sl = F.complex_local_slice()
+        c = np.ascontiguousarray(C[sl])
+        F.dealias = np.ascontiguousarray(M[sl])
+        u = F.ifftn(c.copy(), np.zeros(F.real_shape()), dealias="2/3-rule")
+        ur = F.ifftn(c * M[sl], np.zeros(F.real_shape()))
+        return u, ur
+    for u, ur in run_ranks(P, body):
+        assert np.abs(u - ur).max() <= 1e-14 * max(np.abs(ur).max(), 1e-300) or np.array_equal(u, ur)
+
+
 @pytest.mark.parametrize("decomp", ["slab", "pencilX", "pencilY"])
 def test_two_thirds_rule(decomp):
     """ifftn(dealias='2/3-rule') == ifftn of the masked spectrum (slab.py:237-245)."""
