@@ -79,6 +79,25 @@ from mpifft4py_amd import DeviceArray, Pencil_R2C, Slab_R2C  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when a communicator is created; stdout is for the JSON line."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        try:                                   # the banner sits in the C library's stdout buffer until someone flushes it
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def make_comm(world, rendezvous, transport=None):
     if world == 1:
         return mcomm.SelfComm(int(os.environ.get("LOCAL_RANK", "0")) % max(_lib.device_count(), 1)), None
@@ -192,17 +211,18 @@ def main():
         sys.stderr.write("bench.py --gpus %d was started with WORLD_SIZE=%d: the launcher must start one process per "
                          "GPU (or none: `python bench.py --gpus N` starts its ranks itself)\n" % (args.gpus, world))
         sys.exit(2)
-    # RCCL prints a version banner on stdout at communicator creation; keep stdout for the JSON line
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
-    try:
+    with stdout_to_stderr():
         first = None if args.transport == "auto" else args.transport     # auto: $MFFT_TRANSPORT, else rccl
-        comm, dist = make_comm(world, args.rendezvous, first)
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
+        try:
+            comm, dist = make_comm(world, args.rendezvous, first)
+        except Exception as e:      # noqa: BLE001
+            # auto: a machine on which RCCL cannot build the communicator (it refuses, e.g., two ranks on one device)
+            # still has the IPC transport; communicator creation is collective, so every rank lands here together
+            if args.transport != "auto" or world == 1 or os.environ.get("MFFT_TRANSPORT", "rccl") == "ipc":
+                raise
+            sys.stderr.write("first transport unavailable (%s: %s): IPC transport\n" % (type(e).__name__, e))
+            first = "ipc"
+            comm, dist = make_comm(world, "file", first)
     n = args.n
     N = np.array([n, n, n])
     L = np.array([2 * np.pi] * 3)
@@ -276,6 +296,8 @@ def main():
             "config": {"workload": "%d^3 %s %s R2C forward+inverse, device-resident, %d rank(s)"
                                    % (n, "fp64" if args.precision == "double" else "fp32", args.decomp, world),
                        "roundtrip_rel_l2": rt_err,
+                       # ranks > visible GPUs: several ranks share a device (a functional run, not a scaling point)
+                       "gpus_visible": int(_lib.device_count()),
                        "exchange_pipeline_depth": mres["pipeline"] if world > 1 else None,
                        "exchange_transport": mres["transport"] if world > 1 else None,
                        "exchange_pipeline_tuning_ms_per_pair": tuning,
@@ -324,7 +346,8 @@ def main():
         if args.transport == "auto":
             other = "ipc" if comm.transport_name != "ipc" else "rccl"
             try:
-                c2, _ = make_comm(world, "file", other)
+                with stdout_to_stderr():
+                    c2, _ = make_comm(world, "file", other)
                 c2.transport_name = other
                 c2.selftest(1 << 20, 20000)      # a verified 1 MB-per-peer exchange, at most 20 s: never trust an untried wire
                 comms.append(c2)
@@ -479,6 +502,10 @@ def main():
             out["degraded"] = True
             out["error"] = "round trip rel-L2 %.3e exceeds %.0e: the transform is wrong, the timing means nothing" % (bad, tol)
         print(json.dumps(out))
+    # the line is out: whatever a library still holds in its stdout buffer (RCCL's banner when stdout is a pipe) must
+    # not follow it
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if dist is not None:
         try:
             dist.destroy_process_group()

@@ -144,6 +144,26 @@ def test_bench_starts_its_own_ranks_without_a_launcher(world, transport):
     assert d["n_gpus"] == world and d["value"] > 0 and d["config"]["roundtrip_rel_l2"] < 1e-10 and not d.get("degraded")
 
 
+def test_bench_falls_back_when_rccl_refuses():
+    """`python bench.py --gpus 2` with the REAL librccl on a box with one GPU: RCCL refuses two ranks on one device, every
+    rank gets the same error at communicator creation, and `--transport auto` continues over the IPC transport -- one
+    JSON line, the refusal recorded in the tuning table, `gpus_visible` telling that ranks share a device."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
+                                                             "MFFT_TRANSPORT", "MFFT_RCCL_LIB")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "128", "--steps", "3",
+                        "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    out, err = p.stdout.decode(), p.stderr.decode()
+    assert p.returncode == 0, (out[-2000:], err[-4000:])
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and cfg["roundtrip_rel_l2"] < 1e-10 and not d.get("degraded")
+    if cfg["gpus_visible"] < 2:
+        assert cfg["exchange_transport"] == "ipc" and "error" in cfg["exchange_pipeline_tuning_ms_per_pair"]["rccl"]
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_mpi4py_like_communicator_is_wrapped(world):
     """INTEGRATION.md route A with the caller's own communicator object: the constructors accept anything with
