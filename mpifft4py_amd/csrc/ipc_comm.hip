@@ -106,6 +106,7 @@ struct IpcComm : mfft_comm_s {
   bool creator = false;
   int device = 0;
   IpcFlags* flags = nullptr;                               // mine (device memory, exported at creation)
+  bool flags_fine = false;                                 // allocated fine-grained
   std::vector<IpcFlags*> peer_flags;                       // IPC mappings of the peers' flags
   hipEvent_t release_ev[IPC_MAX_CH] = {};                  // plain events: a record releases kernel-written data
   uint32_t sseq[IPC_MAX_RANKS][IPC_MAX_CH] = {}, rseq[IPC_MAX_RANKS][IPC_MAX_CH] = {};
@@ -433,10 +434,28 @@ int comm_create_ipc(int nranks, int rank, const void* id128, mfft_comm_s** out) 
   (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
   if (!can) return set_error(MFFT_ERR_UNSUPPORTED, "ipc transport: this device has no stream memory operations");
   // my flags: zeroed, exported (the first and only export besides the work segments)
-  MFFT_HIP(hipMalloc(reinterpret_cast<void**>(&c->flags), (size_t)2 << 20));
-  MFFT_HIP(hipMemset(c->flags, 0, sizeof(IpcFlags)));
-  MFFT_HIP(hipDeviceSynchronize());
-  MFFT_HIP(hipIpcGetMemHandle(&sh->rk[rank].flags_h, c->flags));
+  // fine-grained device memory where the runtime has it: these words are written by OTHER devices' stream memory
+  // operations and polled by this device's; ordinary (coarse-grained) memory otherwise
+  {
+    void* fp = nullptr;
+    bool fine = hipExtMallocWithFlags(&fp, (size_t)2 << 20, hipDeviceMallocFinegrained) == hipSuccess && fp != nullptr;
+    if (fine && (hipMemset(fp, 0, sizeof(IpcFlags)) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                 hipIpcGetMemHandle(&sh->rk[rank].flags_h, fp) != hipSuccess)) {
+      (void)hipGetLastError();
+      (void)hipFree(fp);
+      fine = false;
+    }
+    if (!fine) {
+      (void)hipGetLastError();
+      MFFT_HIP(hipMalloc(&fp, (size_t)2 << 20));
+      MFFT_HIP(hipMemset(fp, 0, sizeof(IpcFlags)));
+      MFFT_HIP(hipDeviceSynchronize());
+      MFFT_HIP(hipIpcGetMemHandle(&sh->rk[rank].flags_h, fp));
+    }
+    c->flags = static_cast<IpcFlags*>(fp);
+    c->flags_fine = fine;
+    if (getenv("MFFT_IPC_DEBUG")) fprintf(stderr, "[mfft ipc] rank %d: flag words in %s memory\n", rank, fine ? "fine-grained" : "coarse-grained");
+  }
   sh->rk[rank].device = c->device;
   sh->rk[rank].pid = (int)getpid();
   sh->attached.fetch_add(1);
