@@ -120,6 +120,12 @@ def make_comm(world, rendezvous, transport=None):
     return mcomm.from_env(bcast, transport=transport), dist
 
 
+def _default_grid(p):
+    """MPI.Compute_dims(p, 2): balanced, non-increasing (what pencil.py:1479 gets from mpi4py)."""
+    a = max(d for d in range(1, int(p ** 0.5) + 1) if p % d == 0)
+    return p // a, a
+
+
 def launched_col_kernel(n, precision):
     """The strided-axis kernel the library runs for length n: (plan as "8x8x4x4", tile, full registry name)."""
     import ctypes
@@ -223,16 +229,24 @@ def main():
             sys.stderr.write("first transport unavailable (%s: %s): IPC transport\n" % (type(e).__name__, e))
             first = "ipc"
             comm, dist = make_comm(world, "file", first)
+    if world > 1:
+        comm.transport_name = "ipc" if comm.get_option("ipc_pull") >= 0 else "rccl"      # what was actually built
     n = args.n
     N = np.array([n, n, n])
     L = np.array([2 * np.pi] * 3)
-    def measure(pipeline, comm=comm):
+
+    def set_pull(c, pull):
+        if pull is not None:
+            c.set_option("ipc_pull", pull)
+
+    def measure(pipeline, comm=comm, pull=None, comm_cus=0):
         """W warm-up pairs, then exactly K timed pairs bracketed by stream sync + device sync + barrier."""
+        set_pull(comm, pull)
         if args.decomp == "slab":
-            F = Slab_R2C(N, L, comm, args.precision, pipeline=pipeline)
+            F = Slab_R2C(N, L, comm, args.precision, pipeline=pipeline, comm_cus=comm_cus)
         else:
             F = Pencil_R2C(N, L, comm, args.precision, communication="Alltoallw", alignment="X",
-                           allow_single=True, pipeline=pipeline)
+                           allow_single=True, pipeline=pipeline, comm_cus=comm_cus)
         u = DeviceArray.random(F.real_shape(), F.float, seed=1234 + rank)
         fu = DeviceArray.empty(F.complex_shape(), F.complex)
         u2 = DeviceArray.empty(F.real_shape(), F.float)
@@ -267,10 +281,16 @@ def main():
         a0 = u.leading(0, k).get()
         b0 = u2.leading(0, k).get()
         rt_err = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
-        return {"dt": dt, "stages": stages, "rt_err": rt_err, "pipeline": pipeline, "transport": comm_name(comm)}
+        return {"dt": dt, "stages": stages, "rt_err": rt_err, "pipeline": pipeline, "comm_cus": comm_cus,
+                "transport": cand_name(comm, pull)}
 
     def comm_name(c):
         return getattr(c, "transport_name", "rccl" if world > 1 else "none")
+
+    PULL_NAMES = {1: "", 2: ":streams", 0: ":copy"}      # the IPC transport's ways of pulling (include/mpifft4py_amd.h)
+
+    def cand_name(c, pull):
+        return comm_name(c) + (PULL_NAMES.get(pull, "") if pull is not None else "")
 
     def headline(mres, tuning):
         dt, stages, rt_err = mres["dt"], mres["stages"], mres["rt_err"]
@@ -299,6 +319,7 @@ def main():
                        # ranks > visible GPUs: several ranks share a device (a functional run, not a scaling point)
                        "gpus_visible": int(_lib.device_count()),
                        "exchange_pipeline_depth": mres["pipeline"] if world > 1 else None,
+                       "exchange_comm_cus": mres.get("comm_cus") if world > 1 else None,
                        "exchange_transport": mres["transport"] if world > 1 else None,
                        "exchange_pipeline_tuning_ms_per_pair": tuning,
                        "alg_bytes_per_pair": alg_pair,
@@ -332,10 +353,9 @@ def main():
         return t
 
     tuning = None
-    best = (comm, args.pipeline)
+    best = (comm, args.pipeline, None, 0)
     if args.decomp == "slab" and world > 1 and args.pipeline == 0:
         # 1. the plain, blocking exchange: W + K pairs, a complete measurement that is also the fallback line
-        comm.transport_name = first or os.environ.get("MFFT_TRANSPORT", "rccl")
         base = measure(1)
         tuning = {comm.transport_name: {1: 1e3 * base["dt"] / args.steps}}
         fallback = headline(base, {"note": "blocking exchange; the other candidates did not finish"}) if rank == 0 else None
@@ -357,41 +377,71 @@ def main():
             # every rank must agree on the candidate list
             if -comm.allreduce(-float(len(comms)), op=mcomm.MAX) < 2:
                 comms = comms[:1]
-        best = (comm, 1)
+        ipc_first = comm.get_option("ipc_pull") >= 0
+        base_pull = 1 if ipc_first else None          # the first measurement ran with the transport's default (pull kernel)
+        best = (comm, 1, base_pull, 0)
         best_ms = tuning[comm.transport_name][1]
+        NWARM, NTIMED = 2, 5                          # per candidate; the slowest rank counts
         try:
             ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
             ksample = max(1, min(n // world, 2))
             u_ref = ut.leading(0, ksample).get()              # the candidates transform ut back into itself: it must stay what it was
             tol_c = 1e-9 if args.precision == "double" else 1e-3
             rejected = tuning.setdefault("rejected", {})
+
+            def candidate(c, pull, depth, cus):
+                """ms per pair of one candidate (max over ranks), or None if it no longer computes the right thing here"""
+                nonlocal ut
+                set_pull(c, pull)
+                Ft = Slab_R2C(N, L, c, args.precision, pipeline=depth, comm_cus=cus)
+                fut = DeviceArray.empty(Ft.complex_shape(), Ft.complex)
+                for it in range(NWARM + NTIMED):
+                    if it == NWARM:
+                        Ft.sync()
+                        c.barrier()
+                        tt = time.perf_counter()
+                    Ft.fftn(ut, fut)
+                    Ft.ifftn(fut, ut)
+                Ft.sync()
+                c.barrier()
+                ms = c.allreduce((time.perf_counter() - tt) / NTIMED, op=mcomm.MAX) * 1e3
+                err = float(np.linalg.norm((ut.leading(0, ksample).get() - u_ref).ravel()) / np.linalg.norm(u_ref.ravel()))
+                err = comm.allreduce(err if err == err else 1e30, op=mcomm.MAX)
+                del Ft, fut
+                if not err <= tol_c:
+                    rejected["%s:%d%s" % (cand_name(c, pull), depth, (":cus%d" % cus) if cus else "")] = err
+                    ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
+                    return None
+                return ms
+
+            # The per-peer copy streams are only worth a measurement when every rank owns a device: with ranks SHARING a
+            # device (functional runs) they add seven more queues per process, stream memory operations are spinning
+            # kernels, and the hardware scheduler's time slices are all that gets measured (seconds per pair,
+            # profiles/r03_ipc_pull_modes.txt) -- and the streams, once created, slow every later candidate down.
+            own_device = int(_lib.device_count()) >= world
             for c in comms:
-                tc = tuning.setdefault(c.transport_name, {})
-                for depth in (1, 2, 4, 8, -2, -4, -8):       # 1: blocking; kz slices / (negative) batches of local x rows
-                    if depth in tc:
+                pulls = ((1, 2, 0) if own_device else (1, 0)) if c.get_option("ipc_pull") >= 0 else (None,)
+                for pull in pulls:
+                    tc = tuning.setdefault(cand_name(c, pull), {})
+                    for depth in (1, 2, 4, 8, -2, -4, -8):       # 1: blocking; kz slices / (negative) batches of local x rows
+                        if depth in tc:
+                            continue
+                        ms = candidate(c, pull, depth, -1)       # no CU masks here; tried for the winner below
+                        if ms is None:
+                            continue
+                        tc[depth] = ms
+                        if ms < best_ms:
+                            best, best_ms = (c, depth, pull, -1), ms
+            # CUs of its own for the communication stream (mfft_plan_desc.comm_cus) only matter for a pipelined winner
+            if best[1] != 1:
+                tcu = tuning.setdefault("comm_cus", {"candidate": "%s:%d" % (cand_name(best[0], best[2]), best[1]), "none": best_ms})
+                for cus in (8, 16, 32):
+                    ms = candidate(best[0], best[2], best[1], cus)
+                    if ms is None:
                         continue
-                    Ft = Slab_R2C(N, L, c, args.precision, pipeline=depth)
-                    fut = DeviceArray.empty(Ft.complex_shape(), Ft.complex)
-                    for it in range(4):
-                        if it == 2:
-                            Ft.sync()
-                            c.barrier()
-                            tt = time.perf_counter()
-                        Ft.fftn(ut, fut)
-                        Ft.ifftn(fut, ut)
-                    Ft.sync()
-                    c.barrier()
-                    tc[depth] = c.allreduce((time.perf_counter() - tt) / 2, op=mcomm.MAX) * 1e3
-                    # a candidate only counts if it still computes the right thing on THIS machine's wire
-                    err = float(np.linalg.norm((ut.leading(0, ksample).get() - u_ref).ravel()) / np.linalg.norm(u_ref.ravel()))
-                    err = comm.allreduce(err if err == err else 1e30, op=mcomm.MAX)
-                    del Ft, fut
-                    if not err <= tol_c:
-                        rejected["%s:%d" % (c.transport_name, depth)] = err
-                        ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
-                        continue
-                    if tc[depth] < best_ms:
-                        best, best_ms = (c, depth), tc[depth]
+                    tcu[str(cus)] = ms
+                    if ms < best_ms:
+                        best, best_ms = (best[0], best[1], best[2], cus), ms
             del ut
             if not rejected:
                 del tuning["rejected"]
@@ -399,7 +449,7 @@ def main():
             sys.stderr.write("exchange tuning failed (%s: %s); keeping the best candidate so far\n" % (type(e).__name__, e))
             tuning["error"] = "%s: %s" % (type(e).__name__, e)
         # 3. the timed region with the best candidate (the first measurement stands if nothing beats it)
-        mres = base if best == (comm, 1) else measure(best[1], best[0])
+        mres = base if best == (comm, 1, base_pull, 0) else measure(best[1], best[0], best[2], best[3])
         dog.cancel()
     else:
         mres = measure(args.pipeline)
@@ -412,41 +462,58 @@ def main():
                                                  and world in (1, 4, 8, 16))
     watchdog = None
     if want_pencil and world > 1:
-        watchdog = arm_watchdog(300.0, out, "the pencil measurement did not finish within 300 s")
+        watchdog = arm_watchdog(600.0, out, "the pencil measurement did not finish within 600 s")
     if want_pencil:
         try:
             pcomm = best[0] if (world > 1 and tuning is not None) else comm      # the transport that won the slab measurement
-            per_depth = {}
-            for depth in ((1, 4) if world > 1 else (1,)):        # blocking exchanges / the X pipeline (batches of local x rows)
-                Fp = Pencil_R2C(N, L, pcomm, args.precision, communication="Alltoallw", alignment="X", allow_single=True,
-                                pipeline=depth)
-                up = DeviceArray.random(Fp.real_shape(), Fp.float, seed=99 + rank)
-                fup = DeviceArray.empty(Fp.complex_shape(), Fp.complex)
-                up2 = DeviceArray.empty(Fp.real_shape(), Fp.float)
-                for _ in range(2):
-                    Fp.fftn(up, fup)
-                    Fp.ifftn(fup, up2)
-                Fp.sync()
-                pcomm.barrier()
-                ksteps = max(3, min(args.steps, 10))
-                tp = time.perf_counter()
-                for _ in range(ksteps):
-                    Fp.fftn(up, fup)
-                    Fp.ifftn(fup, up2)
-                Fp.sync()
-                pcomm.barrier()
-                dtp = time.perf_counter() - tp
-                dtp = pcomm.allreduce(dtp, op=mcomm.MAX) if world > 1 else dtp
-                a0 = up.leading(0, 1).get()
-                b0 = up2.leading(0, 1).get()
-                per_depth[depth] = {"grid": [int(Fp.P1), int(Fp.P2)], "pairs_per_s": ksteps / dtp,
-                                    "ms_per_pair": 1e3 * dtp / ksteps, "steps": ksteps, "exchange_pipeline_depth": depth,
-                                    "exchange_transport": comm_name(pcomm) if world > 1 else None,
-                                    "roundtrip_rel_l2": float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))}
-                del Fp, up, fup, up2
-            bestp = min(per_depth, key=lambda k_: per_depth[k_]["ms_per_pair"])
-            extras["pencil_R2CX"] = dict(per_depth[bestp], ms_per_pair_by_depth={str(k_): v["ms_per_pair"] for k_, v in per_depth.items()},
-                                         roundtrip_rel_l2=max(v["roundtrip_rel_l2"] for v in per_depth.values()))
+            if world > 1:
+                set_pull(pcomm, best[2])
+            # process grids: the reference's default (MPI.Compute_dims: 4x2 for 8 ranks) and the others the C ABI takes.
+            # On a fully connected xGMI node an exchange inside a group of g ranks uses g - 1 of a GPU's seven links, so
+            # the P x 1 and 1 x P grids (one exchange over all ranks, like the slab) are candidates, not curiosities.
+            grids = [None]
+            if world > 1:
+                grids = [(a, world // a) for a in range(1, world + 1) if world % a == 0 and n % a == 0 and n % (world // a) == 0
+                         and (n // 2 + 1) % (world // a) <= 1 and (world // a == 1 or (n // (world // a)) % 2 == 0)]
+            per_cand = {}
+            for grid in grids:
+                for depth in ((1, 4) if world > 1 else (1,)):        # blocking exchanges / the X pipeline (batches of local x rows)
+                    Fp = Pencil_R2C(N, L, pcomm, args.precision, P1=(grid[0] if grid else None), communication="Alltoallw",
+                                    alignment="X", allow_single=True, allow_odd_grid=True, pipeline=depth)
+                    up = DeviceArray.random(Fp.real_shape(), Fp.float, seed=99 + rank)
+                    fup = DeviceArray.empty(Fp.complex_shape(), Fp.complex)
+                    up2 = DeviceArray.empty(Fp.real_shape(), Fp.float)
+                    for _ in range(2):
+                        Fp.fftn(up, fup)
+                        Fp.ifftn(fup, up2)
+                    Fp.sync()
+                    pcomm.barrier()
+                    ksteps = max(3, min(args.steps, 10)) if len(grids) == 1 else 5
+                    tp = time.perf_counter()
+                    for _ in range(ksteps):
+                        Fp.fftn(up, fup)
+                        Fp.ifftn(fup, up2)
+                    Fp.sync()
+                    pcomm.barrier()
+                    dtp = time.perf_counter() - tp
+                    dtp = pcomm.allreduce(dtp, op=mcomm.MAX) if world > 1 else dtp
+                    a0 = up.leading(0, 1).get()
+                    b0 = up2.leading(0, 1).get()
+                    rt = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
+                    rt = pcomm.allreduce(rt if rt == rt else 1e30, op=mcomm.MAX) if world > 1 else rt
+                    per_cand[(int(Fp.P1), int(Fp.P2), depth)] = {
+                        "grid": [int(Fp.P1), int(Fp.P2)], "pairs_per_s": ksteps / dtp, "ms_per_pair": 1e3 * dtp / ksteps,
+                        "steps": ksteps, "exchange_pipeline_depth": depth,
+                        "exchange_transport": cand_name(pcomm, best[2]) if world > 1 else None, "roundtrip_rel_l2": rt}
+                    del Fp, up, fup, up2
+            bestp = min(per_cand, key=lambda k_: per_cand[k_]["ms_per_pair"])
+            table = {"%dx%d:%d" % k_: v["ms_per_pair"] for k_, v in per_cand.items()}
+            extras["pencil_R2CX"] = dict(per_cand[bestp], ms_per_pair_by_grid_and_depth=table,
+                                         roundtrip_rel_l2=max(v["roundtrip_rel_l2"] for v in per_cand.values()))
+            # the reference's own default grid, whatever won
+            dflt = [v for k_, v in per_cand.items() if grids[0] is None or list(k_[:2]) == list(_default_grid(world))]
+            if dflt:
+                extras["pencil_R2CX"]["default_grid_ms_per_pair"] = min(v["ms_per_pair"] for v in dflt)
         except Exception as e:      # noqa: BLE001  - the headline (slab) line must survive
             extras["pencil_R2CX"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if watchdog is not None:

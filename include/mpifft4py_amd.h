@@ -85,6 +85,13 @@ MFFT_API int mfft_comm_barrier(mfft_comm_t comm);
  * timeout_ms for the device: 0 = the transport moves data correctly here.  A hung IPC exchange is released from the
  * host and reported as an error instead of blocking forever. */
 MFFT_API int mfft_comm_selftest(mfft_comm_t comm, size_t bytes_per_peer, int timeout_ms);
+/* Transport knobs, per communicator.  The IPC transport (the stand-in for the MPI library's intra-node all-to-all,
+ * slab.py:406/281, pencil.py:741-750) knows "ipc_pull" = how a rank fetches its chunks from the peers' buffers: 1 one
+ * pull kernel over all peers at once (default), 2 one copy-engine transfer per peer on per-peer streams, 0 copy-engine
+ * transfers one after the other; and "ipc_pull_wgs" = workgroups per peer of that kernel.  A rank-local choice (the
+ * flag protocol is the same), other transports reject every key; get returns -1 in *value for an unknown key. */
+MFFT_API int mfft_comm_set_option(mfft_comm_t comm, const char* key, int64_t value);
+MFFT_API int mfft_comm_get_option(mfft_comm_t comm, const char* key, int64_t* value);
 /* host-buffer helpers for tests/demos (tests/test_FFT.py:77-78 Bcast; demo:103 reduce) */
 MFFT_API int mfft_comm_bcast_host(mfft_comm_t comm, void* buf_host, size_t bytes, int root);
 MFFT_API int mfft_comm_allreduce_sum_host(mfft_comm_t comm, double* vals_host, int count);
@@ -113,7 +120,9 @@ typedef struct {
   int line2d;         /* 1: the 2-D class of line.py:41-340, expressed as an x-aligned pencil plan of the mesh
                          (1, Nx, Ny) on a 1 x P grid: padsize^2 scaling, no Nyquist fold on one rank (line.py:185)
                          and, for P > 1, the Nyquist packing of line.py:231 in the padded forward transform */
-  int reserved[5];
+  int comm_cus;       /* pipelined plans: compute units set aside for the communication stream (the compute stream gets
+                         the others): > 0 that many, 0 = $MFFT_COMM_CUS or the library default, < 0 = no CU masks */
+  int reserved[4];
 } mfft_plan_desc;
 
 MFFT_API int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* plan);

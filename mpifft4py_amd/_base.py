@@ -34,10 +34,26 @@ class DistFFTBase(object):
         self.padsize = padsize
         self.threads = threads                  # accepted, unused (FFTW knob)
         self.planner_effort = planner_effort    # accepted, unused (FFTW knob)
+        self._mask_set = False
         self.dealias = np.zeros(0)
         self.work_arrays = work_arrays()
         self._plan = None
         self._stage = {}
+        if not hasattr(self, "_comm_cus"):
+            self._comm_cus = 0
+
+    # The reference reads `self.dealias` on every '2/3-rule' call (slab.py:237-245, pencil.py:455-462), so a caller may
+    # replace the filter at any time.  Here the filter lives on the device: assigning to `dealias` marks the device copy
+    # stale and the next '2/3-rule' transform uploads the new one (mfft_plan_set_dealias_mask -- COLLECTIVE for plans
+    # over more than one rank: every rank must then assign before its next dealiased call, as every rank of the
+    # reference would).  Editing the array IN PLACE is not seen: re-assign it (`F.dealias = F.dealias`).
+    @property
+    def dealias(self):
+        return self._dealias
+
+    @dealias.setter
+    def dealias(self, value):
+        self._dealias = value
         self._mask_set = False
 
     def _create_plan(self, kind, decomp, p1=0, pipeline=0, drop_nyquist=False, line2d=False):
@@ -52,6 +68,7 @@ class DistFFTBase(object):
         d.pipeline = int(pipeline)
         d.drop_nyquist = 1 if drop_nyquist else 0
         d.line2d = 1 if line2d else 0
+        d.comm_cus = int(getattr(self, "_comm_cus", 0) or 0)
         self.comm.use_device()
         h = ctypes.c_void_p()
         _lib.call("mfft_plan_create", self.comm._handle, ctypes.byref(d), ctypes.byref(h))
@@ -98,7 +115,7 @@ class DistFFTBase(object):
     def _ensure_mask(self):
         if self._mask_set:
             return
-        if self.dealias.shape == (0,):
+        if np.shape(self.dealias) == (0,):
             self.dealias = self.get_dealias_filter()
         m = np.ascontiguousarray(np.broadcast_to(self.dealias, self.complex_shape()), dtype=np.uint8)
         _lib.call("mfft_plan_set_dealias_mask", self._plan, m.ctypes.data, m.size)

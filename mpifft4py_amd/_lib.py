@@ -22,7 +22,7 @@ UNIQUE_ID_BYTES = 128
 class PlanDesc(ctypes.Structure):
     _fields_ = [("n", c_int64 * 3), ("precision", c_int), ("kind", c_int), ("decomp", c_int),
                 ("p1", c_int), ("padsize", c_double), ("pipeline", c_int), ("drop_nyquist", c_int),
-                ("line2d", c_int), ("reserved", c_int * 5)]
+                ("line2d", c_int), ("comm_cus", c_int), ("reserved", c_int * 4)]
 
 
 class MfftError(RuntimeError):
@@ -52,6 +52,8 @@ _SIGNATURES = {
     "mfft_comm_rank": ([c_void_p, POINTER(c_int)], c_int),
     "mfft_comm_barrier": ([c_void_p], c_int),
     "mfft_comm_selftest": ([c_void_p, c_size_t, c_int], c_int),
+    "mfft_comm_set_option": ([c_void_p, c_char_p, c_int64], c_int),
+    "mfft_comm_get_option": ([c_void_p, c_char_p, POINTER(c_int64)], c_int),
     "mfft_comm_bcast_host": ([c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_comm_allreduce_sum_host": ([c_void_p, POINTER(c_double), c_int], c_int),
     "mfft_comm_allreduce_max_host": ([c_void_p, POINTER(c_double), c_int], c_int),

@@ -48,6 +48,16 @@ class _CommBase(object):
         """Collective: one small verified all-to-all; raises if the transport does not move data correctly here."""
         _lib.call("mfft_comm_selftest", self._handle, bytes_per_peer, timeout_ms)
 
+    def set_option(self, key, value):
+        """Transport knob (mfft_comm_set_option), e.g. ("ipc_pull", 0 | 1 | 2) on the IPC transport."""
+        _lib.call("mfft_comm_set_option", self._handle, key.encode(), int(value))
+
+    def get_option(self, key):
+        import ctypes
+        v = ctypes.c_int64(-1)
+        _lib.call("mfft_comm_get_option", self._handle, key.encode(), ctypes.byref(v))
+        return int(v.value)
+
     def barrier(self):
         _lib.call("mfft_comm_barrier", self._handle)
 
@@ -173,11 +183,24 @@ def _publisher_alive(pid, same_parent):
     return True
 
 
-def _file_bcast(rank, payload, timeout=300.0):
+def _rdv_timeout():
+    """Not longer than the transports' own attach / barrier timeout ($MFFT_LOCAL_TIMEOUT, 180 s): a rank that waits here
+    for a publisher that has moved on must give up before the publisher's next collective does."""
+    try:
+        return max(5.0, float(os.environ.get("MFFT_LOCAL_TIMEOUT", "180")) - 10.0)
+    except ValueError:
+        return 170.0
+
+
+_UID_FAILED = b"MFFTFAIL"      # rank 0 could not create the id: the rest of the payload is the error text
+
+
+def _file_bcast(rank, payload, timeout=None):
     """Single-node rendezvous through a file: rank 0 publishes, the rest poll.  The file carries the publisher's pid;
     readers only accept it while that process is alive (and is a child of the same launcher), so a file left behind by
     a crashed earlier launch with the same port and parent is never mistaken for this launch's id."""
     path, same_parent = _rendezvous_path()
+    timeout = _rdv_timeout() if timeout is None else timeout
     if rank == 0:
         try:
             os.unlink(path)                # a leftover of an earlier launch
@@ -222,13 +245,19 @@ def from_env(bcast=None, transport=None):
     if world == 1:
         return SelfComm(device)
     _lib.call("mfft_set_device", device)
-    uid = None
+    uid, failure = None, None
     if rank == 0:
         saved = os.environ.get("MFFT_TRANSPORT")
         if transport is not None:
             os.environ["MFFT_TRANSPORT"] = transport
         try:
             uid = get_unique_id()
+        except Exception as e:      # noqa: BLE001
+            # (librccl missing, bad MFFT_TRANSPORT, ...)  The other ranks are about to wait for the id: tell them, so
+            # that every rank leaves THIS rendezvous with the same error instead of timing out in a later one
+            failure = e
+            msg = ("%s: %s" % (type(e).__name__, e)).encode()[:_lib.UNIQUE_ID_BYTES - len(_UID_FAILED)]
+            uid = (_UID_FAILED + msg).ljust(_lib.UNIQUE_ID_BYTES, b"\0")
         finally:
             if transport is not None:
                 if saved is None:
@@ -240,6 +269,11 @@ def from_env(bcast=None, transport=None):
         uid = bcast(uid)
     else:
         uid, path = _file_bcast(rank, uid)
+    if failure is not None:
+        raise failure
+    if bytes(uid[:len(_UID_FAILED)]) == _UID_FAILED:
+        raise _lib.MfftError("rank 0 could not create the communicator id: %s"
+                             % bytes(uid[len(_UID_FAILED):]).rstrip(b"\0").decode(errors="replace"))
     c = DistComm(world, rank, uid, device)
     c.barrier()
     if path and rank == 0:

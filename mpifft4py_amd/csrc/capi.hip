@@ -118,6 +118,15 @@ int mfft_comm_selftest(mfft_comm_t c, size_t bytes_per_peer, int timeout_ms) {
   if (!c || timeout_ms <= 0) return set_error(MFFT_ERR_INVALID, "bad argument");
   return c->selftest(bytes_per_peer ? bytes_per_peer : 4096, timeout_ms);
 }
+int mfft_comm_set_option(mfft_comm_t c, const char* key, int64_t value) {
+  if (!c || !key) return set_error(MFFT_ERR_INVALID, "null argument");
+  return c->set_option(key, (long long)value);
+}
+int mfft_comm_get_option(mfft_comm_t c, const char* key, int64_t* value) {
+  if (!c || !key || !value) return set_error(MFFT_ERR_INVALID, "null argument");
+  *value = (int64_t)c->get_option(key);
+  return 0;
+}
 int mfft_comm_abort(mfft_comm_t c) {
   if (c) c->abort();
   return 0;

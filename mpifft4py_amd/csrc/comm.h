@@ -5,10 +5,11 @@
 //   SelfComm  : P = 1.
 //   RcclComm  : one process per GPU, RCCL (loaded with dlopen at first use) over
 //               xGMI; the exchange is a grouped ncclSend/ncclRecv all-to-all-v.
-//   IpcComm   : one process per GPU on one node; chunks are pushed into the peers'
-//               IPC-mapped receive buffers by the copy engines, cross-process
-//               ordering through stream memory operations (ipc_comm.hip).  Selected
-//               with MFFT_TRANSPORT=ipc on rank 0 (the unique id names the transport).
+//   IpcComm   : one process per GPU on one node; every rank PULLS its chunks out of
+//               the peers' IPC-mapped work buffers (one pull kernel over all peers, or
+//               copy-engine transfers), cross-process ordering through stream memory
+//               operations (ipc_comm.hip).  Selected with MFFT_TRANSPORT=ipc on rank 0
+//               (the unique id names the transport).
 //   LocalComm : P virtual ranks inside ONE process, each driven by its own host
 //               thread, exchanging with peer-to-peer device copies.  Used for
 //               single-process multi-GPU runs and to exercise the full
@@ -42,6 +43,9 @@ struct mfft_comm_s {
   // try a transport on a machine it has never run on without risking a hang (bench.py --transport auto).
   int selftest(size_t bytes_per_peer, int timeout_ms);
   virtual void rescue() {}
+  // transport-specific knobs (mfft_comm_set_option / mfft_comm_get_option); unknown keys are an error / -1
+  virtual int set_option(const char* key, long long value);
+  virtual long long get_option(const char* key);
   // plans hold a reference: a communicator destroyed before its plans lives until the last of them is gone
   int plan_refs = 0;
   bool destroy_requested = false;

@@ -14,6 +14,8 @@
 
 int mfft_comm_s::work_alloc(void** p, size_t bytes) { return mfft::dev_alloc(p, bytes); }
 int mfft_comm_s::work_free(void* p) { return mfft::dev_free(p); }
+int mfft_comm_s::set_option(const char* key, long long) { return mfft::set_error(MFFT_ERR_INVALID, "this transport has no option '%s'", key); }
+long long mfft_comm_s::get_option(const char*) { return -1; }
 
 int mfft_comm_s::selftest(size_t bytes_per_peer, int timeout_ms) {
   using namespace mfft;

@@ -113,7 +113,7 @@ struct ColParams {
   int remap;             // 1: XCD-aware block -> tile mapping, 2: the same with skewed entry points (power-of-two tile ranges)
   int fold;              // PAD == 2: 1 = add the Nyquist row N/3 into row 2N/3 before it is stored
   T scale;
-  int nblocks;           // persistent experiment (fft_persist_experiment.h): workgroups launched; unused by ColFft
+  int nblocks;           // persistent experiment (tools/fft_persist_experiment.h): workgroups launched; unused by ColFft
   const unsigned char* mask;   // PAD == 3: one byte per element of `in` (same offsets); 0 = the element reads as zero
   // PAD == 4 (pruned 2/3-rule pass): rows [b_row_lo, b_row_hi) read as zero without being loaded; column j of outer
   // batch o has z = (b_coff + j) % b_cper and y = b_goff + (b_coff + j) / b_cper + o * b_gstep and is KEPT iff

@@ -1,6 +1,12 @@
 // ipc_comm.hip -- IpcComm: one process per GPU on ONE node; every rank PULLS its chunks out of the peers' send
-// buffers with hipMemcpyAsync through IPC-mapped device memory.  No kernel of the transport ever occupies a CU: on
-// xGMI a peer-to-peer copy is an SDMA transfer.
+// buffers through IPC-mapped device memory.  Three ways to pull (MFFT_IPC_PULL, mfft_comm_set_option "ipc_pull"):
+//   kernel  (default) ONE launch of ipc_pull_kernel (ipc_pull.h) reads from all peers' mappings at once, a few
+//           workgroups per peer: every xGMI link of the fully connected node carries data at the same time; the launch
+//           runs on the plan's communication stream, which plan.hip confines to a handful of CUs (MFFT_COMM_CUS);
+//   streams one hipMemcpyAsync per peer, each on a stream of its own (fork / join events around them): the copy
+//           engines of several links at once, no CU at all;
+//   copy    round 2's path: the hipMemcpyAsync's one after the other on the issuing stream (one link at a time).
+// The flag protocol below is the same for all three.
 //
 // Replaces, like RcclComm, the mpi4py collectives of the reference (comm.Alltoall slab.py:406/281, Alltoallw
 // pencil.py:741-750, 1324-1333).  Why a second transport: RCCL's send/recv are kernels, and the FFT kernels keep every
@@ -8,7 +14,7 @@
 // between processes that share ONE GPU, which RCCL refuses, so the process-per-GPU path is tested for real (no mock)
 // on a single-GPU box.
 //
-// Design, each point decided by a measurement on this pool (csrc/ipc_probe.hip, tests/test_gpu_multiprocess.py):
+// Design, each point decided by a measurement on this pool (tools/ipc_probe.hip, tests/test_gpu_multiprocess.py):
 //  * Only plan work buffers are ever the SOURCE of an exchange (plan.hip), and they come from an arena this
 //    communicator owns (work_alloc): segments of device memory that are exported once, when they are created, and
 //    live as long as the communicator.  Exporting arbitrary buffers on demand does not survive long runs: after a
@@ -37,6 +43,7 @@
 #include <thread>
 #include <vector>
 #include "comm.h"
+#include "ipc_pull.h"
 #include "mfft_internal.h"
 
 namespace mfft {
@@ -118,8 +125,43 @@ struct IpcComm : mfft_comm_s {
   hipStream_t last_stream[IPC_MAX_CH] = {};
   hipEvent_t last_issue[IPC_MAX_CH] = {};
   bool used_ch[IPC_MAX_CH] = {};
+  // how the receiver role moves the bytes (see the head of this file)
+  enum { PULL_COPY = 0, PULL_KERNEL = 1, PULL_STREAMS = 2 };
+  int pull_mode = PULL_KERNEL;
+  int pull_wgs = 8;                                        // kernel mode: workgroups per peer chunk
+  hipStream_t pstream[IPC_MAX_RANKS] = {};                 // streams mode: one copy stream per peer (normal priority)
+  hipEvent_t fork_ev[IPC_MAX_CH] = {}, join_ev[IPC_MAX_RANKS][IPC_MAX_CH] = {};
+
+  IpcComm() {
+    if (const char* e = getenv("MFFT_IPC_PULL")) {
+      if (!strcmp(e, "copy")) pull_mode = PULL_COPY;
+      else if (!strcmp(e, "streams")) pull_mode = PULL_STREAMS;
+      else pull_mode = PULL_KERNEL;
+    }
+    if (const char* e = getenv("MFFT_IPC_PULL_WGS")) pull_wgs = std::max(1, std::min(64, atoi(e)));
+  }
+  int set_option(const char* key, long long v) override {
+    if (!strcmp(key, "ipc_pull")) {
+      if (v < 0 || v > 2) return set_error(MFFT_ERR_INVALID, "ipc_pull: 0 copy, 1 kernel, 2 streams");
+      pull_mode = (int)v;
+      return 0;
+    }
+    if (!strcmp(key, "ipc_pull_wgs")) {
+      if (v < 1 || v > 64) return set_error(MFFT_ERR_INVALID, "ipc_pull_wgs: 1 .. 64 workgroups per peer");
+      pull_wgs = (int)v;
+      return 0;
+    }
+    return mfft_comm_s::set_option(key, v);
+  }
+  long long get_option(const char* key) override {
+    if (!strcmp(key, "ipc_pull")) return pull_mode;
+    if (!strcmp(key, "ipc_pull_wgs")) return pull_wgs;
+    return mfft_comm_s::get_option(key);
+  }
 
   ~IpcComm() override {
+    // a broken group never satisfies the waits that are still enqueued: release mine before waiting for the device
+    if (sh && sh->broken.load()) rescue();
     (void)hipDeviceSynchronize();
     if (sh) {
       // peers may still pull from my segments or wait on my events: leave together (best effort, bounded)
@@ -135,7 +177,12 @@ struct IpcComm : mfft_comm_s {
     for (int ch = 0; ch < IPC_MAX_CH; ++ch) {
       if (release_ev[ch]) (void)hipEventDestroy(release_ev[ch]);
       if (last_issue[ch]) (void)hipEventDestroy(last_issue[ch]);
+      if (fork_ev[ch]) (void)hipEventDestroy(fork_ev[ch]);
+      for (int r = 0; r < IPC_MAX_RANKS; ++r)
+        if (join_ev[r][ch]) (void)hipEventDestroy(join_ev[r][ch]);
     }
+    for (hipStream_t ps : pstream)
+      if (ps) (void)hipStreamDestroy(ps);
     if (flags) (void)hipFree(flags);
     for (Seg& s : segs) (void)hipFree(s.base);
     if (sh) munmap(sh, sizeof(IpcShm));
@@ -245,6 +292,11 @@ struct IpcComm : mfft_comm_s {
   }
   int work_free(void* p) override {
     if (!p) return 0;
+    // As safe as the hipFree it stands in for: the block may be handed to another plan (another stream) at once, while
+    // transforms of the plan that owned it are still in flight and peers still pull from it (their "done" flags are
+    // awaited in-stream only).  Once this device is idle every such wait of mine has been satisfied.  Growth is rare.
+    if (sh && sh->broken.load()) rescue();
+    MFFT_HIP(hipDeviceSynchronize());
     for (Seg& s : segs) {
       if (static_cast<char*>(p) < s.base || static_cast<char*>(p) >= s.base + s.size) continue;
       const uint64_t off = (uint64_t)(static_cast<char*>(p) - s.base);
@@ -290,21 +342,31 @@ struct IpcComm : mfft_comm_s {
   int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
                 const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int channel) override {
     const int rc = exchange(send, scount, sdisp, recv, rcount, rdisp, peers, npeers, s, channel);
-    if (rc != 0) sh->broken.store(1);      // the peers are (or will be) waiting in a host barrier: let them fail fast
+    // the peers are (or will be) waiting in a host barrier: let them fail fast; and whatever this rank has already
+    // enqueued behind a flag that will never come must not block the device for good (plan_sync, memcpy helpers)
+    if (rc != 0) rescue();
     return rc;
+  }
+  int peer_stream(int p, hipStream_t* out) {
+    if (!pstream[p]) MFFT_HIP(hipStreamCreateWithFlags(&pstream[p], hipStreamNonBlocking));
+    *out = pstream[p];
+    return 0;
   }
   int exchange(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
                const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int ch) {
     if (ch < 0 || ch >= IPC_MAX_CH) return set_error(MFFT_ERR_INVALID, "ipc transport: channel %d", ch);
     if (npeers > IPC_MAX_RANKS) return set_error(MFFT_ERR_INVALID, "ipc transport: group of %d", npeers);
+    if (sh->broken.load()) return set_error(MFFT_ERR_INTERNAL, "ipc transport: the group is broken (a rank failed earlier)");
     int myidx = -1;
     for (int i = 0; i < npeers; ++i)
       if (peers[i] == rank) myidx = i;
     if (myidx < 0) return set_error(MFFT_ERR_INVALID, "ipc transport: rank %d not in its own group", rank);
+    if (rcount[myidx] && scount[myidx] != rcount[myidx]) return set_error(MFFT_ERR_INVALID, "ipc transport: self chunk size mismatch");
     // exchanges of one channel execute in the order they are issued, also when the channel moves to another stream
     if (!last_issue[ch]) MFFT_HIP(hipEventCreateWithFlags(&last_issue[ch], hipEventDisableTiming));
     if (used_ch[ch]) MFFT_HIP(hipStreamWaitEvent(s, last_issue[ch], 0));     // (a no-op on the same stream; a new stream may reuse a dead one's handle)
-    if (!release_ev[ch]) MFFT_HIP(hipEventCreateWithFlags(&release_ev[ch], hipEventDisableTiming));
+    // a record of this event is a release to SYSTEM scope of what the kernels before it wrote: the readers are other devices
+    if (!release_ev[ch]) MFFT_HIP(hipEventCreateWithFlags(&release_ev[ch], hipEventDisableTiming | hipEventReleaseToSystem));
     const char* sp = static_cast<const char*>(send);
     char* rp = static_cast<char*>(recv);
     // 1. sender role: say where each peer finds its chunk (host), then, on the stream, that the data is there
@@ -314,7 +376,7 @@ struct IpcComm : mfft_comm_s {
     uint64_t soff = 0;
     if (any_send) {
       MFFT_TRY(locate(send, &seg, &soff));
-      MFFT_HIP(hipEventRecord(release_ev[ch], s));         // system-scope release of what the kernels before us wrote
+      MFFT_HIP(hipEventRecord(release_ev[ch], s));
     }
     std::vector<uint32_t> qs(npeers, 0);
     for (int i = 0; i < npeers; ++i) {
@@ -330,12 +392,10 @@ struct IpcComm : mfft_comm_s {
       post.seq.store(q, std::memory_order_release);
       MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[p]->ready[rank][ch], q, 0));
     }
-    // 2. the self chunk
-    if (rcount[myidx]) {
-      if (scount[myidx] != rcount[myidx]) return set_error(MFFT_ERR_INVALID, "ipc transport: self chunk size mismatch");
-      MFFT_HIP(hipMemcpyAsync(rp + rdisp[myidx], sp + sdisp[myidx], rcount[myidx], hipMemcpyDeviceToDevice, s));
-    }
-    // 3. receiver role: pull every chunk out of its sender's segment (starting with the next rank: spreads the links)
+    // 2. receiver role, host part: where does every chunk lie (starting with the next rank: spreads the links when the
+    //    chunks are pulled one after the other).  Nothing of the receiver role is enqueued before all posts are in.
+    struct Pull { int i, p; uint32_t q; const char* src; };
+    std::vector<Pull> pulls;
     for (int k = 1; k < npeers; ++k) {
       const int i = (myidx + k) % npeers, p = peers[i];
       if (!rcount[i]) continue;
@@ -351,9 +411,53 @@ struct IpcComm : mfft_comm_s {
                          (unsigned long long)bytes);
       char* rbase = nullptr;
       MFFT_TRY(remote_base(p, pseg, &rbase));
-      MFFT_HIP(hipStreamWaitValue32(s, &flags->ready[p][ch], q, hipStreamWaitValueGte, 0xFFFFFFFFu));
-      MFFT_HIP(hipMemcpyAsync(rp + rdisp[i], rbase + off, rcount[i], hipMemcpyDeviceToDevice, s));
-      MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[p]->done[rank][ch], q, 0));
+      pulls.push_back(Pull{i, p, q, rbase + off});
+    }
+    // 3. receiver role, device part
+    if (pull_mode == PULL_KERNEL) {
+      // one launch for the self chunk and every peer's chunk, behind the waits for all of them
+      for (const Pull& u : pulls) MFFT_HIP(hipStreamWaitValue32(s, &flags->ready[u.p][ch], u.q, hipStreamWaitValueGte, 0xFFFFFFFFu));
+      PullArgs pa;
+      memset(&pa, 0, sizeof pa);
+      if (rcount[myidx]) pa.job[pa.njobs++] = PullJob{sp + sdisp[myidx], rp + rdisp[myidx], (unsigned long long)rcount[myidx]};
+      for (const Pull& u : pulls) pa.job[pa.njobs++] = PullJob{u.src, rp + rdisp[u.i], (unsigned long long)rcount[u.i]};
+      // pull_wgs workgroups per chunk is sized for an xGMI link; small groups get more, so that the launch as a whole
+      // (the self chunk is a local copy) never has fewer than 56 workgroups (= 7 peers x 8)
+      pa.wgs = pa.njobs > 0 ? std::max(pull_wgs, (56 + pa.njobs - 1) / pa.njobs) : pull_wgs;
+      MFFT_HIP(launch_pull(pa, s));
+      for (const Pull& u : pulls) MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[u.p]->done[rank][ch], u.q, 0));
+    } else if (pull_mode == PULL_STREAMS && !pulls.empty()) {
+      // every peer's copy on that peer's own stream, forked from and joined back into the issuing stream.  ALL flag
+      // operations stay on the issuing stream (waits before the fork, "done" writes behind the join): the per-peer
+      // streams carry nothing but one copy each.  (With the waits and writes on the per-peer streams -- round 2's
+      // experiment, MFFT_IPC_STREAM_FLAGS=1 -- 8 processes on one device were 100x slower and pipelined transforms
+      // came back wrong now and then; see profiles/r03_ipc_pull_modes.txt for the differential test.)
+      static const bool flags_on_peer_streams = getenv("MFFT_IPC_STREAM_FLAGS") && atoi(getenv("MFFT_IPC_STREAM_FLAGS")) != 0;
+      if (!fork_ev[ch]) MFFT_HIP(hipEventCreateWithFlags(&fork_ev[ch], hipEventDisableTiming));
+      if (!flags_on_peer_streams)
+        for (const Pull& u : pulls) MFFT_HIP(hipStreamWaitValue32(s, &flags->ready[u.p][ch], u.q, hipStreamWaitValueGte, 0xFFFFFFFFu));
+      MFFT_HIP(hipEventRecord(fork_ev[ch], s));
+      for (const Pull& u : pulls) {
+        hipStream_t ps = nullptr;
+        MFFT_TRY(peer_stream(u.p, &ps));
+        if (!join_ev[u.p][ch]) MFFT_HIP(hipEventCreateWithFlags(&join_ev[u.p][ch], hipEventDisableTiming));
+        MFFT_HIP(hipStreamWaitEvent(ps, fork_ev[ch], 0));
+        if (flags_on_peer_streams) MFFT_HIP(hipStreamWaitValue32(ps, &flags->ready[u.p][ch], u.q, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        MFFT_HIP(hipMemcpyAsync(rp + rdisp[u.i], u.src, rcount[u.i], hipMemcpyDeviceToDevice, ps));
+        if (flags_on_peer_streams) MFFT_HIP(hipStreamWriteValue32(ps, &peer_flags[u.p]->done[rank][ch], u.q, 0));
+        MFFT_HIP(hipEventRecord(join_ev[u.p][ch], ps));
+      }
+      if (rcount[myidx]) MFFT_HIP(hipMemcpyAsync(rp + rdisp[myidx], sp + sdisp[myidx], rcount[myidx], hipMemcpyDeviceToDevice, s));
+      for (const Pull& u : pulls) MFFT_HIP(hipStreamWaitEvent(s, join_ev[u.p][ch], 0));
+      if (!flags_on_peer_streams)
+        for (const Pull& u : pulls) MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[u.p]->done[rank][ch], u.q, 0));
+    } else {
+      if (rcount[myidx]) MFFT_HIP(hipMemcpyAsync(rp + rdisp[myidx], sp + sdisp[myidx], rcount[myidx], hipMemcpyDeviceToDevice, s));
+      for (const Pull& u : pulls) {
+        MFFT_HIP(hipStreamWaitValue32(s, &flags->ready[u.p][ch], u.q, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        MFFT_HIP(hipMemcpyAsync(rp + rdisp[u.i], u.src, rcount[u.i], hipMemcpyDeviceToDevice, s));
+        MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[u.p]->done[rank][ch], u.q, 0));
+      }
     }
     // 4. sender role: nobody overwrites its send buffer before all peers have pulled from it
     for (int i = 0; i < npeers; ++i)
@@ -423,6 +527,12 @@ int comm_create_ipc(int nranks, int rank, const void* id128, mfft_comm_s** out) 
   if (m == MAP_FAILED) return set_error(MFFT_ERR_INTERNAL, "mmap of %s failed: %s", c->shm_name.c_str(), strerror(errno));
   c->sh = static_cast<IpcShm*>(m);
   IpcShm* sh = c->sh;
+  // any failure from here on leaves the group unusable: say so, so that the peers' spins fail at once instead of
+  // timing out and this rank's destructor does not wait for them to detach
+  struct BreakOnFailure {
+    IpcShm* sh; bool armed;
+    ~BreakOnFailure() { if (armed) sh->broken.store(1); }
+  } guard{sh, true};
   if (rank == 0) {
     sh->nranks = nranks;                                // the segment is zero-filled by ftruncate
     sh->magic.store(IPC_MAGIC, std::memory_order_release);
@@ -472,6 +582,7 @@ int comm_create_ipc(int nranks, int rank, const void* id128, mfft_comm_s** out) 
     (void)shm_unlink(c->shm_name.c_str());
     c->creator = false;
   }
+  guard.armed = false;
   *out = c.release();
   return 0;
 }

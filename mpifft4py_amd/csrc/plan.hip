@@ -21,6 +21,10 @@ using namespace mfft;
 
 namespace {
 
+#ifndef MFFT_DEFAULT_COMM_CUS
+#define MFFT_DEFAULT_COMM_CUS 0
+#endif
+
 struct StageTimer {
   std::string name;
   double alg_bytes = 0;
@@ -101,6 +105,7 @@ struct mfft_plan_s {
   int nbatch = 1;               // pencils: batches of rows pipelined through the exchanges (X: both together, Y: one after the other)
   std::vector<hipEvent_t> ev2_compute, ev2_comm;
   hipStream_t cstream = nullptr;
+  int comm_cus = 0;             // CUs reserved for the communication stream (0: no CU masks)
   std::vector<hipEvent_t> ev_compute, ev_comm;
   std::vector<Chunk> kslice;    // (len, start) of each kz slice
 
@@ -1787,7 +1792,37 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
     ~Unref() { if (armed) c->plan_refs--; }
   } unref{comm, true};
   MFFT_HIP(hipGetDevice(&p->dev));
-  MFFT_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  const int nev = std::max(p->nslice > 1 ? p->nslice : 0, p->nbatch > 1 ? p->nbatch : 0);
+  // Pipelined plans: the exchange runs on a stream of its own, and that stream gets CUs of its own.  The transform
+  // kernels fill every CU (two 1024-thread workgroups with 80 KB of LDS each), so whatever the exchange launches -- the
+  // IPC transport's pull kernel, RCCL's send / recv kernels -- would otherwise wait for transform workgroups to retire
+  // and then take a whole CU away from them, workgroup by workgroup.  With comm_cus = K > 0 the communication stream
+  // is confined to K CUs and the compute stream to the other ones (hipExtStreamCreateWithCUMask; KFD deals the bits of
+  // a mask round-robin over the XCDs, so the last K = 8k bits are k CUs of every XCD); measured in
+  // profiles/r03_cu_mask_probe.txt.  desc.comm_cus: 0 = $MFFT_COMM_CUS or the default, < 0 = no masks.
+  int comm_cus = desc->comm_cus;
+  if (comm_cus == 0) comm_cus = getenv("MFFT_COMM_CUS") ? atoi(getenv("MFFT_COMM_CUS")) : MFFT_DEFAULT_COMM_CUS;
+  int ncu = 0;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->dev);
+  auto masked = [&](int lo, int hi, hipStream_t* st) {
+    std::vector<uint32_t> m((size_t)(ncu + 31) / 32, 0u);
+    for (int i = lo; i < hi; ++i) m[i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(st, (uint32_t)m.size(), m.data()) == hipSuccess) return true;
+    (void)hipGetLastError();
+    *st = nullptr;
+    return false;
+  };
+  if (nev > 0 && comm_cus > 0 && ncu >= 16 && comm_cus <= ncu / 2) {
+    if (masked(ncu - comm_cus, ncu, &p->cstream)) {
+      if (masked(0, ncu - comm_cus, &p->stream)) {
+        p->comm_cus = comm_cus;
+      } else {
+        (void)hipStreamDestroy(p->cstream);
+        p->cstream = nullptr;
+      }
+    }
+  }
+  if (!p->stream) MFFT_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   {
     // Opt-in (MFFT_GRAPH=1), single rank only (no host-side rendezvous inside the sequence).  Measured:
     // a transform is only three kernels, and replaying a 3-node graph (~16 us) costs more than three
@@ -1796,13 +1831,18 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
     const char* e = getenv("MFFT_GRAPH");
     p->use_graphs = p->P == 1 && e && atoi(e) != 0;
   }
-  const int nev = std::max(p->nslice > 1 ? p->nslice : 0, p->nbatch > 1 ? p->nbatch : 0);
   if (nev > 0) {
-    // The exchange runs on its own stream at the highest priority the device offers: its (RCCL) kernels have to get
-    // onto CUs that the transform kernels of the compute stream would otherwise keep filling block after block.
-    int prio_least = 0, prio_greatest = 0;
-    MFFT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    MFFT_HIP(hipStreamCreateWithPriority(&p->cstream, hipStreamNonBlocking, prio_greatest));
+    if (!p->cstream) {
+      // no CU masks.  MFFT_COMM_PRIORITY=1 asks for the highest stream priority; measured (profiles/r03_cu_mask_probe.txt)
+      // it changes nothing for the pull kernel -- workgroups of a second queue are admitted as transform workgroups
+      // retire, with or without it -- and with several ranks on ONE device it inverts priorities (a high-priority
+      // queue polling for a flag that a normal-priority queue of another process has yet to write: 0.8 -> 45 ms per
+      // pair at two processes, profiles/r03_shared_gpu_pipeline_latency.txt), so the default is the normal priority
+      int prio_least = 0, prio_greatest = 0;
+      MFFT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+      const bool prio = getenv("MFFT_COMM_PRIORITY") && atoi(getenv("MFFT_COMM_PRIORITY")) != 0;
+      MFFT_HIP(hipStreamCreateWithPriority(&p->cstream, hipStreamNonBlocking, prio ? prio_greatest : prio_least));
+    }
     for (std::vector<hipEvent_t>* v : {&p->ev_compute, &p->ev_comm, &p->ev2_compute, &p->ev2_comm}) {
       if ((v == &p->ev2_compute || v == &p->ev2_comm) && p->nbatch <= 1) continue;
       v->resize(nev);

@@ -25,11 +25,14 @@ class R2C(DistFFTBase):
     Extension: pipeline -- the exchange of a multi-rank plan is cut into pieces that travel on a second stream
         while the next piece is transformed: n > 1 = n kz slices, n < -1 = |n| batches of local x rows,
         0 = default (4 kz slices), 1 = one blocking exchange.
+        comm_cus -- pipelined plans: compute units set aside for the communication stream (0 = library default,
+        < 0 = none), see include/mpifft4py_amd.h.
     """
     _kind = _lib.R2C
 
     def __init__(self, N, L, comm, precision, communication="Alltoallw", padsize=1.5, threads=1,
-                 planner_effort=None, pipeline=0):
+                 planner_effort=None, pipeline=0, comm_cus=0):
+        self._comm_cus = comm_cus
         self._init_common(N, L, comm, precision, communication, padsize, threads,
                           planner_effort if planner_effort is not None else default_planner_effort())
         N = self.N
@@ -172,9 +175,9 @@ class C2C(R2C):
     _kind = _lib.C2C
 
     def __init__(self, N, L, comm, precision, communication="Alltoall", padsize=1.5, threads=1,
-                 planner_effort=None, pipeline=0):
+                 planner_effort=None, pipeline=0, comm_cus=0):
         R2C.__init__(self, N, L, comm, precision, communication=communication, padsize=padsize,
-                     threads=threads, planner_effort=planner_effort, pipeline=pipeline)
+                     threads=threads, planner_effort=planner_effort, pipeline=pipeline, comm_cus=comm_cus)
 
     copy_to_padded = staticmethod(_padding.c2c_copy_to_padded)        # slab.py:803-825
     copy_from_padded = staticmethod(_padding.c2c_copy_from_padded)

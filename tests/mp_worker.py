@@ -32,17 +32,32 @@ def main():
     assert comm.bcast({"hello": P} if rank == 0 else None)["hello"] == P
     comm.selftest(1 << 18, 30000)           # verified all-to-all of a byte pattern through the transport under test
 
-    for pipeline in (1, 4, -4):
-        F = Slab_R2C(np.array(N), L, comm, "double", pipeline=pipeline)
-        u = DeviceArray.from_numpy(np.ascontiguousarray(A[F.real_local_slice()]))
-        fu = DeviceArray.empty(F.complex_shape(), F.complex)
-        u2 = DeviceArray.empty(F.real_shape(), F.float)
-        for _ in range(2):
-            F.fftn(u, fu)
-            F.ifftn(fu, u2)
-        F.sync()
-        assert orc.rel_l2(fu.get(), B2[F.complex_local_slice()]) < 1e-10, ("slab", pipeline)
-        assert orc.rel_l2(u2.get(), A[F.real_local_slice()]) < 1e-10
+    # IPC transport: every way of pulling the chunks (one kernel over all peers, per-peer copy streams, copies one after the
+    # other) x CU-masked streams or not must give the SAME bits; the other transports have one mode
+    ipc = comm.get_option("ipc_pull") >= 0
+    modes = [(m, cus) for m in (1, 2, 0) for cus in (-1, 16)] if ipc else [(None, 0)]
+    first = {}
+    for mode, cus in modes:
+        if mode is not None:
+            comm.set_option("ipc_pull", mode)
+        for pipeline in (1, 4, -4):
+            F = Slab_R2C(np.array(N), L, comm, "double", pipeline=pipeline, comm_cus=cus)
+            u = DeviceArray.from_numpy(np.ascontiguousarray(A[F.real_local_slice()]))
+            fu = DeviceArray.empty(F.complex_shape(), F.complex)
+            u2 = DeviceArray.empty(F.real_shape(), F.float)
+            for _ in range(3):
+                F.fftn(u, fu)
+                F.ifftn(fu, u2)
+            F.sync()
+            got, back = fu.get(), u2.get()
+            assert orc.rel_l2(got, B2[F.complex_local_slice()]) < 1e-10, ("slab", pipeline, mode, cus)
+            assert orc.rel_l2(back, A[F.real_local_slice()]) < 1e-10, ("slab", pipeline, mode, cus)
+            if pipeline not in first:
+                first[pipeline] = (got, back)
+            assert np.array_equal(got, first[pipeline][0]) and np.array_equal(back, first[pipeline][1]), ("bits", pipeline, mode, cus)
+            del F, u, fu, u2
+    if ipc:
+        comm.set_option("ipc_pull", int(os.environ.get("MP_WORKER_PULL", "1")))
     # padded + masked paths
     C0 = B2.copy()
     C0[N[0] // 2] = 0

@@ -1,9 +1,10 @@
 """GPU: the process-per-GPU product path with 2, 4 and 8 PROCESSES launched by
 torch.distributed.run -- exactly as the benchmark driver launches bench.py -- on the single
 GPU of the box, over two transports:
-  * "ipc":  the shipped IpcComm (csrc/ipc_comm.hip): IPC-mapped receive buffers, copy-engine pushes, stream memory
-            operations between the processes.  Nothing is mocked: this IS the product's wire, it just runs with all
-            ranks on one device.
+  * "ipc":  the shipped IpcComm (csrc/ipc_comm.hip): every rank pulls its chunks out of the peers' IPC-mapped work
+            buffers (one pull kernel over all peers / per-peer copy streams / copies in sequence), stream memory
+            operations as flags between the processes.  Nothing is mocked: this IS the product's wire, it just runs
+            with all ranks on one device.
   * "mock": RcclComm.  Real RCCL refuses two ranks on one device, so librccl is replaced behind the same dlsym'd entry
             points by tests/mock_rccl (shared-memory mailboxes); everything above the wire (rendezvous, DistComm,
             RcclComm.alltoallv, plans, pipeline, bench.py's rank-0 JSON line) is the shipped code."""
@@ -112,7 +113,11 @@ def test_bench_multi_rank_prints_one_json_line(world, launcher, transport):
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0
     # transport x exchange-pipeline flavour are measured before the timed region, the best candidate is used
     tun = d["config"]["exchange_pipeline_tuning_ms_per_pair"]
-    assert sorted(tun) == (["ipc"] if transport == "ipc" else ["ipc", "rccl"]), tun
+    assert "rejected" not in tun and "error" not in tun, tun
+    cus = tun.pop("comm_cus", None)                  # CU masks tried for a pipelined winner
+    # the IPC transport's ways of pulling, one communicator ("ipc:streams" is measured only when every rank owns a device)
+    ipc_names = ["ipc", "ipc:copy"] + (["ipc:streams"] if d["config"]["gpus_visible"] >= world else [])
+    assert sorted(tun) == sorted(ipc_names if transport == "ipc" else ipc_names + ["rccl"]), tun
     best = None
     for name, per in tun.items():
         assert sorted(int(k) for k in per) == [-8, -4, -2, 1, 2, 4, 8] and all(v > 0 for v in per.values()), tun
@@ -120,9 +125,14 @@ def test_bench_multi_rank_prints_one_json_line(world, launcher, transport):
             if best is None or v < best[0]:
                 best = (v, name, int(k))
     assert (d["config"]["exchange_transport"], d["config"]["exchange_pipeline_depth"]) == best[1:]
-    if world == 4:
-        assert d["extras"]["pencil_R2CX"]["grid"] == [2, 2]
-        assert d["extras"]["pencil_R2CX"]["roundtrip_rel_l2"] < 1e-10
+    if cus is not None:
+        assert best[2] != 1 and cus["candidate"] == "%s:%d" % best[1:] and {"8", "16", "32"} <= set(cus), cus
+    if world >= 4:
+        # every process grid the C ABI accepts is timed, the reference's default among them
+        pen = d["extras"]["pencil_R2CX"]
+        grids = {k.split(":")[0] for k in pen["ms_per_pair_by_grid_and_depth"]}
+        assert grids == ({"1x4", "2x2", "4x1"} if world == 4 else {"1x8", "2x4", "4x2", "8x1"}), pen
+        assert pen["roundtrip_rel_l2"] < 1e-10 and pen["default_grid_ms_per_pair"] > 0
 
 
 @pytest.mark.parametrize("transport", TRANSPORTS)
@@ -162,6 +172,26 @@ def test_bench_falls_back_when_rccl_refuses():
     assert d["n_gpus"] == 2 and cfg["roundtrip_rel_l2"] < 1e-10 and not d.get("degraded")
     if cfg["gpus_visible"] < 2:
         assert cfg["exchange_transport"] == "ipc" and "error" in cfg["exchange_pipeline_tuning_ms_per_pair"]["rccl"]
+
+
+def test_bench_ranks_stay_together_when_rank0_cannot_make_an_id():
+    """a rank 0 that fails BEFORE it publishes the unique id (here: a transport name the library rejects in
+    mfft_get_unique_id) must not leave the other ranks polling for the id while it moves on to the next rendezvous:
+    it publishes the failure, every rank raises at once, and `--transport auto` continues over the IPC transport."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
+                                                             "MFFT_RCCL_LIB")}
+    env["MFFT_TRANSPORT"] = "no-such-transport"
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--steps", "2",
+                        "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off", "--pipeline", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    out, err = p.stdout.decode(), p.stderr.decode()
+    assert p.returncode == 0, (out[-2000:], err[-4000:])
+    assert time.time() - t0 < 150, "the ranks waited for each other's time-outs"
+    d = json.loads([l for l in out.splitlines() if l.strip()][0])
+    assert d["n_gpus"] == 2 and d["config"]["exchange_transport"] == "ipc" and not d.get("degraded")
+    assert "first transport unavailable" in err
 
 
 @pytest.mark.parametrize("world", [2, 4])

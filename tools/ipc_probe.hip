@@ -1,7 +1,7 @@
 // ipc_probe.hip -- what works between two PROCESSES on this pool's GPUs (developer tool): IPC memory handles,
 // interprocess events, stream memory operations (hipStreamWriteValue32 / hipStreamWaitValue32) on IPC-mapped memory,
 // and the rate of a copy-engine push into the peer's buffer.  Forks before the first HIP call.
-//   hipcc --offload-arch=gfx950 -O2 ipc_probe.hip -o build/ipc_probe && build/ipc_probe
+//   make -C tools ipc_probe && tools/build/ipc_probe
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <sys/wait.h>

@@ -1,7 +1,7 @@
 // kbench.hip -- kernel-variant explorer (developer tool, not part of the library).
 // Times strided-axis c2c variants (tile width, twiddle placement, split exchange,
 // radix plan, XCD remap, row pitch) at the 1024^3 shapes of the slab path.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 kbench.hip -o build/kbench && build/kbench [filter]
+//   make -C tools kbench && tools/build/kbench [filter]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,6 +1,6 @@
 // kbench3.hip -- persistent (register double-buffered) strided-axis kernel against the per-tile one
 // (developer tool, not part of the library).  Interleaved rounds in one process, results compared.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 kbench3.hip -o build/kbench3 && build/kbench3 [filter] [rounds]
+//   make -C tools kbench3 && tools/build/kbench3 [filter] [rounds]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>

@@ -4,7 +4,7 @@
 // which property of the ColFft access pattern (in place, 128-byte row segments at a large pitch, loads-then-stores
 // phases, row pitch) costs how much of it.  Also carries a stamped diagnostic build of the strided FFT kernel that
 // records, per workgroup, when its loads landed, its passes ended and its stores drained.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 membench.hip -o build/membench && build/membench [filter]
+//   make -C tools membench && tools/build/membench [filter]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

@@ -2,7 +2,7 @@
 // Stream s: hipStreamWaitValue32(flag >= 1) with the flag still 0, then hipEventRecord(ev, s).  If hipEventQuery(ev)
 // reports completion before the host sets the flag, an event recorded behind a wait does not wait for it, and every
 // cross-stream dependency built on such an event (the plan's ev_comm behind IpcComm's done-flag waits) is void.
-//   hipcc --offload-arch=gfx950 -O2 memop_probe.hip -o build/memop_probe && build/memop_probe
+//   make -C tools memop_probe && tools/build/memop_probe
 #include <hip/hip_runtime.h>
 #include <unistd.h>
 #include <cstdio>
