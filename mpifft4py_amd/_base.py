@@ -138,6 +138,12 @@ class DistFFTBase(object):
             return host_out
         return dst
 
+    def plan_info(self, key):
+        """What the plan decided (mfft_plan_get_info): "pruned_route", "comm_cus", "kz_slices", "row_batches", "zfuse"."""
+        v = ctypes.c_int64(0)
+        _lib.call("mfft_plan_get_info", self._plan, key.encode(), ctypes.byref(v))
+        return int(v.value)
+
     def sync(self):
         """Wait for all transforms enqueued on this object's stream."""
         _lib.call("mfft_plan_sync", self._plan)

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "mfft_backward": ([c_void_p, c_void_p, c_void_p, c_int], c_int),
     "mfft_plan_sync": ([c_void_p], c_int),
     "mfft_plan_set_dealias_mask": ([c_void_p, c_void_p, c_size_t], c_int),
+    "mfft_plan_get_info": ([c_void_p, c_char_p, POINTER(c_int64)], c_int),
     "mfft_plan_timing": ([c_void_p, c_int], c_int),
     "mfft_plan_timing_reset": ([c_void_p], c_int),
     "mfft_plan_timing_get": ([c_void_p, c_int, c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)], c_int),

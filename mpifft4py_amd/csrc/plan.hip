@@ -276,6 +276,7 @@ struct mfft_plan_s {
   // keep [0, a) and [b, N), z keeps [0, a2).  One GPU, real data: the inverse then never loads the removed rows, skips
   // the tiles of removed columns and reads a2 bins per z row (pruned passes).
   bool band_ok = false;
+  bool band_allzero = false;    // P > 1: every ky of this rank is removed (its x pass is a memset)
   int ba0 = 0, bb0 = 0, ba1 = 0, bb1 = 0, ba2 = 0;
   int col_band(const void* in, void* out, int64_t n, int64_t nouter, int64_t ncols, int64_t in_outer, RowSpec in_rows,
                int64_t out_outer, RowSpec out_rows, const ColArgs::Band& b) {
@@ -289,19 +290,27 @@ struct mfft_plan_s {
   }
   void detect_band(const uint8_t* m) {
     band_ok = false;
-    // every rank must take the same route (the pruned exchange has other counts): agree on the outcome below
-    int ok = 0, a0 = 0, b0 = 0, a1 = 0, b1 = 0, a2 = 0;
+    band_allzero = false;
+    // every rank must take the same route (the pruned exchange has other counts): agree on the outcome below.
+    // status: 0 = not a band mask (or no kernels), 1 = band mask, 2 = this rank's local mask is all zeros -- its ky range
+    // lies wholly inside the removed band (1024^3 over 8 ranks: ky in [342, 683) covers ranks 3 and 4) -- which is
+    // compatible with whatever band the others see: it adopts their (a0, b0, a2) and contributes zeros.
+    int st = 0, a0 = 0, b0 = 0, a1 = 0, b1 = 0, a2 = 0;
     std::vector<int> list;
     if (d.decomp == MFFT_SLAB && r2c && N0 >= 2 && N1 >= 2 && N2 >= 4 && N2 % 2 == 0 && band_fusable(N0, prec) &&
         band_fusable(N1, prec) && c2r_limit_supported(N2, prec))
-      ok = analyse_band(m, &a0, &b0, &a1, &b1, &a2, &list) ? 1 : 0;
+      st = analyse_band(m, &a0, &b0, &a1, &b1, &a2, &list);
     if (P > 1) {
-      double v[7] = {(double)ok, (double)a0, -(double)a0, (double)b0, -(double)b0, (double)a2, -(double)a2};
-      if (ok == 0) for (int i = 1; i < 7; ++i) v[i] = 0;
-      double ok_min = -(double)ok;
-      if (comm->allreduce_host(v, 7, 1) != 0 || comm->allreduce_host(&ok_min, 1, 1) != 0) return;
-      if (ok_min != -1.0 || v[1] != -v[2] || v[3] != -v[4] || v[5] != -v[6]) return;      // somebody disagrees or has another mask
-    } else if (!ok) {
+      const double none = -1e18;                 // neutral element of the max-reduction
+      double v[8] = {st == 0 ? 1.0 : 0.0, st == 1 ? 1.0 : 0.0, none, none, none, none, none, none};
+      if (st == 1) { v[2] = a0; v[3] = -a0; v[4] = b0; v[5] = -b0; v[6] = a2; v[7] = -a2; }
+      if (comm->allreduce_host(v, 8, 1) != 0) return;
+      if (v[0] != 0.0 || v[1] != 1.0 || v[2] != -v[3] || v[4] != -v[5] || v[6] != -v[7]) return;   // somebody disagrees, has another mask, or nobody has a band
+      if (st == 2) {                             // all my ky are removed: [g_lo, g_hi) = every local ky
+        a0 = (int)v[2]; b0 = (int)v[4]; a2 = (int)v[6]; a1 = 0; b1 = (int)Np1;
+        band_allzero = true;
+      }
+    } else if (st != 1) {
       return;
     }
     ba0 = a0; bb0 = b0; ba1 = a1; bb1 = b1; ba2 = a2;
@@ -319,7 +328,8 @@ struct mfft_plan_s {
     band_ok = true;
   }
   // local mask (N0, Np1, Nf) == m0[kx] & m1[ky] & m2[kz] with the zeros of m0 and m1 one run each and those of m2 a tail?
-  bool analyse_band(const uint8_t* m, int* a0, int* b0, int* a1, int* b1, int* a2, std::vector<int>* list) const {
+  // 0: no, 1: yes, 2: the local mask is all zeros
+  int analyse_band(const uint8_t* m, int* a0, int* b0, int* a1, int* b1, int* a2, std::vector<int>* list) const {
     const int64_t n1 = Np1;
     std::vector<uint8_t> m0(N0, 0), m1(n1, 0), m2(Nf, 0);
     for (int64_t i = 0; i < N0; ++i)
@@ -330,11 +340,16 @@ struct mfft_plan_s {
         m0[i] |= any; m1[j] |= any;
       }
     for (auto* v : {&m0, &m1, &m2}) for (auto& x : *v) x = x ? 1 : 0;
+    {
+      bool any = false;
+      for (uint8_t x : m2) any = any || x;
+      if (!any) return 2;
+    }
     for (int64_t i = 0; i < N0; ++i)          // the mask must BE the product of the three (values other than 0 / 1 are weights, not a filter)
       for (int64_t j = 0; j < n1; ++j) {
         const uint8_t* row = m + (i * n1 + j) * Nf;
         const uint8_t ij = m0[i] & m1[j];
-        for (int64_t k = 0; k < Nf; ++k) if (row[k] != (uint8_t)(ij & m2[k])) return false;
+        for (int64_t k = 0; k < Nf; ++k) if (row[k] != (uint8_t)(ij & m2[k])) return 0;
       }
     auto run = [](const std::vector<uint8_t>& v, int* a, int* b) {   // zeros form one run [a, b) (none: a = b = first index after the ones)
       const int n = (int)v.size();
@@ -347,11 +362,11 @@ struct mfft_plan_s {
       return true;
     };
     int z0 = 0, z1 = 0;
-    if (!run(m0, a0, b0) || *a0 < 1 || !run(m1, a1, b1) || !run(m2, &z0, &z1) || z1 != (int)Nf || z0 < 1) return false;
+    if (!run(m0, a0, b0) || *a0 < 1 || !run(m1, a1, b1) || !run(m2, &z0, &z1) || z1 != (int)Nf || z0 < 1) return 0;
     *a2 = z0;
     if (P == 1) {      // x pass: tiles of the flattened (ky, kz) columns that hold a kept column, in memory order
       const int w = col_tile_width(N0, prec, true, 6);
-      if (w <= 0) return false;
+      if (w <= 0) return 0;
       const int64_t ncols = n1 * Nf, ntile = (ncols + w - 1) / w;
       for (int64_t t = 0; t < ntile; ++t) {
         bool any = false;
@@ -359,7 +374,7 @@ struct mfft_plan_s {
         if (any) list->push_back((int)t);
       }
     }
-    return true;
+    return 1;
   }
   int* band_tiles = nullptr;
   int band_ntiles = 0;
@@ -679,6 +694,7 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     ColArgs::Band bx;
     bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = true;
     MFFT_TRY(stage("bwd_x", Cb * keep2 * (keep0 + 1.0), [&] {
+      if (band_allzero) return zero(Aw, cbp);        // nothing of this rank's spectrum survives the mask
       return col_band(fu, Aw, N0, Np1, a2, Nf, plain(Np1 * Nf), ap, plain(Np1 * ap), bx);
     }));
     MFFT_TRY(stage("bwd_a2a", 0, [&] { return exchange_equal(world, Aw, Bw, (size_t)(Np0 * Np1 * ap) * es); }));
@@ -788,6 +804,7 @@ int mfft_plan_s::slab_backward_pipelined(const void* src, void* u, bool pruned) 
     const int64_t k0 = kslice[s].start, kz = kslice[s].len;
     const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es;
     MFFT_TRY(stage("bwd_x", 2 * Cb / nslice, [&] {
+      if (pruned && band_allzero) return zero(A + boff, (size_t)(N0 * Np1 * kz) * es);
       if (pruned) return col_band(in + (size_t)k0 * es, A + boff, N0, Np1, kz, Nf, plain(Np1 * Nf), kz, plain(Np1 * kz), bx);
       return col(in + (size_t)k0 * es, A + boff, N0, true, Np1, kz, Nf, plain(Np1 * Nf), kz, plain(Np1 * kz));
     }));
@@ -872,6 +889,7 @@ int mfft_plan_s::slab_backward_rows(const void* src, void* u, bool pruned) {
   char* out = static_cast<char*>(u);
   const int B = nbatch;
   MFFT_TRY(stage("bwd_x", 2 * Cb, [&] {
+    if (pruned && band_allzero) return zero(A, cb);
     if (pruned) {
       ColArgs::Band bx;
       bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = true;
@@ -2043,6 +2061,19 @@ int mfft_plan_set_dealias_mask(mfft_plan_t p, const uint8_t* mask_host, size_t c
   MFFT_HIP(hipMemcpy(p->mask, mask_host, count, hipMemcpyHostToDevice));
   p->mask_count = count;
   p->detect_band(mask_host);
+  return 0;
+}
+
+int mfft_plan_get_info(mfft_plan_t p, const char* key, int64_t* value) {
+  if (!p || !key || !value) return set_error(MFFT_ERR_INVALID, "null argument");
+  const std::string k(key);
+  if (k == "pruned_route") *value = p->band_ok ? (p->band_allzero ? 2 : 1) : 0;
+  else if (k == "comm_cus") *value = p->comm_cus;
+  else if (k == "kz_slices") *value = p->nslice;
+  else if (k == "row_batches") *value = p->nbatch;
+  else if (k == "zfuse") *value = p->zfuse ? 1 : 0;
+  else if (k == "ranks") *value = p->P;
+  else return set_error(MFFT_ERR_INVALID, "mfft_plan_get_info: unknown key '%s'", key);
   return 0;
 }
 

@@ -79,6 +79,12 @@ def main():
         ud = Fd.ifftn(cl.copy(), np.zeros(Fd.real_shape()), dealias="2/3-rule")
         ur = Fd.ifftn(cl * mask, np.zeros(Fd.real_shape()))
         assert orc.rel_l2(ud, ur) < 1e-12, ("2/3-rule", pipeline)
+        # against the oracle's arithmetic on the whole cube, and the route: every rank prunes; at 8 ranks the ky of
+        # ranks 2..5 of this mesh (ky 16..47 of 64, removed: 22..42) are partly, of none wholly, removed -> route 1
+        gm = orc.dealias_mask(N, np.fft.fftfreq(N[0], 1. / N[0]), np.fft.fftfreq(N[1], 1. / N[1]), np.fft.rfftfreq(N[2], 1. / N[2]))
+        want = np.fft.irfftn(B2 * gm, s=N, axes=(0, 1, 2))
+        assert orc.rel_l2(ud, want[Fd.real_local_slice()]) < 4e-10, ("2/3-rule vs oracle", pipeline)
+        assert Fd.plan_info("pruned_route") == (2 if not mask.any() else 1), (Fd.plan_info("pruned_route"), int(mask.sum()))
     # C2C
     Ac = A + 1j * np.random.default_rng(7).random(N)
     Fc = Slab_C2C(np.array(N), L, comm, "single")

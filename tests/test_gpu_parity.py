@@ -257,20 +257,28 @@ def test_two_thirds_rule_mask_on_load(decomp, P, pipeline, prec, fused, monkeypa
         u = F.ifftn(c, np.zeros(out_shape, dtype=out_t), dealias="2/3-rule")
         assert np.array_equal(c, c_in)          # input spectrum untouched
         u_ref = F.ifftn((c * M[sl]).astype(ct), np.zeros(out_shape, dtype=out_t))
-        return u, u_ref
-    for u, u_ref in run_ranks(P, body):
+        return u, u_ref, (F.original_local_slice() if decomp == "c2c" else F.real_local_slice())
+    # the oracle's arithmetic on the whole masked spectrum (numpy.fft: slab.py:249 / 237-245)
+    CM = C.astype(np.complex128) * M
+    want = np.fft.ifftn(CM) if decomp == "c2c" else np.fft.irfftn(CM, s=N, axes=(0, 1, 2))
+    for u, u_ref, rsl in run_ranks(P, body):
         assert np.array_equal(u, u_ref)         # same kernels, same values: bit-identical
+        assert orc.rel_l2(u, want[rsl]) < 4 * TOL[prec], orc.rel_l2(u, want[rsl])
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("P,pipeline", [(1, 1), (2, 1), (4, 1), (2, 0), (4, 2), (4, 3), (2, -2), (4, -3)])
+@pytest.mark.parametrize("P,pipeline", [(1, 1), (2, 1), (4, 1), (2, 0), (4, 2), (4, 3), (2, -2), (4, -3), (8, 1), (8, 0), (8, -2)])
 @pytest.mark.parametrize("N", [[32, 32, 32], [48, 20, 36], [64, 128, 256], [16, 24, 10], [100, 36, 50], [8, 8, 8], [12, 6, 4], [32, 16, 512]])
 def test_two_thirds_rule_pruned(N, P, pipeline, prec, monkeypatch):
     """Real data, the reference's own dealias filter (three 1-D band conditions).  One GPU: the inverse does not load
     the removed rows, skips the tiles of removed columns and reads only the kept bins of every z row; P ranks: the x pass
     writes the kept kz bins only (zeros for removed ky), the exchange carries a2 / Nf of the bytes (plan.hip detect_band,
     ColFft PAD == 4).  Against ifftn(fu * dealias) through the plain kernels and against the same call with
-    MFFT_NO_PRUNE=1 (the general masked-load path); the input spectrum stays untouched."""
+    MFFT_NO_PRUNE=1 (the general masked-load path); the input spectrum stays untouched.  Over 8 ranks some ranks own
+    nothing but removed ky ([32,32,32]: ranks 3 and 4, as ranks 3 and 4 of the 1024^3 BASELINE mesh do): they vote
+    "compatible", adopt the others' band and contribute zeros; the ROUTE every rank took is asserted
+    (mfft_plan_get_info "pruned_route"), and the gathered result is compared with the oracle's arithmetic,
+    numpy.fft.irfftn(C * dealias) (slab.py:237-245)."""
     from mpifft4py_amd import Slab_R2C
     if N[0] % P or N[1] % P:
         pytest.skip("mesh does not divide")
@@ -291,16 +299,32 @@ def test_two_thirds_rule_pruned(N, P, pipeline, prec, monkeypatch):
         u_gen = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt), dealias="2/3-rule")
         comm.barrier()
         os.environ.pop("MFFT_NO_PRUNE", None)
-        return u, u_ref, u_gen, mask
+        return u, u_ref, u_gen, mask, F.plan_info("pruned_route"), F.complex_local_slice(), F.real_local_slice()
     try:
         res = run_ranks(P, body)
     finally:
         os.environ.pop("MFFT_NO_PRUNE", None)
-    for u, u_ref, u_gen, mask in res:
+    M = np.zeros(C.shape, dtype=bool)
+    for u, u_ref, u_gen, mask, route, csl, rsl in res:
         assert np.array_equal(u_gen, u_ref)
         # a different build of the same kernels (the compiler may contract other multiply-adds): round-off apart at most
         assert orc.rel_l2(u, u_ref) < 0.05 * TOL[prec], orc.rel_l2(u, u_ref)
+        M[csl] = mask
     assert 0 < sum(int(r[3].sum()) for r in res) < C.size
+    # the oracle's arithmetic on the gathered arrays
+    want = np.fft.irfftn(C.astype(np.complex128) * M, s=N, axes=(0, 1, 2))
+    for u, _, _, _, _, _, rsl in res:
+        assert orc.rel_l2(u, want[rsl]) < 4 * TOL[prec], orc.rel_l2(u, want[rsl])
+    # every rank took the same kind of route; a rank whose ky are all removed says so
+    routes = [r[4] for r in res]
+    assert all(r > 0 for r in routes) or all(r == 0 for r in routes), routes
+    if N in ([32, 32, 32], [64, 128, 256]):
+        assert all(r > 0 for r in routes), routes        # radix kernels exist: the pruned route must engage
+    for (_, _, _, mask, route, _, _) in res:
+        if route:
+            assert route == (1 if mask.any() or P == 1 else 2), (route, int(mask.sum()))
+    if N == [32, 32, 32] and P == 8:
+        assert routes.count(2) == 2, routes              # ranks 3 and 4 own ky 12..19, all of it removed
 
 
 @pytest.mark.parametrize("P", [1, 2])
@@ -330,9 +354,11 @@ def test_two_thirds_rule_edge_masks(kind, P):
         F.dealias = np.ascontiguousarray(M[sl])
         u = F.ifftn(c.copy(), np.zeros(F.real_shape()), dealias="2/3-rule")
         ur = F.ifftn(c * M[sl], np.zeros(F.real_shape()))
-        return u, ur
-    for u, ur in run_ranks(P, body):
+        return u, ur, F.real_local_slice()
+    want = np.fft.irfftn(C * M, s=N, axes=(0, 1, 2))
+    for u, ur, rsl in run_ranks(P, body):
         assert np.abs(u - ur).max() <= 1e-14 * max(np.abs(ur).max(), 1e-300) or np.array_equal(u, ur)
+        assert np.abs(u - want[rsl]).max() <= 1e-13 * max(np.abs(want).max(), 1e-300), kind     # the oracle's arithmetic
 
 
 @pytest.mark.parametrize("decomp", ["slab", "pencilX", "pencilY"])
@@ -353,14 +379,16 @@ def test_two_thirds_rule(decomp):
         assert np.array_equal(c, c_in)          # input spectrum untouched
         mask = np.broadcast_to(F.get_dealias_filter(), F.complex_shape())
         u_ref = F.ifftn(c * mask, np.zeros(F.real_shape()))
-        return u, u_ref, F.complex_local_slice(), mask
+        return u, u_ref, F.complex_local_slice(), mask, F.real_local_slice()
     kx = np.fft.fftfreq(N[0], 1. / N[0])
     ky = np.fft.fftfreq(N[1], 1. / N[1])
     kz = np.fft.rfftfreq(N[2], 1. / N[2])
     gmask = orc.dealias_mask(N, kx, ky, kz)
-    for u, u_ref, cs, mask in run_ranks(P, body):
+    want = np.fft.irfftn(C * gmask, s=N, axes=(0, 1, 2))       # the oracle's arithmetic with the oracle's mask
+    for u, u_ref, cs, mask, rsl in run_ranks(P, body):
         assert orc.rel_l2(u, u_ref) < 1e-12
         assert np.array_equal(mask, gmask[cs])
+        assert orc.rel_l2(u, want[rsl]) < 4e-10
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
