@@ -192,7 +192,7 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.b_clim = a.band.c_lim; P.b_goff = a.band.g_off; P.b_gstep = a.band.g_step; P.b_glo = a.band.g_lo; P.b_ghi = a.band.g_hi;
   P.tile_list = a.band.on ? a.band.tile_list : nullptr;
   P.ntiles_listed = a.band.ntiles_listed;
-  P.b_gzero = a.band.on && a.band.g_zero ? 1 : 0;
+  P.b_gzero = a.band.on ? a.band.g_zero : 0;
   const int64_t grid = P.tile_list ? (int64_t)P.ntiles_listed : (int64_t)P.ntile_c * a.nouter;
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large (%lld tiles)", (long long)grid);
@@ -293,6 +293,10 @@ bool c2r_limit_supported(int64_t n, int prec) { return n >= 4 && n < 65536 && fi
 bool band_fusable(int64_t n, int prec) { return n >= 2 && n < 65536 && find_kernel(FAM_COL, (int)n, prec, 1, 0, 6) != nullptr; }
 bool mask_fusable(int64_t n, int prec) { return n >= 2 && n < 65536 && find_kernel(FAM_COL, (int)n, prec, 1, 0, 5) != nullptr; }
 
+bool zsplit_limit_supported(int64_t n, int prec) {
+  return n >= 2 && n < 65536 && find_kernel(FAM_R2C, (int)n, prec, 0, 0, 7) && find_kernel(FAM_C2R, (int)n, prec, 1, 0, 7);
+}
+
 bool zsplit_supported(int64_t n, int prec, bool real_transform) {
   if (n < 2 || n > 65536) return false;
   if (real_transform) return find_kernel(FAM_R2C, (int)n, prec, 0, 0, 4) && find_kernel(FAM_C2R, (int)n, prec, 1, 0, 4);
@@ -354,7 +358,9 @@ static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void
 
 static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
   if (a.zs.nchunk) {
-    const KernelEntry* ec = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, 4);
+    // column-limited as well (3/2-rule: only the first `valid` of the n/2+1 bins exist, and those are what is chunked)
+    const bool lim = a.valid > 0 && a.valid < a.n / 2 + 1;
+    const KernelEntry* ec = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, lim ? 7 : 4);
     const int64_t real_stride_c = fam == FAM_R2C ? a.in_stride : a.out_stride;
     if (!ec || real_stride_c % 2 != 0) return set_error(MFFT_ERR_UNSUPPORTED, "no z-chunked real kernel of length %d", a.n);
     void *twc = nullptr, *rtwc = nullptr;

@@ -610,6 +610,54 @@ static void test_real() {
       report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
     }
   }
+  // column-limited AND z-chunked (the 3/2-rule pencil transforms): only the first `valid` bins exist, split into
+  // nch blocks with an uneven last one (valid = 2 * q + 1: the un-padded mesh's Nyquist column on the last rank)
+  if (M >= 12 && M % 3 == 0) {
+    const int valid = M / 3 * 2 / 2 * 2 + 1 <= M ? (M / 3) / 2 * 2 + 1 : 3;      // odd, about a third of the bins
+    const int nch = 2, q = (valid - 1) / nch, last = q + 1, rows_total = nrows + 2, row0 = 1;
+    const ZSplit zs = make_zsplit(q, nch, last, rows_total);
+    std::vector<cx<T>> blocks((size_t)rows_total * (q * (nch - 1) + last), mk<T>((T)7, (T)7));
+    {
+      typedef R2CFft<S, T, ROWS, TWLDS, true, true, SPLIT> K;
+      RealParams<T> P{in.data(), blocks.data(), tw.data(), rtw.data(), pin, 0, nrows, valid, (T)1, zs, row0};
+      emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    }
+    long double nn = 0, dd = 0;
+    for (int r = 0; r < nrows; ++r)
+      for (int k = 0; k < valid; ++k) {
+        const int l = std::min(k / q, nch - 1), len = l == nch - 1 ? last : q;
+        cx<T> g = blocks[(size_t)l * rows_total * q + (size_t)(row0 + r) * len + (k - l * q)], e = out[(size_t)r * pout + k];
+        if (k == 0) e.y = 0;
+        nn += (g.x - e.x) * (g.x - e.x) + (g.y - e.y) * (g.y - e.y);
+        dd += e.x * e.x + e.y * e.y;
+      }
+    snprintf(name, sizeof name, "r2c valid<M+1 z-chunked r%d", ROWS);
+    report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
+    std::vector<T> b4((size_t)nrows * pin, (T)0);
+    {
+      typedef C2RFft<S, T, ROWS, TWLDS, true, true, SPLIT> K;
+      RealParams<T> P{blocks.data(), b4.data(), tw.data(), rtw.data(), 0, pin, nrows, valid, (T)(1.0 / N), zs, row0};
+      emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    }
+    nn = dd = 0;
+    for (int r = 0; r < nrows; ++r) {
+      lvec X(N);
+      for (int k = 0; k < N; ++k) { X[k].x = 0; X[k].y = 0; }
+      for (int k = 0; k < valid; ++k) {
+        const cx<T> z = out[(size_t)r * pout + k];
+        X[k].x = z.x; X[k].y = (k == 0) ? 0 : z.y;
+        if (k > 0) { X[N - k].x = z.x; X[N - k].y = -z.y; }
+      }
+      lvec x = naive_dft(X, +1);
+      for (int i = 0; i < N; ++i) {
+        long double e = x[i].x / N, g = b4[(size_t)r * pin + i];
+        nn += (g - e) * (g - e);
+        dd += e * e;
+      }
+    }
+    snprintf(name, sizeof name, "c2r valid<M+1 z-chunked r%d", ROWS);
+    report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -121,8 +121,10 @@ struct ColParams {
   int b_row_lo, b_row_hi, b_coff, b_cper, b_clim, b_goff, b_gstep, b_glo, b_ghi;
   const int* tile_list;  // PAD == 4: the tiles that hold a kept column (the launch has one workgroup per entry); null: all tiles
   int ntiles_listed;
-  int b_gzero;           // PAD == 4: columns of a removed y are not skipped but read as zeros and WRITTEN (the transform of
-                         // zeros): for outputs that somebody reads whole, e.g. a chunk that goes through an exchange
+  int b_gzero;           // PAD == 4: 1 = columns of a removed y are not skipped but read as zeros and WRITTEN (the transform of
+                         // zeros): for outputs that somebody reads whole, e.g. a chunk that goes through an exchange;
+                         // 2 = the same for the columns of a removed z too, and no tile is skipped: the output is complete
+                         // (the pencils' first inverse pass: the band parameters instead of one mask byte per element)
 };
 
 template <typename T>
@@ -399,26 +401,48 @@ struct ColFft {
     const int nact = P.ncols - col;                // columns of this thread inside the array (may be <= 0)
     const cx<T>* ip = P.in + (i64)outer * P.in_outer + col;
     cx<T>* op = P.out + (i64)outer * P.out_outer + col;
+    bool tile_zero = false;                        // b_gzero == 2: a tile of removed columns only is written as zeros
     if constexpr (PAD == 4) {                      // nothing downstream reads the columns the mask removes
       int t = P.b_coff + tc * COLS;
       int z = t % P.b_cper, y = P.b_goff + t / P.b_cper + outer * P.b_gstep;
       bool any = false;
       for (int i = 0; i < COLS && tc * COLS + i < P.ncols; ++i) {
-        any = any || (z < P.b_clim && (P.b_gzero || y < P.b_glo || y >= P.b_ghi));
+        any = any || (z < P.b_clim && (P.b_gzero == 1 || y < P.b_glo || y >= P.b_ghi));
         if (++z == P.b_cper) { z = 0; ++y; }
       }
-      if (!any) return;                            // the same for every thread of the workgroup
+      if (!any) {                                  // the same for every thread of the workgroup
+        if (P.b_gzero != 2) return;
+        tile_zero = true;                          // complete output wanted: no loads, no passes, zeros stored
+      }
     }
-    bool zero_col = false;                         // b_gzero: this thread's column(s) belong to a removed y
+    // b_gzero: which of this thread's VEC columns belong to a removed y (b_gzero == 2: or to a removed z) and are
+    // therefore transformed as zeros
+    bool zcol[VEC];
+    bool zero_col = false;                         // all of them
     if constexpr (PAD == 4) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) zcol[i] = false;
       if (P.b_gzero) {
-        const int t = P.b_coff + col;
-        const int y = P.b_goff + t / P.b_cper + outer * P.b_gstep;
-        zero_col = !(y < P.b_glo || y >= P.b_ghi);
+        zero_col = true;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const int t = P.b_coff + col + i;
+          const int yq = t / P.b_cper;
+          const int y = P.b_goff + yq + outer * P.b_gstep;
+          zcol[i] = !(y < P.b_glo || y >= P.b_ghi) || (P.b_gzero == 2 && t - yq * P.b_cper >= P.b_clim);
+          zero_col = zero_col && zcol[i];
+        }
       }
     }
 
     cx<T> v[VEC][S::E];
+    if (PAD == 4 && tile_zero) {
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i][k] = mk<T>((T)0, (T)0);
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
       unsigned r = (unsigned)(j + k * S::TPT);
@@ -451,10 +475,9 @@ struct ColFft {
         }
       }
       if constexpr (PAD == 4) {
-        if (zero_row) {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) v[i][k] = mk<T>((T)0, (T)0);
-        }
+        for (int i = 0; i < VEC; ++i)
+          if (zero_row || zcol[i]) v[i][k] = mk<T>((T)0, (T)0);
       }
       if constexpr (PAD == 3) {                    // 2/3-rule: the dealias mask applied while the spectrum is read
         const unsigned char* mp = P.mask + (src - P.in);
@@ -478,6 +501,7 @@ struct ColFft {
       if constexpr (TWLDS) run_passes_v<S, 0, T, VEC>(v, j, (const cx<T>*)ltw, xch);
       else run_passes_v<S, 0, T, VEC>(v, j, P.tw, xch);
     }
+    }     // !tile_zero
 
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {

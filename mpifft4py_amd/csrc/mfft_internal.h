@@ -58,7 +58,8 @@ struct ColArgs {
     int row_lo = 0, row_hi = 0, c_off = 0, c_per = 1 << 30, c_lim = 1 << 30, g_off = 0, g_step = 0, g_lo = 1 << 30, g_hi = 1 << 30;
     const int* tile_list = nullptr;     // device array of the tiles with a kept column (tile = outer * ntile_c + tc), or null
     int ntiles_listed = 0;
-    bool g_zero = false;                // columns of a removed y are transformed as zeros and written instead of skipped
+    int g_zero = 0;                     // 1: columns of a removed y are transformed as zeros and written instead of skipped;
+                                        // 2: columns of a removed z as well, no tile is skipped (complete output)
   } band;
 };
 bool c2r_limit_supported(int64_t n, int prec);   // a c2r kernel of real length n that reads only the first `valid` bins exists
@@ -122,6 +123,7 @@ int launch_fill_uniform(void* data, size_t count, int prec, uint64_t seed, hipSt
 
 bool length_supported(int64_t n, bool real_transform);
 bool zsplit_supported(int64_t n, int prec, bool real_transform);   // radix kernels with fused z-chunk pack exist for n
+bool zsplit_limit_supported(int64_t n, int prec);                  // ... that are column-limited as well (3/2-rule pencils)
 hipStream_t plan_stream(mfft_plan_t plan);   // the plan's compute stream (nullptr plan -> default stream)
 
 }  // namespace mfft

@@ -229,6 +229,11 @@ struct mfft_plan_s {
   // z stage with the z-chunk pack / unpack of the pencils fused in (fft_kernels.h, ZSplit): rows [row0, row0 + nrows)
   // of the Pz blocks (rows_total, len_l) that the z-splitting exchange sends / has received
   bool zfuse = false;
+  // the same for the fused 3/2-rule pencil transforms: real length M2, the Nf kept columns split into the z chunks
+  bool zfuse_pad() const {
+    return getenv("MFFT_NO_ZFUSE") == nullptr && !d.line2d && !d.drop_nyquist && !zc.empty() && zc[0].len < 65536 &&
+           M2 % 2 == 0 && zsplit_limit_supported(M2, prec);
+  }
   ZSplitArgs zsplit(int64_t rows_total, int64_t row0) const {
     ZSplitArgs z;
     z.nchunk = (int)zc.size(); z.q = zc[0].len; z.last_len = zc.back().len; z.rows_total = rows_total; z.row0 = row0;
@@ -265,8 +270,15 @@ struct mfft_plan_s {
     a.in_outer = in_outer; a.out_outer = out_outer; a.in_rows = in_rows; a.out_rows = out_rows;
     a.scale = scale != 0.0 ? scale : (inv ? 1.0 / (double)n : 1.0);
     // 2/3-rule (fuse_mask below): a pass that reads the caller's spectrum applies the dealias mask while it loads
-    if (mask_src && in >= mask_src && static_cast<const char*>(in) < static_cast<const char*>(mask_src) + mask_count * es)
-      a.mask = mask + (static_cast<const char*>(in) - static_cast<const char*>(mask_src)) / es;
+    if (mask_src && in >= mask_src && static_cast<const char*>(in) < static_cast<const char*>(mask_src) + mask_count * es) {
+      const int64_t off = (static_cast<const char*>(in) - static_cast<const char*>(mask_src)) / (int64_t)es;
+      if (lband_use) {           // pencils, the reference's own filter: its three 1-D conditions instead of the bytes
+        a.band = local_band(d.decomp == MFFT_PENCIL_Y ? off / (N1 * q) : 0);
+        a.scale = scale != 0.0 ? scale : 1.0 / (double)n;
+      } else {
+        a.mask = mask + off;
+      }
+    }
     return launch_col(a, stream);
   }
   // `fu * dealias` of the reference's ifftn (slab.py:237-245, pencil.py:455-462) without the masked copy: when the first
@@ -376,15 +388,70 @@ struct mfft_plan_s {
     }
     return 1;
   }
+  // Pencils (R2C): the same recognition, LOCAL to the rank and without any change of layout -- the first inverse pass
+  // (x for the X alignment, y for Y) runs the band kernel in its "complete output" mode (ColFft PAD == 4, b_gzero = 2)
+  // instead of loading one mask byte per element: removed rows are not loaded, removed columns are transformed as zeros.
+  bool lband_ok = false;
+  int lb_row_lo = 0, lb_row_hi = 0, lb_g_lo = 0, lb_g_hi = 0, lb_c_lim = 0;
+  void detect_band_local(const uint8_t* m) {
+    lband_ok = false;
+    if (d.decomp == MFFT_SLAB || !r2c || d.drop_nyquist || d.line2d) return;
+    const bool X = d.decomp == MFFT_PENCIL_X;
+    const int64_t D0 = X ? N0 : N2_0, D1 = X ? N1_1 : N1, D2 = q;
+    if (D0 < 1 || D1 < 1 || D2 < 1 || !band_fusable(X ? N0 : N1, prec) || (X ? N0 : N1) < 2) return;
+    std::vector<uint8_t> m0(D0, 0), m1(D1, 0), m2(D2, 0);
+    for (int64_t i = 0; i < D0; ++i)
+      for (int64_t j = 0; j < D1; ++j) {
+        const uint8_t* row = m + (i * D1 + j) * D2;
+        uint8_t any = 0;
+        for (int64_t k = 0; k < D2; ++k) { any |= row[k]; m2[k] |= row[k]; }
+        m0[i] |= any; m1[j] |= any;
+      }
+    for (auto* v : {&m0, &m1, &m2}) for (auto& x : *v) x = x ? 1 : 0;
+    for (int64_t i = 0; i < D0; ++i)
+      for (int64_t j = 0; j < D1; ++j) {
+        const uint8_t* row = m + (i * D1 + j) * D2;
+        const uint8_t ij = m0[i] & m1[j];
+        for (int64_t k = 0; k < D2; ++k) if (row[k] != (uint8_t)(ij & m2[k])) return;      // not a product of 1-D filters
+      }
+    auto run = [](const std::vector<uint8_t>& v, int* a, int* b) {   // zeros form one run [a, b)
+      const int n = (int)v.size();
+      int lo = 0;
+      while (lo < n && v[lo]) ++lo;
+      int hi = lo;
+      while (hi < n && !v[hi]) ++hi;
+      for (int i = hi; i < n; ++i) if (!v[i]) return false;
+      *a = lo; *b = hi;
+      return true;
+    };
+    int a0, b0, a1, b1, z0, z1;
+    if (!run(m0, &a0, &b0) || !run(m1, &a1, &b1) || !run(m2, &z0, &z1) || z1 != (int)D2) return;   // kz: a kept prefix
+    if (X) { lb_row_lo = a0; lb_row_hi = b0; lb_g_lo = a1; lb_g_hi = b1; }
+    else   { lb_row_lo = a1; lb_row_hi = b1; lb_g_lo = a0; lb_g_hi = b0; }
+    lb_c_lim = z0;
+    lband_ok = getenv("MFFT_NO_PRUNE") == nullptr || atoi(getenv("MFFT_NO_PRUNE")) == 0;
+  }
+  // first inverse pass of a pencil plan over rows [g0, g0 + nouter) of the g axis (X: one launch, the g axis is folded
+  // into the columns; Y: batches of local kx rows)
+  ColArgs::Band local_band(int64_t g0) const {
+    ColArgs::Band b;
+    b.on = true;
+    b.row_lo = lb_row_lo; b.row_hi = lb_row_hi; b.c_lim = lb_c_lim; b.g_lo = lb_g_lo; b.g_hi = lb_g_hi; b.g_zero = 2;
+    if (d.decomp == MFFT_PENCIL_X) { b.c_off = 0; b.c_per = (int)q; b.g_off = 0; b.g_step = 0; }
+    else                           { b.c_off = 0; b.c_per = 1 << 30; b.g_off = (int)g0; b.g_step = 1; }
+    return b;
+  }
   int* band_tiles = nullptr;
   int band_ntiles = 0;
   const void* mask_src = nullptr;
+  bool lband_use = false;       // this call's first pass takes the band kernel (set by fuse_mask, cleared with mask_src)
   int fuse_mask(const void* fu, int64_t first_len, bool* fused) {
     const size_t cnt = (size_t)local_complex_count();
     if (!mask || mask_count != cnt) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask of %zu entries was set", cnt);
     const bool off = getenv("MFFT_NO_MASK_FUSION") && atoi(getenv("MFFT_NO_MASK_FUSION")) != 0;
     *fused = !off && first_len >= 2 && mask_fusable(first_len, prec);
     mask_src = *fused ? fu : nullptr;
+    lband_use = *fused && lband_ok && d.decomp != MFFT_SLAB && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0);
     return 0;
   }
   int col_pad(const void* in, void* out, int64_t n, bool inv, int pad, bool fold, int64_t nouter, int64_t ncols,
@@ -692,7 +759,7 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     void *Aw = work[0], *Bw = work[1];
     const double keep0 = 1.0 - (double)(bb0 - ba0) / (double)N0, keep2 = (double)a2 / (double)Nf;
     ColArgs::Band bx;
-    bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = true;
+    bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = 1;
     MFFT_TRY(stage("bwd_x", Cb * keep2 * (keep0 + 1.0), [&] {
       if (band_allzero) return zero(Aw, cbp);        // nothing of this rank's spectrum survives the mask
       return col_band(fu, Aw, N0, Np1, a2, Nf, plain(Np1 * Nf), ap, plain(Np1 * ap), bx);
@@ -791,7 +858,7 @@ int mfft_plan_s::slab_forward_pipelined(const void* u, void* fu) {
 int mfft_plan_s::slab_backward_pipelined(const void* src, void* u, bool pruned) {
   const double Cb = (double)(N0 * Np1 * Nf) * es, Rb = (double)(Np0 * N1 * N2) * rs;
   ColArgs::Band bx;
-  bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = true;
+  bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = 1;
   auto kept = [&](int s) { return !pruned || kslice[s].start < ba2; };
   const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
   for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, cb));
@@ -892,7 +959,7 @@ int mfft_plan_s::slab_backward_rows(const void* src, void* u, bool pruned) {
     if (pruned && band_allzero) return zero(A, cb);
     if (pruned) {
       ColArgs::Band bx;
-      bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = true;
+      bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = 1;
       return col_band(src, A, N0, Np1, nz, Nf, plain(Np1 * Nf), w, plain(Np1 * w), bx);
     }
     return col(src, A, N0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf));
@@ -1455,7 +1522,7 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
   const void* src = fu;
   struct MaskScope {
     mfft_plan_s* p;
-    ~MaskScope() { p->mask_src = nullptr; }
+    ~MaskScope() { p->mask_src = nullptr; p->lband_use = false; }
   } mask_scope{this};
   if (masked) {
     bool fused = false;
@@ -1521,32 +1588,61 @@ int mfft_plan_s::pencil_backward_padded_fused(const void* fu, void* u) {
   const size_t wb = (size_t)std::max(std::max(M0 * N1_1 * q, mp * M1 * q), std::max(std::max(N2_0 * M1 * q, M0 * np * q), mp * np * Nf)) * es;
   for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
   void *W0 = work[0], *W1 = work[1], *W2 = work[2];
+  // a group of one rank exchanges nothing: with the fused z kernels its exchange is skipped altogether (the transform
+  // on the far side reads the buffer the near side wrote)
+  const bool fz = zfuse_pad();
+  const bool zsolo = fz && (X ? P2 : P1) == 1, g2solo = fz && (X ? P1 : P2) == 1;
+  void* cur = W0;                                    // what the next stage reads
+  auto other = [&](void* b) { return b == W0 ? W1 : W0; };
   if (X) {
     // fu (N0, N1_1, q) -> ifft x over M0 rows, the zero band never read
     MFFT_TRY(stage("bwd_x", 0, [&] {
       return col_pad(fu, W0, M0, true, 1, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q), sc3 / (double)M0);
     }));
-    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, true, W0, W1); }));
-    // W1 = P1 blocks (mp, N1_1, q): gather y through the input row map, pad on load, write P2 blocks (mp, np, q)
+    if (!g2solo) {
+      MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, true, W0, W1); }));
+      cur = W1;
+    }
+    // cur = P1 blocks (mp, N1_1, q): gather y through the input row map, pad on load, write P2 blocks (mp, np, q)
+    void* dst = other(cur);
     MFFT_TRY(stage("bwd_y", 0, [&] {
-      return col_pad(W1, W0, M1, true, 1, false, mp, q, N1_1 * q, two_level(N1_1, mp * N1_1 * q, q), np * q,
+      return col_pad(cur, dst, M1, true, 1, false, mp, q, N1_1 * q, two_level(N1_1, mp * N1_1 * q, q), np * q,
                      two_level(np, mp * np * q, q), 1.0 / (double)M1);
     }));
+    cur = dst;
   } else {
     // fu (N2_0, N1, q) -> ifft y over M1 rows, written as P2 blocks (N2_0, np, q)
     MFFT_TRY(stage("bwd_y", 0, [&] {
       return col_pad(fu, W0, M1, true, 1, false, N2_0, q, N1 * q, plain(q), np * q, two_level(np, N2_0 * np * q, q),
                      sc3 / (double)M1);
     }));
-    MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, true, W0, W1); }));
-    // W1 = (N0, np, q) -> ifft x over M0 rows; its x chunks (mp rows) are the blocks of the next exchange
+    if (!g2solo) {
+      MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, true, W0, W1); }));
+      cur = W1;
+    }
+    // cur = (N0, np, q) -> ifft x over M0 rows; its x chunks (mp rows) are the blocks of the next exchange
+    void* dst = other(cur);
     MFFT_TRY(stage("bwd_x", 0, [&] {
-      return col_pad(W1, W0, M0, true, 1, false, 1, np * q, 0, plain(np * q), 0, plain(np * q), 1.0 / (double)M0);
+      return col_pad(cur, dst, M0, true, 1, false, 1, np * q, 0, plain(np * q), 0, plain(np * q), 1.0 / (double)M0);
     }));
+    cur = dst;
   }
-  MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, true, W0, W1); }));
+  if (!zsolo) {
+    void* dst = other(cur);
+    MFFT_TRY(stage("bwd_a2a_1", 0, [&] { return xchg(0, false, true, cur, dst); }));
+    cur = dst;
+  }
   // only the Nf kept columns exist: c2r reads the others as zeros
-  MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z(this, W2, W1, mp * np, Nf, zc, true); }));
+  if (fz) {                     // ... and reads the kept ones out of the received z-chunk blocks itself
+    MFFT_TRY(stage("bwd_z", 0, [&] {
+      RealArgs a;
+      a.in = cur; a.out = u; a.n = (int)M2; a.prec = prec; a.in_stride = Nf; a.out_stride = M2; a.nrows = mp * np;
+      a.scale = 1.0 / (double)M2; a.valid = (int)Nf; a.zs = zsplit(mp * np, 0);
+      return launch_c2r(a, stream);
+    }));
+    return 0;
+  }
+  MFFT_TRY(stage("bwd_unpackz", 0, [&] { return pack_z(this, W2, cur, mp * np, Nf, zc, true); }));
   MFFT_TRY(stage("bwd_z", 0, [&] { return c2r_rows(W2, u, mp * np, M2, Nf, M2, 1.0 / (double)M2, (int)Nf); }));
   return 0;
 }
@@ -1558,29 +1654,57 @@ int mfft_plan_s::pencil_forward_padded_fused(const void* u, void* fu) {
   const size_t wb = (size_t)std::max(std::max(M0 * N1_1 * q, mp * M1 * q), std::max(std::max(N2_0 * M1 * q, M0 * np * q), mp * np * Nf)) * es;
   for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
   void *W0 = work[0], *W1 = work[1];
-  MFFT_TRY(stage("fwd_z", 0, [&] { return r2c_rows(u, W0, mp * np, M2, M2, Nf, 1.0, (int)Nf); }));
-  MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, mp * np, Nf, zc, false); }));
-  MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, true, W1, W0); }));
-  if (X) {
-    // W0 = P2 blocks (mp, np, q): fft y gathering over M1 rows, truncate + fold on store, straight into
-    // the P1 blocks (mp, N1_1, q) of the next exchange
-    MFFT_TRY(stage("fwd_y", 0, [&] {
-      return col_pad(W0, W1, M1, false, 2, true, mp, q, np * q, two_level(np, mp * np * q, q), N1_1 * q,
-                     two_level(N1_1, mp * N1_1 * q, q), 1.0);
-    }));
-    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, true, W1, W0); }));
-    MFFT_TRY(stage("fwd_x", 0, [&] {
-      return col_pad(W0, fu, M0, false, 2, true, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q), isc3);
+  const bool fz = zfuse_pad();
+  const bool zsolo = fz && (X ? P2 : P1) == 1, g2solo = fz && (X ? P1 : P2) == 1;
+  auto other = [&](void* b) { return b == W0 ? W1 : W0; };
+  if (fz) {                     // r2c stores the kept columns straight into the z-chunk send blocks
+    MFFT_TRY(stage("fwd_z", 0, [&] {
+      RealArgs a;
+      a.in = u; a.out = W1; a.n = (int)M2; a.prec = prec; a.in_stride = M2; a.out_stride = Nf; a.nrows = mp * np;
+      a.scale = 1.0; a.valid = (int)Nf; a.zs = zsplit(mp * np, 0);
+      return launch_r2c(a, stream);
     }));
   } else {
-    // W0 = (M0, np, q): fft x, truncate + fold to (N0, np, q)
-    MFFT_TRY(stage("fwd_x", 0, [&] {
-      return col_pad(W0, W1, M0, false, 2, true, 1, np * q, 0, plain(np * q), 0, plain(np * q), 1.0);
-    }));
-    MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, true, W1, W0); }));
-    // W0 = P2 blocks (N2_0, np, q): fft y gathering over M1 rows, truncate + fold into fu (N2_0, N1, q)
+    MFFT_TRY(stage("fwd_z", 0, [&] { return r2c_rows(u, W0, mp * np, M2, M2, Nf, 1.0, (int)Nf); }));
+    MFFT_TRY(stage("fwd_packz", 0, [&] { return pack_z(this, W0, W1, mp * np, Nf, zc, false); }));
+  }
+  void* cur = W1;
+  if (!zsolo) {
+    MFFT_TRY(stage("fwd_a2a_1", 0, [&] { return xchg(0, true, true, W1, W0); }));
+    cur = W0;
+  }
+  if (X) {
+    // cur = P2 blocks (mp, np, q): fft y gathering over M1 rows, truncate + fold on store, straight into
+    // the P1 blocks (mp, N1_1, q) of the next exchange
+    void* dst = other(cur);
     MFFT_TRY(stage("fwd_y", 0, [&] {
-      return col_pad(W0, fu, M1, false, 2, true, N2_0, q, np * q, two_level(np, N2_0 * np * q, q), N1 * q, plain(q), isc3);
+      return col_pad(cur, dst, M1, false, 2, true, mp, q, np * q, two_level(np, mp * np * q, q), N1_1 * q,
+                     two_level(N1_1, mp * N1_1 * q, q), 1.0);
+    }));
+    cur = dst;
+    if (!g2solo) {
+      dst = other(cur);
+      MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, true, cur, dst); }));
+      cur = dst;
+    }
+    MFFT_TRY(stage("fwd_x", 0, [&] {
+      return col_pad(cur, fu, M0, false, 2, true, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q), isc3);
+    }));
+  } else {
+    // cur = (M0, np, q): fft x, truncate + fold to (N0, np, q)
+    void* dst = other(cur);
+    MFFT_TRY(stage("fwd_x", 0, [&] {
+      return col_pad(cur, dst, M0, false, 2, true, 1, np * q, 0, plain(np * q), 0, plain(np * q), 1.0);
+    }));
+    cur = dst;
+    if (!g2solo) {
+      dst = other(cur);
+      MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, true, cur, dst); }));
+      cur = dst;
+    }
+    // cur = P2 blocks (N2_0, np, q): fft y gathering over M1 rows, truncate + fold into fu (N2_0, N1, q)
+    MFFT_TRY(stage("fwd_y", 0, [&] {
+      return col_pad(cur, fu, M1, false, 2, true, N2_0, q, np * q, two_level(np, N2_0 * np * q, q), N1 * q, plain(q), isc3);
     }));
   }
   return 0;
@@ -2061,6 +2185,7 @@ int mfft_plan_set_dealias_mask(mfft_plan_t p, const uint8_t* mask_host, size_t c
   MFFT_HIP(hipMemcpy(p->mask, mask_host, count, hipMemcpyHostToDevice));
   p->mask_count = count;
   p->detect_band(mask_host);
+  p->detect_band_local(mask_host);
   return 0;
 }
 
@@ -2068,6 +2193,7 @@ int mfft_plan_get_info(mfft_plan_t p, const char* key, int64_t* value) {
   if (!p || !key || !value) return set_error(MFFT_ERR_INVALID, "null argument");
   const std::string k(key);
   if (k == "pruned_route") *value = p->band_ok ? (p->band_allzero ? 2 : 1) : 0;
+  else if (k == "local_band") *value = p->lband_ok ? 1 : 0;
   else if (k == "comm_cus") *value = p->comm_cus;
   else if (k == "kz_slices") *value = p->nslice;
   else if (k == "row_batches") *value = p->nbatch;

@@ -25,7 +25,7 @@ struct KernelEntry {
   int nt;           // COL: 1 = non-temporal variant (128-byte aligned rows only)
   int nt_inplace;   // COL, nt = 1: also faster than the regular variant when the transform is in place
   int pad;          // COL: 1 = zero-padded input (inverse), 2 = truncated output (forward); ROW / R2C / C2R: 3 = column-limited
-                    // (3/2-rule), 4 = complex side split into z chunks (fused pencil pack / unpack)
+                    // (3/2-rule), 4 = complex side split into z chunks (fused pencil pack / unpack), 7 = both (3/2-rule pencils)
   int tile;         // COLS (COL) or ROWS (others)
   int threads;
   int lds_bytes;
@@ -235,6 +235,12 @@ void register_rows(const char* name) {
   if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
     reg.push_back(make_entry<R2CFft<S, T, R, RT, true, false, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
     reg.back().pad = 3;
+    // ... and with the kept columns split into the z chunks of the pencils' exchange (pad = 7): the 3/2-rule pencil
+    // transforms write / read the exchange blocks themselves (pencil.py:511-632, 758-883 do it in the MPI datatypes)
+    reg.push_back(make_entry<R2CFft<S, T, R, RT, true, true, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+    reg.back().pad = 7;
+    reg.push_back(make_entry<C2RFft<S, T, RC, RT, true, true, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.back().pad = 7;
   }
   if constexpr (S::N >= 4) {                    // column-limited c2r: 3/2-rule lengths and the pruned 2/3-rule (any length)
     reg.push_back(make_entry<C2RFft<S, T, RC, RT, true, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));

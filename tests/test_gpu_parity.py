@@ -361,34 +361,41 @@ def test_two_thirds_rule_edge_masks(kind, P):
         assert np.abs(u - want[rsl]).max() <= 1e-13 * max(np.abs(want).max(), 1e-300), kind     # the oracle's arithmetic
 
 
-@pytest.mark.parametrize("decomp", ["slab", "pencilX", "pencilY"])
-def test_two_thirds_rule(decomp):
-    """ifftn(dealias='2/3-rule') == ifftn of the masked spectrum (slab.py:237-245)."""
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("decomp,P,pipeline", [("slab", 2, 0), ("pencilX", 4, 1), ("pencilX", 4, 4), ("pencilX", 8, 2), ("pencilX", 1, 1),
+                                               ("pencilY", 4, 1), ("pencilY", 4, 4), ("pencilY", 8, 1), ("pencilY", 16, 2)])
+def test_two_thirds_rule(decomp, P, pipeline, prec):
+    """ifftn(dealias='2/3-rule') == ifftn of the masked spectrum (slab.py:237-245, pencil.py:455-462).  With the reference's
+    own filter the pencils' first inverse pass takes the band kernel (three 1-D conditions instead of one mask byte per
+    element; plan.hip detect_band_local): asserted through mfft_plan_get_info, result against the oracle's arithmetic."""
     from mpifft4py_amd import Pencil_R2C, Slab_R2C
     rng = np.random.default_rng(600)
     N = NREF
-    C = np.fft.rfftn(rng.random(N))
-    P = 2 if decomp == "slab" else 4
+    ct, rt = cdtype(prec), rdtype(prec)
+    C = np.fft.rfftn(rng.random(N)).astype(ct)
 
     def body(comm):
-        F = (Slab_R2C(np.array(N), L, comm, "double") if decomp == "slab" else
-             Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=decomp[-1]))
+        F = (Slab_R2C(np.array(N), L, comm, prec, pipeline=pipeline) if decomp == "slab" else
+             Pencil_R2C(np.array(N), L, comm, prec, communication="Alltoallw", alignment=decomp[-1], pipeline=pipeline,
+                        allow_single=True))
         c = np.ascontiguousarray(C[F.complex_local_slice()])
         c_in = c.copy()
-        u = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule")
+        u = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt), dealias="2/3-rule")
         assert np.array_equal(c, c_in)          # input spectrum untouched
         mask = np.broadcast_to(F.get_dealias_filter(), F.complex_shape())
-        u_ref = F.ifftn(c * mask, np.zeros(F.real_shape()))
+        u_ref = F.ifftn((c * mask).astype(ct), np.zeros(F.real_shape(), dtype=rt))
+        if decomp != "slab":
+            assert F.plan_info("local_band") == 1
         return u, u_ref, F.complex_local_slice(), mask, F.real_local_slice()
     kx = np.fft.fftfreq(N[0], 1. / N[0])
     ky = np.fft.fftfreq(N[1], 1. / N[1])
     kz = np.fft.rfftfreq(N[2], 1. / N[2])
     gmask = orc.dealias_mask(N, kx, ky, kz)
-    want = np.fft.irfftn(C * gmask, s=N, axes=(0, 1, 2))       # the oracle's arithmetic with the oracle's mask
+    want = np.fft.irfftn(C.astype(np.complex128) * gmask, s=N, axes=(0, 1, 2))       # the oracle's arithmetic with the oracle's mask
     for u, u_ref, cs, mask, rsl in run_ranks(P, body):
-        assert orc.rel_l2(u, u_ref) < 1e-12
+        assert orc.rel_l2(u, u_ref) < 0.05 * TOL[prec]
         assert np.array_equal(mask, gmask[cs])
-        assert orc.rel_l2(u, want[rsl]) < 4e-10
+        assert orc.rel_l2(u, want[rsl]) < 4 * TOL[prec]
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
