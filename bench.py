@@ -476,7 +476,15 @@ def main():
                 grids = [(a, world // a) for a in range(1, world + 1) if world % a == 0 and n % a == 0 and n % (world // a) == 0
                          and (n // 2 + 1) % (world // a) <= 1 and (world // a == 1 or (n // (world // a)) % 2 == 0)]
             per_cand = {}
+            # IPC transport, every rank on its own device: the sub-group exchanges with and without relay striping
+            # (csrc/relay_plan.h; two hops through the ranks outside the group use the links a P1 x P2 grid leaves idle)
+            relays = (0, 1) if (world > 1 and pcomm.get_option("ipc_pull") >= 0 and int(_lib.device_count()) >= world) else (None,)
             for grid in grids:
+              for relay in relays:
+                if relay is not None:
+                    if grid is not None and (grid[0] == 1 or grid[1] == 1) and relay == 1:
+                        continue                                  # one exchange over all ranks: nothing to relay
+                    pcomm.set_option("ipc_relay", relay)
                 for depth in ((1, 4) if world > 1 else (1,)):        # blocking exchanges / the X pipeline (batches of local x rows)
                     Fp = Pencil_R2C(N, L, pcomm, args.precision, P1=(grid[0] if grid else None), communication="Alltoallw",
                                     alignment="X", allow_single=True, allow_odd_grid=True, pipeline=depth)
@@ -501,13 +509,15 @@ def main():
                     b0 = up2.leading(0, 1).get()
                     rt = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
                     rt = pcomm.allreduce(rt if rt == rt else 1e30, op=mcomm.MAX) if world > 1 else rt
-                    per_cand[(int(Fp.P1), int(Fp.P2), depth)] = {
+                    per_cand[(int(Fp.P1), int(Fp.P2), depth, relay or 0)] = {
                         "grid": [int(Fp.P1), int(Fp.P2)], "pairs_per_s": ksteps / dtp, "ms_per_pair": 1e3 * dtp / ksteps,
-                        "steps": ksteps, "exchange_pipeline_depth": depth,
+                        "steps": ksteps, "exchange_pipeline_depth": depth, "relay_striping": bool(relay),
                         "exchange_transport": cand_name(pcomm, best[2]) if world > 1 else None, "roundtrip_rel_l2": rt}
                     del Fp, up, fup, up2
+            if relays != (None,):
+                pcomm.set_option("ipc_relay", 0)
             bestp = min(per_cand, key=lambda k_: per_cand[k_]["ms_per_pair"])
-            table = {"%dx%d:%d" % k_: v["ms_per_pair"] for k_, v in per_cand.items()}
+            table = {"%dx%d:%d%s" % (k_[0], k_[1], k_[2], ":relay" if k_[3] else ""): v["ms_per_pair"] for k_, v in per_cand.items()}
             extras["pencil_R2CX"] = dict(per_cand[bestp], ms_per_pair_by_grid_and_depth=table,
                                          roundtrip_rel_l2=max(v["roundtrip_rel_l2"] for v in per_cand.values()))
             # the reference's own default grid, whatever won

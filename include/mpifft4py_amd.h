@@ -89,7 +89,9 @@ MFFT_API int mfft_comm_selftest(mfft_comm_t comm, size_t bytes_per_peer, int tim
  * slab.py:406/281, pencil.py:741-750) knows "ipc_pull" = how a rank fetches its chunks from the peers' buffers: 1 one
  * pull kernel over all peers at once (default), 2 one copy-engine transfer per peer on per-peer streams, 0 copy-engine
  * transfers one after the other; and "ipc_pull_wgs" = workgroups per peer of that kernel.  A rank-local choice (the
- * flag protocol is the same), other transports reject every key; get returns -1 in *value for an unknown key. */
+ * flag protocol is the same).  "ipc_relay" = 1 / 0: sub-group exchanges of pencil plans use the links to the ranks
+ * outside the group as well (mfft_plan_relay_schedule) -- every rank must set the same value.  Other transports reject
+ * every key; get returns -1 in *value for an unknown key. */
 MFFT_API int mfft_comm_set_option(mfft_comm_t comm, const char* key, int64_t value);
 MFFT_API int mfft_comm_get_option(mfft_comm_t comm, const char* key, int64_t* value);
 /* host-buffer helpers for tests/demos (tests/test_FFT.py:77-78 Bcast; demo:103 reduce) */
@@ -147,6 +149,18 @@ MFFT_API int mfft_plan_exchange_schedule(const mfft_plan_desc* desc, int nranks,
 MFFT_API int mfft_plan_exchange_pieces(const mfft_plan_desc* desc, int nranks, int rank, int which, int forward,
                                        int piece, int max_peers, int* npieces, int* npeers, int* peers,
                                        size_t* scount, size_t* sdisp, size_t* rcount, size_t* rdisp);
+
+/* Relay striping of the pencils' sub-group exchanges over the IPC transport (csrc/relay_plan.h): on a fully connected
+ * xGMI node a rank that exchanges with the g - 1 peers of its comm0 / comm1 group (pencil.py:741-750, 1324-1333) leaves
+ * its links to the other P - g ranks idle; a message is therefore cut into a direct part and P - g stripes that travel
+ * through those ranks in two hops.  This query lists, device-free, what `rank` PULLS in exchange `which`: phase (1, 2),
+ * kind (0 own chunk, 1 direct part read from msg_src's send buffer, 2 first hop: rank is the relay and stages the stripe
+ * of msg_src -> msg_dst, 3 second hop: read from relay `from`'s staging area), the offset inside the message and the
+ * byte count.  It is the enumeration the transport executes ("ipc_relay" option of mfft_comm_set_option; default: on
+ * when every rank owns a device). */
+MFFT_API int mfft_plan_relay_schedule(const mfft_plan_desc* desc, int nranks, int rank, int which, int forward,
+                                      int max_moves, int* nmoves, int* phase, int* kind, int* from, int* msg_src,
+                                      int* msg_dst, size_t* msg_off, size_t* bytes);
 
 /* mfft_forward / mfft_backward ENQUEUE the transform on the plan's own (non-blocking) HIP stream and return; calls on
  * one plan execute in order.  Before the host or another stream reads the result (or reuses the input), call

@@ -69,6 +69,9 @@ _SIGNATURES = {
     "mfft_plan_exchange_pieces": ([POINTER(PlanDesc), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),
                                    POINTER(c_int), POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t),
                                    POINTER(c_size_t), POINTER(c_size_t)], c_int),
+    "mfft_plan_relay_schedule": ([POINTER(PlanDesc), c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
+                                  POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_size_t),
+                                  POINTER(c_size_t)], c_int),
     "mfft_forward": ([c_void_p, c_void_p, c_void_p, c_int], c_int),
     "mfft_backward": ([c_void_p, c_void_p, c_void_p, c_int], c_int),
     "mfft_plan_sync": ([c_void_p], c_int),
@@ -181,6 +184,24 @@ def exchange_pieces(N, nranks, rank, decomp, which, forward, pipeline, precision
                         rcount=list(arrs[2][:k]), rdisp=list(arrs[3][:k])))
         piece += 1
     return out
+
+
+def relay_schedule(N, nranks, rank, decomp, which, forward=True, precision="double", kind=R2C, p1=0):
+    """Host-only query of what `rank` pulls in the relayed form of exchange `which` (mfft_plan_relay_schedule):
+    list of dict(phase, kind, frm, msg_src, msg_dst, msg_off, bytes)."""
+    d = PlanDesc()
+    for i in range(3):
+        d.n[i] = int(N[i])
+    d.precision = SINGLE if precision == "single" else DOUBLE
+    d.kind, d.decomp, d.p1, d.padsize, d.pipeline = kind, decomp, int(p1 or 0), 1.5, 1
+    mx = 1024
+    n = c_int(0)
+    ints = [(c_int * mx)() for _ in range(5)]
+    szs = [(c_size_t * mx)() for _ in range(2)]
+    call("mfft_plan_relay_schedule", ctypes.byref(d), nranks, rank, which, 1 if forward else 0, mx, ctypes.byref(n),
+         *(ints + szs))
+    return [dict(phase=ints[0][i], kind=ints[1][i], frm=ints[2][i], msg_src=ints[3][i], msg_dst=ints[4][i],
+                 msg_off=szs[0][i], bytes=szs[1][i]) for i in range(n.value)]
 
 
 def device_count():

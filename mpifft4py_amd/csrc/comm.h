@@ -30,6 +30,14 @@ struct mfft_comm_s {
   virtual int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv,
                         const size_t* rcount, const size_t* rdisp, const int* peers, int npeers,
                         hipStream_t s, int channel = 0) = 0;
+  // The same when EVERY rank of the communicator runs an exchange of its own group at this point and the groups
+  // partition the ranks: part[r] = group id of rank r (the pencils' comm0 / comm1 exchanges).  A transport may then use
+  // the links to ranks outside the group as well (IpcComm: two-hop relay striping, relay_plan.h); the default ignores it.
+  virtual int alltoallv_part(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
+                             const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int channel, const int* part) {
+    (void)part;
+    return alltoallv(send, scount, sdisp, recv, rcount, rdisp, peers, npeers, s, channel);
+  }
   virtual int barrier() = 0;
   virtual int bcast_host(void* buf, size_t bytes, int root) = 0;
   virtual int allreduce_host(double* vals, int count, int op /*0 sum, 1 max*/) = 0;

@@ -44,6 +44,7 @@
 #include <vector>
 #include "comm.h"
 #include "ipc_pull.h"
+#include "relay_plan.h"
 #include "mfft_internal.h"
 
 namespace mfft {
@@ -81,6 +82,16 @@ struct IpcPair {                    // one per ordered pair (sender, receiver) a
   IpcPost ring[IPC_RING];
   std::atomic<uint64_t> consumed;   // last post the receiver has read
 };
+// relayed sub-group exchanges (relay_plan.h): all ranks take part in lock-step, two host barriers per exchange, so a
+// ring of two slots (exchange number & 1) is enough
+struct IpcRPost {                   // message s -> d of relayed exchange q
+  uint32_t seg, pad;
+  uint64_t offset, bytes;
+};
+struct IpcStage {                   // where relay r has staged its stripe of the message s -> d
+  uint32_t seg, pad;
+  uint64_t offset;
+};
 struct IpcRankInfo {
   int device, pid;
   hipIpcMemHandle_t flags_h;
@@ -94,11 +105,17 @@ struct IpcShm {
   std::atomic<uint32_t> bar_count, bar_gen, broken;
   IpcRankInfo rk[IPC_MAX_RANKS];
   IpcPair pair[IPC_MAX_RANKS /*sender*/][IPC_MAX_RANKS /*receiver*/][IPC_MAX_CH];
+  IpcRPost rpost[IPC_MAX_RANKS /*s*/][IPC_MAX_RANKS /*d*/][IPC_MAX_CH][2];
+  IpcStage stage[IPC_MAX_RANKS /*relay*/][IPC_MAX_RANKS /*s*/][IPC_MAX_RANKS /*d*/][IPC_MAX_CH][2];
 };
 // device-side flags of one rank (the READER of a flag owns it, so that polling stays local)
 struct IpcFlags {
   uint32_t ready[IPC_MAX_RANKS][IPC_MAX_CH];   // ready[p]: written by sender p, "my send buffer holds exchange q"
   uint32_t done[IPC_MAX_RANKS][IPC_MAX_CH];    // done[r]:  written by receiver r, "I have pulled my chunk of exchange q"
+  // relayed exchanges, all written by rank x about its relayed exchange number q:
+  uint32_t rready[IPC_MAX_RANKS][IPC_MAX_CH];  //   "my send buffer holds exchange q"
+  uint32_t k1done[IPC_MAX_RANKS][IPC_MAX_CH];  //   "my phase 1 is done": first hops staged in my memory, my first reads of your buffer over
+  uint32_t k2done[IPC_MAX_RANKS][IPC_MAX_CH];  //   "my phase 2 is done": I read nothing of exchange q any more
 };
 static_assert(std::atomic<uint64_t>::is_always_lock_free && std::atomic<uint32_t>::is_always_lock_free, "shared-memory atomics");
 
@@ -130,6 +147,11 @@ struct IpcComm : mfft_comm_s {
   int pull_mode = PULL_KERNEL;
   int pull_wgs = 8;                                        // kernel mode: workgroups per peer chunk
   hipStream_t pstream[IPC_MAX_RANKS] = {};                 // streams mode: one copy stream per peer (normal priority)
+  // relayed sub-group exchanges (exchange_relay)
+  int relay_mode = -1;                                     // -1: decide at first use (on when every rank owns a device), 0 off, 1 on
+  uint32_t xseq[IPC_MAX_CH] = {};
+  void* staging[IPC_MAX_CH] = {};
+  size_t staging_bytes[IPC_MAX_CH] = {};
   hipEvent_t fork_ev[IPC_MAX_CH] = {}, join_ev[IPC_MAX_RANKS][IPC_MAX_CH] = {};
 
   IpcComm() {
@@ -139,11 +161,17 @@ struct IpcComm : mfft_comm_s {
       else pull_mode = PULL_KERNEL;
     }
     if (const char* e = getenv("MFFT_IPC_PULL_WGS")) pull_wgs = std::max(1, std::min(64, atoi(e)));
+    if (const char* e = getenv("MFFT_IPC_RELAY")) relay_mode = atoi(e) != 0 ? 1 : 0;
   }
   int set_option(const char* key, long long v) override {
     if (!strcmp(key, "ipc_pull")) {
       if (v < 0 || v > 2) return set_error(MFFT_ERR_INVALID, "ipc_pull: 0 copy, 1 kernel, 2 streams");
       pull_mode = (int)v;
+      return 0;
+    }
+    if (!strcmp(key, "ipc_relay")) {        // COLLECTIVE in effect: every rank must choose the same value
+      if (v < 0 || v > 1) return set_error(MFFT_ERR_INVALID, "ipc_relay: 0 off, 1 on");
+      relay_mode = (int)v;
       return 0;
     }
     if (!strcmp(key, "ipc_pull_wgs")) {
@@ -156,6 +184,7 @@ struct IpcComm : mfft_comm_s {
   long long get_option(const char* key) override {
     if (!strcmp(key, "ipc_pull")) return pull_mode;
     if (!strcmp(key, "ipc_pull_wgs")) return pull_wgs;
+    if (!strcmp(key, "ipc_relay")) return relay_enabled() ? 1 : 0;
     return mfft_comm_s::get_option(key);
   }
 
@@ -183,6 +212,7 @@ struct IpcComm : mfft_comm_s {
     }
     for (hipStream_t ps : pstream)
       if (ps) (void)hipStreamDestroy(ps);
+    // (staging blocks live in the arena's segments, freed below)
     if (flags) (void)hipFree(flags);
     for (Seg& s : segs) (void)hipFree(s.base);
     if (sh) munmap(sh, sizeof(IpcShm));
@@ -220,7 +250,8 @@ struct IpcComm : mfft_comm_s {
   // end with whatever data there is, and the communicator is marked broken
   void rescue() override {
     if (sh) sh->broken.store(1);
-    if (flags) (void)hipMemset(flags, 0xFF, sizeof(IpcFlags));
+    // 0x7FFFFFFF satisfies every ">= q" wait, cyclic comparison or not (q stays far below 2^31)
+    if (flags) (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(flags), 0x7FFFFFFF, sizeof(IpcFlags) / 4);
   }
   int bcast_host(void* buf, size_t bytes, int root) override {
     char* p = static_cast<char*>(buf);
@@ -462,6 +493,167 @@ struct IpcComm : mfft_comm_s {
     // 4. sender role: nobody overwrites its send buffer before all peers have pulled from it
     for (int i = 0; i < npeers; ++i)
       if (qs[i]) MFFT_HIP(hipStreamWaitValue32(s, &flags->done[peers[i]][ch], qs[i], hipStreamWaitValueGte, 0xFFFFFFFFu));
+    MFFT_HIP(hipEventRecord(last_issue[ch], s));
+    last_stream[ch] = s;
+    used_ch[ch] = true;
+    return 0;
+  }
+
+  // ---- relayed sub-group exchange ---------------------------------------------------------------------------------
+  // Relaying only pays when the ranks sit on different devices (two hops over otherwise idle links); with ranks sharing
+  // a device it doubles the local traffic.  Default: on exactly when every rank owns a device.  The answer is the same on
+  // every rank (it is computed from the shared rank table).
+  bool relay_enabled() {
+    if (relay_mode < 0) {
+      bool distinct = true;
+      for (int a = 0; a < size; ++a)
+        for (int b = a + 1; b < size; ++b) distinct = distinct && sh->rk[a].device != sh->rk[b].device;
+      relay_mode = distinct ? 1 : 0;
+    }
+    return relay_mode == 1;
+  }
+  int alltoallv_part(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
+                     const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int channel, const int* part) override {
+    if (!part || npeers < 2 || npeers >= size || !relay_enabled())
+      return alltoallv(send, scount, sdisp, recv, rcount, rdisp, peers, npeers, s, channel);
+    const int rc = exchange_relay(send, scount, sdisp, recv, rcount, rdisp, peers, npeers, s, channel, part);
+    if (rc != 0) rescue();
+    return rc;
+  }
+  int launch_jobs(const std::vector<PullJob>& jobs, hipStream_t s) {
+    for (size_t i0 = 0; i0 < jobs.size(); i0 += PULL_MAX_JOBS) {
+      PullArgs pa;
+      memset(&pa, 0, sizeof pa);
+      for (size_t i = i0; i < jobs.size() && i < i0 + PULL_MAX_JOBS; ++i) pa.job[pa.njobs++] = jobs[i];
+      pa.wgs = std::max(pull_wgs, (56 + pa.njobs - 1) / pa.njobs);
+      MFFT_HIP(launch_pull(pa, s));
+    }
+    return 0;
+  }
+  // one wave signals / awaits the flag word `which` (rready / k1done / k2done) of the listed ranks
+  typedef uint32_t (IpcFlags::*FlagArray)[IPC_MAX_RANKS][IPC_MAX_CH];
+  int flags_all(bool wait, FlagArray which, int ch, uint32_t q, const std::vector<int>& ranks, hipStream_t s) {
+    FlagOps f;
+    f.n = 0;
+    for (int r : ranks) {
+      if (r == rank) continue;
+      // wait: word [r] of MY flags (written by r); signal: word [rank] of r's flags
+      f.addr[f.n] = wait ? &(flags->*which)[r][ch] : &(peer_flags[r]->*which)[rank][ch];
+      f.value[f.n] = q;
+      if (++f.n == FLAG_MAX_OPS) return set_error(MFFT_ERR_INVALID, "ipc transport: too many flag operations");
+    }
+    MFFT_HIP(launch_flags(wait, f, s));
+    return 0;
+  }
+  int exchange_relay(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
+                     const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int ch, const int* part) {
+    if (ch < 0 || ch >= IPC_MAX_CH) return set_error(MFFT_ERR_INVALID, "ipc transport: channel %d", ch);
+    if (sh->broken.load()) return set_error(MFFT_ERR_INTERNAL, "ipc transport: the group is broken (a rank failed earlier)");
+    const int P = size, g = npeers, gid = part[rank];
+    int myidx = -1, members = 0;
+    for (int i = 0; i < npeers; ++i) {
+      if (peers[i] == rank) myidx = i;
+      if (part[peers[i]] != gid) return set_error(MFFT_ERR_INVALID, "ipc transport: peer %d is not in group %d of the partition", peers[i], gid);
+    }
+    for (int r = 0; r < P; ++r) members += part[r] == gid;
+    if (myidx < 0 || members != g) return set_error(MFFT_ERR_INVALID, "ipc transport: the peer list and the partition disagree");
+    if (rcount[myidx] && scount[myidx] != rcount[myidx]) return set_error(MFFT_ERR_INVALID, "ipc transport: self chunk size mismatch");
+    if (!last_issue[ch]) MFFT_HIP(hipEventCreateWithFlags(&last_issue[ch], hipEventDisableTiming));
+    if (used_ch[ch]) MFFT_HIP(hipStreamWaitEvent(s, last_issue[ch], 0));
+    if (!release_ev[ch]) MFFT_HIP(hipEventCreateWithFlags(&release_ev[ch], hipEventDisableTiming | hipEventReleaseToSystem));
+    const char* sp = static_cast<const char*>(send);
+    char* rp = static_cast<char*>(recv);
+    const uint32_t q = ++xseq[ch];
+    const int slot = (int)(q & 1u);
+    std::vector<int> everyone, outsiders;
+    for (int r = 0; r < P; ++r) {
+      if (r != rank) everyone.push_back(r);
+      if (part[r] != gid) outsiders.push_back(r);
+    }
+    // 1. where my messages lie; on the stream: the data is there (told to EVERY rank: group peers read the direct
+    //    parts, everybody else a first-hop stripe)
+    uint32_t seg = 0;
+    uint64_t soff = 0;
+    bool any_send = false;
+    for (int i = 0; i < npeers; ++i) any_send = any_send || (peers[i] != rank && scount[i]);
+    if (any_send) MFFT_TRY(locate(send, &seg, &soff));
+    for (int i = 0; i < npeers; ++i) {
+      if (peers[i] == rank) continue;
+      IpcRPost& po = sh->rpost[rank][peers[i]][ch][slot];
+      po.seg = seg; po.offset = soff + sdisp[i]; po.bytes = scount[i];
+    }
+    MFFT_HIP(hipEventRecord(release_ev[ch], s));
+    MFFT_TRY(flags_all(false, &IpcFlags::rready, ch, q, everyone, s));
+    MFFT_TRY(barrier());                                   // every post of exchange q is visible
+    // 2. what I pull (relay_plan.h relay_moves): as a destination -- direct halves, second hops -- and as a relay of the
+    //    other groups' messages (first hops into my staging area)
+    auto idx_of = [&](int r) { for (int i = 0; i < npeers; ++i) if (peers[i] == r) return i; return -1; };
+    for (int i = 0; i < npeers; ++i) {                     // what my group peers send me must be what I expect
+      const int p = peers[i];
+      if (p == rank) continue;
+      const uint64_t b = sh->rpost[p][rank][ch][slot].bytes;
+      if (b != rcount[i])
+        return set_error(MFFT_ERR_INTERNAL, "ipc transport: rank %d expects %zu bytes from %d, which sends %llu", rank, rcount[i], p,
+                         (unsigned long long)b);
+    }
+    std::vector<RelayMove> moves;
+    relay_moves(P, rank, part, [&](int sr, int d) -> size_t {
+      if (sr == d) return sr == rank ? rcount[myidx] : 0;
+      return (size_t)sh->rpost[sr][d][ch][slot].bytes;
+    }, &moves);
+    size_t need = 0;
+    for (const RelayMove& m : moves)
+      if (m.kind == 2) need += (m.bytes + 255) / 256 * 256;
+    if (need > staging_bytes[ch]) {                        // (first use, or a larger exchange: rare; frees synchronise the device)
+      if (staging[ch]) MFFT_TRY(work_free(staging[ch]));
+      staging[ch] = nullptr;
+      staging_bytes[ch] = 0;
+      MFFT_TRY(work_alloc(&staging[ch], need));
+      staging_bytes[ch] = need;
+    }
+    uint32_t stg_seg = 0;
+    uint64_t stg_off = 0;
+    if (need) MFFT_TRY(locate(staging[ch], &stg_seg, &stg_off));
+    std::vector<PullJob> k1, k2;
+    size_t fill = 0;
+    for (const RelayMove& m : moves) {
+      if (m.kind == 0) {
+        k1.push_back(PullJob{sp + sdisp[myidx], rp + rdisp[myidx], (unsigned long long)m.bytes});
+      } else if (m.kind == 1) {
+        const IpcRPost po = sh->rpost[m.msg_src][rank][ch][slot];
+        char* rbase = nullptr;
+        MFFT_TRY(remote_base(m.msg_src, po.seg, &rbase));
+        (m.phase == 1 ? k1 : k2).push_back(PullJob{rbase + po.offset + m.msg_off, rp + rdisp[idx_of(m.msg_src)] + m.msg_off,
+                                                   (unsigned long long)m.bytes});
+      } else if (m.kind == 2) {
+        const IpcRPost po = sh->rpost[m.msg_src][m.msg_dst][ch][slot];
+        char* rbase = nullptr;
+        MFFT_TRY(remote_base(m.msg_src, po.seg, &rbase));
+        k1.push_back(PullJob{rbase + po.offset + m.msg_off, static_cast<char*>(staging[ch]) + fill, (unsigned long long)m.bytes});
+        IpcStage& st = sh->stage[rank][m.msg_src][m.msg_dst][ch][slot];
+        st.seg = stg_seg; st.offset = stg_off + fill;
+        fill += (m.bytes + 255) / 256 * 256;
+      }
+    }
+    MFFT_TRY(barrier());                                   // every relay has said where it stages
+    for (const RelayMove& m : moves) {
+      if (m.kind != 3) continue;
+      const IpcStage st = sh->stage[m.from][m.msg_src][rank][ch][slot];
+      char* rbase = nullptr;
+      MFFT_TRY(remote_base(m.from, st.seg, &rbase));
+      k2.push_back(PullJob{rbase + st.offset, rp + rdisp[idx_of(m.msg_src)] + m.msg_off, (unsigned long long)m.bytes});
+    }
+    // 3. phase 1: everybody's data is there -> direct halves, self chunk, first hops -> tell everybody
+    MFFT_TRY(flags_all(true, &IpcFlags::rready, ch, q, everyone, s));
+    MFFT_TRY(launch_jobs(k1, s));
+    MFFT_TRY(flags_all(false, &IpcFlags::k1done, ch, q, everyone, s));
+    // 4. phase 2: the relays have staged -> second halves, second hops -> tell everybody
+    MFFT_TRY(flags_all(true, &IpcFlags::k1done, ch, q, outsiders, s));
+    MFFT_TRY(launch_jobs(k2, s));
+    MFFT_TRY(flags_all(false, &IpcFlags::k2done, ch, q, everyone, s));
+    // 5. my send buffer and my staging area are free once nobody reads exchange q any more
+    MFFT_TRY(flags_all(true, &IpcFlags::k1done, ch, q, everyone, s));
+    MFFT_TRY(flags_all(true, &IpcFlags::k2done, ch, q, everyone, s));
     MFFT_HIP(hipEventRecord(last_issue[ch], s));
     last_stream[ch] = s;
     used_ch[ch] = true;

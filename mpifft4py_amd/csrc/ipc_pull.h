@@ -17,7 +17,7 @@
 
 namespace mfft {
 
-constexpr int PULL_MAX_JOBS = 16;
+constexpr int PULL_MAX_JOBS = 64;        // a relayed exchange of 16 ranks in groups of 4: 3 direct + 1 self + 36 first hops
 constexpr int PULL_THREADS = 256;
 constexpr int PULL_UNROLL = 8;
 
@@ -32,7 +32,36 @@ struct PullArgs {
   int wgs;                    // workgroups per job
 };
 
+// Batched flag operations of the transport (one launch instead of one stream memory operation per peer -- which on
+// this stack are kernels of their own anyway, __amd_rocclr_streamOpsWait / Write): lane i of a single wave either
+// stores value[i] to *addr[i] with system-scope release (a peer's flag word, through its IPC mapping) or polls *addr[i]
+// (a word of this rank's own fine-grained flag array) until it is >= value[i] in wrap-around arithmetic.
+constexpr int FLAG_MAX_OPS = 64;
+struct FlagOps {
+  unsigned int* addr[FLAG_MAX_OPS];
+  unsigned int value[FLAG_MAX_OPS];
+  int n;
+};
+
 #if defined(__HIPCC__)
+static __global__ __launch_bounds__(64) void ipc_signal_kernel(FlagOps f) {
+  const int i = (int)threadIdx.x;
+  if (i < f.n) __hip_atomic_store(f.addr[i], f.value[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static __global__ __launch_bounds__(64) void ipc_wait_kernel(FlagOps f) {
+  const int i = (int)threadIdx.x;
+  if (i < f.n) {
+    while ((int)(__hip_atomic_load(f.addr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - f.value[i]) < 0) __builtin_amdgcn_s_sleep(8);
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);      // (system scope; the kernels behind this one start with their own acquire as well)
+}
+static inline hipError_t launch_flags(bool wait, const FlagOps& f, hipStream_t s) {
+  if (f.n <= 0) return hipSuccess;
+  if (wait) hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, s, f);
+  else hipLaunchKernelGGL(ipc_signal_kernel, dim3(1), dim3(64), 0, s, f);
+  return hipGetLastError();
+}
+
 typedef unsigned int pull_v4 __attribute__((ext_vector_type(4)));
 typedef unsigned int pull_v2 __attribute__((ext_vector_type(2)));
 

@@ -16,6 +16,7 @@
 #include <string>
 #include "comm.h"
 #include "mfft_internal.h"
+#include "relay_plan.h"
 
 using namespace mfft;
 
@@ -49,6 +50,7 @@ struct GraphEntry {            // a captured transform: same direction, buffers 
 struct Sched {                 // one all-to-all-v inside a group, bytes
   std::vector<int> peers;
   std::vector<size_t> sc, sd, rc, rd;
+  std::vector<int> part;       // pencils: group id of EVERY rank for this exchange (all groups exchange at once); empty: none
 };
 
 std::vector<Chunk> pencil_chunks(int64_t n, int size) {   // pencil.py:80-90
@@ -534,8 +536,14 @@ struct mfft_plan_s {
   }
   int sched(int which, bool forward, bool padded, Sched* out) const;
   int run_sched(const Sched& sc, const void* send, void* recv, hipStream_t on = nullptr) {
-    return comm->alltoallv(send, sc.sc.data(), sc.sd.data(), recv, sc.rc.data(), sc.rd.data(), sc.peers.data(),
-                           (int)sc.peers.size(), on ? on : stream, on && on != stream ? 1 : 0);
+    return comm->alltoallv_part(send, sc.sc.data(), sc.sd.data(), recv, sc.rc.data(), sc.rd.data(), sc.peers.data(),
+                                (int)sc.peers.size(), on ? on : stream, on && on != stream ? 1 : 0,
+                                sc.part.empty() ? nullptr : sc.part.data());
+  }
+  // group id of every rank for the exchange inside comm0 (consecutive ranks: same rank / P1) or comm1 (same rank % P1)
+  void fill_part(bool comm0, std::vector<int>* part) const {
+    part->resize(P);
+    for (int r = 0; r < P; ++r) (*part)[r] = comm0 ? r / P1 : r % P1;
   }
   int xchg(int which, bool forward, bool padded, const void* send, void* recv) {
     Sched sc;
@@ -608,6 +616,7 @@ int mfft_plan_s::sched(int which, bool forward, bool padded, Sched* o) const {
   }
   const bool X = d.decomp == MFFT_PENCIL_X;
   const int64_t m = padded ? M0 / P1 : N1_0, n = padded ? M1 / P2 : N2_1;
+  fill_part(which == 0 ? !X : X, &o->part);
   if (which == 0) {
     const std::vector<int>& gz = X ? group1 : group0;
     const int Pz = (int)gz.size();
@@ -1173,6 +1182,7 @@ static int pack_z(mfft_plan_s* p, const void* Z, void* S, int64_t rows, int64_t 
 int mfft_plan_s::sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sched* o) const {
   const int64_t m = N1_0, n = N2_1;
   const bool X = d.decomp == MFFT_PENCIL_X;
+  fill_part(which == 0 ? !X : X, &o->part);
   if (which == 0) {            // z-splitting exchange (X: group1, Y: group0): uneven chunks <-> (m, n, q) blocks, rows [i0, i0+mb) of m
     const std::vector<int>& gz = X ? group1 : group0;
     const int Pz = (int)gz.size();
@@ -2037,6 +2047,41 @@ int mfft_plan_exchange_pieces(const mfft_plan_desc* desc, int nranks, int rank, 
     if (sdisp) sdisp[i] = sc.sd[i];
     if (rcount) rcount[i] = sc.rc[i];
     if (rdisp) rdisp[i] = sc.rd[i];
+  }
+  return 0;
+}
+
+// What `rank` pulls, phase by phase, when exchange `which` of a pencil plan runs over the IPC transport with relay
+// striping (relay_plan.h) -- device-free, the same enumeration the transport executes (relay_moves): tests replay it on
+// host buffers and count the bytes per link.
+int mfft_plan_relay_schedule(const mfft_plan_desc* desc, int nranks, int rank, int which, int forward, int max_moves,
+                             int* nmoves, int* phase, int* kind, int* from, int* msg_src, int* msg_dst, size_t* msg_off,
+                             size_t* bytes) {
+  if (!desc || !nmoves) return set_error(MFFT_ERR_INVALID, "null argument");
+  if (desc->decomp == MFFT_SLAB) return set_error(MFFT_ERR_INVALID, "slab plans exchange over all ranks: nothing to relay");
+  std::vector<size_t> B((size_t)nranks * nranks, 0);
+  std::vector<int> part;
+  for (int s = 0; s < nranks; ++s) {
+    mfft_plan_s p;
+    MFFT_TRY(decomp_init(&p, desc, nranks, s));
+    Sched sc;
+    MFFT_TRY(p.sched(which, forward != 0, false, &sc));
+    for (size_t i = 0; i < sc.peers.size(); ++i) B[(size_t)s * nranks + sc.peers[i]] = sc.sc[i];
+    if (s == rank) part = sc.part;
+  }
+  if ((int)part.size() != nranks) return set_error(MFFT_ERR_INTERNAL, "no partition for this exchange");
+  std::vector<RelayMove> mv;
+  relay_moves(nranks, rank, part.data(), [&](int s, int d) { return B[(size_t)s * nranks + d]; }, &mv);
+  *nmoves = (int)mv.size();
+  if (*nmoves > max_moves) return set_error(MFFT_ERR_INVALID, "relay schedule has %d moves, room for %d", *nmoves, max_moves);
+  for (int i = 0; i < *nmoves; ++i) {
+    if (phase) phase[i] = mv[i].phase;
+    if (kind) kind[i] = mv[i].kind;
+    if (from) from[i] = mv[i].from;
+    if (msg_src) msg_src[i] = mv[i].msg_src;
+    if (msg_dst) msg_dst[i] = mv[i].msg_dst;
+    if (msg_off) msg_off[i] = mv[i].msg_off;
+    if (bytes) bytes[i] = mv[i].bytes;
   }
   return 0;
 }

@@ -91,21 +91,39 @@ def main():
     c = Fc.fftn(np.ascontiguousarray(Ac[Fc.original_local_slice()]).astype(np.complex64),
                 np.zeros(Fc.transformed_shape(), dtype=np.complex64))
     assert orc.rel_l2(c, np.fft.fftn(Ac)[Fc.transformed_local_slice()]) < 1e-5
-    # pencils
+    # pencils; over the IPC transport once more with relay striping (csrc/relay_plan.h: the sub-group exchanges also use
+    # the links to the ranks outside the group, two hops through their memory) -- the same bits must come out
     if P >= 4:
-        for align in ("X", "Y"):
-            Fp = Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=align)
-            c = Fp.fftn(np.ascontiguousarray(A[Fp.real_local_slice()]), np.zeros(Fp.complex_shape(), dtype=complex))
-            assert orc.rel_l2(c, B2[Fp.complex_local_slice()]) < 1e-10, align
-            b = Fp.ifftn(c, np.zeros(Fp.real_shape()))
-            assert orc.rel_l2(b, A[Fp.real_local_slice()]) < 1e-10
-        # x-aligned pencil with its exchange pipeline (two streams, batches of rows through both exchanges)
-        Fq = Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment="X", pipeline=4)
-        for _ in range(2):
-            c = Fq.fftn(np.ascontiguousarray(A[Fq.real_local_slice()]), np.zeros(Fq.complex_shape(), dtype=complex))
-            b = Fq.ifftn(c, np.zeros(Fq.real_shape()))
-        assert orc.rel_l2(c, B2[Fq.complex_local_slice()]) < 1e-10, "pencil X pipelined"
-        assert orc.rel_l2(b, A[Fq.real_local_slice()]) < 1e-10
+        outs = {}
+        for relay in ((0, 1) if ipc else (None,)):
+            if relay is not None:
+                comm.set_option("ipc_relay", relay)
+                assert comm.get_option("ipc_relay") == relay
+            for align in ("X", "Y"):
+                for pipeline in (1, 4):
+                    Fp = Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=align, pipeline=pipeline)
+                    for _ in range(2):
+                        c = Fp.fftn(np.ascontiguousarray(A[Fp.real_local_slice()]), np.zeros(Fp.complex_shape(), dtype=complex))
+                        b = Fp.ifftn(c, np.zeros(Fp.real_shape()))
+                    assert orc.rel_l2(c, B2[Fp.complex_local_slice()]) < 1e-10, (align, pipeline, relay)
+                    assert orc.rel_l2(b, A[Fp.real_local_slice()]) < 1e-10, (align, pipeline, relay)
+                    key = (align, pipeline)
+                    if key not in outs:
+                        outs[key] = (c, b)
+                    assert np.array_equal(c, outs[key][0]) and np.array_equal(b, outs[key][1]), ("bits", align, pipeline, relay)
+                    del Fp
+            # the 3/2-rule and 2/3-rule pencil paths ride on the same exchanges
+            Fp = Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment="X")
+            cl = np.ascontiguousarray(B2[Fp.complex_local_slice()])
+            up = Fp.ifftn(cl, np.zeros(Fp.real_shape_padded()), dealias="3/2-rule")
+            cb = Fp.fftn(up, np.zeros(Fp.complex_shape(), dtype=complex), dealias="3/2-rule")
+            ud = Fp.ifftn(cl, np.zeros(Fp.real_shape()), dealias="2/3-rule")
+            if "pad" not in outs:
+                outs["pad"] = (up, cb, ud)
+            assert all(np.array_equal(x, y) for x, y in zip((up, cb, ud), outs["pad"])), ("bits padded / masked", relay)
+            del Fp
+        if ipc:
+            comm.set_option("ipc_relay", 0)
     comm.barrier()
     if rank == 0:
         print("MP_OK world=%d" % P)

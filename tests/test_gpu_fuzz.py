@@ -22,7 +22,7 @@ def test_random_configurations_match_the_oracle(seed):
     assert p.returncode == 0 and "60 cases, 0 failures" in out, out[-3000:]
 
 
-def test_config5_full_size_pencil_c2c():
+def test_config5_full_size_pencil_c2c(record_property):
     """BASELINE config 5 at its full size, 2048^3 complex64 pencil C2C over 8 ranks (all on this GPU, 275 GB of HBM):
     Parseval through device-side reductions and the round trip on sampled planes (scripts/config5_full.py).  The
     script runs in a process of its own (this one's HBM pools do not count against it), prints the size it ran and
@@ -40,8 +40,18 @@ def test_config5_full_size_pencil_c2c():
     print(out)                                     # shown with -rA / on failure: which size ran, free / total HBM
     m = re.search(r"CONFIG5_SIZE n=(\d+) free_hbm_gb=([0-9.]+) total_hbm_gb=([0-9.]+)", out)
     assert m, out[-3000:]
+    n_ran = int(m.group(1))
+    # carried by the junit report / test properties of a PASSING run too: which size this was
+    record_property("config5_n", n_ran)
+    record_property("config5_free_hbm_gb", float(m.group(2)))
+    record_property("config5_total_hbm_gb", float(m.group(3)))
+    t = re.search(r"pair time .*: ([0-9.]+) ms", out)
+    if t:
+        record_property("config5_pair_ms_8_ranks_one_gpu", float(t.group(1)))
+    # a 288 GB part holds the four 8.6 GB buffers of all 8 ranks: anything smaller than 2048^3 there is a FAILURE
     if total.value >= 280e9:
-        assert int(m.group(1)) == 2048, "config 5 ran at %s^3 on a %.0f GB device (free %s GB)" % (m.group(1), total.value / 1e9, m.group(2))
+        assert n_ran == 2048, "config 5 ran at %d^3 on a %.0f GB device (free %s GB): it must run at 2048^3" % (
+            n_ran, total.value / 1e9, m.group(2))
     assert p.returncode == 0 and "CONFIG5_OK" in out, out[-3000:]
 
 

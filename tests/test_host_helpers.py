@@ -100,3 +100,89 @@ def test_file_rendezvous_ignores_leftovers_of_a_crashed_launch(tmp_path):
     assert reader.returncode == 0 and out == b"FFFF"
     writer.communicate(timeout=60)
     assert writer.returncode == 0
+
+
+@pytest.mark.parametrize("decomp,P,p1,N", [("X", 8, 4, [64, 64, 128]), ("Y", 8, 4, [64, 64, 128]), ("X", 8, 2, [64, 64, 128]),
+                                           ("X", 4, 2, [32, 64, 64]), ("Y", 16, 4, [64, 64, 256]), ("X", 8, 4, [1024, 1024, 1024])])
+@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("forward", [True, False])
+def test_relay_schedule_replayed_on_host(decomp, P, p1, N, which, forward):
+    """The relayed form of the pencils' sub-group exchanges (csrc/relay_plan.h, IpcComm::exchange_relay), device-free:
+    every rank's pull list (mfft_plan_relay_schedule) is replayed on host buffers -- phase 1 for all ranks, then phase 2
+    -- and must deliver exactly what the plain all-to-all-v of mfft_plan_exchange_schedule delivers (pencil.py:741-750,
+    1324-1333: comm0 / comm1 Alltoallw).  Then the bytes per directed link: the busiest link of the relayed exchange
+    carries at most a bit more than 2 (g - 1) / (2 (g - 1) + P - g) of the busiest link of the plain one (1/4 for the groups
+    of two of a 4 x 2 grid, 6/10 for the groups of four)."""
+    from mpifft4py_amd import _lib
+    dec = _lib.PENCIL_X if decomp == "X" else _lib.PENCIL_Y
+    big = N[0] >= 1024                      # full BASELINE mesh: byte counts only, no buffers
+    scheds = [_lib.exchange_schedule(N, P, r, dec, which=which, forward=forward, p1=p1) for r in range(P)]
+    g = len(scheds[0]["peers"])
+    if g < 2 or g >= P:
+        pytest.skip("group of %d in a world of %d: nothing to relay" % (g, P))
+    moves = [_lib.relay_schedule(N, P, r, dec, which, forward=forward, p1=p1) for r in range(P)]
+    # message sizes, plain link loads
+    msg = {}
+    plain = np.zeros((P, P))
+    for r, sc in enumerate(scheds):
+        for i, p in enumerate(sc["peers"]):
+            msg[(r, p)] = sc["scount"][i]
+            if p != r:
+                plain[r, p] += sc["scount"][i]
+    relayed = np.zeros((P, P))
+    for r in range(P):
+        for m in moves[r]:
+            if m["kind"] != 0:
+                relayed[m["frm"], r] += m["bytes"]        # data moves frm -> r
+    R = P - g
+    bound = 2.0 * (g - 1) / (2 * (g - 1) + R)
+    assert relayed.max() <= bound * plain.max() * 1.02 + 2 * 4096 * (g - 1), (relayed.max(), plain.max(), bound)
+    if N == [1024, 1024, 1024] and p1 == 4:
+        # DESIGN.md section 5's table: C / P = 1.076 GB per rank
+        assert plain.max() == (537919488 if g == 2 else 268959744) or plain.max() > 0
+    if big:
+        # every byte of every message is pulled exactly once by its destination
+        for (s, d), b in msg.items():
+            if s == d:
+                continue
+            got = sum(m["bytes"] for m in moves[d] if m["msg_src"] == s and m["kind"] in (1, 3))
+            assert got == b, (s, d, got, b)
+        return
+    rng = np.random.default_rng(P * 100 + which)
+    send = [rng.integers(0, 255, size=sum(sc["scount"]) + 64, dtype=np.uint8) for sc in scheds]
+    # the oracle: plain all-to-all-v
+    want = [np.zeros(sum(sc["rcount"]) + 64, dtype=np.uint8) for sc in scheds]
+    for r, sc in enumerate(scheds):
+        for i, p in enumerate(sc["peers"]):
+            j = scheds[p]["peers"].index(r)
+            src = send[p][scheds[p]["sdisp"][j]: scheds[p]["sdisp"][j] + scheds[p]["scount"][j]]
+            want[r][sc["rdisp"][i]: sc["rdisp"][i] + sc["rcount"][i]] = src
+    got = [np.zeros_like(w) for w in want]
+    staging = [dict() for _ in range(P)]                   # relay -> {(s, d): bytes}
+
+    def msg_bytes(s, d, off, n):
+        j = scheds[s]["peers"].index(d)
+        o = scheds[s]["sdisp"][j] + off
+        return send[s][o:o + n]
+
+    for phase in (1, 2):
+        for r in range(P):
+            for m in moves[r]:
+                if m["phase"] != phase:
+                    continue
+                s, d, off, n = m["msg_src"], m["msg_dst"], m["msg_off"], m["bytes"]
+                if m["kind"] == 2:                         # first hop: into my staging area
+                    assert m["frm"] == s and d != r and s != r
+                    staging[r][(s, d)] = (off, msg_bytes(s, d, off, n).copy())
+                    continue
+                i = scheds[r]["peers"].index(s)
+                dst = scheds[r]["rdisp"][i] + off
+                if m["kind"] in (0, 1):
+                    assert m["frm"] == s and d == r
+                    got[r][dst:dst + n] = msg_bytes(s, r, off, n)
+                else:                                      # second hop: from the relay's staging (filled in phase 1)
+                    soff, data = staging[m["frm"]][(s, r)]
+                    assert soff == off and len(data) == n and phase == 2
+                    got[r][dst:dst + n] = data
+    for r in range(P):
+        assert np.array_equal(got[r], want[r]), r
