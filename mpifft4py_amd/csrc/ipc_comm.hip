@@ -410,6 +410,11 @@ struct IpcComm : mfft_comm_s {
       MFFT_HIP(hipEventRecord(release_ev[ch], s));
     }
     std::vector<uint32_t> qs(npeers, 0);
+    // kernel mode: the flag words of all peers are written / awaited by ONE small launch each (ipc_pull.h FlagOps) instead
+    // of one stream memory operation per peer (each of which is a kernel launch of its own on this stack)
+    const bool batched = pull_mode == PULL_KERNEL;
+    FlagOps sig, wt;
+    sig.n = wt.n = 0;
     for (int i = 0; i < npeers; ++i) {
       const int p = peers[i];
       if (p == rank || !scount[i]) continue;
@@ -421,8 +426,10 @@ struct IpcComm : mfft_comm_s {
       IpcPost& post = pr.ring[q % IPC_RING];
       post.seg = seg; post.offset = soff + sdisp[i]; post.bytes = scount[i];
       post.seq.store(q, std::memory_order_release);
-      MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[p]->ready[rank][ch], q, 0));
+      if (batched) { sig.addr[sig.n] = &peer_flags[p]->ready[rank][ch]; sig.value[sig.n++] = q; }
+      else MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[p]->ready[rank][ch], q, 0));
     }
+    if (batched) MFFT_HIP(launch_flags(false, sig, s));      // one launch tells every peer
     // 2. receiver role, host part: where does every chunk lie (starting with the next rank: spreads the links when the
     //    chunks are pulled one after the other).  Nothing of the receiver role is enqueued before all posts are in.
     struct Pull { int i, p; uint32_t q; const char* src; };
@@ -447,7 +454,8 @@ struct IpcComm : mfft_comm_s {
     // 3. receiver role, device part
     if (pull_mode == PULL_KERNEL) {
       // one launch for the self chunk and every peer's chunk, behind the waits for all of them
-      for (const Pull& u : pulls) MFFT_HIP(hipStreamWaitValue32(s, &flags->ready[u.p][ch], u.q, hipStreamWaitValueGte, 0xFFFFFFFFu));
+      for (const Pull& u : pulls) { wt.addr[wt.n] = &flags->ready[u.p][ch]; wt.value[wt.n++] = u.q; }
+      MFFT_HIP(launch_flags(true, wt, s));
       PullArgs pa;
       memset(&pa, 0, sizeof pa);
       if (rcount[myidx]) pa.job[pa.njobs++] = PullJob{sp + sdisp[myidx], rp + rdisp[myidx], (unsigned long long)rcount[myidx]};
@@ -456,7 +464,9 @@ struct IpcComm : mfft_comm_s {
       // (the self chunk is a local copy) never has fewer than 56 workgroups (= 7 peers x 8)
       pa.wgs = pa.njobs > 0 ? std::max(pull_wgs, (56 + pa.njobs - 1) / pa.njobs) : pull_wgs;
       MFFT_HIP(launch_pull(pa, s));
-      for (const Pull& u : pulls) MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[u.p]->done[rank][ch], u.q, 0));
+      sig.n = 0;
+      for (const Pull& u : pulls) { sig.addr[sig.n] = &peer_flags[u.p]->done[rank][ch]; sig.value[sig.n++] = u.q; }
+      MFFT_HIP(launch_flags(false, sig, s));
     } else if (pull_mode == PULL_STREAMS && !pulls.empty()) {
       // every peer's copy on that peer's own stream, forked from and joined back into the issuing stream.  ALL flag
       // operations stay on the issuing stream (waits before the fork, "done" writes behind the join): the per-peer
@@ -491,8 +501,15 @@ struct IpcComm : mfft_comm_s {
       }
     }
     // 4. sender role: nobody overwrites its send buffer before all peers have pulled from it
-    for (int i = 0; i < npeers; ++i)
-      if (qs[i]) MFFT_HIP(hipStreamWaitValue32(s, &flags->done[peers[i]][ch], qs[i], hipStreamWaitValueGte, 0xFFFFFFFFu));
+    if (batched) {
+      wt.n = 0;
+      for (int i = 0; i < npeers; ++i)
+        if (qs[i]) { wt.addr[wt.n] = &flags->done[peers[i]][ch]; wt.value[wt.n++] = qs[i]; }
+      MFFT_HIP(launch_flags(true, wt, s));
+    } else {
+      for (int i = 0; i < npeers; ++i)
+        if (qs[i]) MFFT_HIP(hipStreamWaitValue32(s, &flags->done[peers[i]][ch], qs[i], hipStreamWaitValueGte, 0xFFFFFFFFu));
+    }
     MFFT_HIP(hipEventRecord(last_issue[ch], s));
     last_stream[ch] = s;
     used_ch[ch] = true;
