@@ -156,8 +156,8 @@ MFFT_API int mfft_plan_exchange_pieces(const mfft_plan_desc* desc, int nranks, i
  * through those ranks in two hops.  This query lists, device-free, what `rank` PULLS in exchange `which`: phase (1, 2),
  * kind (0 own chunk, 1 direct part read from msg_src's send buffer, 2 first hop: rank is the relay and stages the stripe
  * of msg_src -> msg_dst, 3 second hop: read from relay `from`'s staging area), the offset inside the message and the
- * byte count.  It is the enumeration the transport executes ("ipc_relay" option of mfft_comm_set_option; default: on
- * when every rank owns a device). */
+ * byte count.  It is the enumeration the transport executes when the "ipc_relay" option of mfft_comm_set_option (or
+ * MFFT_IPC_RELAY=1) is on; the default is off. */
 MFFT_API int mfft_plan_relay_schedule(const mfft_plan_desc* desc, int nranks, int rank, int which, int forward,
                                       int max_moves, int* nmoves, int* phase, int* kind, int* from, int* msg_src,
                                       int* msg_dst, size_t* msg_off, size_t* bytes);

@@ -1,0 +1,50 @@
+#!/bin/bash
+# The command behind every file under profiles/ (run on an MI355X box; from the development container prefix a line with
+# `gpurun --timeout 1800 -- '...'`).  `scripts/reproduce_profiles.sh list` prints the table, `scripts/reproduce_profiles.sh
+# <file>` runs the command(s) of one file and leaves the raw output under gpurun_out/ (the files under profiles/ are the
+# summaries that were kept, some with hand-written headers).
+set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R"
+tools() { make -C mpifft4py_amd/csrc -j8 >/dev/null && make -C tools "$@" >/dev/null; }
+run() {
+  case "$1" in
+    r01_final_*|r01_v0_*) echo "(round-1 builds: git checkout the round-1 tag, then) scripts/profile_cmd.sh r01 bench.py --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off" ;;
+    r01_kbench_variants.txt) tools kbench; tools/build/kbench ;;
+    r01_kbench2_long_and_fp32.txt) tools kbench2; tools/build/kbench2 ;;
+    r01_size_sweep.txt|r02_size_sweep.txt) bash scripts/size_sweep.sh ;;
+    r02_final_*) bash scripts/profile_r02.sh bench; python scripts/summarize_profiles.py r02_final gpurun_out/prof_r02/trace gpurun_out/prof_r02/fetch gpurun_out/prof_r02/write "bench.py 1024^3 fp64"; python scripts/summarize_profiles.py sq r02_final gpurun_out/prof_r02/sq1 gpurun_out/prof_r02/sq2 ;;
+    r02_pack_*) bash scripts/profile_r02.sh pack; python scripts/summarize_profiles.py r02_pack gpurun_out/prof_r02/pack_trace gpurun_out/prof_r02/pack_fetch gpurun_out/prof_r02/pack_write "scripts/pack_workload.py 512" ;;
+    r02_mask_*) bash scripts/profile_cmd.sh mask scripts/maskprof.py 1024 double; python scripts/summarize_profiles.py r02_mask gpurun_out/prof_mask/trace gpurun_out/prof_mask/fetch gpurun_out/prof_mask/write "scripts/maskprof.py 1024 double" ;;
+    r02_membench_yardsticks.txt|r02_membench_stamped.txt|r02_infinity_cache_probe.txt) tools membench; tools/build/membench; tools/build/membench stamp; tools/build/membench mall ;;
+    r02_kbench3_variants.txt|r02_colfft_experiments.md) tools kbench3; tools/build/kbench3 "" 5; tools/build/kbench3 persist 5 ;;
+    r02_kbench3_long_lengths.txt) tools kbench3 membench; tools/build/membench tilelong; for f in long twl occ small f32long half f32k2 h1536; do tools/build/kbench3 $f 3; done ;;
+    r02_power_of_two_stride.txt) tools kbench3; KB_PADSWEEP=1 tools/build/kbench3 padplane 3; KB_STRIDESWEEP=1 tools/build/kbench3 padplane 3; python scripts/c2cprof.py 1024 double; python scripts/c2cprof.py 1024 single; python scripts/c2cprof.py 2048 single ;;
+    r02_cache_fusion_sweeps.txt) echo "(experimental plan paths, removed after the measurement: see r02_colfft_experiments.md)" ;;
+    r02_c2c_stage_times.txt) python scripts/c2cprof.py 1024 double; python scripts/c2cprof.py 2048 single ;;
+    r02_row_kernels_long_lengths.txt) for n in 1152 1280 1536; do python scripts/r2cprof.py $n double; done; python scripts/padprof.py 1024 slab ;;
+    r02_pencil_zfuse_512.txt) python scripts/pencil_prof.py 512 8; MFFT_NO_ZFUSE=1 python scripts/pencil_prof.py 512 8 ;;
+    r02_run_to_run_spread.txt) bash scripts/bimodal_r02.sh ;;
+    r02_placement_probe.txt) python scripts/placement_probe.py ;;
+    r02_placement_reroll.txt) python scripts/reroll_probe.py ;;
+    r02_two_thirds_rule_mask.txt) python scripts/maskprof.py 1024 double; python scripts/maskprof.py 1024 single; python scripts/maskprof_ranks.py 1024 2; python scripts/maskprof_ranks.py 1024 8 ;;
+    r02_ipc_fanout_probe.txt) MFFT_IPC_PULL=streams MFFT_IPC_STREAM_FLAGS=1 python bench.py --gpus 8 --size 128 --steps 3 --warmup 1 --cpu-baseline off --pencil-extra off --transport ipc ;;
+    r02_bench_after_two_wg_plan.json|r02_final_bench_1024cubed.json|r03_final_bench_1024cubed.json) python bench.py --steps 10 --warmup 3 ;;
+    r03_final_*) bash scripts/profile_r03.sh bench; python scripts/summarize_profiles.py r03_final gpurun_out/prof_r03/trace gpurun_out/prof_r03/fetch gpurun_out/prof_r03/write "bench.py --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off: 1024^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_final gpurun_out/prof_r03/sq1 gpurun_out/prof_r03/sq2 ;;
+    r03_cu_mask_probe.txt) tools overlap_probe; tools/build/overlap_probe 8 16 32 ;;
+    r03_overlap.txt) for c in "p4_kz4 4 1024 4 1" "p4_rows4 4 1024 -4 1" "p2_kz4 2 1024 4 1" "p4_kz4_copy 4 1024 4 0" "p8_kz4 8 1024 4 1"; do scripts/overlap_trace.sh $c; set -- $c; python scripts/summarize_overlap.py gpurun_out/overlap_$1; done ;;
+    r03_ipc_pull_modes.txt) bash scripts/r03_first_gpu.sh; bash scripts/r03_gpu3.sh; MFFT_IPC_STREAM_FLAGS=1 python scripts/ipc_stress.py 8 2 -4 60 128 ;;
+    r03_shared_gpu_pipeline_latency.txt) bash scripts/r03_gpu2.sh ;;
+    r03_two_thirds_rule_ranks.txt) python scripts/maskprof_ranks.py 1024 8 ;;
+    r03_pencil_dealias.txt) for k in X Y; do for p in double single; do python scripts/maskprof.py 1024 $p $k; MFFT_NO_PRUNE=1 python scripts/maskprof.py 1024 $p $k; done; python scripts/padprof.py 512 $k; done; python scripts/padprof.py 512 slab ;;
+    *) echo "no recipe for $1" >&2; return 1 ;;
+  esac
+}
+if [ "${1:-list}" = "list" ]; then
+  for f in profiles/r0*; do
+    b=$(basename "$f")
+    printf "%-44s %s\n" "$b" "$(grep -F -m1 "$(echo "$b" | sed 's/_final_.*/_final_*/; s/_pack_.*/_pack_*/; s/_mask_[a-z_]*\.\(csv\|json\)/_mask_*/')" "$0" | sed 's/^ *[^)]*) *//; s/ ;;$//' | cut -c1-150)"
+  done
+  exit 0
+fi
+run "$1"
