@@ -45,6 +45,7 @@ def _free_port():
 def _env(transport="mock"):
     env = {k: v for k, v in os.environ.items() if k not in ("MFFT_TRANSPORT", "MFFT_RCCL_LIB")}
     env["OMP_NUM_THREADS"] = "1"
+    env.setdefault("MP_WORKER_VERBOSE", "1")
     if transport == "ipc":
         env["MFFT_TRANSPORT"] = "ipc"
     else:
@@ -80,7 +81,14 @@ def _spawn(nproc, script_args, timeout=600, transport="mock"):
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
-            raise
+            tails = []
+            for q in procs:
+                try:
+                    o2, e2 = q.communicate(timeout=10)
+                    tails.append(e2.decode()[-1500:])
+                except Exception:  # noqa: BLE001
+                    pass
+            raise AssertionError("ranks still running after %d s; stderr tails:\n%s" % (timeout, "\n----\n".join(tails)))
         rc = rc or p.returncode
         outs.append(o.decode())
         errs.append(e.decode())
