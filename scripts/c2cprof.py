@@ -20,5 +20,8 @@ for _ in range(5):
 F.sync()
 dt = (time.perf_counter() - t) / 5
 V = u.nbytes
-print("n=%d %s C2C pair %.3f ms  (12 V / t = %.0f GB/s = %.1f%% of 8 TB/s)" % (n, prec, dt * 1e3, 12 * V / dt / 1e9, 12 * V / dt / 8e12 * 100))
+a, b = u.leading(0, 1).get(), u2.leading(0, 1).get()
+rt = float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(a.ravel()))
+print("n=%d %s C2C pair %.3f ms  (12 V / t = %.0f GB/s = %.1f%% of 8 TB/s)  round trip %.1e%s"
+      % (n, prec, dt * 1e3, 12 * V / dt / 1e9, 12 * V / dt / 8e12 * 100, rt, "" if rt < (1e-5 if prec == "single" else 1e-12) else "  WRONG"))
 print(" ".join("%s=%.3f" % (k, v[0] / max(v[1], 1)) for k, v in sorted(F.stage_times().items())))
