@@ -340,11 +340,12 @@ def main():
         taken earlier, marked "degraded": true) and every rank leaves with exit code 3: the number survives a
         transport problem in an optional step, but the run does not look green."""
         def give_up():
-            if rank == 0 and fallback_line is not None:
-                fallback_line["extras"] = {"note": why}
-                fallback_line["degraded"] = True
-                fallback_line.setdefault("cpu_baseline", None)
-                sys.stdout.write(json.dumps(fallback_line) + "\n")
+            line = fallback_line() if callable(fallback_line) else fallback_line     # the latest complete measurement
+            if rank == 0 and line is not None:
+                line["extras"] = {"note": why}
+                line["degraded"] = True
+                line.setdefault("cpu_baseline", None)
+                sys.stdout.write(json.dumps(line) + "\n")
                 sys.stdout.flush()
             os._exit(3)                    # a step that hangs is a failure, whatever was measured before it
         t = threading.Timer(seconds, give_up)
@@ -358,8 +359,9 @@ def main():
         # 1. the plain, blocking exchange: W + K pairs, a complete measurement that is also the fallback line
         base = measure(1)
         tuning = {comm.transport_name: {1: 1e3 * base["dt"] / args.steps}}
-        fallback = headline(base, {"note": "blocking exchange; the other candidates did not finish"}) if rank == 0 else None
-        dog = arm_watchdog(900.0, fallback, "the exchange candidates (transport, pipeline) did not finish within 900 s")
+        held = {"line": headline(base, {"note": "blocking exchange; the other candidates did not finish"}) if rank == 0 else None,
+                "mres": base, "key": None}
+        dog = arm_watchdog(600.0, lambda: held["line"], "the exchange candidates (transport, pipeline) did not finish within 600 s")
         # 2. transport x exchange pipeline (flavour and depth) measured on this machine's links, like a planner's MEASURE
         #    mode: 2 untimed + 2 timed pairs per candidate, slowest rank counts
         comms = [comm]
@@ -419,7 +421,7 @@ def main():
             # kernels, and the hardware scheduler's time slices are all that gets measured (seconds per pair,
             # profiles/r03_ipc_pull_modes.txt) -- and the streams, once created, slow every later candidate down.
             own_device = int(_lib.device_count()) >= world
-            for c in comms:
+            for ci, c in enumerate(comms):
                 pulls = ((1, 2, 0) if own_device else (1, 0)) if c.get_option("ipc_pull") >= 0 else (None,)
                 for pull in pulls:
                     tc = tuning.setdefault(cand_name(c, pull), {})
@@ -432,6 +434,13 @@ def main():
                         tc[depth] = ms
                         if ms < best_ms:
                             best, best_ms = (c, depth, pull, -1), ms
+                if ci == 0 and len(comms) > 1 and best != (comm, 1, base_pull, 0):
+                    # the first transport is through: take its winner's complete measurement NOW, so that a second
+                    # transport that misbehaves on this machine costs the run its green light but not this number
+                    held["mres"] = measure(best[1], best[0], best[2], best[3])
+                    held["key"] = best
+                    if rank == 0:
+                        held["line"] = headline(held["mres"], dict(tuning, note="the second transport's candidates did not finish"))
             # CUs of its own for the communication stream (mfft_plan_desc.comm_cus) only matter for a pipelined winner
             if best[1] != 1:
                 tcu = tuning.setdefault("comm_cus", {"candidate": "%s:%d" % (cand_name(best[0], best[2]), best[1]), "none": best_ms})
@@ -449,7 +458,7 @@ def main():
             sys.stderr.write("exchange tuning failed (%s: %s); keeping the best candidate so far\n" % (type(e).__name__, e))
             tuning["error"] = "%s: %s" % (type(e).__name__, e)
         # 3. the timed region with the best candidate (the first measurement stands if nothing beats it)
-        mres = base if best == (comm, 1, base_pull, 0) else measure(best[1], best[0], best[2], best[3])
+        mres = base if best == (comm, 1, base_pull, 0) else held["mres"] if best == held["key"] else measure(best[1], best[0], best[2], best[3])
         dog.cancel()
     else:
         mres = measure(args.pipeline)
@@ -462,7 +471,7 @@ def main():
                                                  and world in (1, 4, 8, 16))
     watchdog = None
     if want_pencil and world > 1:
-        watchdog = arm_watchdog(600.0, out, "the pencil measurement did not finish within 600 s")
+        watchdog = arm_watchdog(400.0, out, "the pencil measurement did not finish within 400 s")
     if want_pencil:
         try:
             pcomm = best[0] if (world > 1 and tuning is not None) else comm      # the transport that won the slab measurement
