@@ -89,6 +89,10 @@ __device__ __forceinline__ void pull_stream(const char* __restrict__ src, char* 
 }
 
 static __global__ __launch_bounds__(PULL_THREADS) void ipc_pull_kernel(PullArgs a) {
+  // The sources were written by OTHER devices' kernels and released to system scope before their "ready" words were set
+  // (ipc_comm.hip); this launch sits behind the wait for those words.  An explicit system-scope acquire on top of the
+  // one the launch itself carries: no line of a peer's memory cached by an earlier exchange may be served again.
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const int j = (int)blockIdx.x % a.njobs, w = (int)blockIdx.x / a.njobs;
   const PullJob jb = a.job[j];
   const char* src = static_cast<const char*>(jb.src);

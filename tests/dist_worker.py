@@ -44,6 +44,75 @@ def exchange(rank, sched, send, recv_bytes):
     return recv.view(np.complex128)
 
 
+def exchange_relayed(rank, P, N, dec, which, forward, p1, send, recv_bytes):
+    """The same all-to-all-v, relay-striped as the IPC transport does it (csrc/relay_plan.h, mfft_plan_relay_schedule):
+    every rank PULLS what its move list says, phase 1 (direct first halves, first hops into a staging area) for all
+    ranks, then phase 2 (direct second halves, second hops out of the relays' staging areas).  Over gloo a pull is a
+    message from the rank that is read: every rank knows every rank's list (the query is device-free), so the owner
+    of the bytes sends them, tagged with the puller's move number."""
+    send = np.ascontiguousarray(send).view(np.uint8).reshape(-1)
+    recv = np.zeros(recv_bytes, dtype=np.uint8)
+    scheds = [_lib.exchange_schedule(N, P, r, dec, which, forward, p1=p1) for r in range(P)]
+    moves = [_lib.relay_schedule(N, P, r, dec, which, forward=forward, p1=p1) for r in range(P)]
+    staging = {}
+
+    def src_slice(s_, d_, off, n):          # bytes [off, off + n) of the message s_ -> d_ inside s_'s send buffer
+        j = scheds[s_]["peers"].index(d_)
+        o = scheds[s_]["sdisp"][j] + off
+        return o, o + n
+
+    def dst_slice(s_, off, n):              # ... inside MY receive buffer
+        i = scheds[rank]["peers"].index(s_)
+        o = scheds[rank]["rdisp"][i] + off
+        return o, o + n
+
+    for phase in (1, 2):
+        reqs, keep, staged_in = [], [], []
+        # what I am read for: everybody else's moves of this phase whose data lies with me
+        for x in range(P):
+            if x == rank:
+                continue
+            for t, m in enumerate(moves[x]):
+                if m["phase"] != phase or m["frm"] != rank or m["kind"] == 0:
+                    continue
+                if m["kind"] in (1, 2):
+                    a, b = src_slice(m["msg_src"], m["msg_dst"], m["msg_off"], m["bytes"])
+                    assert m["msg_src"] == rank
+                    buf = send[a:b].copy()
+                else:                       # second hop: out of my staging area
+                    off, data = staging[(m["msg_src"], m["msg_dst"])]
+                    assert off == m["msg_off"] and len(data) == m["bytes"]
+                    buf = data
+                tt = torch.from_numpy(buf)
+                keep.append(tt)
+                reqs.append(dist.isend(tt, dst=x, tag=t))
+        # what I pull
+        for t, m in enumerate(moves[rank]):
+            if m["phase"] != phase:
+                continue
+            if m["kind"] == 0:
+                a, b = src_slice(rank, rank, 0, m["bytes"])
+                c, d = dst_slice(rank, 0, m["bytes"])
+                recv[c:d] = send[a:b]
+            elif m["kind"] == 2:
+                buf = np.zeros(m["bytes"], dtype=np.uint8)
+                tt = torch.from_numpy(buf)
+                keep.append(tt)
+                staged_in.append(((m["msg_src"], m["msg_dst"]), m["msg_off"], buf))
+                reqs.append(dist.irecv(tt, src=m["frm"], tag=t))
+            else:
+                c, d = dst_slice(m["msg_src"], m["msg_off"], m["bytes"])
+                tt = torch.from_numpy(recv[c:d])
+                keep.append(tt)
+                reqs.append(dist.irecv(tt, src=m["frm"], tag=t))
+        for r in reqs:
+            r.wait()
+        for key, off, buf in staged_in:
+            staging[key] = (off, buf)
+        dist.barrier()                      # phase 2 reads what phase 1 staged (the transport: the k1done flags)
+    return recv.view(np.complex128)
+
+
 def exchange_pieces(rank, pieces, send, recv_bytes):
     """A pipelined exchange, piece by piece into ONE receive buffer (displacements are relative to the whole buffers)."""
     send = np.ascontiguousarray(send).view(np.uint8).reshape(-1)
@@ -132,13 +201,15 @@ def slab(rank, P, N, A):
     assert orc.rel_l2(back, u) < 1e-13
 
 
-def pencil(rank, P, N, A, align, P1=None, pipeline=1):
+def pencil(rank, P, N, A, align, P1=None, pipeline=1, relay=False):
     """pipeline != 1: every exchange runs piece by piece with the schedules of mfft_plan_exchange_pieces (X: batches
     of local x rows through both exchanges; Y: batches of local x rows in the z-splitting exchange, batches of the
     rows owned afterwards in the x-chunk exchange), into the same buffers as the un-pipelined exchange."""
     lay = orc.PencilLayout(N, P, P1, align)
 
     def exchange(rank_, sched, send, recv_bytes, which=None, forward=None):
+        if relay and len(sched["peers"]) < P:
+            return exchange_relayed(rank_, P, N, dec, which, forward, P1 or 0, send, recv_bytes)
         if pipeline == 1:
             return globals()["exchange"](rank_, sched, send, recv_bytes)
         pieces = _lib.exchange_pieces(N, P, rank, dec, which, forward, pipeline, p1=P1 or 0)
@@ -222,6 +293,13 @@ def main():
         if P == 8:
             for align in ("X", "Y"):
                 pencil(rank, P, N, A, align, P1=2)
+        # relay striping of the sub-group exchanges (IPC transport): two-hop schedule executed over gloo
+        Nr = [32, 64, 128]                                 # messages large enough for 4 KiB stripes
+        Ar = np.random.default_rng(2028).random(Nr)
+        for align in ("X", "Y"):
+            pencil(rank, P, Nr, Ar, align, relay=True)
+            if P == 8:
+                pencil(rank, P, Nr, Ar, align, P1=2, relay=True)
     dist.barrier()
     if rank == 0:
         print("DIST_OK world=%d" % P)
