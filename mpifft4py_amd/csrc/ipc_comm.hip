@@ -656,6 +656,7 @@ struct IpcComm : mfft_comm_s {
     // 3. phase 1: everybody's data is there -> direct halves, self chunk, first hops -> tell everybody
     MFFT_TRY(flags_all(true, &IpcFlags::rready, ch, q, everyone, s));
     MFFT_TRY(launch_jobs(k1, s));
+    MFFT_HIP(hipEventRecord(release_ev[ch], s));           // the first hops staged in MY memory are read by other devices next
     MFFT_TRY(flags_all(false, &IpcFlags::k1done, ch, q, everyone, s));
     // 4. phase 2: the relays have staged -> second halves, second hops -> tell everybody
     MFFT_TRY(flags_all(true, &IpcFlags::k1done, ch, q, outsiders, s));
