@@ -179,6 +179,12 @@ class R2CY(DistFFTBase):
         return np.array((abs(K[0]) < kmax[0]) * (abs(K[1]) < kmax[1]) * (abs(K[2]) < kmax[2]), dtype=np.uint8)
 
     # -- transforms ----------------------------------------------------------------
+    def get_subarrays(self, padsize=1):
+        """The Alltoallw boxes of the reference (pencil.py:218-246 for Y, 971-999 for X) as `Subarray` descriptors."""
+        from . import _subarrays
+        fn = _subarrays.pencil_x_subarrays if self._decomp == _lib.PENCIL_X else _subarrays.pencil_y_subarrays
+        return fn([int(x) for x in self.N], self.Nf, self.P1, self.P2, self.comm0_rank, self.comm1_rank, padsize)
+
     def fftn(self, u, fu, dealias=None):
         """Forward transform (pencil.py:634-883 / 1228-1475); returns fu."""
         assert dealias in ('3/2-rule', '2/3-rule', 'None', None)

@@ -146,6 +146,12 @@ class R2C(DistFFTBase):
         return np.array((abs(K[0]) < kmax[0]) * (abs(K[1]) < kmax[1]) * (abs(K[2]) < kmax[2]), dtype=np.uint8)
 
     # -- transforms ---------------------------------------------------------------
+    def get_subarrays(self, padsize=1):
+        """Subarrays for Alltoallw transforms (slab.py:199-211): the boxes every peer's chunk occupies in the send /
+        receive arrays, as `Subarray(sizes, subsizes, starts)` descriptors instead of committed MPI datatypes."""
+        from . import _subarrays
+        return _subarrays.slab_subarrays([int(x) for x in self.N], [int(x) for x in self.Np], self.Nf, self.num_processes, padsize)
+
     def fftn(self, u, fu, dealias=None):
         """Forward transform (slab.py:349-485).  u: real_shape() (or
         real_shape_padded() with dealias='3/2-rule'); fu: complex_shape().

@@ -187,6 +187,37 @@ def line_golden():
     print("line fixtures written")
 
 
+def _boxes(lst):
+    return [[list(b.sizes), [int(x.stop - x.start) for x in b.slices], [int(x.start) for x in b.slices]] for b in lst]
+
+
+def subarrays():
+    """get_subarrays of the reference classes (slab.py:199-211, pencil.py:218-246, 971-999): (sizes, subsizes, starts) of
+    every box, for padsize 1 and 1.5."""
+    table = []
+    for N in ([8, 16, 32], [32, 64, 128], [1024, 1024, 1024]):
+        for P in (2, 4, 8):
+            for pad in (1, 1.5):
+                def slab(rank):
+                    F = RefSlab(np.array(N), L, MPI.COMM_WORLD, "double")
+                    A, B, cd = F.get_subarrays(padsize=pad)
+                    return dict(decomp="slab", N=N, P=P, rank=rank, padsize=pad, lists=[_boxes(A), _boxes(B)],
+                                counts_displs=[[list(map(int, cd[0])), list(map(int, cd[1]))]])
+                table += fake_mpi.run(P, slab)
+                if P < 4:
+                    continue
+                for align in ("X", "Y"):
+                    for P1 in (None, 2):
+                        def pen(rank):
+                            F = RefPencil(np.array(N), L, MPI.COMM_WORLD, "double", P1=P1, communication="Alltoallw", alignment=align)
+                            r = F.get_subarrays(padsize=pad)
+                            return dict(decomp="pencil" + align, N=N, P=P, rank=rank, padsize=pad, P1_arg=P1,
+                                        lists=[_boxes(x) for x in r[:4]],
+                                        counts_displs=[[list(map(int, c[0])), list(map(int, c[1]))] for c in r[4:]])
+                        table += fake_mpi.run(P, pen)
+    return table
+
+
 def main():
     import sys
     os.makedirs(OUT, exist_ok=True)
@@ -195,6 +226,8 @@ def main():
     line_golden()
     with open(os.path.join(OUT, "layouts.json"), "w") as f:
         json.dump(layouts(), f, separators=(",", ":"))
+    with open(os.path.join(OUT, "subarrays.json"), "w") as f:
+        json.dump(subarrays(), f, separators=(",", ":"))
 
     N = [8, 16, 32]
     rng = np.random.default_rng(20260210)

@@ -1172,3 +1172,30 @@ def test_pencil_x_exchange_pipeline(P, P1, depth, prec):
         assert orc.rel_l2(piped[0], B2[piped[5]]) < TOL[prec]
         assert orc.rel_l2(piped[1], A[piped[6]]) < 4 * TOL[prec]
         assert orc.rel_l2(piped[4], piped[7]) < 4 * TOL[prec]
+
+
+def test_get_subarrays_methods(golden_dir):
+    """The classes' get_subarrays (slab.py:199-211, pencil.py:218-246, 971-999) against the reference's own boxes
+    (tests/golden/subarrays.json), rank by rank on 4 and 8 ranks."""
+    import json
+    from mpifft4py_amd import Pencil_R2C, Slab_R2C
+    table = json.load(open(os.path.join(golden_dir, "subarrays.json")))
+    N = [32, 64, 128]
+    for P in (4, 8):
+        for decomp in ("slab", "pencilX", "pencilY"):
+            def body(comm):
+                F = (Slab_R2C(np.array(N), L, comm, "double") if decomp == "slab" else
+                     Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=decomp[-1]))
+                out = {}
+                for pad in (1, 1.5):
+                    r = F.get_subarrays(padsize=pad)
+                    nl = 2 if decomp == "slab" else 4
+                    out[pad] = ([[list(map(list, b.args())) for b in lst] for lst in r[:nl]],
+                                [[list(c[0]), list(c[1])] for c in r[nl:]])
+                return comm.Get_rank(), out
+            for rank, out in run_ranks(P, body):
+                for pad in (1, 1.5):
+                    rec = [t for t in table if t["decomp"] == decomp and t["N"] == N and t["P"] == P and t["rank"] == rank
+                           and t["padsize"] == pad and t.get("P1_arg") is None]
+                    assert len(rec) == 1
+                    assert out[pad][0] == rec[0]["lists"] and out[pad][1] == rec[0]["counts_displs"], (decomp, P, rank, pad)

@@ -186,3 +186,28 @@ def test_relay_schedule_replayed_on_host(decomp, P, p1, N, which, forward):
                     got[r][dst:dst + n] = data
     for r in range(P):
         assert np.array_equal(got[r], want[r]), r
+
+
+def test_get_subarrays_match_the_reference(golden_dir):
+    """get_subarrays (slab.py:199-211, pencil.py:218-246, 971-999): the (sizes, subsizes, starts) of every Alltoallw
+    box, against what the REAL reference classes returned (tests/golden/subarrays.json, written by
+    oracle/refharness/make_golden.py from Create_subarray's arguments), for padsize 1 and 1.5, slab and both pencils,
+    2 - 8 ranks, meshes up to 1024^3."""
+    import json
+    from mpifft4py_amd import _subarrays as sa
+    table = json.load(open(os.path.join(golden_dir, "subarrays.json")))
+    assert len(table) > 300
+    for rec in table:
+        N, P, rank, pad = rec["N"], rec["P"], rec["rank"], rec["padsize"]
+        Nf = N[2] // 2 + 1
+        if rec["decomp"] == "slab":
+            got = sa.slab_subarrays(N, [n // P for n in N], Nf, P, pad)
+            lists, cds = got[:2], got[2:]
+        else:
+            P1 = rec["P1_arg"] or {4: 2, 8: 4}[P]
+            P2 = P // P1
+            fn = sa.pencil_x_subarrays if rec["decomp"] == "pencilX" else sa.pencil_y_subarrays
+            got = fn(N, Nf, P1, P2, rank % P1, rank // P1, pad)
+            lists, cds = got[:4], got[4:]
+        assert [[list(map(list, b.args())) for b in lst] for lst in lists] == rec["lists"], rec
+        assert [[list(c[0]), list(c[1])] for c in cds] == rec["counts_displs"], rec
