@@ -59,7 +59,11 @@ constexpr bool mfft_has_row_override(int n) {
 // other's passes.  Interleaved A/B at 1024^3 (kbench3, profiles/r02_kbench3_variants.txt): y in place 3.52 -> 3.44 ms,
 // x in place 3.57 -> 3.35 ms (with non-temporal accesses, which only pay in place at two workgroups per CU),
 // x out of place 3.63 -> 3.19 ms.  The same change loses in single precision (1.85 -> 2.4 ms) and is neutral at 512.
-#define MFFT_COLPLANS_F64_B(X) X(1024, 8, 8, 4, 4)
+// Round 3, 512 in double precision (BASELINE config 2): 4x4x4x4x2 (E = 4, 1024 threads, ~40 KB of LDS with LDS twiddles and the
+// split exchange), two workgroups per CU = 2048 threads instead of 1024 (kbench3 `occ512`, profiles/r03_kbench3_occ512.txt):
+// y in place 0.478 -> 0.422 ms, x in place / out of place 0.478 -> 0.456 ms; 8x8x8 with the split exchange at 4 workgroups per CU
+// gets half of that (0.446 / 0.460).
+#define MFFT_COLPLANS_F64_B(X) X(1024, 8, 8, 4, 4) X(512, 4, 4, 4, 4, 2)
 // 384 and 1152 in double precision: 12 instead of 24 values per thread, i.e. twice the threads per CU (384: 3 workgroups of
 // 256 instead of 128 threads; 1152: 768 threads and, with the register cap of registry.h col_wgs, two workgroups per CU
 // instead of one).  kbench3 `small` / `occ` (profiles/r02_kbench3_long_lengths.txt), y in place / x in place / x out of
@@ -68,7 +72,7 @@ constexpr bool mfft_has_row_override(int n) {
 #define MFFT_COLPLANS_F64_E(X) X(384, 4, 4, 4, 3, 2)
 #define MFFT_COLPLANS_F64_I(X) X(1152, 4, 4, 4, 3, 3, 2)
 template <typename T> constexpr bool mfft_has_col_override(int n) {
-  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && (n == 1024 || n == 384 || n == 1152));
+  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && (n == 1024 || n == 512 || n == 384 || n == 1152));
 }
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \

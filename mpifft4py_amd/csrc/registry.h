@@ -62,6 +62,7 @@ const KernelEntry* find_chirpz(int family, int n, int prec, int inv);
 template <class S, typename T> constexpr bool col_pair() {
   constexpr long long tile = (long long)S::N * 128;
   constexpr int lanes = 128 / (int)sizeof(cx<T>);
+  if (S::N == 512 && sizeof(T) == 8 && S::E == 4) return true;      // plans.h MFFT_COLPLANS_F64_B: 1024 threads, two per CU
   return S::NP > 1 && tile > 81920 && tile <= 131072 && S::TPT * lanes <= 1024 &&
          (S::N != 1024 || sizeof(T) == 4 || S::E == 8);
 }
@@ -114,7 +115,7 @@ template <class S, typename T> constexpr bool row_twlds() { return S::NP > 1 && 
 // for two workgroups 3.7 - 3.9 -> 2.9 - 3.0 ms per pass; 1536 as 64-byte tiles (8 columns, 512 threads, 48 KiB) with the
 // cap for three 7.9 - 8.7 -> 7.3 - 7.8 ms (the same tiling changes nothing in double precision).
 template <class S, typename T> constexpr int col_wgs() {
-  if (sizeof(T) == 8) return (S::N == 1152 && S::E == 12) ? 2 : 0;
+  if (sizeof(T) == 8) return ((S::N == 1152 && S::E == 12) || (S::N == 512 && S::E == 4)) ? 2 : 0;
   return (S::N == 1152 && S::E == 24) ? 2 : (S::N == 1536 && S::E == 24) ? 3 : 0;
 }
 
@@ -190,7 +191,7 @@ void register_col(const char* name) {
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 3>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
     reg.back().pad = 5;
     reg.back().nt = 1;
-    reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
+    reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;
   }
   // pruned 2/3-rule passes (pad = 6)
   reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 4>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
@@ -199,15 +200,15 @@ void register_col(const char* name) {
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 4>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
     reg.back().pad = 6;
     reg.back().nt = 1;
-    reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
+    reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;
   }
   if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {     // aligned-row (non-temporal) variants
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
     reg.back().nt = 1;
-    reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
+    reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
     reg.back().nt = 1;
-    reg.back().nt_inplace = col_pair<S, T>() ? 1 : 0;
+    reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;
   }
 }
 

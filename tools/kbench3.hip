@@ -610,6 +610,38 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (filter[0] && strstr("occ256", filter)) {      // round 3: 256 and 768 fp64: fewer values per thread, more threads per CU?
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<256, 16, 16>, double, 8, true, false, 1>("16x16"));                          // shipped
+      vs.push_back(make_tile_occ<Spec<256, 4, 4, 4, 4>, double, 8, true, true, 1, false, 4>("4x4x4x4"));
+      vs.push_back(make_tile_occ<Spec<256, 4, 4, 4, 4>, double, 8, true, false, 1, false, 4>("4x4x4x4"));
+      vs.push_back(make_tile_occ<Spec<256, 8, 8, 4>, double, 8, true, false, 1, false, 4>("8x8x4"));
+      vs.push_back(make_tile_occ<Spec<256, 8, 8, 4>, double, 8, true, true, 1, false, 8>("8x8x4"));
+      run_all<double>(vs, 256, "", rounds);
+    }
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<Spec<768, 8, 8, 4, 3>, double, 8, true, true, 1>("8x8x4x3"));                     // shipped (split, LDS twiddles)
+      vs.push_back(make_tile_occ<Spec<768, 4, 4, 4, 4, 3>, double, 8, true, true, 1, false, 2>("4x4x4x4x3"));
+      vs.push_back(make_tile_occ<Spec<768, 4, 4, 4, 4, 3>, double, 8, true, true, 1, false, 3>("4x4x4x4x3"));
+      vs.push_back(make_tile_occ<Spec<768, 4, 4, 4, 4, 3>, double, 8, false, true, 1, false, 3>("4x4x4x4x3"));
+      run_all<double>(vs, 768, "", rounds);
+    }
+    return 0;
+  }
+  if (filter[0] && strstr("occ512", filter)) {      // round 3: 512 fp64 (BASELINE config 2): more workgroups per CU?
+    std::vector<Variant<double>> vs;
+    vs.push_back(make_tile<Spec<512, 8, 8, 8>, double, 8, false, false, 1>("8x8x8"));                       // shipped: 64 KB whole-complex exchange
+    vs.push_back(make_tile_occ<Spec<512, 8, 8, 8>, double, 8, true, true, 1, false, 3>("8x8x8"));           // split + LDS twiddles, 3 per CU
+    vs.push_back(make_tile_occ<Spec<512, 8, 8, 8>, double, 8, true, true, 1, false, 4>("8x8x8"));           // 4 per CU (64 VGPRs)
+    vs.push_back(make_tile_occ<Spec<512, 8, 8, 8>, double, 8, true, true, 1, true, 4>("8x8x8"));            // ... non-temporal
+    vs.push_back(make_tile_occ<Spec<512, 8, 8, 4, 2>, double, 8, true, true, 1, false, 4>("8x8x4x2"));
+    vs.push_back(make_tile_occ<Spec<512, 8, 4, 4, 4>, double, 8, true, true, 1, false, 4>("8x4x4x4"));
+    vs.push_back(make_tile_occ<Spec<512, 4, 4, 4, 4, 2>, double, 8, true, true, 1, false, 2>("4x4x4x4x2"));  // E = 4, 1024 threads, 2 per CU
+    run_all<double>(vs, 512, "", rounds);
+    return 0;
+  }
   if (filter[0] && strstr("small", filter)) {       // 384 / 640 / 576: fewer values per thread, more threads per CU?
     {
       std::vector<Variant<double>> vs;
