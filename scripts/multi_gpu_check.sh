@@ -14,6 +14,10 @@ for P in 2 4 8; do
     MP_N=$n timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 \
       --master-port $((PORT++)) scripts/mp_big_check.py 2>&1 | grep -E "BIG_OK|Error|error|assert" | head -5
   done
+  echo "== IPC transport over real links: every pull mode, CU masks, relay striping (tests/mp_worker.py), then a short soak"
+  MFFT_TRANSPORT=ipc timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 \
+    --master-port $((PORT++)) tests/mp_worker.py 2>&1 | grep -E "MP_OK|Error|error|assert" | head -5
+  timeout 600 python scripts/ipc_stress.py $P 1 4 100 256 2>&1 | grep -E "IPC_STRESS|rank" | tail -3
   echo "== bench: $P ranks"
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 \
     --master-port $((PORT++)) bench.py --gpus $P --steps 10 --warmup 3 2>/dev/null | python scripts/show_bench.py

@@ -610,6 +610,15 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (filter[0] && strstr("occ2048", filter)) {     // round 3: 2048 fp64: 64-byte tiles with 8 values per thread, 2048 threads per CU
+    std::vector<Variant<double>> vs;
+    vs.push_back(make_tile<Spec<2048, 16, 16, 8>, double, 8, false, true, 1>("16x16x8"));                    // shipped
+    vs.push_back(make_tile_occ<Spec<2048, 8, 8, 8, 4>, double, 4, true, true, 1, false, 2>("8x8x8x4"));
+    vs.push_back(make_tile_occ<Spec<2048, 8, 8, 8, 4>, double, 4, false, true, 1, false, 2>("8x8x8x4"));
+    vs.push_back(make_tile_occ<Spec<2048, 16, 16, 8>, double, 4, false, true, 1, false, 2>("16x16x8"));
+    run_all<double>(vs, 2048, "", rounds);
+    return 0;
+  }
   if (filter[0] && strstr("occ256", filter)) {      // round 3: 256 and 768 fp64: fewer values per thread, more threads per CU?
     {
       std::vector<Variant<double>> vs;
