@@ -610,6 +610,16 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (filter[0] && strstr("occ512f", filter)) {     // round 3: 512 fp32: the same question as occ512
+    std::vector<Variant<float>> vs;
+    vs.push_back(make_tile<Spec<512, 8, 8, 8>, float, 16, false, false, 2>("8x8x8"));                         // shipped: two columns per lane
+    vs.push_back(make_tile_occ<Spec<512, 4, 4, 4, 4, 2>, float, 16, true, true, 2, false, 2>("4x4x4x4x2"));
+    vs.push_back(make_tile_occ<Spec<512, 4, 4, 4, 4, 2>, float, 16, true, false, 2, false, 2>("4x4x4x4x2"));
+    vs.push_back(make_tile_occ<Spec<512, 8, 8, 8>, float, 16, true, true, 2, false, 4>("8x8x8"));
+    vs.push_back(make_tile_occ<Spec<512, 8, 8, 8>, float, 16, true, true, 1, false, 2>("8x8x8"));
+    run_all<float>(vs, 512, "", rounds);
+    return 0;
+  }
   if (filter[0] && strstr("occ2048", filter)) {     // round 3: 2048 fp64: 64-byte tiles with 8 values per thread, 2048 threads per CU
     std::vector<Variant<double>> vs;
     vs.push_back(make_tile<Spec<2048, 16, 16, 8>, double, 8, false, true, 1>("16x16x8"));                    // shipped
