@@ -393,6 +393,29 @@ static void test_col_band() {
   char name[64];
   snprintf(name, sizeof name, "col c%d v%d inv pruned (kept %d, skipped %d)", COLS, VEC, kept, skipped / N);
   report(name, N, pname<T>(), bad || kept == 0 ? 1.0 : (double)sqrtl(num / (den > 0 ? den : 1)), 1e-30);
+  // complete-output mode (b_gzero = 2, the pencils' first inverse pass): EVERY column is written -- kept ones as the plain
+  // kernel on the row-zeroed input, columns of a removed y or z as exact zeros (per column, also inside a lane's VEC pair)
+  std::vector<cx<T>> out2(in.size(), sentinel);
+  P.b_gzero = 2;
+  P.in = in.data(); P.out = out2.data();
+  emu_launch(P.ntile_c * nouter, KB::THREADS, KB::LDS_BYTES, [&](int b, int t, char* lds) { KB::body(P, b, t, lds); });
+  num = den = 0;
+  bad = 0;
+  for (int o = 0; o < nouter; ++o)
+    for (int c = 0; c < ncols; ++c) {
+      const int t = 2 + c, z = t % 5, y = 1 + t / 5 + o * 2;
+      const bool keep = z < 3 && (y < 3 || y >= 5);
+      for (int r = 0; r < N; ++r) {
+        const size_t i = (size_t)o * N * pin + (size_t)r * pin + c;
+        if (out2[i].x == sentinel.x && out2[i].y == sentinel.y) { ++bad; continue; }       // nothing may stay unwritten
+        const cx<T> want = keep ? out0[i] : mk<T>((T)0, (T)0);
+        if (!keep && (out2[i].x != (T)0 || out2[i].y != (T)0)) ++bad;
+        num += (out2[i].x - want.x) * (out2[i].x - want.x) + (out2[i].y - want.y) * (out2[i].y - want.y);
+        den += want.x * want.x + want.y * want.y;
+      }
+    }
+  snprintf(name, sizeof name, "col c%d v%d inv band, complete output", COLS, VEC);
+  report(name, N, pname<T>(), bad ? 1.0 : (double)sqrtl(num / (den > 0 ? den : 1)), 1e-30);
 }
 
 template <class S, bool HAS3 = (S::E % 3 == 0 && S::N >= 6)> struct PadTests {
