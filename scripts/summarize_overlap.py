@@ -54,7 +54,36 @@ def intersect(a, b):
     return tot
 
 
+def by_thread(root):
+    """One trace of ONE process whose ranks are host threads (scripts/overlap_local.py): kernels grouped by the
+    dispatching thread; a rank's exchange = the device-copy kernels its thread issued."""
+    per = {}
+    for path in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            name = row.get("Kernel_Name", "")
+            s, e = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
+            kind = "xchg" if "copyBuffer" in name else "fft" if "mfft_kern" in name else None
+            if kind:
+                per.setdefault(row["Thread_Id"], {"xchg": [], "fft": []})[kind].append((s, e))
+    print("# %s: kernels of %d dispatching threads" % (root, len(per)))
+    tx = tov = 0
+    for i, (tid, d) in enumerate(sorted(per.items(), key=lambda kv: kv[0])):
+        if not d["xchg"] or not d["fft"]:
+            continue
+        fft = merged(d["fft"])
+        t_x = sum(e - s for s, e in d["xchg"])
+        t_ov = sum(intersect(iv, fft) for iv in d["xchg"])
+        tx += t_x; tov += t_ov
+        print("thread %s: %d copies %.2f ms, %d transform kernels %.2f ms, copy time beside a transform kernel of the same "
+              "rank: %.2f ms = %.0f %%" % (tid, len(d["xchg"]), t_x / 1e6, len(d["fft"]), sum(e - s for s, e in fft) / 1e6,
+                                          t_ov / 1e6, 100.0 * t_ov / max(t_x, 1)))
+    if tx:
+        print("# all ranks: %.0f %% of the copy time ran beside a transform kernel of the same rank" % (100.0 * tov / tx))
+
+
 def main():
+    if sys.argv[1] == "--by-thread":
+        return by_thread(sys.argv[2])
     root = sys.argv[1]
     ranks = sorted(glob.glob(os.path.join(root, "rank*/")), key=lambda p: int(re.search(r"rank(\d+)", p).group(1)))
     print("# %s: %d rank traces" % (root, len(ranks)))
