@@ -37,6 +37,7 @@ def parse_args():
                     help="how rank 0's RCCL unique id reaches the other ranks (torch = gloo process group)")
     ap.add_argument("--pencil-extra", default="auto", choices=["auto", "on", "off"],
                     help="also time the pencil (R2CX) decomposition of the same cube and report it under 'extras'")
+    ap.add_argument("--tune-child", default=None, choices=["rccl", "ipc"], help=argparse.SUPPRESS)   # internal: see tune_in_children
     ap.add_argument("--stage-timing", default="on", choices=["on", "off"],
                     help="HIP events around every stage inside the timed region (roofline numbers)")
     return ap.parse_args()
@@ -209,8 +210,148 @@ def cpu_baseline(n_full, seconds_budget=30.0):
                       % (ns, cores, t_s, err, n_full, scale)}
 
 
+PULL_NAMES = {1: "", 2: ":streams", 0: ":copy"}      # the IPC transport's ways of pulling (include/mpifft4py_amd.h)
+DEPTHS = (1, 2, 4, 8, -2, -4, -8)                    # 1: blocking; kz slices / (negative) batches of local x rows
+NWARM, NTIMED = 2, 5                                 # pairs per candidate; the slowest rank counts
+
+
+def transport_of(c):
+    return "ipc" if c.get_option("ipc_pull") >= 0 else "rccl"
+
+
+def cand_label(c, pull):
+    return transport_of(c) + (PULL_NAMES.get(pull, "") if pull is not None else "")
+
+
+class Tuner:
+    """The exchange candidates of ONE communicator on a cube of edge n: transforms a scratch array back into itself and
+    checks that it stays what it was, so a candidate only counts if it still computes the right thing on this wire."""
+
+    def __init__(self, c, n, precision, world, rank):
+        self.c, self.n, self.precision, self.world, self.rank = c, n, precision, world, rank
+        self.N, self.L = np.array([n, n, n]), np.array([2 * np.pi] * 3)
+        self.dtype = np.float64 if precision == "double" else np.float32
+        self.tol = 1e-9 if precision == "double" else 1e-3
+        self.rejected = {}
+        self._fresh()
+
+    def _fresh(self):
+        self.ut = DeviceArray.random((self.n // self.world, self.n, self.n), self.dtype, seed=7 + self.rank)
+        self.k = max(1, min(self.n // self.world, 2))
+        self.u_ref = self.ut.leading(0, self.k).get()
+
+    def candidate(self, pull, depth, cus):
+        """ms per pair (max over ranks) or None"""
+        c = self.c
+        if pull is not None:
+            c.set_option("ipc_pull", pull)
+        Ft = Slab_R2C(self.N, self.L, c, self.precision, pipeline=depth, comm_cus=cus)
+        fut = DeviceArray.empty(Ft.complex_shape(), Ft.complex)
+        for it in range(NWARM + NTIMED):
+            if it == NWARM:
+                Ft.sync()
+                c.barrier()
+                tt = time.perf_counter()
+            Ft.fftn(self.ut, fut)
+            Ft.ifftn(fut, self.ut)
+        Ft.sync()
+        c.barrier()
+        ms = c.allreduce((time.perf_counter() - tt) / NTIMED, op=mcomm.MAX) * 1e3
+        got = self.ut.leading(0, self.k).get()
+        err = float(np.linalg.norm((got - self.u_ref).ravel()) / np.linalg.norm(self.u_ref.ravel()))
+        err = c.allreduce(err if err == err else 1e30, op=mcomm.MAX)
+        del Ft, fut
+        if not err <= self.tol:
+            self.rejected["%s:%d%s" % (cand_label(c, pull), depth, (":cus%d" % cus) if cus and cus > 0 else "")] = err
+            self._fresh()
+            return None
+        return ms
+
+    def sweep(self, tuning, skip=()):
+        """every (pull mode, depth) of this communicator into tuning[label][depth]; returns the best (ms, depth, pull)"""
+        # The per-peer copy streams are only worth a measurement when every rank owns a device: with ranks SHARING a
+        # device (functional runs) they add seven more queues per process, stream memory operations are spinning
+        # kernels, and the hardware scheduler's time slices are all that gets measured (seconds per pair,
+        # profiles/r03_ipc_pull_modes.txt) -- and the streams, once created, slow every later candidate down.
+        own_device = int(_lib.device_count()) >= self.world
+        pulls = ((1, 2, 0) if own_device else (1, 0)) if self.c.get_option("ipc_pull") >= 0 else (None,)
+        best = None
+        for pull in pulls:
+            tc = tuning.setdefault(cand_label(self.c, pull), {})
+            for depth in DEPTHS:
+                if (cand_label(self.c, pull), depth) in skip:
+                    continue
+                ms = self.candidate(pull, depth, -1)             # no CU masks here; tried for the winner later
+                if ms is None:
+                    continue
+                tc[depth] = ms
+                if best is None or ms < best[0]:
+                    best = (ms, depth, pull)
+        return best
+
+
+def tune_child(args):
+    """A rank of a CHILD group (bench.py --tune-child T, started by tune_in_children): builds transport T among the
+    children, verifies it, sweeps its candidates and lets rank 0 print the table.  Whatever goes wrong here -- a
+    refusal, a hang, a GPU fault -- stays in the children."""
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    with stdout_to_stderr():
+        c = mcomm.from_env(None, transport=args.tune_child)
+        if os.environ.get("MFFT_BENCH_CHILD_FAULT") == str(rank):      # test hook: this child dies the way a GPU fault kills
+            os.abort()
+        c.selftest(1 << 20, 20000)          # a verified 1 MB-per-peer exchange, at most 20 s: never trust an untried wire
+        tuning = {}
+        t = Tuner(c, args.n, args.precision, world, rank)
+        t.sweep(tuning)
+        c.barrier()
+    if rank == 0:
+        sys.stdout.write(json.dumps({"tuning": tuning, "rejected": t.rejected}) + "\n")
+        sys.stdout.flush()
+
+
+def tune_in_children(comm, other, args, world, rank, timeout_s=300.0):
+    """Measure the OTHER transport without letting it near this process: every rank starts a child (same GPU, fresh HIP
+    context), the children build the transport among themselves and sweep its candidates (tune_child).  Returns
+    (table, rejected) -- the same on every rank -- or raises with what went wrong.  A transport that refuses, hangs or
+    faults on this machine costs a few seconds here and nothing else."""
+    import tempfile
+    path = None
+    if rank == 0:
+        d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mfft-%d" % os.getuid())
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        fd, path = tempfile.mkstemp(prefix="tunechild_", dir=d)
+        os.close(fd)
+        os.unlink(path)
+    path = comm.bcast(path, root=0)
+    env = {k: v for k, v in os.environ.items() if k not in ("MFFT_TRANSPORT",)}
+    env.update(MFFT_RENDEZVOUS_FILE=path, MFFT_LOCAL_TIMEOUT="60")
+    cmd = [sys.executable, os.path.abspath(__file__), "--tune-child", other, "--gpus", str(world), "--size", str(args.n),
+           "--precision", args.precision]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+        rc, why = p.returncode, (err.decode(errors="replace").strip().splitlines() or ["exit code %d" % p.returncode])[-1]
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out, err = p.communicate()
+        rc, why = -1, "no answer within %.0f s" % timeout_s
+    bad = comm.allreduce(0.0 if rc == 0 else 1.0, op=mcomm.MAX)
+    res = None
+    if rank == 0 and rc == 0:
+        try:
+            res = json.loads([l for l in out.decode().splitlines() if l.strip()][-1])
+        except Exception as e:      # noqa: BLE001
+            res, why = None, "unreadable answer (%s)" % e
+    res = comm.bcast(res if bad == 0 else None, root=0)
+    if res is None:
+        raise RuntimeError(comm.bcast(why if rank == 0 else None, root=0) or "a rank's child failed")
+    return res["tuning"], res["rejected"]
+
+
 def main():
     args = ARGS if ARGS is not None else parse_args()
+    if args.tune_child:
+        return tune_child(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != args.gpus:
@@ -287,8 +428,6 @@ def main():
     def comm_name(c):
         return getattr(c, "transport_name", "rccl" if world > 1 else "none")
 
-    PULL_NAMES = {1: "", 2: ":streams", 0: ":copy"}      # the IPC transport's ways of pulling (include/mpifft4py_amd.h)
-
     def cand_name(c, pull):
         return comm_name(c) + (PULL_NAMES.get(pull, "") if pull is not None else "")
 
@@ -363,102 +502,70 @@ def main():
                 "mres": base, "key": None}
         dog = arm_watchdog(600.0, lambda: held["line"], "the exchange candidates (transport, pipeline) did not finish within 600 s")
         # 2. transport x exchange pipeline (flavour and depth) measured on this machine's links, like a planner's MEASURE
-        #    mode: 2 untimed + 2 timed pairs per candidate, slowest rank counts
-        comms = [comm]
-        if args.transport == "auto":
-            other = "ipc" if comm.transport_name != "ipc" else "rccl"
-            try:
-                with stdout_to_stderr():
-                    c2, _ = make_comm(world, "file", other)
-                c2.transport_name = other
-                c2.selftest(1 << 20, 20000)      # a verified 1 MB-per-peer exchange, at most 20 s: never trust an untried wire
-                comms.append(c2)
-            except Exception as e:      # noqa: BLE001
-                sys.stderr.write("transport %s unavailable (%s: %s)\n" % (other, type(e).__name__, e))
-                tuning[other] = {"error": "%s: %s" % (type(e).__name__, e)}
-            # every rank must agree on the candidate list
-            if -comm.allreduce(-float(len(comms)), op=mcomm.MAX) < 2:
-                comms = comms[:1]
+        #    mode: 2 untimed + 5 timed pairs per candidate, slowest rank counts
         ipc_first = comm.get_option("ipc_pull") >= 0
         base_pull = 1 if ipc_first else None          # the first measurement ran with the transport's default (pull kernel)
-        best = (comm, 1, base_pull, 0)
-        best_ms = tuning[comm.transport_name][1]
-        NWARM, NTIMED = 2, 5                          # per candidate; the slowest rank counts
+        base_key = (comm, 1, base_pull, 0)
+        best, best_ms = base_key, tuning[comm.transport_name][1]
+        rejected = {}
         try:
-            ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
-            ksample = max(1, min(n // world, 2))
-            u_ref = ut.leading(0, ksample).get()              # the candidates transform ut back into itself: it must stay what it was
-            tol_c = 1e-9 if args.precision == "double" else 1e-3
-            rejected = tuning.setdefault("rejected", {})
-
-            def candidate(c, pull, depth, cus):
-                """ms per pair of one candidate (max over ranks), or None if it no longer computes the right thing here"""
-                nonlocal ut
-                set_pull(c, pull)
-                Ft = Slab_R2C(N, L, c, args.precision, pipeline=depth, comm_cus=cus)
-                fut = DeviceArray.empty(Ft.complex_shape(), Ft.complex)
-                for it in range(NWARM + NTIMED):
-                    if it == NWARM:
-                        Ft.sync()
-                        c.barrier()
-                        tt = time.perf_counter()
-                    Ft.fftn(ut, fut)
-                    Ft.ifftn(fut, ut)
-                Ft.sync()
-                c.barrier()
-                ms = c.allreduce((time.perf_counter() - tt) / NTIMED, op=mcomm.MAX) * 1e3
-                err = float(np.linalg.norm((ut.leading(0, ksample).get() - u_ref).ravel()) / np.linalg.norm(u_ref.ravel()))
-                err = comm.allreduce(err if err == err else 1e30, op=mcomm.MAX)
-                del Ft, fut
-                if not err <= tol_c:
-                    rejected["%s:%d%s" % (cand_name(c, pull), depth, (":cus%d" % cus) if cus else "")] = err
-                    ut = DeviceArray.random((n // world, n, n), np.float64 if args.precision == "double" else np.float32, seed=7 + rank)
-                    return None
-                return ms
-
-            # The per-peer copy streams are only worth a measurement when every rank owns a device: with ranks SHARING a
-            # device (functional runs) they add seven more queues per process, stream memory operations are spinning
-            # kernels, and the hardware scheduler's time slices are all that gets measured (seconds per pair,
-            # profiles/r03_ipc_pull_modes.txt) -- and the streams, once created, slow every later candidate down.
-            own_device = int(_lib.device_count()) >= world
-            for ci, c in enumerate(comms):
-                pulls = ((1, 2, 0) if own_device else (1, 0)) if c.get_option("ipc_pull") >= 0 else (None,)
-                for pull in pulls:
-                    tc = tuning.setdefault(cand_name(c, pull), {})
-                    for depth in (1, 2, 4, 8, -2, -4, -8):       # 1: blocking; kz slices / (negative) batches of local x rows
-                        if depth in tc:
-                            continue
-                        ms = candidate(c, pull, depth, -1)       # no CU masks here; tried for the winner below
-                        if ms is None:
-                            continue
-                        tc[depth] = ms
-                        if ms < best_ms:
-                            best, best_ms = (c, depth, pull, -1), ms
-                if ci == 0 and len(comms) > 1 and best != (comm, 1, base_pull, 0):
-                    # the first transport is through: take its winner's complete measurement NOW, so that a second
-                    # transport that misbehaves on this machine costs the run its green light but not this number
+            # 2a. this process's own transport
+            tuner = Tuner(comm, n, args.precision, world, rank)
+            got = tuner.sweep(tuning, skip={(cand_label(comm, base_pull), 1)})
+            rejected.update(tuner.rejected)
+            if got is not None and got[0] < best_ms:
+                best, best_ms = (comm, got[1], got[2], -1), got[0]
+            if args.transport == "auto":
+                if best != base_key:
+                    # take the winner's complete measurement NOW: whatever the second transport does on this machine, this
+                    # number is in hand (the watchdog prints it)
                     held["mres"] = measure(best[1], best[0], best[2], best[3])
                     held["key"] = best
                     if rank == 0:
                         held["line"] = headline(held["mres"], dict(tuning, note="the second transport's candidates did not finish"))
-            # CUs of its own for the communication stream (mfft_plan_desc.comm_cus) only matter for a pipelined winner
+                # 2b. the other transport, in CHILD processes first: a transport that refuses, hangs or faults on this
+                #     machine never gets near the process that holds the measurement
+                other = "ipc" if comm.transport_name != "ipc" else "rccl"
+                try:
+                    table, rej = tune_in_children(comm, other, args, world, rank)
+                    rejected.update(rej)
+                    cand = None
+                    for label, per in table.items():
+                        tuning[label] = {int(k_): v for k_, v in per.items()}
+                        for k_, v in per.items():
+                            if cand is None or v < cand[0]:
+                                cand = (v, int(k_), label)
+                    if cand is not None and cand[0] < best_ms:
+                        # it wins: build it here too (it has just worked between the children, on the same devices and links)
+                        with stdout_to_stderr():
+                            c2, _ = make_comm(world, "file", other)
+                        c2.transport_name = other
+                        pull2 = {v: k_ for k_, v in PULL_NAMES.items()}.get(cand[2][len(other):], None) if other == "ipc" else None
+                        best, best_ms = (c2, cand[1], pull2, -1), cand[0]
+                except Exception as e:      # noqa: BLE001  - the same on every rank (tune_in_children agrees on it)
+                    sys.stderr.write("transport %s unavailable (%s: %s)\n" % (other, type(e).__name__, e))
+                    tuning[other] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # 2c. CUs of its own for the communication stream (mfft_plan_desc.comm_cus) only matter for a pipelined winner
             if best[1] != 1:
+                t2 = tuner if best[0] is comm else Tuner(best[0], n, args.precision, world, rank)
                 tcu = tuning.setdefault("comm_cus", {"candidate": "%s:%d" % (cand_name(best[0], best[2]), best[1]), "none": best_ms})
                 for cus in (8, 16, 32):
-                    ms = candidate(best[0], best[2], best[1], cus)
+                    ms = t2.candidate(best[2], best[1], cus)
                     if ms is None:
                         continue
                     tcu[str(cus)] = ms
                     if ms < best_ms:
                         best, best_ms = (best[0], best[1], best[2], cus), ms
-            del ut
-            if not rejected:
-                del tuning["rejected"]
+                rejected.update(t2.rejected)
+                del t2
+            del tuner
+            if rejected:
+                tuning["rejected"] = rejected
         except Exception as e:      # noqa: BLE001  - every rank takes the same path
             sys.stderr.write("exchange tuning failed (%s: %s); keeping the best candidate so far\n" % (type(e).__name__, e))
             tuning["error"] = "%s: %s" % (type(e).__name__, e)
         # 3. the timed region with the best candidate (the first measurement stands if nothing beats it)
-        mres = base if best == (comm, 1, base_pull, 0) else held["mres"] if best == held["key"] else measure(best[1], best[0], best[2], best[3])
+        mres = base if best == base_key else held["mres"] if best == held["key"] else measure(best[1], best[0], best[2], best[3])
         dog.cancel()
     else:
         mres = measure(args.pipeline)

@@ -182,6 +182,25 @@ def test_bench_falls_back_when_rccl_refuses():
         assert cfg["exchange_transport"] == "ipc" and "error" in cfg["exchange_pipeline_tuning_ms_per_pair"]["rccl"]
 
 
+def test_bench_survives_a_second_transport_that_faults():
+    """`--transport auto` measures the second transport in CHILD processes (bench.py tune_in_children): a child that dies
+    the way a GPU fault kills a process (abort) costs the run nothing -- one JSON line from the first transport, rc 0,
+    the failure recorded in the tuning table."""
+    env = {k: v for k, v in _env("mock").items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["MFFT_BENCH_CHILD_FAULT"] = "1"               # rank 1's child aborts right after the communicator is built
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--steps", "2",
+                        "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    out, err = p.stdout.decode(), p.stderr.decode()
+    assert p.returncode == 0, (out[-2000:], err[-4000:])
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    tun = d["config"]["exchange_pipeline_tuning_ms_per_pair"]
+    assert d["config"]["exchange_transport"] == "rccl" and not d.get("degraded") and "error" in tun["ipc"], tun
+    assert sorted(int(k) for k in tun["rccl"]) == [-8, -4, -2, 1, 2, 4, 8]
+
+
 def test_bench_ranks_stay_together_when_rank0_cannot_make_an_id():
     """a rank 0 that fails BEFORE it publishes the unique id (here: a transport name the library rejects in
     mfft_get_unique_id) must not leave the other ranks polling for the id while it moves on to the next rendezvous:
