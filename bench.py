@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--pencil-extra", default="auto", choices=["auto", "on", "off"],
                     help="also time the pencil (R2CX) decomposition of the same cube and report it under 'extras'")
     ap.add_argument("--tune-child", default=None, choices=["rccl", "ipc"], help=argparse.SUPPRESS)   # internal: see tune_in_children
+    ap.add_argument("--child-task", default="slab", choices=["slab", "pencil_relay"], help=argparse.SUPPRESS)
     ap.add_argument("--stage-timing", default="on", choices=["on", "off"],
                     help="HIP events around every stage inside the timed region (roofline numbers)")
     return ap.parse_args()
@@ -223,6 +224,41 @@ def cand_label(c, pull):
     return transport_of(c) + (PULL_NAMES.get(pull, "") if pull is not None else "")
 
 
+def pencil_grids(n, world):
+    """P1 x P2 grids the C ABI takes for an n^3 R2C cube over `world` ranks (x-aligned pencils)"""
+    return [(a, world // a) for a in range(1, world + 1) if world % a == 0 and n % a == 0 and n % (world // a) == 0
+            and (n // 2 + 1) % (world // a) <= 1 and (world // a == 1 or (n // (world // a)) % 2 == 0)]
+
+
+def pencil_candidate(pcomm, n, precision, world, rank, grid, depth, ksteps):
+    """one x-aligned pencil configuration: 2 untimed + ksteps timed pairs, round trip of the first plane"""
+    N, L = np.array([n, n, n]), np.array([2 * np.pi] * 3)
+    Fp = Pencil_R2C(N, L, pcomm, precision, P1=(grid[0] if grid else None), communication="Alltoallw",
+                    alignment="X", allow_single=True, allow_odd_grid=True, pipeline=depth)
+    up = DeviceArray.random(Fp.real_shape(), Fp.float, seed=99 + rank)
+    fup = DeviceArray.empty(Fp.complex_shape(), Fp.complex)
+    up2 = DeviceArray.empty(Fp.real_shape(), Fp.float)
+    for _ in range(2):
+        Fp.fftn(up, fup)
+        Fp.ifftn(fup, up2)
+    Fp.sync()
+    pcomm.barrier()
+    tp = time.perf_counter()
+    for _ in range(ksteps):
+        Fp.fftn(up, fup)
+        Fp.ifftn(fup, up2)
+    Fp.sync()
+    pcomm.barrier()
+    dtp = time.perf_counter() - tp
+    dtp = pcomm.allreduce(dtp, op=mcomm.MAX) if world > 1 else dtp
+    a0 = up.leading(0, 1).get()
+    b0 = up2.leading(0, 1).get()
+    rt = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
+    rt = pcomm.allreduce(rt if rt == rt else 1e30, op=mcomm.MAX) if world > 1 else rt
+    return {"grid": [int(Fp.P1), int(Fp.P2)], "pairs_per_s": ksteps / dtp, "ms_per_pair": 1e3 * dtp / ksteps,
+            "steps": ksteps, "exchange_pipeline_depth": depth, "roundtrip_rel_l2": rt}
+
+
 class Tuner:
     """The exchange candidates of ONE communicator on a cube of edge n: transforms a scratch array back into itself and
     checks that it stays what it was, so a candidate only counts if it still computes the right thing on this wire."""
@@ -300,16 +336,27 @@ def tune_child(args):
         if os.environ.get("MFFT_BENCH_CHILD_FAULT") == str(rank):      # test hook: this child dies the way a GPU fault kills
             os.abort()
         c.selftest(1 << 20, 20000)          # a verified 1 MB-per-peer exchange, at most 20 s: never trust an untried wire
-        tuning = {}
-        t = Tuner(c, args.n, args.precision, world, rank)
-        t.sweep(tuning)
+        tuning, rej = {}, {}
+        if args.child_task == "pencil_relay":
+            # the pencils' sub-group exchanges relay-striped over the links to the ranks outside the group
+            # (csrc/relay_plan.h): every grid with two real groups x blocking / pipelined
+            c.set_option("ipc_relay", 1)
+            for grid in pencil_grids(args.n, world):
+                if grid[0] == 1 or grid[1] == 1:
+                    continue                  # one exchange over all ranks: nothing to relay
+                for depth in (1, 4):
+                    tuning["%dx%d:%d:relay" % (grid[0], grid[1], depth)] = pencil_candidate(c, args.n, args.precision, world, rank, grid, depth, 5)
+        else:
+            t = Tuner(c, args.n, args.precision, world, rank)
+            t.sweep(tuning)
+            rej = t.rejected
         c.barrier()
     if rank == 0:
-        sys.stdout.write(json.dumps({"tuning": tuning, "rejected": t.rejected}) + "\n")
+        sys.stdout.write(json.dumps({"tuning": tuning, "rejected": rej}) + "\n")
         sys.stdout.flush()
 
 
-def tune_in_children(comm, other, args, world, rank, timeout_s=300.0):
+def tune_in_children(comm, other, args, world, rank, timeout_s=300.0, task="slab"):
     """Measure the OTHER transport without letting it near this process: every rank starts a child (same GPU, fresh HIP
     context), the children build the transport among themselves and sweep its candidates (tune_child).  Returns
     (table, rejected) -- the same on every rank -- or raises with what went wrong.  A transport that refuses, hangs or
@@ -325,8 +372,8 @@ def tune_in_children(comm, other, args, world, rank, timeout_s=300.0):
     path = comm.bcast(path, root=0)
     env = {k: v for k, v in os.environ.items() if k not in ("MFFT_TRANSPORT",)}
     env.update(MFFT_RENDEZVOUS_FILE=path, MFFT_LOCAL_TIMEOUT="60")
-    cmd = [sys.executable, os.path.abspath(__file__), "--tune-child", other, "--gpus", str(world), "--size", str(args.n),
-           "--precision", args.precision]
+    cmd = [sys.executable, os.path.abspath(__file__), "--tune-child", other, "--child-task", task, "--gpus", str(world),
+           "--size", str(args.n), "--precision", args.precision]
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     try:
         out, err = p.communicate(timeout=timeout_s)
@@ -587,51 +634,28 @@ def main():
             # process grids: the reference's default (MPI.Compute_dims: 4x2 for 8 ranks) and the others the C ABI takes.
             # On a fully connected xGMI node an exchange inside a group of g ranks uses g - 1 of a GPU's seven links, so
             # the P x 1 and 1 x P grids (one exchange over all ranks, like the slab) are candidates, not curiosities.
-            grids = [None]
-            if world > 1:
-                grids = [(a, world // a) for a in range(1, world + 1) if world % a == 0 and n % a == 0 and n % (world // a) == 0
-                         and (n // 2 + 1) % (world // a) <= 1 and (world // a == 1 or (n // (world // a)) % 2 == 0)]
+            grids = pencil_grids(n, world) if world > 1 else [None]
             per_cand = {}
-            # IPC transport, every rank on its own device: the sub-group exchanges with and without relay striping
-            # (csrc/relay_plan.h; two hops through the ranks outside the group use the links a P1 x P2 grid leaves idle)
-            relays = (0, 1) if (world > 1 and pcomm.get_option("ipc_pull") >= 0 and int(_lib.device_count()) >= world) else (None,)
             for grid in grids:
-              for relay in relays:
-                if relay is not None:
-                    if grid is not None and (grid[0] == 1 or grid[1] == 1) and relay == 1:
-                        continue                                  # one exchange over all ranks: nothing to relay
-                    pcomm.set_option("ipc_relay", relay)
                 for depth in ((1, 4) if world > 1 else (1,)):        # blocking exchanges / the X pipeline (batches of local x rows)
-                    Fp = Pencil_R2C(N, L, pcomm, args.precision, P1=(grid[0] if grid else None), communication="Alltoallw",
-                                    alignment="X", allow_single=True, allow_odd_grid=True, pipeline=depth)
-                    up = DeviceArray.random(Fp.real_shape(), Fp.float, seed=99 + rank)
-                    fup = DeviceArray.empty(Fp.complex_shape(), Fp.complex)
-                    up2 = DeviceArray.empty(Fp.real_shape(), Fp.float)
-                    for _ in range(2):
-                        Fp.fftn(up, fup)
-                        Fp.ifftn(fup, up2)
-                    Fp.sync()
-                    pcomm.barrier()
                     ksteps = max(3, min(args.steps, 10)) if len(grids) == 1 else 5
-                    tp = time.perf_counter()
-                    for _ in range(ksteps):
-                        Fp.fftn(up, fup)
-                        Fp.ifftn(fup, up2)
-                    Fp.sync()
-                    pcomm.barrier()
-                    dtp = time.perf_counter() - tp
-                    dtp = pcomm.allreduce(dtp, op=mcomm.MAX) if world > 1 else dtp
-                    a0 = up.leading(0, 1).get()
-                    b0 = up2.leading(0, 1).get()
-                    rt = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
-                    rt = pcomm.allreduce(rt if rt == rt else 1e30, op=mcomm.MAX) if world > 1 else rt
-                    per_cand[(int(Fp.P1), int(Fp.P2), depth, relay or 0)] = {
-                        "grid": [int(Fp.P1), int(Fp.P2)], "pairs_per_s": ksteps / dtp, "ms_per_pair": 1e3 * dtp / ksteps,
-                        "steps": ksteps, "exchange_pipeline_depth": depth, "relay_striping": bool(relay),
-                        "exchange_transport": cand_name(pcomm, best[2]) if world > 1 else None, "roundtrip_rel_l2": rt}
-                    del Fp, up, fup, up2
-            if relays != (None,):
-                pcomm.set_option("ipc_relay", 0)
+                    r_ = pencil_candidate(pcomm, n, args.precision, world, rank, grid, depth, ksteps)
+                    r_.update(relay_striping=False, exchange_transport=cand_name(pcomm, best[2]) if world > 1 else None)
+                    per_cand[(r_["grid"][0], r_["grid"][1], depth, 0)] = r_
+            # Relay striping of the sub-group exchanges (IPC transport, csrc/relay_plan.h) when every rank owns a device:
+            # measured in CHILD processes, like every transport path that has never run on this machine's links
+            relay_env = os.environ.get("MFFT_BENCH_RELAY", "auto")       # "0": never, "force": also with ranks sharing a device (tests)
+            if world > 1 and any(g[0] > 1 and g[1] > 1 for g in grids) and relay_env != "0" \
+                    and (int(_lib.device_count()) >= world or relay_env == "force"):
+                try:
+                    table_r, _ = tune_in_children(pcomm, "ipc", args, world, rank, task="pencil_relay")
+                    for key, r_ in table_r.items():
+                        a_, b_ = r_["grid"]
+                        r_.update(relay_striping=True, exchange_transport="ipc", measured_in="child processes")
+                        per_cand[(a_, b_, r_["exchange_pipeline_depth"], 1)] = r_
+                except Exception as e:      # noqa: BLE001
+                    sys.stderr.write("relay striping not measured (%s: %s)\n" % (type(e).__name__, e))
+                    extras["pencil_relay_striping"] = {"error": "%s: %s" % (type(e).__name__, e)}
             # a candidate that does not reproduce its input on THIS machine's wire is rejected, not reported (and not fatal:
             # the line is about the configurations that work)
             tolp = 1e-10 if args.precision == "double" else 1e-4

@@ -182,6 +182,23 @@ def test_bench_falls_back_when_rccl_refuses():
         assert cfg["exchange_transport"] == "ipc" and "error" in cfg["exchange_pipeline_tuning_ms_per_pair"]["rccl"]
 
 
+def test_bench_measures_relay_striping_in_children():
+    """The pencil extra's relay-striped candidates (csrc/relay_plan.h) run in child processes over the IPC transport
+    (bench.py tune_in_children, task pencil_relay); forced here although the ranks share the box's one GPU."""
+    env = {k: v for k, v in _env("ipc").items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["MFFT_BENCH_RELAY"] = "force"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--size", "128", "--steps", "2",
+                        "--warmup", "1", "--cpu-baseline", "off", "--transport", "ipc", "--pipeline", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    out, err = p.stdout.decode(), p.stderr.decode()
+    assert p.returncode == 0, (out[-2000:], err[-4000:])
+    d = json.loads([l for l in out.splitlines() if l.strip()][0])
+    pen = d["extras"]["pencil_R2CX"]
+    table = pen["ms_per_pair_by_grid_and_depth"]
+    assert {"2x2:1", "2x2:4", "2x2:1:relay", "2x2:4:relay", "1x4:1", "4x1:1"} <= set(table), table
+    assert "rejected" not in pen and pen["roundtrip_rel_l2"] < 1e-10 and "pencil_relay_striping" not in d["extras"]
+
+
 def test_bench_survives_a_second_transport_that_faults():
     """`--transport auto` measures the second transport in CHILD processes (bench.py tune_in_children): a child that dies
     the way a GPU fault kills a process (abort) costs the run nothing -- one JSON line from the first transport, rc 0,
