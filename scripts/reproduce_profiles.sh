@@ -12,7 +12,8 @@ run() {
     r01_final_*|r01_v0_*) echo "(round-1 builds: git checkout the round-1 tag, then) scripts/profile_cmd.sh r01 bench.py --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off" ;;
     r01_kbench_variants.txt) tools kbench; tools/build/kbench ;;
     r01_kbench2_long_and_fp32.txt) tools kbench2; tools/build/kbench2 ;;
-    r01_size_sweep.txt|r02_size_sweep.txt) bash scripts/size_sweep.sh ;;
+    r01_size_sweep.txt|r02_size_sweep.txt|r03_size_sweep.txt) bash scripts/size_sweep.sh ;;
+    r03_kbench3_occ512.txt) tools kbench3; tools/build/kbench3 occ512 5; tools/build/kbench3 occ256 5 ;;
     r02_final_*) bash scripts/profile_r02.sh bench; python scripts/summarize_profiles.py r02_final gpurun_out/prof_r02/trace gpurun_out/prof_r02/fetch gpurun_out/prof_r02/write "bench.py 1024^3 fp64"; python scripts/summarize_profiles.py sq r02_final gpurun_out/prof_r02/sq1 gpurun_out/prof_r02/sq2 ;;
     r02_pack_*) bash scripts/profile_r02.sh pack; python scripts/summarize_profiles.py r02_pack gpurun_out/prof_r02/pack_trace gpurun_out/prof_r02/pack_fetch gpurun_out/prof_r02/pack_write "scripts/pack_workload.py 512" ;;
     r02_mask_*) bash scripts/profile_cmd.sh mask scripts/maskprof.py 1024 double; python scripts/summarize_profiles.py r02_mask gpurun_out/prof_mask/trace gpurun_out/prof_mask/fetch gpurun_out/prof_mask/write "scripts/maskprof.py 1024 double" ;;
