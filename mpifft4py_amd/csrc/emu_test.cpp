@@ -954,6 +954,12 @@ int main() {
 #if EMU_HAS(6)
   MFFT_PLANS_K(MFFT_PLAN)
 #endif
+#if EMU_HAS(7)
+  MFFT_PLANS_L(MFFT_PLAN)
+#endif
+#if EMU_HAS(8)
+  MFFT_PLANS_M(MFFT_PLAN)
+#endif
 #if EMU_HAS(5)
   MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN)
 #endif

@@ -27,7 +27,30 @@
 #if defined(__HIPCC__)
 #define MFFT_D __device__ __forceinline__
 #define MFFT_BARRIER() __syncthreads()
+// hipcc (ROCm 7.2) miscompiles the contiguous-axis kernels of the 30-values-per-thread plans when the thread's index inside
+// its transform has a known power-of-two range (j = tid % 8 or tid % 16: lengths 240 and 480 -- a third of the output bins
+// wrong, the same bins for every radix order and every number of rows per workgroup, while the workgroup emulator and the
+// strided kernels of the same plans, whose j = tid / columns has no such range, are right; tools/rowcheck.hip).  Passing j
+// through an empty asm hides the range from the optimiser and the results are exact again.  Applied to those plans only: the
+// other kernels are verified as compiled (tests/test_gpu_stages.py) and keep their code.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MFFT_OPAQUE(x) asm volatile("" : "+v"(x))
 #else
+#define MFFT_OPAQUE(x) ((void)0)
+#endif
+template <class S> MFFT_D int row_thread_index(int tid) {
+  int j = tid % S::TPT;
+  if constexpr (S::E % 15 == 0) {
+#if defined(MFFT_NO_LAUNDER_J)      /* tools/rowcheck.hip: show the miscompile */
+#else
+    MFFT_OPAQUE(j);
+#endif
+  }
+  return j;
+}
+#else
+#define MFFT_OPAQUE(x) ((void)0)
+template <class S> inline int row_thread_index(int tid) { return tid % S::TPT; }
 #define MFFT_D inline
 namespace mfft { void emu_barrier(); }
 #define MFFT_BARRIER() ::mfft::emu_barrier()
@@ -564,7 +587,7 @@ struct RowFft {
   static MFFT_D void body(const RowParams<T>& P, int bid, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
     const int rl = tid / S::TPT;
-    const int j = tid % S::TPT;
+    const int j = row_thread_index<S>(tid);
     XE* xch = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;
@@ -631,7 +654,7 @@ struct R2CFft {
   static MFFT_D void body(const RealParams<T>& P, int bid, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
     const int rl = tid / S::TPT;
-    const int j = tid % S::TPT;
+    const int j = row_thread_index<S>(tid);
     XE* xch = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;
@@ -751,7 +774,7 @@ struct C2RFft {
   static MFFT_D void body(const RealParams<T>& P, int bid, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
     const int rl = tid / S::TPT;
-    const int j = tid % S::TPT;
+    const int j = row_thread_index<S>(tid);
     XE* xch = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
     const bool active = row < P.nrows;

@@ -7,7 +7,7 @@
 // what the reference's power-of-two meshes and their 3/2-rule padded
 // counterparts (slab.py:75-76, 487-489) produce; 9*2^a (18..2304) are the 3/2-rule
 // images of the 3*2^a meshes, 25*2^a (50..1600) and 125*2^a (250..2000: 1000^3 is a mesh people run) round off the
-// 5-smooth sizes.  Every
+// 5-smooth sizes; groups L and M (below) the lengths with both 3 and 5 among their factors.  Every
 // other length goes through the chirp-z kernels (fft_chirpz.h).  The groups only exist
 // so the instantiations can be compiled in parallel translation units.
 #pragma once
@@ -23,6 +23,14 @@
 #define MFFT_PLANS_I(X) X(1152, 8, 8, 3, 3, 2) X(2304, 8, 8, 4, 3, 3)
 #define MFFT_PLANS_J(X) X(50, 5, 5, 2) X(100, 5, 5, 4) X(200, 5, 5, 4, 2) X(400, 5, 5, 4, 4) X(800, 5, 5, 4, 4, 2) X(1600, 5, 5, 4, 4, 4)
 #define MFFT_PLANS_K(X) X(250, 5, 5, 5, 2) X(500, 5, 5, 5, 4) X(1000, 5, 5, 5, 4, 2) X(2000, 5, 5, 5, 4, 4)
+// Round 3: lengths with BOTH 3 and 5 among their factors (15 * 2^a, 45 * 2^a, 75 * 2^a, 225 * 2^a: 720, 900, 960, 1200 ... are meshes
+// people run, and went through chirp-z at 0.12 - 0.22 of the roofline).  E = lcm(radices) must contain 15, so these plans
+// hold 30 values per thread and use radix-2 passes only next to the 3s and 5s (radix 4 would make it 60): more passes
+// and LDS exchanges than the other families, still several times faster than two chained transforms of twice the length.
+#define MFFT_PLANS_L(X) X(30, 5, 3, 2) X(60, 5, 3, 2, 2) X(90, 5, 3, 3, 2) X(120, 5, 3, 2, 2, 2) X(150, 5, 5, 3, 2) X(180, 5, 3, 3, 2, 2) \
+  X(240, 5, 3, 2, 2, 2, 2) X(300, 5, 5, 3, 2, 2) X(360, 5, 3, 3, 2, 2, 2) X(450, 5, 5, 3, 3, 2) X(480, 5, 3, 2, 2, 2, 2, 2)
+#define MFFT_PLANS_M(X) X(600, 5, 5, 3, 2, 2, 2) X(720, 5, 3, 3, 2, 2, 2, 2) X(900, 5, 5, 3, 3, 2, 2) X(960, 5, 3, 2, 2, 2, 2, 2, 2) \
+  X(1200, 5, 5, 3, 2, 2, 2, 2) X(1440, 5, 3, 3, 2, 2, 2, 2, 2) X(1800, 5, 5, 3, 3, 2, 2, 2)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -37,6 +45,8 @@
 #define MFFT_ROWPLANS_I(X) X(1152, 4, 4, 4, 3, 3, 2) X(2304, 4, 4, 4, 4, 3, 3)
 #define MFFT_ROWPLANS_J(X)
 #define MFFT_ROWPLANS_K(X)
+#define MFFT_ROWPLANS_L(X)
+#define MFFT_ROWPLANS_M(X)
 #define MFFT_ROWPLANS_A(X)
 #define MFFT_ROWPLANS_B(X)
 #define MFFT_ROWPLANS_C(X)
@@ -77,4 +87,4 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
-  MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X)
+  MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X)

@@ -289,15 +289,18 @@ void register_rows_z(const char* name) {
 }
 
 // a plan of the main list: strided kernels always, row kernels unless the length has an override
+// (the 30-values-per-thread plans of the lengths divisible by 15 are not offered as chirp-z convolution lengths: every
+// length they could serve has a cheaper 2-, 3- or 5-smooth neighbour, and each plan costs ~40 more kernels)
 template <class S, typename T>
 void register_plan(const char* name) {
+  constexpr bool chirp = S::N % 15 != 0;
   if constexpr (!mfft_has_col_override<T>(S::N)) {
     register_col<S, T>(name);
-    register_col_z<S, T>(name);
+    if constexpr (chirp) register_col_z<S, T>(name);
   }
   if constexpr (!mfft_has_row_override(S::N)) {
     register_rows<S, T>(name);
-    register_rows_z<S, T>(name);
+    if constexpr (chirp) register_rows_z<S, T>(name);
   }
 }
 template <class S, typename T>

@@ -753,6 +753,43 @@ def test_round2_plans_against_pocketfft(N):
     assert orc.rel_l2(u3.get(), want) < 1e-10
 
 
+@pytest.mark.parametrize("N", [[480, 480, 480], [240, 720, 360], [900, 60, 1200], [90, 1440, 300], [150, 180, 3600], [960, 30, 120]])
+def test_round3_plans_against_pocketfft(N):
+    """The lengths with both 3 and 5 among their factors (plans.h groups L and M, 30 values per thread; chirp-z before
+    round 3), every axis of the slab transform: 240 and 480 complex rows are the two contiguous-axis kernels hipcc
+    miscompiled before fft_kernels.h row_thread_index (480 also as the real length 960 and 240 as 480) -- against the
+    host's pocketfft on the same input, with the pruned 2/3-rule inverse and the 3/2-rule padded pair."""
+    import os
+    import scipy.fft as sfft
+    from mpifft4py_amd import DeviceArray, SelfComm, Slab_R2C
+    F = Slab_R2C(np.array(N), L, SelfComm(0), "double")
+    A = np.random.default_rng(sum(N)).random(tuple(N))
+    u = DeviceArray.from_numpy(A)
+    fu = DeviceArray.empty(F.complex_shape(), F.complex)
+    u2 = DeviceArray.empty(F.real_shape(), F.float)
+    u3 = DeviceArray.empty(F.real_shape(), F.float)
+    F.fftn(u, fu)
+    F.ifftn(fu, u2)
+    F.ifftn(fu, u3, dealias="2/3-rule")
+    F.sync()
+    C = sfft.rfftn(A, workers=os.cpu_count())
+    assert orc.rel_l2(fu.get(), C) < 1e-10
+    assert orc.rel_l2(u2.get(), A) < 1e-10
+    mask = np.broadcast_to(F.get_dealias_filter(), F.complex_shape())
+    want = sfft.irfftn(C * mask, s=tuple(N), workers=os.cpu_count())
+    assert orc.rel_l2(u3.get(), want) < 1e-10
+    del u3, want
+    if max(N) <= 1200:                               # padded lengths 3N/2 must have kernels: 1800 complex, real 3600
+        up = DeviceArray.empty(F.real_shape_padded(), F.float)
+        fu2 = DeviceArray.empty(F.complex_shape(), F.complex)
+        F.ifftn(fu, up, dealias="3/2-rule")
+        F.fftn(up, fu2, dealias="3/2-rule")
+        F.sync()
+        want_p = orc.slab_r2c_backward_padded([C], N, "double")[0]
+        assert orc.rel_l2(up.get(), want_p) < 1e-10
+        assert orc.rel_l2(fu2.get(), orc.slab_r2c_forward_padded([want_p], N, "double")[0]) < 1e-10
+
+
 def test_full_size_1024_cubed():
     """BASELINE workload at full size: 1024^3 fp64, device-resident.  Forward spectrum against
     the host's pocketfft (scipy.fft, all cores) on the SAME input, round trip, input preserved.

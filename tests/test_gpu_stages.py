@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 LENGTHS = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096,
            6, 12, 24, 48, 96, 192, 384, 768, 1536, 3072,
            10, 20, 40, 80, 160, 320, 640, 1280, 2560,
-           18, 36, 72, 144, 288, 576, 1152, 2304, 50, 100, 200, 400, 800, 1600, 250, 500, 1000, 2000]
+           18, 36, 72, 144, 288, 576, 1152, 2304, 50, 100, 200, 400, 800, 1600, 250, 500, 1000, 2000,
+           # lengths with both 3 and 5 among their factors (plans.h groups L, M: 30 values per thread)
+           30, 60, 90, 120, 150, 180, 240, 300, 360, 450, 480, 600, 720, 900, 960, 1200, 1440, 1800]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -153,9 +155,9 @@ def test_unsupported_length_raises():
 
 
 # lengths without a radix plan: chirp-z kernels (csrc/fft_chirpz.h); primes, prime powers, 7-smooth,
-# 9*2^a / 15*2^a (the 3/2-rule images of 3*2^a / 5*2^a), and the range ends of several convolution lengths
-CHIRPZ = [3, 5, 7, 9, 11, 13, 15, 17, 25, 27, 31, 33, 49, 60, 84, 127, 129, 240, 255, 257, 504,
-          720, 729, 1008, 1023, 1025, 1201, 1537, 2047]
+# odd 15-smooth ones, and the range ends of several convolution lengths
+CHIRPZ = [3, 5, 7, 9, 11, 13, 15, 17, 25, 27, 31, 33, 45, 49, 75, 84, 127, 129, 255, 257, 504,
+          675, 729, 1008, 1023, 1025, 1201, 1537, 2047]
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
