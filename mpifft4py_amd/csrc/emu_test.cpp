@@ -959,6 +959,7 @@ int main() {
 #endif
 #if EMU_HAS(8)
   MFFT_PLANS_M(MFFT_PLAN)
+  MFFT_COLPLANS_F64_M(MFFT_PLAN)
 #endif
 #if EMU_HAS(5)
   MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN)

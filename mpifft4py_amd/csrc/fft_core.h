@@ -209,6 +209,53 @@ template <> struct Bfly<16> {
 template <> struct Bfly<32> {
   template <typename T> static MFFT_HD void run(cx<T> (&v)[32]) { BflyCT<32, 4>::run(v); }
 };
+// Good-Thomas (prime-factor) composition R = RA * RB for COPRIME factors -- radices 6, 10, 15, 30: with the input index
+// n = (RB n1 + RA n2) mod R and the output index k = (RB qb k1 + RA qa k2) mod R, qb = RB^-1 mod RA, qa = RA^-1 mod RB,
+// the product n k mod R is RB n1 k1 * (RB qb) + RA n2 k2 * (RA qa), i.e. X[k1, k2] = sum_n1 W_RA^{n1 k1} sum_n2
+// W_RB^{n2 k2} x[n1, n2]: two rounds of small butterflies and NO twiddles between them; both index maps are
+// compile-time register renamings.  The plans with 3 and 5 among their factors (plans.h groups L, M) must keep 30 values
+// per thread, which rules radix 4 out; these composites are what lets them run 3 - 6 passes instead of 6 - 8.
+MFFT_HDC int cinv_mod(int a, int m) {   // a^-1 mod m (m small, gcd = 1)
+  for (int x = 1; x < m; ++x)
+    if ((a * x) % m == 1) return x;
+  return 1;
+}
+template <int RA, int RB> struct BflyPFA {
+  static constexpr int R = RA * RB;
+  static constexpr int QB = cinv_mod(RB % RA, RA), QA = cinv_mod(RA % RB, RB);
+  static_assert(cgcd(RA, RB) == 1, "prime-factor butterfly needs coprime factors");
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[R]) {
+    cx<T> s[RA][RB];
+#pragma unroll
+    for (int n1 = 0; n1 < RA; ++n1) {
+#pragma unroll
+      for (int n2 = 0; n2 < RB; ++n2) s[n1][n2] = v[(RB * n1 + RA * n2) % R];
+      Bfly<RB>::run(s[n1]);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) {
+      cx<T> t[RA];
+#pragma unroll
+      for (int n1 = 0; n1 < RA; ++n1) t[n1] = s[n1][k2];
+      Bfly<RA>::run(t);
+#pragma unroll
+      for (int k1 = 0; k1 < RA; ++k1) v[(RB * QB * k1 + RA * QA * k2) % R] = t[k1];
+    }
+  }
+};
+template <> struct Bfly<6> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[6]) { BflyPFA<2, 3>::run(v); }
+};
+template <> struct Bfly<10> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[10]) { BflyPFA<2, 5>::run(v); }
+};
+template <> struct Bfly<15> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[15]) { BflyPFA<3, 5>::run(v); }
+};
+template <> struct Bfly<30> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[30]) { BflyPFA<2, 15>::run(v); }
+};
+
 
 // ---------------------------------------------------------------------------
 // Transform specification: length N and its radix sequence (first pass first).

@@ -25,12 +25,13 @@
 #define MFFT_PLANS_K(X) X(250, 5, 5, 5, 2) X(500, 5, 5, 5, 4) X(1000, 5, 5, 5, 4, 2) X(2000, 5, 5, 5, 4, 4)
 // Round 3: lengths with BOTH 3 and 5 among their factors (15 * 2^a, 45 * 2^a, 75 * 2^a, 225 * 2^a: 720, 900, 960, 1200 ... are meshes
 // people run, and went through chirp-z at 0.12 - 0.22 of the roofline).  E = lcm(radices) must contain 15, so these plans
-// hold 30 values per thread and use radix-2 passes only next to the 3s and 5s (radix 4 would make it 60): more passes
-// and LDS exchanges than the other families, still several times faster than two chained transforms of twice the length.
-#define MFFT_PLANS_L(X) X(30, 5, 3, 2) X(60, 5, 3, 2, 2) X(90, 5, 3, 3, 2) X(120, 5, 3, 2, 2, 2) X(150, 5, 5, 3, 2) X(180, 5, 3, 3, 2, 2) \
-  X(240, 5, 3, 2, 2, 2, 2) X(300, 5, 5, 3, 2, 2) X(360, 5, 3, 3, 2, 2, 2) X(450, 5, 5, 3, 3, 2) X(480, 5, 3, 2, 2, 2, 2, 2)
-#define MFFT_PLANS_M(X) X(600, 5, 5, 3, 2, 2, 2) X(720, 5, 3, 3, 2, 2, 2, 2) X(900, 5, 5, 3, 3, 2, 2) X(960, 5, 3, 2, 2, 2, 2, 2, 2) \
-  X(1200, 5, 5, 3, 2, 2, 2, 2) X(1440, 5, 3, 3, 2, 2, 2, 2, 2) X(1800, 5, 5, 3, 3, 2, 2, 2)
+// hold 30 values per thread and radix 4 is out (it would make it 60); the prime-factor butterflies of radix 6, 10, 15, 30
+// (fft_core.h BflyPFA: no twiddles inside, index maps are register renamings) keep the pass count at 1 - 6.
+// With radices 5, 3, 2 only (6 - 8 passes) the same lengths ran 8 - 30 % slower: 720^3 pair 10.5 -> 8.4 ms, 1200^3 58.8 -> 45.1.
+#define MFFT_PLANS_L(X) X(30, 30) X(60, 10, 6) X(90, 15, 6) X(120, 10, 6, 2) X(150, 15, 10) X(180, 10, 6, 3) \
+  X(240, 10, 6, 2, 2) X(300, 10, 10, 3) X(360, 10, 6, 6) X(450, 15, 10, 3) X(480, 10, 6, 2, 2, 2)
+#define MFFT_PLANS_M(X) X(600, 10, 10, 6) X(720, 10, 6, 6, 2) X(900, 15, 10, 6) X(960, 10, 6, 2, 2, 2, 2) \
+  X(1200, 10, 10, 6, 2) X(1440, 10, 6, 6, 2, 2) X(1800, 15, 10, 6, 2)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -81,8 +82,12 @@ constexpr bool mfft_has_row_override(int n) {
 // The same exchange of plans is neutral at 576, 640, 1280 and loses at 1536 (1024 threads, one workgroup either way).
 #define MFFT_COLPLANS_F64_E(X) X(384, 4, 4, 4, 3, 2)
 #define MFFT_COLPLANS_F64_I(X) X(1152, 4, 4, 4, 3, 3, 2)
+// 900 in double precision: the strided kernels keep the plain 5x5x3x3x2x2 sequence -- with the composite radices they
+// came out 15 % slower (x / y passes of the 900^3 pair 2.5 / 2.25 -> 3.0 / 2.6 ms, the same for 10x10x3x3, 10x15x6 and
+// 10x6x15), the only length of groups L and M where that happened; the contiguous-axis kernels gain from 15x10x6 like the rest.
+#define MFFT_COLPLANS_F64_M(X) X(900, 5, 5, 3, 3, 2, 2)
 template <typename T> constexpr bool mfft_has_col_override(int n) {
-  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && (n == 1024 || n == 512 || n == 384 || n == 1152));
+  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && (n == 1024 || n == 512 || n == 384 || n == 1152 || n == 900));
 }
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \

@@ -94,19 +94,34 @@ template <class S, typename T> constexpr bool col_twlds() {
 // LDS twiddles -> with the split exchange as well: 1152^3 5.49/6.04 -> 5.02/4.96; 1280^3 8.60/10.03 -> 7.05/7.24;
 // 1536^3 12.43/12.18 -> 11.38/10.76 (profiles/r02_row_kernels_long_lengths.txt).
 // (single precision: measured worse -- 1152^3 z stages 2.71 / 2.74 -> 2.95 / 3.58 ms, 1536^3 6.4 / 5.7 -> 6.9 / 6.3)
-template <class S, typename T> constexpr bool row_lean() { return sizeof(T) == 8 && S::E >= 12 && S::N >= 384; }
-template <class S, typename T, bool C2R = false> constexpr bool row_split() {
-  return S::NP > 1 && row_lean<S, T>() && !(C2R && S::E >= 20);   // the c2r kernels of the E = 20 plans lose with it (1280: 7.2 -> 8.3 ms)
+// Round 3, the 30-values-per-thread plans (lengths with 3 and 5 among their factors): 8 or 16 threads per row, so the 40 KB
+// budget meant 64 - 128 threads per workgroup and 4 workgroups = 256 - 512 threads per CU.  From length 120 on they run
+// lean with half the LDS budget per workgroup -- in double precision every contiguous-axis kernel, in single precision
+// the c2r kernels only (z stages r2c / c2r of the R2C pair, ms, 40 KB + LDS twiddles -> lean, profiles/r03_mixed_radix_15.txt:
+// fp64 960^3 6.30 / 4.11 -> 4.90 / 4.08, 720^3 2.88 / 2.15 -> 2.72 / 1.93, 480^3 0.80 / 0.54 -> 0.64 / 0.43;
+// fp32 960^3 2.25 / 3.41 -> 2.71 / 2.56, 720^3 0.94 / 1.47 -> 1.11 / 1.05, 1200^3 4.45 / 6.48 -> 5.14 / 4.91).
+// Their real kernels stay the slowest of the family either way: 120 data registers per lane in double precision plus the
+// mirror values put them at 256 VGPRs + 20 - 160 AGPRs, one wave per SIMD.
+template <class S, typename T, bool C2R = false> constexpr bool row_lean15() {
+  return S::E % 15 == 0 && S::N >= 120 && (sizeof(T) == 8 || C2R);
 }
-template <class S, typename T, bool SPLIT> constexpr int row_rows_n() {
+template <class S, typename T, bool C2R = false> constexpr bool row_lean() {
+  return (sizeof(T) == 8 && S::E >= 12 && S::N >= 384) || row_lean15<S, T, C2R>();
+}
+template <class S, typename T, bool C2R = false> constexpr bool row_split() {
+  // the c2r kernels of the E = 20 plans lose with it (1280: 7.2 -> 8.3 ms)
+  return S::NP > 1 && row_lean<S, T, C2R>() && !(C2R && S::E >= 20 && !row_lean15<S, T, C2R>());
+}
+template <class S, typename T, bool SPLIT, bool C2R = false> constexpr int row_rows_n() {
   int rows = 256 / S::TPT;
   if (rows < 1) rows = 1;
   const long long per_row = (long long)(S::N + S::N / S::R(0) + 1) * (int)(SPLIT ? sizeof(T) : sizeof(cx<T>));
-  while (rows > 1 && per_row * rows > 40960 && S::TPT * (rows / 2) >= 64) rows /= 2;   // never below one wave
+  const long long budget = row_lean15<S, T, C2R>() ? 20480 : 40960;
+  while (rows > 1 && per_row * rows > budget && S::TPT * (rows / 2) >= 64) rows /= 2;   // never below one wave
   return rows;
 }
-template <class S, typename T, bool C2R = false> constexpr int row_rows() { return row_rows_n<S, T, row_split<S, T, C2R>()>(); }
-template <class S, typename T> constexpr bool row_twlds() { return S::NP > 1 && !row_lean<S, T>(); }
+template <class S, typename T, bool C2R = false> constexpr int row_rows() { return row_rows_n<S, T, row_split<S, T, C2R>(), C2R>(); }
+template <class S, typename T, bool C2R = false> constexpr bool row_twlds() { return S::NP > 1 && !row_lean<S, T, C2R>(); }
 
 // Workgroups per CU the strided kernel's REGISTER allocation must leave room for (0: whatever the compiler takes).
 // 1152 in double precision runs 768 threads with ~88 VGPRs: one register more than two workgroups per CU allow
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(K::THREADS) void mfft_kern(P p) {
 }
 // the same with a register cap: WGS workgroups per CU = WGS * THREADS / 256 waves per SIMD
 template <class K, class P, int WGS>
-__global__ __launch_bounds__(K::THREADS, WGS * K::THREADS / 256) void mfft_kern_occ(P p) {
+__global__ __launch_bounds__(K::THREADS, (WGS * K::THREADS + 255) / 256) void mfft_kern_occ(P p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
 }
@@ -220,10 +235,11 @@ void register_rows(const char* name) {
   constexpr bool SP = row_split<S, T>();
   constexpr int RC = row_rows<S, T, true>();      // the c2r kernels may differ
   constexpr bool SC = row_split<S, T, true>();
+  constexpr bool RTC = row_twlds<S, T, true>();
   reg.push_back(make_entry<RowFft<S, T, R, false, RT, false, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
   reg.push_back(make_entry<RowFft<S, T, R, true, RT, false, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
   reg.push_back(make_entry<R2CFft<S, T, R, RT, false, false, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
-  reg.push_back(make_entry<C2RFft<S, T, RC, RT, false, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
   // pencil decompositions: the z-chunk pack / unpack fused into the stores / loads (pad = 4)
   reg.push_back(make_entry<RowFft<S, T, R, false, RT, true, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
   reg.back().pad = 4;
@@ -231,7 +247,7 @@ void register_rows(const char* name) {
   reg.back().pad = 4;
   reg.push_back(make_entry<R2CFft<S, T, R, RT, false, true, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<C2RFft<S, T, RC, RT, false, true, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, true, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
   reg.back().pad = 4;
   if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
     reg.push_back(make_entry<R2CFft<S, T, R, RT, true, false, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
@@ -240,11 +256,11 @@ void register_rows(const char* name) {
     // transforms write / read the exchange blocks themselves (pencil.py:511-632, 758-883 do it in the MPI datatypes)
     reg.push_back(make_entry<R2CFft<S, T, R, RT, true, true, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
     reg.back().pad = 7;
-    reg.push_back(make_entry<C2RFft<S, T, RC, RT, true, true, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, true, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 7;
   }
   if constexpr (S::N >= 4) {                    // column-limited c2r: 3/2-rule lengths and the pruned 2/3-rule (any length)
-    reg.push_back(make_entry<C2RFft<S, T, RC, RT, true, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 3;
   }
 }

@@ -77,5 +77,13 @@ int main() {
   check<Spec<480, 5, 3, 2, 2, 2, 2, 2>, float, 8, false, false>("480 5x3x2^5");
   check<Spec<120, 5, 3, 2, 2, 2>, double, 16, true, false>("120 5x3x2x2x2");
   check<Spec<960, 5, 3, 2, 2, 2, 2, 2, 2>, double, 2, false, true>("960 5x3x2^6");
+  // the composite-radix plans that replaced them (plans.h groups L, M as shipped)
+  check<Spec<240, 10, 6, 2, 2>, double, 8, false, true>("240 10x6x2x2");
+  check<Spec<240, 10, 6, 2, 2>, double, 8, true, false>("240 10x6x2x2");
+  check<Spec<240, 10, 6, 2, 2>, float, 8, true, false>("240 10x6x2x2");
+  check<Spec<480, 10, 6, 2, 2, 2>, double, 4, false, true>("480 10x6x2x2x2");
+  check<Spec<480, 10, 6, 2, 2, 2>, double, 8, false, true>("480 10x6x2x2x2");
+  check<Spec<480, 10, 6, 2, 2, 2>, float, 8, false, false>("480 10x6x2x2x2");
+  check<Spec<960, 10, 6, 2, 2, 2, 2>, double, 2, false, true>("960 10x6x2^4");
   return 0;
 }
