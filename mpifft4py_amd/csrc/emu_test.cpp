@@ -962,7 +962,7 @@ int main() {
   MFFT_COLPLANS_F64_M(MFFT_PLAN)
 #endif
 #if EMU_HAS(5)
-  MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN)
+  MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN) MFFT_ROWPLANS_F64_K(MFFT_PLAN)
 #endif
 #undef MFFT_PLAN
   printf("%s (%d failures)\n", g_fail ? "EMU TESTS FAILED" : "EMU TESTS PASSED", g_fail);

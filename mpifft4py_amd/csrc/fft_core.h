@@ -252,6 +252,18 @@ template <> struct Bfly<10> {
 template <> struct Bfly<15> {
   template <typename T> static MFFT_HD void run(cx<T> (&v)[15]) { BflyPFA<3, 5>::run(v); }
 };
+template <> struct Bfly<12> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[12]) { BflyPFA<3, 4>::run(v); }
+};
+template <> struct Bfly<20> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[20]) { BflyPFA<5, 4>::run(v); }
+};
+template <> struct Bfly<24> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[24]) { BflyPFA<3, 8>::run(v); }
+};
+template <> struct Bfly<40> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[40]) { BflyPFA<5, 8>::run(v); }
+};
 template <> struct Bfly<30> {
   template <typename T> static MFFT_HD void run(cx<T> (&v)[30]) { BflyPFA<2, 15>::run(v); }
 };

@@ -19,10 +19,14 @@
 #define MFFT_PLANS_E(X) X(384, 8, 8, 3, 2) X(768, 8, 8, 4, 3) X(1536, 8, 8, 8, 3) X(3072, 8, 8, 4, 4, 3)
 #define MFFT_PLANS_F(X) X(10, 5, 2) X(20, 5, 4) X(40, 5, 4, 2) X(80, 5, 4, 4) X(160, 8, 4, 5)
 #define MFFT_PLANS_G(X) X(320, 8, 8, 5) X(640, 8, 4, 4, 5) X(1280, 8, 8, 4, 5) X(2560, 8, 8, 8, 5)
-#define MFFT_PLANS_H(X) X(18, 3, 3, 2) X(36, 4, 3, 3) X(72, 8, 3, 3) X(144, 8, 3, 3, 2) X(288, 8, 4, 3, 3) X(576, 8, 8, 3, 3)
-#define MFFT_PLANS_I(X) X(1152, 8, 8, 3, 3, 2) X(2304, 8, 8, 4, 3, 3)
-#define MFFT_PLANS_J(X) X(50, 5, 5, 2) X(100, 5, 5, 4) X(200, 5, 5, 4, 2) X(400, 5, 5, 4, 4) X(800, 5, 5, 4, 4, 2) X(1600, 5, 5, 4, 4, 4)
-#define MFFT_PLANS_K(X) X(250, 5, 5, 5, 2) X(500, 5, 5, 5, 4) X(1000, 5, 5, 5, 4, 2) X(2000, 5, 5, 5, 4, 4)
+#define MFFT_PLANS_H(X) X(18, 6, 3) X(36, 12, 3) X(72, 24, 3) X(144, 24, 6) X(288, 24, 12) X(576, 24, 24)
+#define MFFT_PLANS_I(X) X(1152, 24, 24, 2) X(2304, 24, 24, 4)
+#define MFFT_PLANS_J(X) X(50, 10, 5) X(100, 20, 5) X(200, 20, 10) X(400, 20, 20) X(800, 20, 20, 2) X(1600, 20, 20, 4)
+#define MFFT_PLANS_K(X) X(250, 10, 5, 5) X(500, 20, 5, 5) X(1000, 20, 10, 5) X(2000, 20, 20, 5)
+// Round 3: the 9-, 25- and 125-smooth groups (H - K) and the row plans of groups G - I use the prime-factor butterflies of
+// radix 12 = 3x4, 20 = 5x4, 24 = 3x8 (fft_core.h BflyPFA) so that, with the same number of values per thread, a
+// transform takes 2 - 4 passes instead of 4 - 6 (profiles/r03_composite_radix.txt: 1000^3 fp32 pair 14.8 -> 11.3 ms,
+// 1600^3 fp64 103.5 -> 87.4, 800^3 fp64 11.6 -> 10.1, 576^3 fp64 3.85 -> 3.5).
 // Round 3: lengths with BOTH 3 and 5 among their factors (15 * 2^a, 45 * 2^a, 75 * 2^a, 225 * 2^a: 720, 900, 960, 1200 ... are meshes
 // people run, and went through chirp-z at 0.12 - 0.22 of the roofline).  E = lcm(radices) must contain 15, so these plans
 // hold 30 values per thread and radix 4 is out (it would make it 60); the prime-factor butterflies of radix 6, 10, 15, 30
@@ -41,9 +45,9 @@
 #define MFFT_ROWPLANS_D(X) X(96, 4, 4, 3, 2) X(192, 4, 4, 4, 3)
 #define MFFT_ROWPLANS_E(X) X(384, 4, 4, 4, 3, 2) X(768, 4, 4, 4, 4, 3) X(1536, 4, 4, 4, 4, 3, 2) X(3072, 4, 4, 4, 4, 4, 3)
 #define MFFT_ROWPLANS_F(X) X(160, 4, 4, 5, 2)
-#define MFFT_ROWPLANS_G(X) X(320, 4, 4, 4, 5) X(640, 4, 4, 4, 5, 2) X(1280, 4, 4, 4, 4, 5) X(2560, 4, 4, 4, 4, 5, 2)
-#define MFFT_ROWPLANS_H(X) X(144, 4, 4, 3, 3) X(288, 4, 4, 3, 3, 2) X(576, 4, 4, 4, 3, 3)
-#define MFFT_ROWPLANS_I(X) X(1152, 4, 4, 4, 3, 3, 2) X(2304, 4, 4, 4, 4, 3, 3)
+#define MFFT_ROWPLANS_G(X) X(320, 20, 4, 4) X(640, 20, 4, 4, 2) X(1280, 20, 4, 4, 4) X(2560, 20, 4, 4, 4, 2)
+#define MFFT_ROWPLANS_H(X) X(144, 12, 12) X(288, 12, 12, 2) X(576, 12, 12, 4)
+#define MFFT_ROWPLANS_I(X) X(1152, 12, 12, 4, 2) X(2304, 12, 12, 4, 4)
 #define MFFT_ROWPLANS_J(X)
 #define MFFT_ROWPLANS_K(X)
 #define MFFT_ROWPLANS_L(X)
@@ -54,11 +58,16 @@
 #define MFFT_FOR_EACH_ROWPLAN(X) \
   MFFT_ROWPLANS_D(X) MFFT_ROWPLANS_E(X) MFFT_ROWPLANS_F(X) MFFT_ROWPLANS_G(X) MFFT_ROWPLANS_H(X) MFFT_ROWPLANS_I(X)
 
+// Double precision only: the contiguous-axis kernels of 500 keep 5x5x5x4 -- with 20x5x5 the c2r kernel of real length 1000
+// doubled its time (1000^3 bwd_z 3.3 -> 6.6 ms) while single precision gains from it (2.03 -> 1.88 ms).
+#define MFFT_ROWPLANS_F64_K(X) X(500, 5, 5, 5, 4)
 // true if complex length n takes its row kernels from MFFT_ROWPLANS_*
 constexpr bool mfft_has_row_override(int n) {
   return n == 96 || n == 192 || n == 384 || n == 768 || n == 1536 || n == 3072 || n == 160 || n == 320 || n == 640 ||
          n == 1280 || n == 2560 || n == 144 || n == 288 || n == 576 || n == 1152 || n == 2304;
 }
+
+template <typename T> constexpr bool mfft_has_row_override_t(int n) { return mfft_has_row_override(n) || (sizeof(T) == 8 && n == 500); }
 
 // Strided-kernel overrides for SINGLE precision: the longest lengths run with E = 32 plans, one column per lane,
 // 1024 threads and 128-byte tiles (kbench2: 2048 2.7 -> 3.8 TB/s, 4096 2.0 -> 3.1 TB/s; the E = 16 plans would need
@@ -81,7 +90,7 @@ constexpr bool mfft_has_row_override(int n) {
 // place, ms:  384: 0.231 -> 0.184, 0.217 -> 0.186, 0.245 -> 0.191;  1152: 6.72 -> 5.64, 7.14 -> 5.45, 7.36 -> 5.44.
 // The same exchange of plans is neutral at 576, 640, 1280 and loses at 1536 (1024 threads, one workgroup either way).
 #define MFFT_COLPLANS_F64_E(X) X(384, 4, 4, 4, 3, 2)
-#define MFFT_COLPLANS_F64_I(X) X(1152, 4, 4, 4, 3, 3, 2)
+#define MFFT_COLPLANS_F64_I(X) X(1152, 12, 12, 4, 2)
 // 900 in double precision: the strided kernels keep the plain 5x5x3x3x2x2 sequence -- with the composite radices they
 // came out 15 % slower (x / y passes of the 900^3 pair 2.5 / 2.25 -> 3.0 / 2.6 ms, the same for 10x10x3x3, 10x15x6 and
 // 10x6x15), the only length of groups L and M where that happened; the contiguous-axis kernels gain from 15x10x6 like the rest.

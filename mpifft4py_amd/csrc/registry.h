@@ -314,7 +314,7 @@ void register_plan(const char* name) {
     register_col<S, T>(name);
     if constexpr (chirp) register_col_z<S, T>(name);
   }
-  if constexpr (!mfft_has_row_override(S::N)) {
+  if constexpr (!mfft_has_row_override_t<T>(S::N)) {
     register_rows<S, T>(name);
     if constexpr (chirp) register_rows_z<S, T>(name);
   }
