@@ -943,13 +943,13 @@ int main() {
   MFFT_PLANS_B(MFFT_PLAN) MFFT_PLANS_C(MFFT_PLAN) MFFT_COLPLANS_F32_C(MFFT_PLAN) MFFT_COLPLANS_F64_B(MFFT_PLAN)
 #endif
 #if EMU_HAS(2)
-  MFFT_PLANS_D(MFFT_PLAN) MFFT_PLANS_E(MFFT_PLAN)
+  MFFT_PLANS_D(MFFT_PLAN) MFFT_PLANS_E(MFFT_PLAN) MFFT_COLPLANS_F64_E(MFFT_PLAN)
 #endif
 #if EMU_HAS(3)
   MFFT_PLANS_F(MFFT_PLAN) MFFT_PLANS_G(MFFT_PLAN)
 #endif
 #if EMU_HAS(4)
-  MFFT_PLANS_H(MFFT_PLAN) MFFT_PLANS_I(MFFT_PLAN) MFFT_PLANS_J(MFFT_PLAN)
+  MFFT_PLANS_H(MFFT_PLAN) MFFT_PLANS_I(MFFT_PLAN) MFFT_PLANS_J(MFFT_PLAN) MFFT_COLPLANS_F64_I(MFFT_PLAN)
 #endif
 #if EMU_HAS(6)
   MFFT_PLANS_K(MFFT_PLAN)

@@ -15,10 +15,10 @@
 #define MFFT_PLANS_A(X) X(2, 2) X(4, 4) X(8, 8) X(16, 16) X(32, 8, 4) X(64, 8, 8) X(128, 16, 8) X(256, 16, 16)
 #define MFFT_PLANS_B(X) X(512, 8, 8, 8) X(1024, 16, 8, 8)
 #define MFFT_PLANS_C(X) X(2048, 16, 16, 8) X(4096, 16, 16, 16)
-#define MFFT_PLANS_D(X) X(6, 3, 2) X(12, 4, 3) X(24, 8, 3) X(48, 4, 4, 3) X(96, 8, 4, 3) X(192, 8, 8, 3)
-#define MFFT_PLANS_E(X) X(384, 8, 8, 3, 2) X(768, 8, 8, 4, 3) X(1536, 8, 8, 8, 3) X(3072, 8, 8, 4, 4, 3)
-#define MFFT_PLANS_F(X) X(10, 5, 2) X(20, 5, 4) X(40, 5, 4, 2) X(80, 5, 4, 4) X(160, 8, 4, 5)
-#define MFFT_PLANS_G(X) X(320, 8, 8, 5) X(640, 8, 4, 4, 5) X(1280, 8, 8, 4, 5) X(2560, 8, 8, 8, 5)
+#define MFFT_PLANS_D(X) X(6, 6) X(12, 12) X(24, 24) X(48, 12, 4) X(96, 24, 4) X(192, 24, 8)
+#define MFFT_PLANS_E(X) X(384, 24, 8, 2) X(768, 24, 8, 4) X(1536, 8, 8, 8, 3) X(3072, 8, 8, 4, 4, 3)
+#define MFFT_PLANS_F(X) X(10, 10) X(20, 20) X(40, 20, 2) X(80, 20, 4) X(160, 40, 4)
+#define MFFT_PLANS_G(X) X(320, 40, 8) X(640, 8, 4, 4, 5) X(1280, 8, 8, 4, 5) X(2560, 8, 8, 8, 5)
 #define MFFT_PLANS_H(X) X(18, 6, 3) X(36, 12, 3) X(72, 24, 3) X(144, 24, 6) X(288, 24, 12) X(576, 24, 24)
 #define MFFT_PLANS_I(X) X(1152, 24, 24, 2) X(2304, 24, 24, 4)
 #define MFFT_PLANS_J(X) X(50, 10, 5) X(100, 20, 5) X(200, 20, 10) X(400, 20, 20) X(800, 20, 20, 2) X(1600, 20, 20, 4)
@@ -26,7 +26,9 @@
 // Round 3: the 9-, 25- and 125-smooth groups (H - K) and the row plans of groups G - I use the prime-factor butterflies of
 // radix 12 = 3x4, 20 = 5x4, 24 = 3x8 (fft_core.h BflyPFA) so that, with the same number of values per thread, a
 // transform takes 2 - 4 passes instead of 4 - 6 (profiles/r03_composite_radix.txt: 1000^3 fp32 pair 14.8 -> 11.3 ms,
-// 1600^3 fp64 103.5 -> 87.4, 800^3 fp64 11.6 -> 10.1, 576^3 fp64 3.85 -> 3.5).
+// 1600^3 fp64 103.5 -> 87.4, 800^3 fp64 11.6 -> 10.1, 576^3 fp64 3.85 -> 3.5).  The 3- and 5-smooth groups D - G use them
+// (24 = 3x8, 40 = 5x8) up to 768 / 320 and in their row plans: worth 3 - 8 % at 192 ... 768, nothing measurable
+// beyond (640 / 1280 / 2560 / 1536 / 3072 strided keep the radix-8 sequences).
 // Round 3: lengths with BOTH 3 and 5 among their factors (15 * 2^a, 45 * 2^a, 75 * 2^a, 225 * 2^a: 720, 900, 960, 1200 ... are meshes
 // people run, and went through chirp-z at 0.12 - 0.22 of the roofline).  E = lcm(radices) must contain 15, so these plans
 // hold 30 values per thread and radix 4 is out (it would make it 60); the prime-factor butterflies of radix 6, 10, 15, 30
@@ -42,9 +44,9 @@
 // the CU of waves.  For the 3- and 5-smooth lengths >= 96 the row kernels therefore use radix
 // 4/2 passes around one radix-3/5 pass (E = 12 / 20) instead of the strided kernels' E = 24 / 40.
 // A length listed here is NOT given row kernels by its MFFT_PLANS_* entry.
-#define MFFT_ROWPLANS_D(X) X(96, 4, 4, 3, 2) X(192, 4, 4, 4, 3)
-#define MFFT_ROWPLANS_E(X) X(384, 4, 4, 4, 3, 2) X(768, 4, 4, 4, 4, 3) X(1536, 4, 4, 4, 4, 3, 2) X(3072, 4, 4, 4, 4, 4, 3)
-#define MFFT_ROWPLANS_F(X) X(160, 4, 4, 5, 2)
+#define MFFT_ROWPLANS_D(X) X(96, 12, 4, 2) X(192, 12, 4, 4)
+#define MFFT_ROWPLANS_E(X) X(384, 12, 4, 4, 2) X(768, 12, 4, 4, 4) X(1536, 12, 4, 4, 4, 2) X(3072, 12, 4, 4, 4, 4)
+#define MFFT_ROWPLANS_F(X) X(160, 20, 4, 2)
 #define MFFT_ROWPLANS_G(X) X(320, 20, 4, 4) X(640, 20, 4, 4, 2) X(1280, 20, 4, 4, 4) X(2560, 20, 4, 4, 4, 2)
 #define MFFT_ROWPLANS_H(X) X(144, 12, 12) X(288, 12, 12, 2) X(576, 12, 12, 4)
 #define MFFT_ROWPLANS_I(X) X(1152, 12, 12, 4, 2) X(2304, 12, 12, 4, 4)
@@ -89,14 +91,16 @@ template <typename T> constexpr bool mfft_has_row_override_t(int n) { return mff
 // instead of one).  kbench3 `small` / `occ` (profiles/r02_kbench3_long_lengths.txt), y in place / x in place / x out of
 // place, ms:  384: 0.231 -> 0.184, 0.217 -> 0.186, 0.245 -> 0.191;  1152: 6.72 -> 5.64, 7.14 -> 5.45, 7.36 -> 5.44.
 // The same exchange of plans is neutral at 576, 640, 1280 and loses at 1536 (1024 threads, one workgroup either way).
-#define MFFT_COLPLANS_F64_E(X) X(384, 4, 4, 4, 3, 2)
+// 768 in double precision keeps 8x8x4x3 for the strided kernels: with 24x8x4 the inverse y pass of the 768^3 pair was 8 %
+// slower in three sessions (1.40 -> 1.52 ms) while single precision gains 5 % overall from it.
+#define MFFT_COLPLANS_F64_E(X) X(384, 12, 4, 4, 2) X(768, 8, 8, 4, 3)
 #define MFFT_COLPLANS_F64_I(X) X(1152, 12, 12, 4, 2)
 // 900 in double precision: the strided kernels keep the plain 5x5x3x3x2x2 sequence -- with the composite radices they
 // came out 15 % slower (x / y passes of the 900^3 pair 2.5 / 2.25 -> 3.0 / 2.6 ms, the same for 10x10x3x3, 10x15x6 and
 // 10x6x15), the only length of groups L and M where that happened; the contiguous-axis kernels gain from 15x10x6 like the rest.
 #define MFFT_COLPLANS_F64_M(X) X(900, 5, 5, 3, 3, 2, 2)
 template <typename T> constexpr bool mfft_has_col_override(int n) {
-  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && (n == 1024 || n == 512 || n == 384 || n == 1152 || n == 900));
+  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && (n == 1024 || n == 512 || n == 384 || n == 768 || n == 1152 || n == 900));
 }
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
