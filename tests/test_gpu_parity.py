@@ -790,6 +790,49 @@ def test_round3_plans_against_pocketfft(N):
         assert orc.rel_l2(fu2.get(), orc.slab_r2c_forward_padded([want_p], N, "double")[0]) < 1e-10
 
 
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("align", ["X", "Y"])
+@pytest.mark.parametrize("N,P", [([60, 120, 240], 4), ([120, 180, 480], 8), ([240, 60, 360], 4)])
+def test_pencil_round3_lengths(N, P, align, prec):
+    """Pencil transforms whose every axis is one of the 15-smooth radix lengths of round 3 (plans.h groups L, M): the z-chunk
+    (CHUNK), column-limited (LIMIT) and band variants of those kernels, which the slab tests do not reach -- plain pair
+    against numpy's rfftn, 2/3-rule against irfftn(C * mask), 3/2-rule pair against the oracle (pencil.py:511-632, 758-883)."""
+    from mpifft4py_amd import Pencil_R2C
+    rng = np.random.default_rng(sum(N) + P)
+    ct, rt = cdtype(prec), rdtype(prec)
+    A = rng.random(N)
+    C = np.fft.rfftn(A)
+    C0 = C.astype(ct).copy()
+    C0[N[0] // 2] = 0
+    C0[:, N[1] // 2] = 0
+    C0[:, :, -1] = 0
+    lay = orc.PencilLayout(N, P, None, align)
+    want_pad = orc.pencil_r2c_backward_padded(orc.scatter_complex(C0, lay), N, None, align, prec)
+    kx = np.fft.fftfreq(N[0], 1. / N[0])
+    ky = np.fft.fftfreq(N[1], 1. / N[1])
+    kz = np.fft.rfftfreq(N[2], 1. / N[2])
+    want_23 = np.fft.irfftn(C.astype(ct).astype(np.complex128) * orc.dealias_mask(N, kx, ky, kz), s=N, axes=(0, 1, 2))
+
+    def body(comm):
+        F = Pencil_R2C(np.array(N), L, comm, prec, communication="Alltoallw", alignment=align)
+        a = np.ascontiguousarray(A[F.real_local_slice()]).astype(rt)
+        c = F.fftn(a, np.zeros(F.complex_shape(), dtype=ct))
+        b = F.ifftn(c, np.zeros(F.real_shape(), dtype=rt))
+        cg = np.ascontiguousarray(C[F.complex_local_slice()]).astype(ct)
+        u23 = F.ifftn(cg, np.zeros(F.real_shape(), dtype=rt), dealias="2/3-rule")
+        c0 = np.ascontiguousarray(C0[F.complex_local_slice()])
+        ap = F.ifftn(c0, np.zeros(F.real_shape_padded(), dtype=rt), dealias="3/2-rule")
+        cp = F.fftn(ap, np.zeros(F.complex_shape(), dtype=ct), dealias="3/2-rule")
+        return F.complex_local_slice(), F.real_local_slice(), c, b, u23, ap, cp, F.plan_info("zfuse"), F.plan_info("local_band")
+    for r, (cs, rs, c, b, u23, ap, cp, zfuse, lband) in enumerate(run_ranks(P, body)):
+        assert zfuse == 1 and lband == 1        # the fused z-chunk kernels and the band route ran, not their copy-based fallbacks
+        assert orc.rel_l2(c, C[cs]) < 4 * TOL[prec]
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
+        assert orc.rel_l2(u23, want_23[rs]) < 4 * TOL[prec]
+        assert orc.rel_l2(ap, want_pad[r]) < 4 * TOL[prec]
+        assert orc.rel_l2(cp, C0[cs]) < 4 * TOL[prec]
+
+
 def test_full_size_1024_cubed():
     """BASELINE workload at full size: 1024^3 fp64, device-resident.  Forward spectrum against
     the host's pocketfft (scipy.fft, all cores) on the SAME input, round trip, input preserved.
