@@ -205,7 +205,7 @@ MFFT_API int mfft_slab_unpack(const void* u_mpi, void* uc_hatT, int P, int64_t n
 /* fu[i] *= mask[i] (cython/maths.pyx:9-19 dealias_filter) */
 MFFT_API int mfft_dealias_filter(void* fu, const uint8_t* mask_dev, size_t count, int precision);
 /* 1 if a transform of length n along an axis is supported: radix plans for 2^a <= 4096, 3*2^a <= 3072,
- * 5*2^a <= 2560, 9*2^a <= 2304, 25*2^a <= 1600, 125*2^a <= 2000, 15*2^a <= 960, 45*2^a <= 1440, 75*2^a <= 1200, 225*2^a <= 1800 (real: twice that), chirp-z kernels for every other length up to 2048 */
+ * 5*2^a <= 2560, 9*2^a <= 2304, 25*2^a <= 1600, 125*2^a <= 2000, 15*2^a <= 3840, 45*2^a <= 1440, 75*2^a <= 2400, 225*2^a <= 1800, 375*2^a <= 3000 (real: twice that), chirp-z kernels for every other length up to 2048 */
 MFFT_API int mfft_length_supported(int64_t n, int real_transform);
 /* Which compiled kernel a strided-axis (family 0), contiguous-axis c2c (1), r2c (2) or c2r (3) transform of length n
  * runs: "<plan name> tile=<columns or rows> threads=<n> lds=<bytes>[ nt]", e.g.

@@ -961,6 +961,9 @@ int main() {
   MFFT_PLANS_M(MFFT_PLAN)
   MFFT_COLPLANS_F64_M(MFFT_PLAN)
 #endif
+#if EMU_HAS(9)
+  MFFT_PLANS_N(MFFT_PLAN)
+#endif
 #if EMU_HAS(5)
   MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN) MFFT_ROWPLANS_F64_K(MFFT_PLAN)
 #endif

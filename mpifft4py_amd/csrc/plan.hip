@@ -1924,7 +1924,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   // every transform length must have a kernel
   auto need = [&](int64_t n, bool real) -> int {
     if (n == 1 && !real) return 0;
-    if (!length_supported(n, real)) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %lld%s has no kernel (radix plans: 2^a <= 4096, 3*2^a, 5*2^a, 9*2^a, 15*2^a, 25*2^a, 45*2^a, 75*2^a, 125*2^a, 225*2^a; any other length up to 2048)", (long long)n, real ? " (real)" : "");
+    if (!length_supported(n, real)) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %lld%s has no kernel (radix plans: 2^a <= 4096, 3*2^a, 5*2^a, 9*2^a, 15*2^a, 25*2^a, 45*2^a, 75*2^a, 125*2^a, 225*2^a, 375*2^a; any other length up to 2048)", (long long)n, real ? " (real)" : "");
     return 0;
   };
   MFFT_TRY(need(p->N0, false));

@@ -38,6 +38,10 @@
   X(240, 10, 6, 2, 2) X(300, 10, 10, 3) X(360, 10, 6, 6) X(450, 15, 10, 3) X(480, 10, 6, 2, 2, 2)
 #define MFFT_PLANS_M(X) X(600, 10, 10, 6) X(720, 10, 6, 6, 2) X(900, 15, 10, 6) X(960, 10, 6, 2, 2, 2, 2) \
   X(1200, 10, 10, 6, 2) X(1440, 10, 6, 6, 2, 2) X(1800, 15, 10, 6, 2)
+// Group N: the 3/2-rule images of the longest 5-, 25- and 125-smooth meshes (1280 -> 1920, 2560 -> 3840, 1600 -> 2400,
+// 500 / 1000 / 2000 -> 750 / 1500 / 3000): chirp-z (1920, 1500, 750) or no kernel at all (beyond 2048) before.
+#define MFFT_PLANS_N(X) X(750, 15, 10, 5) X(1500, 15, 10, 10) X(1920, 10, 6, 2, 2, 2, 2, 2) X(2400, 10, 10, 6, 2, 2) \
+  X(3000, 10, 10, 10, 3) X(3840, 10, 6, 2, 2, 2, 2, 2, 2)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -54,6 +58,7 @@
 #define MFFT_ROWPLANS_K(X)
 #define MFFT_ROWPLANS_L(X)
 #define MFFT_ROWPLANS_M(X)
+#define MFFT_ROWPLANS_N(X)
 #define MFFT_ROWPLANS_A(X)
 #define MFFT_ROWPLANS_B(X)
 #define MFFT_ROWPLANS_C(X)
@@ -105,4 +110,4 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
-  MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X)
+  MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X) MFFT_PLANS_N(X)

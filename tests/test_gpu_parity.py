@@ -195,7 +195,10 @@ def test_padded_generic_data(decomp, P, prec, fused, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("N", [[768, 8, 8], [8, 768, 8], [8, 8, 768], [1024, 8, 8], [8, 1024, 8], [8, 8, 1024], [256, 8, 8]])
+@pytest.mark.parametrize("N", [[768, 8, 8], [8, 768, 8], [8, 8, 768], [1024, 8, 8], [8, 1024, 8], [8, 8, 1024], [256, 8, 8],
+                               # padded images on the round-3 plans: 1280 -> 1920, 2560 -> 3840, 1600 -> 2400, 2000 -> 3000, 1000 -> 1500
+                               [1280, 8, 8], [8, 1280, 8], [8, 8, 1280], [2560, 8, 8], [8, 8, 2560], [8, 1600, 8], [8, 8, 1600],
+                               [2000, 8, 8], [8, 8, 2000], [8, 1000, 8], [8, 8, 1000], [8, 500, 8]])
 def test_padded_long_axes(N, prec):
     """3/2-rule with one LONG axis: the pad-on-load / truncate-on-store builds of the 1152- and 1536-point strided
     kernels (12 values per thread, register caps, 64-byte tiles in single precision: registry.h col_wgs) and the

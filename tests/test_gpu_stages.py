@@ -16,7 +16,8 @@ LENGTHS = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096,
            10, 20, 40, 80, 160, 320, 640, 1280, 2560,
            18, 36, 72, 144, 288, 576, 1152, 2304, 50, 100, 200, 400, 800, 1600, 250, 500, 1000, 2000,
            # lengths with both 3 and 5 among their factors (plans.h groups L, M: 30 values per thread)
-           30, 60, 90, 120, 150, 180, 240, 300, 360, 450, 480, 600, 720, 900, 960, 1200, 1440, 1800]
+           30, 60, 90, 120, 150, 180, 240, 300, 360, 450, 480, 600, 720, 900, 960, 1200, 1440, 1800,
+           750, 1500, 1920, 2400, 3000, 3840]
 
 
 @pytest.fixture(scope="module", autouse=True)
