@@ -56,6 +56,13 @@ namespace mfft { void emu_barrier(); }
 #define MFFT_BARRIER() ::mfft::emu_barrier()
 #endif
 
+// nothing is scheduled across it (device code only)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MFFT_NO_R2C_FENCE)
+#define MFFT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MFFT_SCHED_FENCE() ((void)0)
+#endif
+
 namespace mfft {
 
 typedef long long i64;
@@ -713,11 +720,17 @@ struct R2CFft {
         cx<T> pm = mk<T>(__shfl(give.x, src, 64), __shfl(give.y, src, 64));
         if (j == 0) pm = v[(S::E - k) % S::E];
         if (active) emit(j + k * S::TPT, v[k], pm);
+        // 30 values per thread: keep the scheduler from hoisting every shuffle above the first store (all mirrors live at
+        // once = 120 more registers in double precision, one wave per SIMD)
+        if constexpr (S::E % 15 == 0) {
+          if (k % 3 == 2) MFFT_SCHED_FENCE();
+        }
       }
 #endif
     } else if constexpr (SPLIT) {
-      // the mirrored partners through the half-size buffer: real parts, then imaginary parts
-      cx<T> pm[S::E];
+      // the mirrored partners through the half-size buffer: real parts, then imaginary parts (the imaginary parts are
+      // consumed as they are read: only the real parts of the mirrors are held)
+      T pmx[S::E];
       if constexpr (S::NP > 1) MFFT_BARRIER();
 #pragma unroll
       for (int k = 0; k < S::E; ++k) xch[padpos<PD>(j + k * S::TPT)] = v[k].x;
@@ -725,20 +738,21 @@ struct R2CFft {
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {
         const int pos = j + k * S::TPT;
-        pm[k].x = xch[padpos<PD>(pos == 0 ? 0 : M - pos)];
+        pmx[k] = xch[padpos<PD>(pos == 0 ? 0 : M - pos)];
       }
       MFFT_BARRIER();
 #pragma unroll
       for (int k = 0; k < S::E; ++k) xch[padpos<PD>(j + k * S::TPT)] = v[k].y;
       MFFT_BARRIER();
-#pragma unroll
-      for (int k = 0; k < S::E; ++k) {
-        const int pos = j + k * S::TPT;
-        pm[k].y = xch[padpos<PD>(pos == 0 ? 0 : M - pos)];
-      }
       if (active) {
 #pragma unroll
-        for (int k = 0; k < S::E; ++k) emit(j + k * S::TPT, v[k], pm[k]);
+        for (int k = 0; k < S::E; ++k) {
+          const int pos = j + k * S::TPT;
+          emit(pos, v[k], mk<T>(pmx[k], xch[padpos<PD>(pos == 0 ? 0 : M - pos)]));
+          if constexpr (S::E % 15 == 0) {
+            if (k % 3 == 2) MFFT_SCHED_FENCE();
+          }
+        }
       }
     } else {
       if constexpr (S::NP > 1) MFFT_BARRIER();
@@ -848,6 +862,9 @@ struct C2RFft {
         carry = b;                                       // lane 0's partner register of the next step
         v[k] = prepass(a, pm1, j + k * S::TPT);
         v[kp] = prepass(b, pm2, j + kp * S::TPT);
+        if constexpr (S::E % 15 == 0) {        // see R2CFft: keep the shuffles from all being hoisted to the front
+          if (k % 3 == 2) MFFT_SCHED_FENCE();
+        }
       }
 #endif
     } else {

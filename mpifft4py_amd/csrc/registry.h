@@ -227,40 +227,58 @@ void register_col(const char* name) {
   }
 }
 
+// Register cap of the contiguous-axis kernels: the 30-values-per-thread plans in double precision come out at 256 VGPRs plus
+// 4 - 36 AGPRs (c2c and r2c), i.e. ONE wave per SIMD; capped for two (512 threads per CU) they spill a few registers and
+// run faster (MFFT_ROW_OCC=0 switches it off): z stage of the R2C pair, r2c: 480^3 0.62 -> 0.38 ms, 720^3 2.14 -> 1.41,
+// 960^3 4.1 -> 3.0, 1200^3 9.3 -> 7.5, 1440^3 17.9 -> 12.5 (with the scheduling fences of fft_kernels.h R2CFft).
+#ifndef MFFT_ROW_OCC_C2R
+#define MFFT_ROW_OCC_C2R 1
+#endif
+#ifndef MFFT_ROW_OCC
+#define MFFT_ROW_OCC 1
+#endif
+template <class S, typename T> constexpr int row_occ_wgs(int threads) {
+  return (MFFT_ROW_OCC && sizeof(T) == 8 && S::E % 15 == 0 && threads <= 256) ? 512 / threads : 0;
+}
+
 template <class S, typename T>
 void register_rows(const char* name) {
   auto& reg = kernel_registry();
   constexpr int R = row_rows<S, T>();
+  constexpr int WO = row_occ_wgs<S, T>(S::TPT * R);
+  // c2r: only where the mirrored bins come through wave shuffles (threads per transform a power of two up to 64: 12 - 28
+  // bytes of scratch under the cap); the variants that load both bins would spill 470 - 680 bytes per lane
+  constexpr int WOC = (MFFT_ROW_OCC_C2R && S::TPT <= 64 && 64 % S::TPT == 0) ? row_occ_wgs<S, T>(S::TPT * row_rows<S, T, true>()) : 0;
   constexpr bool RT = row_twlds<S, T>();
   constexpr bool SP = row_split<S, T>();
   constexpr int RC = row_rows<S, T, true>();      // the c2r kernels may differ
   constexpr bool SC = row_split<S, T, true>();
   constexpr bool RTC = row_twlds<S, T, true>();
-  reg.push_back(make_entry<RowFft<S, T, R, false, RT, false, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
-  reg.push_back(make_entry<RowFft<S, T, R, true, RT, false, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
-  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, false, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
-  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
+  reg.push_back(make_entry<RowFft<S, T, R, false, RT, false, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 0, R, name));
+  reg.push_back(make_entry<RowFft<S, T, R, true, RT, false, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 1, R, name));
+  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, false, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, false, SC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
   // pencil decompositions: the z-chunk pack / unpack fused into the stores / loads (pad = 4)
-  reg.push_back(make_entry<RowFft<S, T, R, false, RT, true, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 0, R, name));
+  reg.push_back(make_entry<RowFft<S, T, R, false, RT, true, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 0, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<RowFft<S, T, R, true, RT, true, SP>, RowParams<T>, S, T>(FAM_ROW, S::N, 1, R, name));
+  reg.push_back(make_entry<RowFft<S, T, R, true, RT, true, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 1, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, true, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, true, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, true, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, true, SC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
   reg.back().pad = 4;
   if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
-    reg.push_back(make_entry<R2CFft<S, T, R, RT, true, false, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+    reg.push_back(make_entry<R2CFft<S, T, R, RT, true, false, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
     reg.back().pad = 3;
     // ... and with the kept columns split into the z chunks of the pencils' exchange (pad = 7): the 3/2-rule pencil
     // transforms write / read the exchange blocks themselves (pencil.py:511-632, 758-883 do it in the MPI datatypes)
-    reg.push_back(make_entry<R2CFft<S, T, R, RT, true, true, SP>, RealParams<T>, S, T>(FAM_R2C, 2 * S::N, 0, R, name));
+    reg.push_back(make_entry<R2CFft<S, T, R, RT, true, true, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
     reg.back().pad = 7;
-    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, true, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, true, SC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 7;
   }
   if constexpr (S::N >= 4) {                    // column-limited c2r: 3/2-rule lengths and the pruned 2/3-rule (any length)
-    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, false, SC>, RealParams<T>, S, T>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, false, SC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 3;
   }
 }
