@@ -238,7 +238,7 @@ void register_col(const char* name) {
 #define MFFT_ROW_OCC 1
 #endif
 template <class S, typename T> constexpr int row_occ_wgs(int threads) {
-  return (MFFT_ROW_OCC && sizeof(T) == 8 && S::E % 15 == 0 && threads <= 256) ? 512 / threads : 0;
+  return (MFFT_ROW_OCC && sizeof(T) == 8 && S::E % 15 == 0 && S::N >= 120 && threads <= 256) ? 512 / threads : 0;   // shorter: 500+ bytes of scratch
 }
 
 template <class S, typename T>
