@@ -161,7 +161,7 @@ template <typename T> static double tol_of() { return sizeof(T) == 8 ? 1e-14 : 5
 template <typename T> static const char* pname() { return sizeof(T) == 8 ? "double" : "single"; }
 
 // ---------------------------------------------------------------------------
-template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false, int VEC = 1>
+template <class S, typename T, int COLS, bool INV, bool TWLDS, int SPLIT = 0, int VEC = 1>
 static void test_col(bool two_level) {
   typedef ColFft<S, T, COLS, INV, TWLDS, SPLIT, VEC> K;
   const int N = S::N;
@@ -216,7 +216,7 @@ static void test_col(bool two_level) {
       }
     }
   char name[64];
-  snprintf(name, sizeof name, "col c%d v%d %s%s%s%s", COLS, VEC, INV ? "inv" : "fwd", TWLDS ? " twlds" : "", two_level ? " 2lvl" : "", SPLIT ? " split" : "");
+  snprintf(name, sizeof name, "col c%d v%d %s%s%s%s", COLS, VEC, INV ? "inv" : "fwd", TWLDS ? " twlds" : "", two_level ? " 2lvl" : "", SPLIT == 2 ? " quarter" : SPLIT ? " split" : "");
   report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
 }
 
@@ -892,6 +892,11 @@ template <class S> static void test_spec_all() {
   test_col<S, float, 8, false, true, false, 2>(true);
   test_col<S, float, 8, true, false, true, 2>(false);
   test_col<S, float, 16, false, false, false, 4>(true);
+  if constexpr (S::E % 2 == 0 && S::NP > 1) {        // the four-round exchange (fft_kernels.h XchQuarterV)
+    test_col<S, double, 8, false, false, 2>(true);
+    test_col<S, double, 4, true, true, 2>(false);
+    test_col<S, float, 8, true, false, 2, 2>(true);
+  }
   test_row<S, double, 2, false, true>();
   test_row<S, double, 2, true, false>();
   test_row<S, float, 3, false, false>();

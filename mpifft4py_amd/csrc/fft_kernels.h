@@ -311,6 +311,67 @@ struct XchSplitV {
   }
 };
 
+// The same in FOUR rounds through a buffer of N/2 reals per column: real parts of the positions below N/2, real parts of the
+// rest, then the imaginary parts likewise.  A gathering thread knows at compile time which half a register comes from
+// (register k reads position j + k TPT: the lower half for k < E/2); a scattering thread decides per value.  Half the LDS
+// of XchSplitV for twice the barriers and store instructions: worth it only where it buys a second workgroup per CU.
+template <typename T, int VEC, class Slot>
+struct XchQuarterV {
+  PackV<T, VEC>* buf;
+  Slot slot;
+  template <class S, int P>
+  MFFT_D void exchange(cx<T> (&v)[VEC][S::E], int j, bool pre_barrier) {
+    component<S, P, 0>(v, j, pre_barrier);
+    component<S, P, 1>(v, j, true);
+  }
+  // One component: the registers gathered in the first round (k < E/2) still hold values the second round has to scatter,
+  // so the first round's gathers wait in E/2 temporaries until the second round's scatters are out.
+  template <class S, int P, int COMP>
+  MFFT_D void component(cx<T> (&v)[VEC][S::E], int j, bool pre_barrier) {
+    static_assert(S::E % 2 == 0, "the quarter exchange splits the registers in two halves");
+    constexpr int H = S::N / 2, EH = S::E / 2;
+    T low[VEC][EH];
+    if (pre_barrier) MFFT_BARRIER();
+    pass_scatter<S, P>(j, [&](int pos, int reg) {
+      if (pos < H) {
+        PackV<T, VEC> p;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) p.e[i] = COMP == 0 ? v[i][reg].x : v[i][reg].y;
+        buf[slot(pos)] = p;
+      }
+    });
+    MFFT_BARRIER();
+    pass_gather<S>(j, [&](int pos, int reg) {
+      if (reg < EH) {
+        const PackV<T, VEC> p = buf[slot(pos)];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) low[i][reg < EH ? reg : 0] = p.e[i];
+      }
+    });
+    MFFT_BARRIER();
+    pass_scatter<S, P>(j, [&](int pos, int reg) {
+      if (pos >= H) {
+        PackV<T, VEC> p;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) p.e[i] = COMP == 0 ? v[i][reg].x : v[i][reg].y;
+        buf[slot(pos - H)] = p;
+      }
+    });
+    MFFT_BARRIER();
+    pass_gather<S>(j, [&](int pos, int reg) {
+      if (reg >= EH) {
+        const PackV<T, VEC> p = buf[slot(pos - H)];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) (COMP == 0 ? v[i][reg].x : v[i][reg].y) = p.e[i];
+      }
+    });
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+#pragma unroll
+      for (int k = 0; k < EH; ++k) (COMP == 0 ? v[i][k].x : v[i][k].y) = low[i][k];
+  }
+};
+
 // PB0: also synchronise before the FIRST scatter (persistent kernels: the previous tile's last gather)
 template <class S, int P, typename T, int VEC, class TwPtr, class Xch, bool PB0 = false>
 MFFT_D void run_passes_v(cx<T> (&v)[VEC][S::E], int j, TwPtr tw, Xch& xch) {
@@ -367,7 +428,8 @@ MFFT_D void stage_twiddles(cx<T>* lds_tw, const cx<T>* gtw, int tid, int nthread
 //   PAD == 2: only logical rows [0, N/3) and [2N/3, N) are stored, to n physical rows
 //             (copy_from_padded); with P.fold the Nyquist rows N/3 and 2N/3, which sit in the
 //             same thread (j = 0), are summed as `fu[n/2:] += fp[-n/2:]` does.
-template <class S, typename T, int COLS, bool INV, bool TWLDS, bool SPLIT = false, int VEC = 1, bool NT = false,
+// SPLIT: 0 whole complex values through LDS, 1 real then imaginary parts (XchSplitV), 2 in four rounds (XchQuarterV)
+template <class S, typename T, int COLS, bool INV, bool TWLDS, int SPLIT = 0, int VEC = 1, bool NT = false,
           int PAD = 0>
 struct ColFft {
   static_assert(COLS % VEC == 0, "VEC must divide COLS");
@@ -377,7 +439,7 @@ struct ColFft {
   static constexpr int CG = COLS / VEC;            // lanes along the contiguous axis
   static constexpr int THREADS = S::TPT * CG;
   static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
-  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(S::N * COLS * (SPLIT ? sizeof(T) : sizeof(cx<T>))) : 0;
+  static constexpr int XCH_BYTES = S::NP > 1 ? (int)(S::N * COLS * (SPLIT ? sizeof(T) : sizeof(cx<T>)) / (SPLIT == 2 ? 2 : 1)) : 0;
   static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
 
   struct Slot {
@@ -522,7 +584,11 @@ struct ColFft {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
     }
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT == 2) {
+      XchQuarterV<T, VEC, Slot> xch{reinterpret_cast<PackV<T, VEC>*>(lds + TW_BYTES), Slot{c}};
+      if constexpr (TWLDS) run_passes_v<S, 0, T, VEC>(v, j, (const cx<T>*)ltw, xch);
+      else run_passes_v<S, 0, T, VEC>(v, j, P.tw, xch);
+    } else if constexpr (SPLIT) {
       XchSplitV<T, VEC, Slot> xch{reinterpret_cast<PackV<T, VEC>*>(lds + TW_BYTES), Slot{c}};
       if constexpr (TWLDS) run_passes_v<S, 0, T, VEC>(v, j, (const cx<T>*)ltw, xch);
       else run_passes_v<S, 0, T, VEC>(v, j, P.tw, xch);

@@ -35,6 +35,7 @@ run() {
     r03_512_*) bash scripts/profile_cmd.sh b512 bench.py --size 512 --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off; python scripts/summarize_profiles.py r03_512 gpurun_out/prof_b512/trace gpurun_out/prof_b512/fetch gpurun_out/prof_b512/write "bench.py --size 512: 512^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_512 gpurun_out/prof_b512/sq1 gpurun_out/prof_b512/sq2 ;;
     r03_mixed_radix_15.txt) tools rowcheck; tools rowcheck_nolaunder; bash scripts/r03_plans15.sh ;;
     r03_composite_radix.txt) for n in 288 400 500 576 640 800 1000 1152 1280 1600; do python bench.py --size $n --steps 5 --cpu-baseline off --pencil-extra off 2>/dev/null | python scripts/show_bench.py | head -1; done; for n in 576 800 1000 1152 1280 1600; do python bench.py --size $n --precision single --steps 5 --cpu-baseline off --pencil-extra off 2>/dev/null | python scripts/show_bench.py | head -1; done; echo '(old library: git checkout a8df077 -- mpifft4py_amd/csrc/plans.h, rebuild, rerun)' ;;
+    r03_kbench3_quarter_exchange.txt) tools kbench3; tools/build/kbench3 q1536 5 ;;
     r03_cu_mask_probe.txt) tools overlap_probe; tools/build/overlap_probe 8 16 32 ;;
     r03_overlap.txt) for c in "p4_kz4 4 1024 4 1" "p4_rows4 4 1024 -4 1" "p2_kz4 2 1024 4 1" "p4_kz4_copy 4 1024 4 0" "p8_kz4 8 1024 4 1"; do scripts/overlap_trace.sh $c; set -- $c; python scripts/summarize_overlap.py gpurun_out/overlap_$1; done ;;
     r03_ipc_pull_modes.txt) bash scripts/r03_first_gpu.sh; bash scripts/r03_gpu3.sh; MFFT_IPC_STREAM_FLAGS=1 python scripts/ipc_stress.py 8 2 -4 60 128 ;;

@@ -71,20 +71,20 @@ void launch_k_occ(const ColParams<T>& p, int grid) {
   }
   hipLaunchKernelGGL((kern_occ<K, ColParams<T>, WGS>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, 0, p);
 }
-template <class S, typename T, int COLS, bool TWLDS, bool SPLIT, int VEC, bool NT, int WGS>
+template <class S, typename T, int COLS, bool TWLDS, int SPLIT, int VEC, bool NT, int WGS>
 Variant<T> make_tile_occ(const char* plan) {
   typedef ColFft<S, T, COLS, false, TWLDS, SPLIT, VEC, NT> K;
   char nm[128];
-  snprintf(nm, sizeof nm, "tile    %s c%d v%d%s%s%s thr%d lds%dK wgs%d", plan, COLS, VEC, TWLDS ? " twlds" : "", SPLIT ? " split" : "", NT ? " nt" : "", K::THREADS,
+  snprintf(nm, sizeof nm, "tile    %s c%d v%d%s%s%s thr%d lds%dK wgs%d", plan, COLS, VEC, TWLDS ? " twlds" : "", SPLIT == 2 ? " quarter" : SPLIT ? " split" : "", NT ? " nt" : "", K::THREADS,
            K::LDS_BYTES / 1024, WGS);
   return Variant<T>{nm, false, COLS, &launch_k_occ<K, T, WGS>, build_pass_twiddles<S, T>()};
 }
 
-template <class S, typename T, int COLS, bool TWLDS, bool SPLIT, int VEC, bool NT = false>
+template <class S, typename T, int COLS, bool TWLDS, int SPLIT, int VEC, bool NT = false>
 Variant<T> make_tile(const char* plan) {
   typedef ColFft<S, T, COLS, false, TWLDS, SPLIT, VEC, NT> K;
   char nm[128];
-  snprintf(nm, sizeof nm, "tile    %s c%d v%d%s%s%s thr%d lds%dK", plan, COLS, VEC, TWLDS ? " twlds" : "", SPLIT ? " split" : "", NT ? " nt" : "", K::THREADS,
+  snprintf(nm, sizeof nm, "tile    %s c%d v%d%s%s%s thr%d lds%dK", plan, COLS, VEC, TWLDS ? " twlds" : "", SPLIT == 2 ? " quarter" : SPLIT ? " split" : "", NT ? " nt" : "", K::THREADS,
            K::LDS_BYTES / 1024);
   return Variant<T>{nm, false, COLS, &launch_k<K, T>, build_pass_twiddles<S, T>()};
 }
@@ -551,6 +551,15 @@ int main(int argc, char** argv) {
       run_all<double>(vs, 1600, "", rounds);
     }
     return 0;
+  }
+  if (filter[0] && strstr("q1536", filter)) {       // round 3: the quarter exchange (49 KB) for two workgroups per CU at 1536 / 1600 / 2048
+    std::vector<Variant<double>> vs;
+    vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, false, 1, 1>("8x8x8x3"));
+    vs.push_back(make_tile<Spec<1536, 8, 8, 8, 3>, double, 8, false, 2, 1>("8x8x8x3"));
+    vs.push_back(make_tile_occ<Spec<1536, 8, 8, 8, 3>, double, 8, false, 2, 1, false, 2>("8x8x8x3"));
+    vs.push_back(make_tile_occ<Spec<1536, 8, 8, 8, 3>, double, 8, false, 2, 1, true, 2>("8x8x8x3"));
+    vs.push_back(make_tile_occ<Spec<1536, 24, 8, 8>, double, 8, false, 2, 1, false, 2>("24x8x8"));
+    run_all<double>(vs, 1536, "", rounds);
   }
   if (filter[0] && strstr("h1536", filter)) {       // 1536 fp64: 12 values per thread on 64-byte tiles, three workgroups per CU
     std::vector<Variant<double>> vs;
