@@ -45,6 +45,10 @@ def test_version_and_lengths(lib):
     assert lib.mfft_version() >= 100
     for n in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 48, 96, 192, 768, 1536, 3072, 80, 640, 250, 1000, 2000):
         assert lib.mfft_length_supported(n, 0) == 1, n
+    for n in (30, 240, 480, 720, 900, 960, 1200, 1440, 1800, 750, 1500, 1920, 2400, 3000, 3840):   # round 3: 3 and 5 among the factors
+        assert lib.mfft_length_supported(n, 0) == 1, n
+        assert lib.mfft_length_supported(2 * n, 1) == 1, n
+    assert lib.mfft_length_supported(2100, 0) == 0 and lib.mfft_length_supported(3600, 0) == 0     # no plan, beyond chirp-z
     for n in (8, 64, 1024, 2048, 8192, 48, 96, 1536, 4000):
         assert lib.mfft_length_supported(n, 1) == 1, n
     for n in (7, 11, 13, 17, 36, 1001, 2047):           # chirp-z range: 2n-1 <= 4096
