@@ -247,8 +247,13 @@ void register_rows(const char* name) {
   constexpr int R = row_rows<S, T>();
   constexpr int WO = row_occ_wgs<S, T>(S::TPT * R);
   // c2r: only where the mirrored bins come through wave shuffles (threads per transform a power of two up to 64: 12 - 28
-  // bytes of scratch under the cap); the variants that load both bins would spill 470 - 680 bytes per lane
+  // bytes of scratch under the cap); the variants that load both bins would spill 470 - 680 bytes per lane (with scheduling
+  // fences every five values as well)
   constexpr int WOC = (MFFT_ROW_OCC_C2R && S::TPT <= 64 && 64 % S::TPT == 0) ? row_occ_wgs<S, T>(S::TPT * row_rows<S, T, true>()) : 0;
+  // the 20-values-per-thread plans in double precision: their column-limited / chunked c2r kernels come out at 256 VGPRs +
+  // 10 - 40 AGPRs (1000^3 2/3-rule: c2r 5.6 ms against 3.3 ms for the plain kernel that reads half as much again)
+  constexpr int WOV = (MFFT_ROW_OCC_C2R && sizeof(T) == 8 && S::E == 20 && S::N >= 160 && S::TPT * row_rows<S, T, true>() <= 256)
+                          ? 512 / (S::TPT * row_rows<S, T, true>()) : WOC;
   constexpr bool RT = row_twlds<S, T>();
   constexpr bool SP = row_split<S, T>();
   constexpr int RC = row_rows<S, T, true>();      // the c2r kernels may differ
@@ -265,7 +270,7 @@ void register_rows(const char* name) {
   reg.back().pad = 4;
   reg.push_back(make_entry<R2CFft<S, T, R, RT, false, true, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, true, SC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, true, SC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
   reg.back().pad = 4;
   if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
     reg.push_back(make_entry<R2CFft<S, T, R, RT, true, false, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
@@ -274,11 +279,11 @@ void register_rows(const char* name) {
     // transforms write / read the exchange blocks themselves (pencil.py:511-632, 758-883 do it in the MPI datatypes)
     reg.push_back(make_entry<R2CFft<S, T, R, RT, true, true, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
     reg.back().pad = 7;
-    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, true, SC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, true, SC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 7;
   }
   if constexpr (S::N >= 4) {                    // column-limited c2r: 3/2-rule lengths and the pruned 2/3-rule (any length)
-    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, false, SC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, false, SC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 3;
   }
 }
