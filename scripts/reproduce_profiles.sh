@@ -32,6 +32,7 @@ run() {
     r02_ipc_fanout_probe.txt) MFFT_IPC_PULL=streams MFFT_IPC_STREAM_FLAGS=1 python bench.py --gpus 8 --size 128 --steps 3 --warmup 1 --cpu-baseline off --pencil-extra off --transport ipc ;;
     r02_bench_after_two_wg_plan.json|r02_final_bench_1024cubed.json|r03_final_bench_1024cubed.json) python bench.py --steps 10 --warmup 3 ;;
     r03_final_*) bash scripts/profile_r03.sh bench; python scripts/summarize_profiles.py r03_final gpurun_out/prof_r03/trace gpurun_out/prof_r03/fetch gpurun_out/prof_r03/write "bench.py --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off: 1024^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_final gpurun_out/prof_r03/sq1 gpurun_out/prof_r03/sq2 ;;
+    r03_720_*) bash scripts/profile_cmd.sh b720 bench.py --size 720 --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off; python scripts/summarize_profiles.py r03_720 gpurun_out/prof_b720/trace gpurun_out/prof_b720/fetch gpurun_out/prof_b720/write "bench.py --size 720: 720^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_720 gpurun_out/prof_b720/sq1 gpurun_out/prof_b720/sq2 ;;
     r03_512_*) bash scripts/profile_cmd.sh b512 bench.py --size 512 --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off; python scripts/summarize_profiles.py r03_512 gpurun_out/prof_b512/trace gpurun_out/prof_b512/fetch gpurun_out/prof_b512/write "bench.py --size 512: 512^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_512 gpurun_out/prof_b512/sq1 gpurun_out/prof_b512/sq2 ;;
     r03_mixed_radix_15.txt) tools rowcheck; tools rowcheck_nolaunder; bash scripts/r03_plans15.sh ;;
     r03_composite_radix.txt) for n in 288 400 500 576 640 800 1000 1152 1280 1600; do python bench.py --size $n --steps 5 --cpu-baseline off --pencil-extra off 2>/dev/null | python scripts/show_bench.py | head -1; done; for n in 576 800 1000 1152 1280 1600; do python bench.py --size $n --precision single --steps 5 --cpu-baseline off --pencil-extra off 2>/dev/null | python scripts/show_bench.py | head -1; done; echo '(old library: git checkout a8df077 -- mpifft4py_amd/csrc/plans.h, rebuild, rerun)' ;;
