@@ -49,7 +49,7 @@ run() {
 if [ "${1:-list}" = "list" ]; then
   for f in profiles/r0*; do
     b=$(basename "$f")
-    printf "%-44s %s\n" "$b" "$(grep -F -m1 "$(echo "$b" | sed 's/_final_.*/_final_*/; s/_pack_.*/_pack_*/; s/_mask_[a-z_]*\.\(csv\|json\)/_mask_*/')" "$0" | sed 's/^ *[^)]*) *//; s/ ;;$//' | cut -c1-150)"
+    printf "%-44s %s\n" "$b" "$(grep -F -m1 "$(echo "$b" | sed 's/_final_.*/_final_*/; s/_pack_.*/_pack_*/; s/^\(r03_[0-9]*\)_.*/\1_*/; s/_mask_[a-z_]*\.\(csv\|json\)/_mask_*/')" "$0" | sed 's/^ *[^)]*) *//; s/ ;;$//' | cut -c1-150)"
   done
   exit 0
 fi
