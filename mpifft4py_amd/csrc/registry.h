@@ -100,8 +100,7 @@ template <class S, typename T> constexpr bool col_twlds() {
 // the c2r kernels only (z stages r2c / c2r of the R2C pair, ms, 40 KB + LDS twiddles -> lean, profiles/r03_mixed_radix_15.txt:
 // fp64 960^3 6.30 / 4.11 -> 4.90 / 4.08, 720^3 2.88 / 2.15 -> 2.72 / 1.93, 480^3 0.80 / 0.54 -> 0.64 / 0.43;
 // fp32 960^3 2.25 / 3.41 -> 2.71 / 2.56, 720^3 0.94 / 1.47 -> 1.11 / 1.05, 1200^3 4.45 / 6.48 -> 5.14 / 4.91).
-// Their real kernels stay the slowest of the family either way: 120 data registers per lane in double precision plus the
-// mirror values put them at 256 VGPRs + 20 - 160 AGPRs, one wave per SIMD.
+// (their double-precision kernels then get a register cap as well: row_occ_wgs below)
 template <class S, typename T, bool C2R = false> constexpr bool row_lean15() {
   return S::E % 15 == 0 && S::N >= 120 && (sizeof(T) == 8 || C2R);
 }
@@ -251,7 +250,8 @@ void register_rows(const char* name) {
   // fences every five values as well)
   constexpr int WOC = (MFFT_ROW_OCC_C2R && S::TPT <= 64 && 64 % S::TPT == 0) ? row_occ_wgs<S, T>(S::TPT * row_rows<S, T, true>()) : 0;
   // the 20-values-per-thread plans in double precision: their column-limited / chunked c2r kernels come out at 256 VGPRs +
-  // 10 - 40 AGPRs (1000^3 2/3-rule: c2r 5.6 ms against 3.3 ms for the plain kernel that reads half as much again)
+  // 10 - 40 AGPRs = one wave per SIMD; capped for two: 1000^3 2/3-rule c2r stage 5.6 -> 4.7 ms (the plain kernel, which reads
+  // half as much again, takes 3.3)
   constexpr int WOV = (MFFT_ROW_OCC_C2R && sizeof(T) == 8 && S::E == 20 && S::N >= 160 && S::TPT * row_rows<S, T, true>() <= 256)
                           ? 512 / (S::TPT * row_rows<S, T, true>()) : WOC;
   constexpr bool RT = row_twlds<S, T>();
