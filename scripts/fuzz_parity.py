@@ -12,7 +12,8 @@ from mpifft4py_amd.slab import C2C as Slab_C2C
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 NICE = [4, 6, 8, 10, 12, 16, 18, 20, 24, 32, 36, 40, 48, 50, 64, 72, 80, 96, 100, 128, 144, 160, 192, 200, 256]
-ODD = [14, 22, 26, 28, 30, 34, 42, 44, 52, 54, 56, 60, 66, 70, 84, 90, 98, 110, 126, 130, 150, 170, 210, 250]
+ODD = [14, 22, 26, 28, 30, 34, 42, 44, 52, 54, 56, 60, 66, 70, 84, 90, 98, 110, 126, 130, 150, 170, 210, 250,
+       120, 180, 240, 300]      # round 3: more of the lengths with 3 and 5 among their factors (plans.h group L)
 
 
 def pick(P, need_div, even_quot=False):
