@@ -32,7 +32,7 @@ extern "C" {
 typedef enum {
   MFFT_OK = 0,
   MFFT_ERR_INVALID = -1,      /* bad argument */
-  MFFT_ERR_UNSUPPORTED = -2,  /* e.g. transform length that is not 2^a*{1,3,5} */
+  MFFT_ERR_UNSUPPORTED = -2,  /* e.g. a transform length beyond mfft_length_supported */
   MFFT_ERR_HIP = -3,          /* HIP runtime failure */
   MFFT_ERR_RCCL = -4,         /* RCCL failure / library not loadable */
   MFFT_ERR_NOMEM = -5,
@@ -123,7 +123,10 @@ typedef struct {
                          (1, Nx, Ny) on a 1 x P grid: padsize^2 scaling, no Nyquist fold on one rank (line.py:185)
                          and, for P > 1, the Nyquist packing of line.py:231 in the padded forward transform */
   int comm_cus;       /* pipelined plans: compute units set aside for the communication stream (the compute stream gets
-                         the others): > 0 that many, 0 = $MFFT_COMM_CUS or the library default, < 0 = no CU masks */
+                         the others): > 0 that many, 0 = $MFFT_COMM_CUS or the library default, < 0 = no CU masks.
+                         CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags): work
+                         on the legacy null stream of the device then orders against the plan's streams, which the
+                         plain (non-blocking) plan streams do not.  The library itself never relies on either. */
   int reserved[4];
 } mfft_plan_desc;
 
@@ -133,6 +136,13 @@ MFFT_API int mfft_plan_destroy(mfft_plan_t plan);
 MFFT_API int mfft_plan_layout(mfft_plan_t plan, int64_t real_shape[3], int64_t complex_shape[3],
                               int64_t real_start[3], int64_t complex_start[3],
                               int64_t real_shape_padded[3], int64_t grid[2], int64_t subranks[2]);
+/* The same layout for rank `rank` of `nranks`, computed on the host WITHOUT a plan, a communicator or a device (the
+ * decomposition bookkeeping of slab.py:82-144, pencil.py:187-287, 903-943 is integer arithmetic); it also rejects what
+ * mfft_plan_create would reject (indivisible meshes, lengths without a kernel).  The Python classes build their shape,
+ * slice and mesh helpers (slab.py:146-197, pencil.py:289-349) on it, so those work on a machine without a GPU. */
+MFFT_API int mfft_layout_query(const mfft_plan_desc* desc, int nranks, int rank, int64_t real_shape[3],
+                               int64_t complex_shape[3], int64_t real_start[3], int64_t complex_start[3],
+                               int64_t real_shape_padded[3], int64_t grid[2], int64_t subranks[2]);
 MFFT_API int mfft_plan_workspace_bytes(mfft_plan_t plan, size_t* bytes);
 /* The all-to-all-v a rank performs, computed on the host WITHOUT a device: the peer
  * list (world ranks, in group order) and byte counts / displacements of every chunk.
@@ -204,8 +214,10 @@ MFFT_API int mfft_slab_pack(const void* uc_hatT, void* u_mpi, int P, int64_t np0
 MFFT_API int mfft_slab_unpack(const void* u_mpi, void* uc_hatT, int P, int64_t np0, int64_t np1, int64_t nf, int precision);
 /* fu[i] *= mask[i] (cython/maths.pyx:9-19 dealias_filter) */
 MFFT_API int mfft_dealias_filter(void* fu, const uint8_t* mask_dev, size_t count, int precision);
-/* 1 if a transform of length n along an axis is supported: radix plans for 2^a <= 4096, 3*2^a <= 3072,
- * 5*2^a <= 2560, 9*2^a <= 2304, 25*2^a <= 1600, 125*2^a <= 2000, 15*2^a <= 3840, 45*2^a <= 1440, 75*2^a <= 2400, 225*2^a <= 1800, 375*2^a <= 3000 (real: twice that), chirp-z kernels for every other length up to 2048 */
+/* 1 if a transform of length n along an axis is supported: radix plans for 2^a <= 8192, 3*2^a <= 3072,
+ * 5*2^a <= 2560, 7*2^a <= 3584, 9*2^a <= 2304, 25*2^a <= 1600, 125*2^a <= 2000, 15*2^a <= 3840, 45*2^a <= 1440,
+ * 75*2^a <= 2400, 225*2^a <= 1800, 375*2^a <= 3000 (real: twice that), chirp-z kernels for EVERY other length up to 4096
+ * (even real lengths up to 8192) -- numpy.fft / FFTW, the reference's backends, take any n (numpy_fft.py:25-46) */
 MFFT_API int mfft_length_supported(int64_t n, int real_transform);
 /* Which compiled kernel a strided-axis (family 0), contiguous-axis c2c (1), r2c (2) or c2r (3) transform of length n
  * runs: "<plan name> tile=<columns or rows> threads=<n> lds=<bytes>[ nt]", e.g.

@@ -20,6 +20,6 @@ from .pencil import C2C as Pencil_C2C  # noqa: F401  (extension: no reference co
 from .line import R2C as Line_R2C  # noqa: F401
 from .mpibase import work_arrays, datatypes, empty, zeros  # noqa: F401
 from .device import DeviceArray  # noqa: F401
-from .comm import SelfComm, LocalGroup, DistComm, from_env, from_mpi4py  # noqa: F401
+from .comm import SelfComm, LocalGroup, LayoutComm, DistComm, from_env, from_mpi4py  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,13 +1,15 @@
 """Shared machinery of the slab / pencil classes: plan handle, host<->device
 marshalling, dealias handling.  All arithmetic happens in libmpifft4py_amd.so."""
 import ctypes
+import zlib
 from collections import defaultdict
 
 import numpy as np
 
 from . import _lib
-from .comm import as_comm
+from .comm import MAX, as_comm
 from .device import DeviceArray, is_device_array
+from ._mesh import Block
 from .mpibase import datatypes, work_arrays
 
 _DEALIAS = {None: _lib.DEALIAS_NONE, "None": _lib.DEALIAS_NONE,
@@ -21,9 +23,9 @@ def default_planner_effort():
 class DistFFTBase(object):
     """Owns one mfft_plan_t.  Subclasses define the shape API of the reference."""
 
-    def _init_common(self, N, L, comm, precision, communication, padsize, threads, planner_effort):
-        assert len(L) == 3
-        assert len(N) == 3
+    def _init_common(self, N, L, comm, precision, communication, padsize, threads, planner_effort, ndim=3):
+        assert len(L) == ndim
+        assert len(N) == ndim
         self.N = np.asarray(N, dtype=int)
         self.comm = as_comm(comm)
         self.float, self.complex, self.mpitype = datatypes(precision)
@@ -35,6 +37,7 @@ class DistFFTBase(object):
         self.threads = threads                  # accepted, unused (FFTW knob)
         self.planner_effort = planner_effort    # accepted, unused (FFTW knob)
         self._mask_set = False
+        self._mask_fp = None
         self.dealias = np.zeros(0)
         self.work_arrays = work_arrays()
         self._plan = None
@@ -43,10 +46,19 @@ class DistFFTBase(object):
             self._comm_cus = 0
 
     # The reference reads `self.dealias` on every '2/3-rule' call (slab.py:237-245, pencil.py:455-462), so a caller may
-    # replace the filter at any time.  Here the filter lives on the device: assigning to `dealias` marks the device copy
-    # stale and the next '2/3-rule' transform uploads the new one (mfft_plan_set_dealias_mask -- COLLECTIVE for plans
-    # over more than one rank: every rank must then assign before its next dealiased call, as every rank of the
-    # reference would).  Editing the array IN PLACE is not seen: re-assign it (`F.dealias = F.dealias`).
+    # replace the filter, or edit it in place, at any time.  Here the filter lives on the device.  Assigning to `dealias`
+    # marks the device copy stale.  In-place edits are found by a fingerprint taken at upload and compared on every
+    # '2/3-rule' call (`dealias_check`, on by default): the whole array up to 4 MB, above that 65 536 elements at fixed
+    # pseudo-random positions (an edit of a fraction f of a large mask goes unnoticed with probability (1 - f)^65536:
+    # planes, bands and blocks are always seen, a single changed element of a 500 MB mask is not -- re-assign then).
+    # The upload is COLLECTIVE for plans over more than one rank (mfft_plan_set_dealias_mask), so the ranks vote on
+    # "somebody's filter changed" with one small host all-reduce per '2/3-rule' call; `F.dealias_check = False` (on
+    # every rank) switches fingerprint and vote off, and only assignment re-uploads.
+    dealias_check = True
+    _FULL_HASH_BYTES = 4 << 20
+    _SAMPLES = 1 << 16
+    _sample_index = {}
+
     @property
     def dealias(self):
         return self._dealias
@@ -56,10 +68,24 @@ class DistFFTBase(object):
         self._dealias = value
         self._mask_set = False
 
-    def _create_plan(self, kind, decomp, p1=0, pipeline=0, drop_nyquist=False, line2d=False):
+    def _mask_fingerprint(self):
+        a = np.asarray(self._dealias)
+        flat = a.reshape(-1)
+        if flat.nbytes > self._FULL_HASH_BYTES:
+            idx = DistFFTBase._sample_index.get(flat.size)
+            if idx is None:
+                idx = np.sort(np.random.default_rng(0x6d666674).integers(0, flat.size, self._SAMPLES))
+                DistFFTBase._sample_index = {flat.size: idx}
+            flat = flat[idx]
+        return (a.shape, a.dtype.str, zlib.adler32(np.ascontiguousarray(flat).view(np.uint8)))
+
+    def _describe(self, kind, decomp, mesh=None, p1=0, pipeline=0, drop_nyquist=False, line2d=False):
+        """Fill the plan descriptor and ask the library -- on the host, no device involved (mfft_layout_query) -- for
+        this rank's block: local shapes, global start offsets, process grid.  Raises what plan creation would raise for
+        an impossible decomposition or a length without a kernel."""
         d = _lib.PlanDesc()
-        for i in range(3):
-            d.n[i] = int(self.N[i])
+        for i, n in enumerate(self.N if mesh is None else mesh):
+            d.n[i] = int(n)
         d.precision = _lib.precision_code(self.precision)
         d.kind = kind
         d.decomp = decomp
@@ -69,14 +95,12 @@ class DistFFTBase(object):
         d.drop_nyquist = 1 if drop_nyquist else 0
         d.line2d = 1 if line2d else 0
         d.comm_cus = int(getattr(self, "_comm_cus", 0) or 0)
-        self.comm.use_device()
-        h = ctypes.c_void_p()
-        _lib.call("mfft_plan_create", self.comm._handle, ctypes.byref(d), ctypes.byref(h))
-        self._plan = h.value
+        self._desc = d
         arrs = [(ctypes.c_int64 * 3)() for _ in range(5)]
         grid = (ctypes.c_int64 * 2)()
         sub = (ctypes.c_int64 * 2)()
-        _lib.call("mfft_plan_layout", self._plan, arrs[0], arrs[1], arrs[2], arrs[3], arrs[4], grid, sub)
+        _lib.call("mfft_layout_query", ctypes.byref(d), self.num_processes, self.rank,
+                  arrs[0], arrs[1], arrs[2], arrs[3], arrs[4], grid, sub)
         self._c_real_shape = tuple(arrs[0])
         self._c_complex_shape = tuple(arrs[1])
         self._c_real_start = tuple(arrs[2])
@@ -84,6 +108,26 @@ class DistFFTBase(object):
         self._c_real_shape_padded = tuple(arrs[4])
         self._c_grid = tuple(grid)
         self._c_sub = tuple(sub)
+
+    def _block(self, half_axis=2, drop_axes=0):
+        """This rank's block for the mesh helpers (`drop_axes`: leading axes of the plan's mesh the class does not
+        show, 1 for the 2-D class)."""
+        a = drop_axes
+        return Block(self.N, self.L,
+                     list(zip(self._c_real_start[a:], self._c_real_shape[a:])),
+                     list(zip(self._c_complex_start[a:], self._c_complex_shape[a:])),
+                     None if half_axis is None else half_axis - a)
+
+    def _create_plan(self):
+        """The device side.  A class built on a LayoutComm (no device) stays without a plan: its shape, slice and mesh
+        helpers work, its transforms raise."""
+        if getattr(self.comm, "_handle", None) is None:
+            self._plan = None
+            return
+        self.comm.use_device()
+        h = ctypes.c_void_p()
+        _lib.call("mfft_plan_create", self.comm._handle, ctypes.byref(self._desc), ctypes.byref(h))
+        self._plan = h.value
 
     # -- marshalling ----------------------------------------------------------
     def _staging(self, tag, shape, dtype):
@@ -113,17 +157,28 @@ class DistFFTBase(object):
         return self._staging(tag, shape, dtype), a
 
     def _ensure_mask(self):
-        if self._mask_set:
-            return
         if np.shape(self.dealias) == (0,):
             self.dealias = self.get_dealias_filter()
+        stale = not self._mask_set
+        fp = None
+        if self.dealias_check:
+            fp = self._mask_fingerprint()
+            stale = stale or fp != self._mask_fp
+            if self.num_processes > 1:
+                stale = self.comm.allreduce(1.0 if stale else 0.0, MAX) > 0
+        if not stale:
+            return
         m = np.ascontiguousarray(np.broadcast_to(self.dealias, self.complex_shape()), dtype=np.uint8)
         _lib.call("mfft_plan_set_dealias_mask", self._plan, m.ctypes.data, m.size)
         self._mask_set = True
+        self._mask_fp = fp
 
     def _run(self, forward, src, dst, dealias, src_shape, src_dtype, dst_shape, dst_dtype):
         assert dealias in ('3/2-rule', '2/3-rule', 'None', None)
         code = _DEALIAS[dealias]
+        if not self._plan:
+            raise _lib.MfftError("this object has no device plan (it was built on a LayoutComm, which serves the shape "
+                                 "and mesh helpers only): transforms need a communicator with a GPU behind it")
         self.comm.use_device()
         if code == _lib.DEALIAS_2_3 and not forward:
             self._ensure_mask()

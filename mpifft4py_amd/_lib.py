@@ -62,6 +62,7 @@ _SIGNATURES = {
     "mfft_plan_create": ([c_void_p, POINTER(PlanDesc), POINTER(c_void_p)], c_int),
     "mfft_plan_destroy": ([c_void_p], c_int),
     "mfft_plan_layout": ([c_void_p] + [POINTER(c_int64)] * 7, c_int),
+    "mfft_layout_query": ([POINTER(PlanDesc), c_int, c_int] + [POINTER(c_int64)] * 7, c_int),
     "mfft_plan_workspace_bytes": ([c_void_p, POINTER(c_size_t)], c_int),
     "mfft_plan_exchange_schedule": ([POINTER(PlanDesc), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),
                                      POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t),

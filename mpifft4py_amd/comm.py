@@ -298,6 +298,35 @@ def from_mpi4py(comm):
     return DistComm(world, rank, uid, device)
 
 
+class LayoutComm(_CommBase):
+    """Rank `rank` of `size` with NO device and no transport behind it: enough for everything the classes answer from
+    the decomposition alone -- shapes, slices, `get_local_mesh`, `get_local_wavenumbermesh`, `get_dealias_filter`,
+    `get_subarrays` -- e.g. to prepare initial conditions or inspect a layout on a machine without a GPU.  A class
+    built on it has no plan: its transforms raise MfftError."""
+
+    def __init__(self, size=1, rank=0):
+        if not 0 <= int(rank) < int(size):
+            raise ValueError("rank %r is not in [0, %r)" % (rank, size))
+        _CommBase.__init__(self, None, int(size), int(rank), None)
+
+    def use_device(self):
+        raise _lib.MfftError("a LayoutComm has no device")
+
+    def barrier(self):
+        if self._size > 1:
+            raise _lib.MfftError("a LayoutComm has no transport")
+
+    Barrier = barrier
+
+    def allreduce(self, x, op=SUM):
+        if self._size > 1:
+            raise _lib.MfftError("a LayoutComm has no transport")
+        return _CommBase.allreduce(self, x, op)
+
+    def free(self):
+        pass
+
+
 def as_comm(comm):
     """Accept None, one of this module's communicators, or an mpi4py one."""
     if comm is None:

@@ -153,8 +153,11 @@ struct RcclComm : mfft_comm_s {
   RcclApi* api = nullptr;
   ncclComm_t comm = nullptr;
   hipStream_t hstream = nullptr;     // for the host-buffer helpers
+  void* small_d = nullptr;           // device scratch of the small host all-reduces: allocated once (hipMalloc / hipFree per
+  static constexpr size_t SMALL = 4096;   // call would synchronise the whole device under every agreement vote)
   ~RcclComm() override {
     if (comm) api->CommDestroy(comm);
+    if (small_d) (void)hipFree(small_d);
     if (hstream) (void)hipStreamDestroy(hstream);
   }
   int alltoallv(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
@@ -199,16 +202,22 @@ struct RcclComm : mfft_comm_s {
     if (count <= 0) return 0;
     void* d = nullptr;
     const size_t bytes = sizeof(double) * (size_t)count;
-    MFFT_HIP(hipMalloc(&d, bytes));
+    const bool small = bytes <= SMALL;
+    if (small) {
+      if (!small_d) MFFT_HIP(hipMalloc(&small_d, SMALL));
+      d = small_d;
+    } else {
+      MFFT_HIP(hipMalloc(&d, bytes));
+    }
     MFFT_HIP(hipMemcpyAsync(d, vals, bytes, hipMemcpyHostToDevice, hstream));
     ncclResult_t r = api->AllReduce(d, d, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, comm, hstream);
     if (r != ncclSuccess) {
-      (void)hipFree(d);
+      if (!small) (void)hipFree(d);
       return set_error(MFFT_ERR_RCCL, "ncclAllReduce failed: %s", api->GetErrorString(r));
     }
     MFFT_HIP(hipMemcpyAsync(vals, d, bytes, hipMemcpyDeviceToHost, hstream));
     MFFT_HIP(hipStreamSynchronize(hstream));
-    MFFT_HIP(hipFree(d));
+    if (!small) MFFT_HIP(hipFree(d));
     return 0;
   }
 };

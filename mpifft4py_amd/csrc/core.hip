@@ -246,7 +246,7 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   void* tw = nullptr;
   if (!e) {   // no radix plan for this length: chirp-z on the next compiled length >= 2n-1
     e = find_chirpz(FAM_COLZ, a.n, a.prec, a.inverse ? 1 : 0);
-    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d (maximum 2048 for lengths without a radix plan: plans.h)", a.n);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d (maximum 4096 for lengths without a radix plan: plans.h)", a.n);
     void *chirp = nullptr, *bhat = nullptr;
     MFFT_TRY(prepare_kernel(e, &tw));
     MFFT_TRY(chirpz_tables(a.n, e->n, a.prec, &chirp, &bhat));
@@ -315,7 +315,7 @@ int launch_row(const RowArgs& a, hipStream_t s) {
   void* tw = nullptr;
   if (!e) {
     e = find_chirpz(FAM_ROWZ, a.n, a.prec, a.inverse ? 1 : 0);
-    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d (maximum 2048 for lengths without a radix plan: plans.h)", a.n);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d (maximum 4096 for lengths without a radix plan: plans.h)", a.n);
     void *chirp = nullptr, *bhat = nullptr;
     MFFT_TRY(prepare_kernel(e, &tw));
     MFFT_TRY(chirpz_tables(a.n, e->n, a.prec, &chirp, &bhat));
@@ -380,7 +380,7 @@ static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
     const bool half = a.n % 2 == 0 && a.n >= 4 && real_stride % 2 == 0;
     const int nz = half ? a.n / 2 : a.n;
     e = find_chirpz(half ? (r2c ? FAM_R2CZH : FAM_C2RZH) : (r2c ? FAM_R2CZ : FAM_C2RZ), nz, a.prec, r2c ? 0 : 1);
-    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a real transform of length %d (maximum 2048 for lengths without a radix plan: plans.h)", a.n);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a real transform of length %d (maximum 4096 for lengths without a radix plan: plans.h)", a.n);
     void *chirp = nullptr, *bhat = nullptr;
     MFFT_TRY(prepare_kernel(e, &tw));
     MFFT_TRY(chirpz_tables(nz, e->n, a.prec, &chirp, &bhat));

@@ -969,6 +969,13 @@ int main() {
 #if EMU_HAS(9)
   MFFT_PLANS_N(MFFT_PLAN)
 #endif
+#if EMU_HAS(10)
+  MFFT_PLANS_O(MFFT_PLAN)
+#endif
+#if EMU_HAS(11)
+  MFFT_PLANS_P(MFFT_PLAN)
+  test_chirpz_all<Spec<8192, 32, 16, 16>>();
+#endif
 #if EMU_HAS(5)
   MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN) MFFT_ROWPLANS_F64_K(MFFT_PLAN)
 #endif

@@ -135,6 +135,33 @@ template <> struct Bfly<5> {
   }
 };
 
+template <> struct Bfly<7> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[7]) {
+    const T c1 = (T)0.623489801858733530525L;    // cos(2pi/7)
+    const T c2 = (T)-0.222520933956314404289L;   // cos(4pi/7)
+    const T c3 = (T)-0.900968867902419126236L;   // cos(6pi/7)
+    const T s1 = (T)0.781831482468029808708L;    // sin(2pi/7)
+    const T s2 = (T)0.974927912181823607018L;    // sin(4pi/7)
+    const T s3 = (T)0.433883739117558120476L;    // sin(6pi/7)
+    cx<T> a1 = v[1] + v[6], a2 = v[2] + v[5], a3 = v[3] + v[4];
+    cx<T> b1 = v[1] - v[6], b2 = v[2] - v[5], b3 = v[3] - v[4];
+    // X[k] = x0 + sum_n a_n cos(2 pi n k / 7) - i sum_n b_n sin(2 pi n k / 7); X[7 - k] its mirror
+    cx<T> p1 = mk<T>(v[0].x + c1 * a1.x + c2 * a2.x + c3 * a3.x, v[0].y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
+    cx<T> p2 = mk<T>(v[0].x + c2 * a1.x + c3 * a2.x + c1 * a3.x, v[0].y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
+    cx<T> p3 = mk<T>(v[0].x + c3 * a1.x + c1 * a2.x + c2 * a3.x, v[0].y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
+    cx<T> q1 = mk<T>(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y);
+    cx<T> q2 = mk<T>(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y);
+    cx<T> q3 = mk<T>(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y);
+    v[0] = v[0] + a1 + a2 + a3;
+    v[1] = p1 + mul_mi(q1);
+    v[6] = p1 + mul_pi(q1);
+    v[2] = p2 + mul_mi(q2);
+    v[5] = p2 + mul_pi(q2);
+    v[3] = p3 + mul_mi(q3);
+    v[4] = p3 + mul_pi(q3);
+  }
+};
+
 // multiply by W_32^K = exp(-2 pi i K / 32), K compile-time
 template <int K, typename T> MFFT_HD cx<T> mul_w32(cx<T> a) {
   constexpr int k = ((K % 32) + 32) % 32;
@@ -266,6 +293,13 @@ template <> struct Bfly<40> {
 };
 template <> struct Bfly<30> {
   template <typename T> static MFFT_HD void run(cx<T> (&v)[30]) { BflyPFA<2, 15>::run(v); }
+};
+// round 4: the 7 * 2^a lengths (plans.h group O) hold 28 values per thread: radix 28 = 7 x 4 first, radix-4 / 2 passes after
+template <> struct Bfly<14> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[14]) { BflyPFA<2, 7>::run(v); }
+};
+template <> struct Bfly<28> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[28]) { BflyPFA<7, 4>::run(v); }
 };
 
 

@@ -153,6 +153,7 @@ struct IpcComm : mfft_comm_s {
   void* staging[IPC_MAX_CH] = {};
   size_t staging_bytes[IPC_MAX_CH] = {};
   hipEvent_t fork_ev[IPC_MAX_CH] = {}, join_ev[IPC_MAX_RANKS][IPC_MAX_CH] = {};
+  hipStream_t rescue_stream = nullptr;                     // rescue(): non-blocking, never used for anything else
 
   IpcComm() {
     if (const char* e = getenv("MFFT_IPC_PULL")) {
@@ -169,10 +170,10 @@ struct IpcComm : mfft_comm_s {
       pull_mode = (int)v;
       return 0;
     }
-    if (!strcmp(key, "ipc_relay")) {        // COLLECTIVE in effect: every rank must choose the same value
-      if (v < 0 || v > 1) return set_error(MFFT_ERR_INVALID, "ipc_relay: 0 off, 1 on");
+    if (!strcmp(key, "ipc_relay")) {        // COLLECTIVE: the relayed exchange is another protocol (host barriers, other
+      if (v < 0 || v > 1) return set_error(MFFT_ERR_INVALID, "ipc_relay: 0 off, 1 on");     // flag words), so the ranks must agree
       relay_mode = (int)v;
-      return 0;
+      return agree_on_relay();
     }
     if (!strcmp(key, "ipc_pull_wgs")) {
       if (v < 1 || v > 64) return set_error(MFFT_ERR_INVALID, "ipc_pull_wgs: 1 .. 64 workgroups per peer");
@@ -191,7 +192,7 @@ struct IpcComm : mfft_comm_s {
   ~IpcComm() override {
     // a broken group never satisfies the waits that are still enqueued: release mine before waiting for the device
     if (sh && sh->broken.load()) rescue();
-    (void)hipDeviceSynchronize();
+    (void)quiesce();                          // bounded: a peer that vanished cannot hold this process for ever
     if (sh) {
       // peers may still pull from my segments or wait on my events: leave together (best effort, bounded)
       sh->detached.fetch_add(1);
@@ -212,6 +213,7 @@ struct IpcComm : mfft_comm_s {
     }
     for (hipStream_t ps : pstream)
       if (ps) (void)hipStreamDestroy(ps);
+    if (rescue_stream) (void)hipStreamDestroy(rescue_stream);
     // (staging blocks live in the arena's segments, freed below)
     if (flags) (void)hipFree(flags);
     for (Seg& s : segs) (void)hipFree(s.base);
@@ -248,10 +250,22 @@ struct IpcComm : mfft_comm_s {
   }
   // release every device-side wait of THIS rank (the flags are in my own memory): a hung exchange then runs to its
   // end with whatever data there is, and the communicator is marked broken
+  // The fill runs on a stream of its own created hipStreamNonBlocking: a null-stream memset would queue behind every
+  // BLOCKING stream of the device -- the CU-masked plan streams are such streams (hipExtStreamCreateWithCUMask has no
+  // flags argument) -- i.e. behind the very wait kernel it is meant to release.
   void rescue() override {
     if (sh) sh->broken.store(1);
+    if (!flags) return;
+    if (!rescue_stream && hipStreamCreateWithFlags(&rescue_stream, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      rescue_stream = nullptr;
+      return;
+    }
     // 0x7FFFFFFF satisfies every ">= q" wait, cyclic comparison or not (q stays far below 2^31)
-    if (flags) (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(flags), 0x7FFFFFFF, sizeof(IpcFlags) / 4);
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags), 0x7FFFFFFF, sizeof(IpcFlags) / 4, rescue_stream) == hipSuccess)
+      (void)hipStreamSynchronize(rescue_stream);
+    else
+      (void)hipGetLastError();
   }
   int bcast_host(void* buf, size_t bytes, int root) override {
     char* p = static_cast<char*>(buf);
@@ -321,13 +335,51 @@ struct IpcComm : mfft_comm_s {
     *p = base;
     return 0;
   }
+  // Wait until nothing enqueued so far can touch a work block any more: the last exchange issued on every channel
+  // (its event also covers the transform kernels queued before it on that stream) and, because a plan's kernels may run
+  // on streams this object has never seen, the rest of the device -- but BOUNDED: a peer that died without marking the
+  // group broken (SIGKILL) leaves a wait kernel spinning for ever, and hipDeviceSynchronize would block the host with
+  // it.  After the transport's timeout the waits are released (rescue) and the group is broken.
+  int quiesce() {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      MFFT_HIP(hipDeviceSynchronize());
+      return 0;
+    }
+    // a record on the legacy null stream completes when all prior work of every BLOCKING stream has; the non-blocking
+    // plan streams are covered by the channels' last_issue events
+    hipError_t e = hipEventRecord(ev, nullptr);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool released = false;
+    auto pending = [&]() {
+      if (e == hipSuccess && hipEventQuery(ev) == hipErrorNotReady) return true;
+      for (int ch = 0; ch < IPC_MAX_CH; ++ch)
+        if (used_ch[ch] && last_issue[ch] && hipEventQuery(last_issue[ch]) == hipErrorNotReady) return true;
+      return false;
+    };
+    int n = 0;
+    while (pending()) {
+      if (++n > 200) std::this_thread::sleep_for(std::chrono::microseconds(100));
+      if (!released && ((sh && sh->broken.load()) ||
+                        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(ipc_timeout_s()))) {
+        rescue();
+        released = true;
+      }
+      if (released && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(ipc_timeout_s() + 30)) break;
+    }
+    (void)hipGetLastError();
+    (void)hipEventDestroy(ev);
+    if (!released) MFFT_HIP(hipDeviceSynchronize());      // nothing of mine is waiting on a peer: cheap, and covers every stream
+    return 0;
+  }
   int work_free(void* p) override {
     if (!p) return 0;
     // As safe as the hipFree it stands in for: the block may be handed to another plan (another stream) at once, while
     // transforms of the plan that owned it are still in flight and peers still pull from it (their "done" flags are
     // awaited in-stream only).  Once this device is idle every such wait of mine has been satisfied.  Growth is rare.
     if (sh && sh->broken.load()) rescue();
-    MFFT_HIP(hipDeviceSynchronize());
+    MFFT_TRY(quiesce());
     for (Seg& s : segs) {
       if (static_cast<char*>(p) < s.base || static_cast<char*>(p) >= s.base + s.size) continue;
       const uint64_t off = (uint64_t)(static_cast<char*>(p) - s.base);
@@ -470,28 +522,24 @@ struct IpcComm : mfft_comm_s {
     } else if (pull_mode == PULL_STREAMS && !pulls.empty()) {
       // every peer's copy on that peer's own stream, forked from and joined back into the issuing stream.  ALL flag
       // operations stay on the issuing stream (waits before the fork, "done" writes behind the join): the per-peer
-      // streams carry nothing but one copy each.  (With the waits and writes on the per-peer streams -- round 2's
-      // experiment, MFFT_IPC_STREAM_FLAGS=1 -- 8 processes on one device were 100x slower and pipelined transforms
-      // came back wrong now and then; see profiles/r03_ipc_pull_modes.txt for the differential test.)
-      static const bool flags_on_peer_streams = getenv("MFFT_IPC_STREAM_FLAGS") && atoi(getenv("MFFT_IPC_STREAM_FLAGS")) != 0;
+      // streams carry nothing but one copy each.  (Round 2's first form had the waits and writes on the per-peer
+      // streams: 8 processes on one device were 100x slower and pipelined transforms came back wrong in 3 of 6 runs,
+      // profiles/r03_ipc_pull_modes.txt; that form was kept behind an environment switch through round 3 and is gone
+      // since round 4 -- the last commit that has it is 292508d.)
       if (!fork_ev[ch]) MFFT_HIP(hipEventCreateWithFlags(&fork_ev[ch], hipEventDisableTiming));
-      if (!flags_on_peer_streams)
-        for (const Pull& u : pulls) MFFT_HIP(hipStreamWaitValue32(s, &flags->ready[u.p][ch], u.q, hipStreamWaitValueGte, 0xFFFFFFFFu));
+      for (const Pull& u : pulls) MFFT_HIP(hipStreamWaitValue32(s, &flags->ready[u.p][ch], u.q, hipStreamWaitValueGte, 0xFFFFFFFFu));
       MFFT_HIP(hipEventRecord(fork_ev[ch], s));
       for (const Pull& u : pulls) {
         hipStream_t ps = nullptr;
         MFFT_TRY(peer_stream(u.p, &ps));
         if (!join_ev[u.p][ch]) MFFT_HIP(hipEventCreateWithFlags(&join_ev[u.p][ch], hipEventDisableTiming));
         MFFT_HIP(hipStreamWaitEvent(ps, fork_ev[ch], 0));
-        if (flags_on_peer_streams) MFFT_HIP(hipStreamWaitValue32(ps, &flags->ready[u.p][ch], u.q, hipStreamWaitValueGte, 0xFFFFFFFFu));
         MFFT_HIP(hipMemcpyAsync(rp + rdisp[u.i], u.src, rcount[u.i], hipMemcpyDeviceToDevice, ps));
-        if (flags_on_peer_streams) MFFT_HIP(hipStreamWriteValue32(ps, &peer_flags[u.p]->done[rank][ch], u.q, 0));
         MFFT_HIP(hipEventRecord(join_ev[u.p][ch], ps));
       }
       if (rcount[myidx]) MFFT_HIP(hipMemcpyAsync(rp + rdisp[myidx], sp + sdisp[myidx], rcount[myidx], hipMemcpyDeviceToDevice, s));
       for (const Pull& u : pulls) MFFT_HIP(hipStreamWaitEvent(s, join_ev[u.p][ch], 0));
-      if (!flags_on_peer_streams)
-        for (const Pull& u : pulls) MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[u.p]->done[rank][ch], u.q, 0));
+      for (const Pull& u : pulls) MFFT_HIP(hipStreamWriteValue32(s, &peer_flags[u.p]->done[rank][ch], u.q, 0));
     } else {
       if (rcount[myidx]) MFFT_HIP(hipMemcpyAsync(rp + rdisp[myidx], sp + sdisp[myidx], rcount[myidx], hipMemcpyDeviceToDevice, s));
       for (const Pull& u : pulls) {
@@ -522,9 +570,35 @@ struct IpcComm : mfft_comm_s {
   // every rank): it has moved real data between processes on one device only, and bench.py measures it as a candidate
   // of the pencil runs whenever every rank owns a device.
   bool relay_enabled() const { return relay_mode == 1; }
+  // every rank calls this with its own choice; a disagreement switches relaying off everywhere and is an error everywhere
+  int agree_on_relay() {
+    double v[2] = {(double)relay_mode, -(double)relay_mode};
+    MFFT_TRY(allreduce_host(v, 2, 1));                     // max and -min
+    if (v[0] != -v[1]) {
+      relay_mode = 0;
+      return set_error(MFFT_ERR_INVALID, "ipc transport: the ranks disagree on ipc_relay (MFFT_IPC_RELAY / the \"ipc_relay\" option "
+                                         "must be the same on every rank); relaying is switched off");
+    }
+    return 0;
+  }
+  // A relayed exchange needs every group of the partition to have the same size g with 2 <= g < P (the stripes of a
+  // message are cut by the sender's group size and read by relays of other groups with theirs).  Decided from the
+  // partition alone, which every rank holds, so all ranks take the same branch.
+  static bool relay_fits(const int* part, int P) {
+    int cnt[IPC_MAX_RANKS] = {};
+    for (int r = 0; r < P; ++r) {
+      if (part[r] < 0 || part[r] >= IPC_MAX_RANKS) return false;
+      ++cnt[part[r]];
+    }
+    const int g = cnt[part[0]];
+    if (g < 2 || g >= P) return false;
+    for (int i = 0; i < IPC_MAX_RANKS; ++i)
+      if (cnt[i] && cnt[i] != g) return false;
+    return true;
+  }
   int alltoallv_part(const void* send, const size_t* scount, const size_t* sdisp, void* recv, const size_t* rcount,
                      const size_t* rdisp, const int* peers, int npeers, hipStream_t s, int channel, const int* part) override {
-    if (!part || npeers < 2 || npeers >= size || !relay_enabled())
+    if (!part || !relay_enabled() || !relay_fits(part, size))
       return alltoallv(send, scount, sdisp, recv, rcount, rdisp, peers, npeers, s, channel);
     const int rc = exchange_relay(send, scount, sdisp, recv, rcount, rdisp, peers, npeers, s, channel, part);
     if (rc != 0) rescue();
@@ -781,6 +855,7 @@ int comm_create_ipc(int nranks, int rank, const void* id128, mfft_comm_s** out) 
     c->peer_flags[r] = static_cast<IpcFlags*>(p);
   }
   MFFT_TRY(c->barrier());
+  MFFT_TRY(c->agree_on_relay());                        // MFFT_IPC_RELAY is read per process
   if (rank == 0) {                                      // everybody holds a mapping: the name can go
     (void)shm_unlink(c->shm_name.c_str());
     c->creator = false;

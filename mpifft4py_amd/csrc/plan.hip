@@ -1924,7 +1924,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   // every transform length must have a kernel
   auto need = [&](int64_t n, bool real) -> int {
     if (n == 1 && !real) return 0;
-    if (!length_supported(n, real)) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %lld%s has no kernel (radix plans: 2^a <= 4096, 3*2^a, 5*2^a, 9*2^a, 15*2^a, 25*2^a, 45*2^a, 75*2^a, 125*2^a, 225*2^a, 375*2^a; any other length up to 2048)", (long long)n, real ? " (real)" : "");
+    if (!length_supported(n, real)) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %lld%s has no kernel (radix plans: 2^a <= 8192, 3*2^a, 5*2^a, 7*2^a, 9*2^a, 15*2^a, 25*2^a, 45*2^a, 75*2^a, 125*2^a, 225*2^a, 375*2^a; any other length up to 4096, even real lengths up to 8192)", (long long)n, real ? " (real)" : "");
     return 0;
   };
   MFFT_TRY(need(p->N0, false));
@@ -1985,15 +1985,20 @@ int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* 
   }
   if (nev > 0) {
     if (!p->cstream) {
-      // no CU masks.  MFFT_COMM_PRIORITY=1 asks for the highest stream priority; measured (profiles/r03_cu_mask_probe.txt)
-      // it changes nothing for the pull kernel -- workgroups of a second queue are admitted as transform workgroups
-      // retire, with or without it -- and with several ranks on ONE device it inverts priorities (a high-priority
-      // queue polling for a flag that a normal-priority queue of another process has yet to write: 0.8 -> 45 ms per
-      // pair at two processes, profiles/r03_shared_gpu_pipeline_latency.txt), so the default is the normal priority
+      // no CU masks.  The communication stream is created at the LOWEST priority of the device's range (HIP: least = 1 =
+      // low, 0 = normal, greatest = -1 = high; the compute stream is a plain non-blocking stream = normal) -- this is
+      // what every round-3 profile was taken with (its notes call it "normal": ADVICE r03), and it is kept because it is
+      // the measured configuration.  MFFT_COMM_PRIORITY=0 asks for normal, 1 for the highest priority: measured
+      // (profiles/r03_cu_mask_probe.txt) the highest changes nothing for the pull kernel -- workgroups of a second queue
+      // are admitted as transform workgroups retire, with or without it -- and with several ranks on ONE device it
+      // inverts priorities (a high-priority queue polling for a flag that a lower-priority queue of another process has
+      // yet to write: 0.8 -> 45 ms per pair at two processes, profiles/r03_shared_gpu_pipeline_latency.txt).
       int prio_least = 0, prio_greatest = 0;
       MFFT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-      const bool prio = getenv("MFFT_COMM_PRIORITY") && atoi(getenv("MFFT_COMM_PRIORITY")) != 0;
-      MFFT_HIP(hipStreamCreateWithPriority(&p->cstream, hipStreamNonBlocking, prio ? prio_greatest : prio_least));
+      int prio = prio_least;
+      if (const char* e = getenv("MFFT_COMM_PRIORITY")) prio = atoi(e) > 0 ? prio_greatest : atoi(e) == 0 ? 0 : prio_least;
+      prio = std::max(prio_greatest, std::min(prio_least, prio));
+      MFFT_HIP(hipStreamCreateWithPriority(&p->cstream, hipStreamNonBlocking, prio));
     }
     for (std::vector<hipEvent_t>* v : {&p->ev_compute, &p->ev_comm, &p->ev2_compute, &p->ev2_comm}) {
       if ((v == &p->ev2_compute || v == &p->ev2_comm) && p->nbatch <= 1) continue;
@@ -2095,9 +2100,8 @@ int mfft_plan_destroy(mfft_plan_t plan) {
   return 0;
 }
 
-int mfft_plan_layout(mfft_plan_t p, int64_t rshape[3], int64_t cshape[3], int64_t rstart[3], int64_t cstart[3],
+static int layout_of(const mfft_plan_s* p, int64_t rshape[3], int64_t cshape[3], int64_t rstart[3], int64_t cstart[3],
                      int64_t rshape_pad[3], int64_t grid[2], int64_t sub[2]) {
-  if (!p) return set_error(MFFT_ERR_INVALID, "null plan");
   int64_t rs_[3], cs_[3], r0[3], c0_[3], rp[3];
   if (p->d.decomp == MFFT_SLAB) {
     rs_[0] = p->Np0; rs_[1] = p->N1; rs_[2] = p->N2;
@@ -2129,6 +2133,22 @@ int mfft_plan_layout(mfft_plan_t p, int64_t rshape[3], int64_t cshape[3], int64_
     if (rshape_pad) rshape_pad[i] = rp[i];
   }
   return 0;
+}
+
+int mfft_plan_layout(mfft_plan_t p, int64_t rshape[3], int64_t cshape[3], int64_t rstart[3], int64_t cstart[3],
+                     int64_t rshape_pad[3], int64_t grid[2], int64_t sub[2]) {
+  if (!p) return set_error(MFFT_ERR_INVALID, "null plan");
+  return layout_of(p, rshape, cshape, rstart, cstart, rshape_pad, grid, sub);
+}
+
+// The same answers for rank `rank` of `nranks` WITHOUT a plan, a communicator or a device: the decomposition
+// bookkeeping of the constructors (slab.py:82-96, pencil.py:187-216, 903-913) is host arithmetic.
+int mfft_layout_query(const mfft_plan_desc* desc, int nranks, int rank, int64_t rshape[3], int64_t cshape[3],
+                      int64_t rstart[3], int64_t cstart[3], int64_t rshape_pad[3], int64_t grid[2], int64_t sub[2]) {
+  if (!desc) return set_error(MFFT_ERR_INVALID, "null argument");
+  mfft_plan_s p;
+  MFFT_TRY(decomp_init(&p, desc, nranks, rank));
+  return layout_of(&p, rshape, cshape, rstart, cstart, rshape_pad, grid, sub);
 }
 
 int mfft_plan_workspace_bytes(mfft_plan_t p, size_t* bytes) {

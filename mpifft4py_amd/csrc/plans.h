@@ -42,6 +42,14 @@
 // 500 / 1000 / 2000 -> 750 / 1500 / 3000): chirp-z (1920, 1500, 750) or no kernel at all (beyond 2048) before.
 #define MFFT_PLANS_N(X) X(750, 15, 10, 5) X(1500, 15, 10, 10) X(1920, 10, 6, 2, 2, 2, 2, 2) X(2400, 10, 10, 6, 2, 2) \
   X(3000, 10, 10, 10, 3) X(3840, 10, 6, 2, 2, 2, 2, 2, 2)
+// Group O (round 4): 7 * 2^a -- 896, 1792, 3584 are ordinary meshes (numpy / FFTW take every n: numpy_fft.py:25-46) and went
+// through chirp-z (896) or had no kernel at all.  28 values per thread (radix 28 = the prime-factor butterfly 7 x 4, no
+// inner twiddles), radix-4 / 2 passes after it.
+#define MFFT_PLANS_O(X) X(14, 14) X(28, 28) X(56, 28, 2) X(112, 28, 4) X(224, 28, 4, 2) X(448, 28, 4, 4) \
+  X(896, 28, 4, 4, 2) X(1792, 28, 4, 4, 4) X(3584, 28, 4, 4, 4, 2)
+// Group P (round 4): 8192, first of all as the convolution length M of the chirp-z kernels, which makes EVERY length up to
+// 4096 a supported one (2 n - 1 <= 8192), as it is for numpy / FFTW (numpy_fft.py:25-46); real rows up to 16384.
+#define MFFT_PLANS_P(X) X(8192, 32, 16, 16)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -59,6 +67,8 @@
 #define MFFT_ROWPLANS_L(X)
 #define MFFT_ROWPLANS_M(X)
 #define MFFT_ROWPLANS_N(X)
+#define MFFT_ROWPLANS_O(X)
+#define MFFT_ROWPLANS_P(X)
 #define MFFT_ROWPLANS_A(X)
 #define MFFT_ROWPLANS_B(X)
 #define MFFT_ROWPLANS_C(X)
@@ -110,4 +120,5 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
-  MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X) MFFT_PLANS_N(X)
+  MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X) MFFT_PLANS_N(X) \
+  MFFT_PLANS_O(X) MFFT_PLANS_P(X)

@@ -332,7 +332,7 @@ void register_rows_z(const char* name) {
 // length they could serve has a cheaper 2-, 3- or 5-smooth neighbour, and each plan costs ~40 more kernels)
 template <class S, typename T>
 void register_plan(const char* name) {
-  constexpr bool chirp = S::N % 15 != 0;
+  constexpr bool chirp = S::N % 15 != 0 && S::N % 7 != 0;      // (nor the 28-values-per-thread plans of 7 * 2^a)
   if constexpr (!mfft_has_col_override<T>(S::N)) {
     register_col<S, T>(name);
     if constexpr (chirp) register_col_z<S, T>(name);

@@ -108,7 +108,9 @@ inline void relay_moves(int P, int rank, const int* part, BytesOf bytes_of, std:
       if (d == s || part[d] != part[s]) continue;
       const size_t b = bytes_of(s, d);
       if (!b) continue;
-      const RelayCut c = relay_cut(b, g, P);
+      int gs = 0;                              // the message is cut by ITS group's size (the destination cuts it the same way)
+      for (int r = 0; r < P; ++r) gs += part[r] == part[s];
+      const RelayCut c = relay_cut(b, gs, P);
       if (j < 0 || j >= c.R || !c.stripe) continue;
       out->push_back(RelayMove{1, 2, s, s, d, c.stripe_off(j), c.stripe});
     }

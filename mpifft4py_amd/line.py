@@ -18,12 +18,10 @@ On one rank the reference indexes the padded rows with (fftfreq(n) * n).astype(i
 truncates e.g. 4.999999999999999 to 4 for n = 24, 28, 36, 48, ...; exact indices are used here.
 """
 import numpy as np
-from numpy.fft import fftfreq, rfftfreq
 
 from . import _lib, _padding
 from ._base import DistFFTBase, default_planner_effort
-from .comm import as_comm
-from .mpibase import datatypes, work_arrays
+from ._mesh import dft_modes
 
 __all__ = ["R2C"]
 
@@ -32,35 +30,21 @@ class R2C(DistFFTBase):
     def __init__(self, N, L, comm, precision, padsize=1.5, threads=1, planner_effort=None):
         assert len(L) == 2
         assert len(N) == 2
-        self.N = np.asarray(N, dtype=int)
-        self.L = np.asarray(L).astype(float)
-        self.comm = as_comm(comm)
-        self.float, self.complex, self.mpitype = datatypes(precision)
-        self.precision = precision
-        self.num_processes = self.comm.Get_size()
-        self.rank = self.comm.Get_rank()
-        self.padsize = padsize
-        self.threads = threads
-        self.planner_effort = planner_effort if planner_effort is not None else default_planner_effort()
-        self.dealias = np.zeros(0)
-        self.work_arrays = work_arrays()
-        self._plan = None
-        self._stage = {}
-        self._mask_set = False
+        self._init_common(N, L, comm, precision, None, padsize, threads,
+                          planner_effort if planner_effort is not None else default_planner_effort(), ndim=2)
+        self.L = np.asarray(L)
         P = self.num_processes
         self.Np = self.N // P
         self.Nf = int(self.N[1] // 2 + 1)
         self.Npf = int(self.Np[1] // 2 + 1) if self.rank + 1 == P else int(self.Np[1] // 2)
         self.Nfp = int(padsize * self.N[1] / 2 + 1)
-        self.ks = np.rint(fftfreq(int(self.N[0])) * self.N[0]).astype(int)
-        N2 = self.N
-        self.N = np.array([1, int(N2[0]), int(N2[1])])        # the 3-D mesh the plan sees
-        try:
-            self._create_plan(_lib.R2C, _lib.PENCIL_X, p1=1, line2d=True)
-        finally:
-            self.N = N2
+        self.ks = dft_modes(self.N[0])
+        # the 3-D mesh the plan sees: (1, Nx, Ny) on a 1 x P grid
+        self._describe(_lib.R2C, _lib.PENCIL_X, mesh=(1, int(self.N[0]), int(self.N[1])), p1=1, line2d=True)
         assert self._c_real_shape[1:] == tuple(self.real_shape()), (self._c_real_shape, self.real_shape())
         assert self._c_complex_shape[1:] == tuple(self.complex_shape()), (self._c_complex_shape, self.complex_shape())
+        self._mesh = self._block(half_axis=2, drop_axes=1)
+        self._create_plan()
 
     # -- shapes (line.py:76-160) ----------------------------------------------------
     def real_shape(self):
@@ -116,34 +100,21 @@ class R2C(DistFFTBase):
         fu[:] = fp[:, :self.Nf]
         return fu
 
-    # -- host-side mesh helpers (line.py:105-134) -------------------------------------
+    # -- host-side mesh helpers (line.py:105-134), answered by _mesh.Block from the layout --------------------------
     def get_local_mesh(self):
-        X = np.mgrid[self.rank * self.Np[0]:(self.rank + 1) * self.Np[0], :self.N[1]].astype(self.float)
-        X[0] *= self.L[0] / self.N[0]
-        X[1] *= self.L[1] / self.N[1]
-        return X
+        """(2, *real_shape()) array of coordinates."""
+        return self._mesh.coordinates_dense(self.float)
 
     def get_local_wavenumbermesh(self, scaled=True, broadcast=False, eliminate_highest_freq=False):
-        kx = fftfreq(int(self.N[0]), 1. / self.N[0])
-        ky = rfftfreq(int(self.N[1]), 1. / self.N[1])
-        if eliminate_highest_freq:
-            for i, k in enumerate((kx, ky)):
-                if self.N[i] % 2 == 0:
-                    k[self.N[i] // 2] = 0
-        s = self.complex_local_slice()[1]
-        Ks = list(np.meshgrid(kx, ky[s], indexing='ij', sparse=True))
-        if scaled is True:
-            Lp = 2 * np.pi / self.L
-            Ks[0] = Ks[0] * Lp[0]
-            Ks[1] = Ks[1] * Lp[1]
-        if broadcast is True:
-            return [np.broadcast_to(k, self.complex_shape()) for k in Ks]
-        return Ks
+        """[Kx, Ky] of this rank's spectral block in double precision whatever the class's (as upstream); note the
+        default `scaled=True`, unlike the 3-D classes."""
+        return self._mesh.wavenumber_grid(dtype=np.float64, factors=2 * np.pi / self.L if scaled is True else None,
+                                          cast_first=True, zero_nyquist=eliminate_highest_freq,
+                                          dense=broadcast is True)
 
     def get_dealias_filter(self):
-        K = self.get_local_wavenumbermesh()
-        kmax = 2. / 3. * (self.N // 2 + 1)
-        return np.array((abs(K[0]) < kmax[0]) * (abs(K[1]) < kmax[1]), dtype=np.uint8)
+        """2/3-rule mask; upstream tests the SCALED wave numbers against the integer bound (line.py:131-134) -- kept."""
+        return self._mesh.two_thirds_filter(self.get_local_wavenumbermesh())
 
     # -- transforms (line.py:177-338) ---------------------------------------------------
     def fft2(self, u, fu, dealias=None):

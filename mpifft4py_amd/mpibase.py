@@ -24,50 +24,68 @@ def zeros(N, dtype=float, bytes=None):
     return np.zeros(N, dtype=dtype)
 
 
-class work_arrays(collections.abc.MutableMapping):
-    def __init__(self):
-        self.store = {}
-        self.fillzero = True
+def _parse_work_key(key):
+    """Normalise a work-array key to ((shape, dtype, index), fillzero).
 
-    def _key(self, key):
-        if isinstance(key[0], np.ndarray):
-            shape, dtype, i = key[0].shape, key[0].dtype, key[1]
-            zero = True if len(key) == 2 else key[2]
-        elif isinstance(key[0], tuple):
-            if len(key) == 3:
-                shape, dtype, i = key
-                zero = True
-            elif len(key) == 4:
-                shape, dtype, i, zero = key
-            else:
-                raise TypeError("Wrong type of key for work array")
-        else:
-            raise TypeError("Wrong type of key for work array")
-        assert isinstance(zero, bool)
-        assert isinstance(i, int)
-        self.fillzero = zero
-        return (tuple(shape), np.dtype(dtype), i)
+    Two spellings name the same buffer (mpibase.py:64-73): `(shape, dtype, index[, fillzero])` with a tuple shape, and
+    `(array, index[, fillzero])`, which borrows shape and dtype from an existing array.  Anything else is a TypeError;
+    a non-int index or a non-bool fillzero is an AssertionError, as upstream."""
+    if not isinstance(key, tuple) or not key:
+        raise TypeError("Wrong type of key for work array")
+    head, rest = key[0], key[1:]
+    if isinstance(head, np.ndarray):
+        spec = (head.shape, head.dtype)
+    elif isinstance(head, tuple) and rest:
+        spec, rest = (head, rest[0]), rest[1:]
+    else:
+        raise TypeError("Wrong type of key for work array")
+    if len(rest) not in (1, 2):
+        raise TypeError("Wrong type of key for work array")
+    index = rest[0]
+    fill = rest[1] if len(rest) == 2 else True
+    assert isinstance(fill, bool)
+    assert isinstance(index, int)
+    return (tuple(int(n) for n in spec[0]), np.dtype(spec[1]), index), fill
+
+
+class work_arrays(collections.abc.MutableMapping):
+    """Cache of host work arrays keyed by (shape, dtype, index): created zeroed on first use, handed out again on every
+    later access -- cleared first unless the key says `fillzero=False` (mpibase.py:61-131; the demo fetches its
+    scratch fields through it, demo/spectral_dns_solver.py:67-68).  Device-side work buffers are owned by the plans and
+    never pass through here."""
+
+    def __init__(self):
+        self._arrays = {}
+        self.fillzero = True          # what the most recent key asked for (an attribute of the upstream class)
+
+    @property
+    def store(self):
+        return self._arrays
+
+    def _slot(self, key):
+        ident, self.fillzero = _parse_work_key(key)
+        return ident
 
     def __getitem__(self, key):
-        k = self._key(key)
-        if k not in self.store:
-            self.store[k] = np.zeros(k[0], dtype=k[1])
-        val = self.store[k]
-        if self.fillzero is True:
-            val.fill(0)
-        return val
+        ident = self._slot(key)
+        arr = self._arrays.get(ident)
+        if arr is None:
+            arr = self._arrays[ident] = np.zeros(ident[0], dtype=ident[1])
+        elif self.fillzero:
+            arr.fill(0)
+        return arr
 
     def __setitem__(self, key, value):
-        self.store[self._key(key)] = value
+        self._arrays[self._slot(key)] = value
 
     def __delitem__(self, key):
-        del self.store[self._key(key)]
+        del self._arrays[self._slot(key)]
 
     def __iter__(self):
-        return iter(self.store)
+        return iter(self._arrays)
 
     def __len__(self):
-        return len(self.store)
+        return len(self._arrays)
 
     def values(self):
         raise TypeError("Work arrays not iterable")

@@ -7,7 +7,6 @@ Real data (N0/P1, N1/P2, N2); complex data aligned in y (R2CY:
 world ranks, comm1 = P2 ranks of stride P1 (pencil.py:192-195).
 """
 import numpy as np
-from numpy.fft import fftfreq, rfftfreq
 
 from . import _lib, _padding
 from ._base import DistFFTBase, default_planner_effort
@@ -42,7 +41,7 @@ class R2CY(DistFFTBase):
                           planner_effort if planner_effort is not None else default_planner_effort())
         N = self.N
         self.Nf = int(N[2] // 2 + 1)
-        self.L = np.asarray(L).astype(float)
+        self.L = np.asarray(L).astype(self.float)      # upstream's `float` is the class dtype there (pencil.py:174-177)
         P = self.num_processes
         if not allow_single:
             assert P > 1
@@ -79,9 +78,11 @@ class R2CY(DistFFTBase):
             assert self._kind == _lib.R2C
             self.N1f = int(self.N1[2] // 2)
             self.N2f = int(self.N2[2] // 2)
-        self._create_plan(self._kind, self._decomp, p1=P1, pipeline=pipeline, drop_nyquist=drop)
+        self._describe(self._kind, self._decomp, p1=P1, pipeline=pipeline, drop_nyquist=drop)
         assert self._c_real_shape == tuple(self.real_shape())
         assert self._c_complex_shape == tuple(self.complex_shape()), (self._c_complex_shape, self.complex_shape())
+        self._mesh = self._block(half_axis=2 if self._kind == _lib.R2C else None)
+        self._create_plan()
 
     # -- shapes (pencil.py:248-287) ------------------------------------------------
     def real_shape(self):
@@ -141,42 +142,28 @@ class R2CY(DistFFTBase):
         fu.fill(0)
         return _padding.gather_fold(fp, fu, self.N[1], 1)
 
-    # -- host-side mesh helpers (pencil.py:289-349) ----------------------------------
+    # -- host-side mesh helpers (pencil.py:289-349, 945-969), answered by _mesh.Block from the layout ---------------
+    # One contract for both alignments (upstream's x-aligned class returns ky unsliced from
+    # `complex_local_wavenumbers` and has a kwarg-less `get_local_wavenumbermesh` that mis-slices kz on the ranks that
+    # hold the Nyquist column; neither is reproduced).
     def complex_local_wavenumbers(self):
-        s = self.complex_local_slice()
-        return (fftfreq(self.N[0], 1. / self.N[0]).astype(int)[s[0]],
-                fftfreq(self.N[1], 1. / self.N[1]).astype(int)[s[1]],
-                rfftfreq(self.N[2], 1. / self.N[2]).astype(int)[s[2]])
+        """Integer (kx, ky, kz) vectors of this rank's spectral block."""
+        return tuple(self._mesh.mode_vectors())
 
     def get_local_mesh(self):
-        s = self.real_local_slice()
-        X = list(np.ogrid[s[0], s[1], :self.N[2]])
-        for i in range(3):
-            X[i] = (X[i] * self.L[i] / self.N[i]).astype(self.float)
-        return [np.broadcast_to(x, self.real_shape()) for x in X]
+        """[x, y, z] of this rank's pencil as read-only views of real_shape() (y-aligned class, pencil.py:299-312)."""
+        return self._mesh.coordinates_sparse(self.float)
 
     def get_local_wavenumbermesh(self, scaled=False, broadcast=False, eliminate_highest_freq=False):
-        s = self.complex_local_slice()
-        kx = fftfreq(self.N[0], 1. / self.N[0]).astype(int)
-        ky = fftfreq(self.N[1], 1. / self.N[1]).astype(int)
-        kz = rfftfreq(self.N[2], 1. / self.N[2]).astype(int)
-        if eliminate_highest_freq:
-            for i, k in enumerate((kx, ky, kz)):
-                if self.N[i] % 2 == 0:
-                    k[self.N[i] // 2] = 0
-        Ks = list(np.meshgrid(kx[s[0]], ky[s[1]], kz[s[2]], indexing='ij', sparse=True))
-        if scaled is True:
-            Lp = 2 * np.pi / self.L
-            for i in range(3):
-                Ks[i] = (Ks[i] * Lp[i]).astype(self.float)
-        if broadcast is True:
-            return [np.broadcast_to(k, self.complex_shape()) for k in Ks]
-        return Ks
+        """[Kx, Ky, Kz] of this rank's spectral block: integers, or -- `scaled` by 2 pi / L -- the class's real dtype;
+        open unless `broadcast`; `eliminate_highest_freq` reports the Nyquist modes as zero."""
+        return self._mesh.wavenumber_grid(dtype=self.float, factors=2 * np.pi / self.L if scaled is True else None,
+                                          cast_first=False, zero_nyquist=eliminate_highest_freq,
+                                          dense=broadcast is True)
 
     def get_dealias_filter(self):
-        K = self.get_local_wavenumbermesh()
-        kmax = 2. / 3. * (self.N // 2 + 1)
-        return np.array((abs(K[0]) < kmax[0]) * (abs(K[1]) < kmax[1]) * (abs(K[2]) < kmax[2]), dtype=np.uint8)
+        """The 2/3-rule mask of this rank's spectral block (uint8)."""
+        return self._mesh.two_thirds_filter()
 
     # -- transforms ----------------------------------------------------------------
     def get_subarrays(self, padsize=1):
@@ -218,6 +205,10 @@ class R2CX(R2CY):
 
     def complex_shape(self):
         return (int(self.N[0]), int(self.N1[1]), self.N2f)
+
+    def get_local_mesh(self):
+        """(3, *real_shape()) array of coordinates (the x-aligned class returns a dense mesh, pencil.py:945-957)."""
+        return self._mesh.coordinates_dense(self.float)
 
     def complex_local_slice(self):
         c0, c1 = self.comm0_rank, self.comm1_rank

@@ -7,10 +7,10 @@ file keeps the reference's constructor signature, attributes, shape/slice
 methods, mesh helpers and exception types.
 """
 import numpy as np
-from numpy.fft import fftfreq, rfftfreq
 
 from . import _lib, _padding
 from ._base import DistFFTBase, default_planner_effort
+from ._mesh import dft_modes
 
 __all__ = ["R2C", "C2C"]
 
@@ -48,9 +48,11 @@ class R2C(DistFFTBase):
         if self.num_processes not in [2 ** i for i in range(int(np.log2(N[0])) + 1)]:
             raise IOError("Number of cpus must be in ", [2 ** i for i in range(int(np.log2(N[0])) + 1)])
         self._post_init()
-        self._create_plan(self._kind, _lib.SLAB, pipeline=pipeline)
+        self._describe(self._kind, _lib.SLAB, pipeline=pipeline)
         assert self._c_real_shape == tuple(self.real_shape())
         assert self._c_complex_shape == tuple(self.complex_shape())
+        self._mesh = self._block(half_axis=2 if self._kind == _lib.R2C else None)
+        self._create_plan()
 
     def _post_init(self):
         pass
@@ -109,41 +111,25 @@ class R2C(DistFFTBase):
                 slice(int(self.rank * self.Np[1]), int((self.rank + 1) * self.Np[1]), 1),
                 slice(0, self.Nf, 1))
 
-    # -- host-side mesh helpers (slab.py:146-197) ---------------------------------
+    # -- host-side mesh helpers (slab.py:146-197), answered by _mesh.Block from the layout --------------------------
     def complex_local_wavenumbers(self):
-        return (fftfreq(self.N[0], 1. / self.N[0]).astype(self.float),
-                fftfreq(self.N[1], 1. / self.N[1])[self.complex_local_slice()[1]].astype(self.float),
-                rfftfreq(self.N[2], 1. / self.N[2]).astype(self.float))
+        """(kx, ky of this rank's columns, kz) as vectors of the class's real dtype."""
+        return tuple(k.astype(self.float) for k in self._mesh.mode_vectors())
 
     def get_local_mesh(self):
-        X = list(np.ogrid[self.rank * self.Np[0]:(self.rank + 1) * self.Np[0], :self.N[1], :self.N[2]])
-        for i in range(3):
-            X[i] = (X[i] * self.L[i] / self.N[i]).astype(self.float)
-        return [np.broadcast_to(x, self.real_shape()) for x in X]
+        """[x, y, z] of this rank's planes, each a read-only view of real_shape()."""
+        return self._mesh.coordinates_sparse(self.float)
 
     def get_local_wavenumbermesh(self, scaled=False, broadcast=False, eliminate_highest_freq=False):
-        kx, ky, kz = self.complex_local_wavenumbers()
-        if eliminate_highest_freq:
-            ky = fftfreq(self.N[1], 1. / float(self.N[1]))
-            for i, k in enumerate((kx, ky, kz)):
-                if self.N[i] % 2 == 0:
-                    k[self.N[i] // 2] = 0
-            ky = ky[self.complex_local_slice()[1]]
-        Ks = list(np.meshgrid(kx, ky, kz, indexing='ij', sparse=True))
-        for i in range(3):
-            Ks[i] = Ks[i].astype(self.float)
-        if scaled:
-            Lp = 2 * np.pi / self.L
-            for i in range(3):
-                Ks[i] = Ks[i] * Lp[i]
-        if broadcast is True:
-            return [np.broadcast_to(k, self.complex_shape()) for k in Ks]
-        return Ks
+        """[Kx, Ky, Kz] of this rank's spectral block in the class's real dtype: open (1-D along their own axis) unless
+        `broadcast`; `scaled` by 2 pi / L; `eliminate_highest_freq` reports the Nyquist modes as zero."""
+        return self._mesh.wavenumber_grid(dtype=self.float, factors=2 * np.pi / self.L if scaled else None,
+                                          cast_first=True, zero_nyquist=eliminate_highest_freq,
+                                          dense=broadcast is True)
 
     def get_dealias_filter(self):
-        K = self.get_local_wavenumbermesh()
-        kmax = 2. / 3. * (self.N // 2 + 1)
-        return np.array((abs(K[0]) < kmax[0]) * (abs(K[1]) < kmax[1]) * (abs(K[2]) < kmax[2]), dtype=np.uint8)
+        """The 2/3-rule mask of this rank's spectral block (uint8)."""
+        return self._mesh.two_thirds_filter()
 
     # -- transforms ---------------------------------------------------------------
     def get_subarrays(self, padsize=1):
@@ -197,19 +183,14 @@ class C2C(R2C):
         self.transformed_shape = self.complex_shape
         self.original_local_slice = self.real_local_slice
         self.transformed_local_slice = self.complex_local_slice
-        self.ks = np.rint(fftfreq(N[2]) * N[2]).astype(int)      # exact (the reference truncates: see oracle._exact_ks)
+        self.ks = dft_modes(N[2])      # exact integers (the reference truncates a float: see oracle._exact_ks)
 
     def global_shape(self, padsize=1.):
         return (int(padsize * self.N[0]), int(padsize * self.N[1]), int(padsize * self.N[2]))
 
     def transformed_local_wavenumbers(self):
-        return (fftfreq(self.N[0], 1. / self.N[0]),
-                fftfreq(self.N[1], 1. / self.N[1])[self.transformed_local_slice()[1]],
-                fftfreq(self.N[2], 1. / self.N[2]))
-
-    def complex_local_wavenumbers(self):
-        kx, ky, kz = self.transformed_local_wavenumbers()
-        return (kx.astype(self.float), ky.astype(self.float), kz.astype(self.float))
+        """Float64 wave vectors of the transformed block (slab.py:612-616)."""
+        return tuple(k.astype(np.float64) for k in self._mesh.mode_vectors())
 
     def _in_dtype(self):
         return self.complex

@@ -218,11 +218,78 @@ def subarrays():
     return table
 
 
+def helpers_golden():
+    """Host helper API of the reference classes (slab.py:146-197, pencil.py:289-349, 945-957, line.py:105-134,
+    mpibase.py:61-131), every rank of every decomposition on a mesh with three different box lengths:
+    get_local_mesh, complex_local_wavenumbers, get_local_wavenumbermesh for all 8 (scaled, broadcast,
+    eliminate_highest_freq) combinations, get_dealias_filter.  Keys: <class>_P<P>[_P1<p1>]_r<rank>_<what>[_<axis>]."""
+    N = [8, 16, 32]
+    Lb = np.array([2 * np.pi, 4 * np.pi, 3.0])
+    combos = [(s, b, e) for s in (False, True) for b in (False, True) for e in (False, True)]
+    for prec in ("double", "single"):
+        out = dict(N=np.array(N), L=Lb)
+
+        def put(tag, rank, F, mesh_kw=True, kvec=True):
+            pre = "%s_r%d_" % (tag, rank)
+            res = {}
+            X = F.get_local_mesh()
+            for i in range(len(X)):
+                res[pre + "mesh_%d" % i] = np.array(X[i])
+            if kvec:
+                for i, k in enumerate(F.complex_local_wavenumbers()):
+                    res[pre + "kvec_%d" % i] = np.array(k)
+            if mesh_kw:
+                for (s_, b_, e_) in combos:
+                    K = F.get_local_wavenumbermesh(scaled=s_, broadcast=b_, eliminate_highest_freq=e_)
+                    for i in range(len(K)):
+                        res[pre + "K_s%d_b%d_e%d_%d" % (s_, b_, e_, i)] = np.array(K[i])
+            res[pre + "dealias"] = np.array(F.get_dealias_filter())
+            return res
+
+        for P in (1, 2, 4, 8):
+            def slab(rank):
+                return put("slab_P%d" % P, rank, RefSlab(np.array(N), Lb.copy(), MPI.COMM_WORLD, prec))
+            for d in fake_mpi.run(P, slab):
+                out.update(d)
+        for P in (1, 2):
+            def slabc(rank):
+                # upstream's C2C class inherits the R2C wave-number helpers (half-spectrum kz for a full-spectrum array):
+                # only the helper that is its own is recorded
+                F = RefSlabC2C(np.array(N), Lb.copy(), MPI.COMM_WORLD, prec)
+                return {"slabc2c_P%d_r%d_tkvec_%d" % (P, rank, i): np.array(k)
+                        for i, k in enumerate(F.transformed_local_wavenumbers())}
+            for d in fake_mpi.run(P, slabc):
+                out.update(d)
+        for P, P1 in ((4, None), (8, None), (8, 2)):
+            for align in ("Y", "X"):
+                def pen(rank):
+                    F = RefPencil(np.array(N), Lb.copy(), MPI.COMM_WORLD, prec, P1=P1, communication="Alltoallw",
+                                  alignment=align)
+                    # x-aligned: only the mesh, the wave vectors (upstream leaves ky unsliced there: recorded as it is)
+                    # and the filter follow the common contract; its get_local_wavenumbermesh has another signature
+                    return put("pencil%s_P%d_P1%s" % (align, P, P1), rank, F, mesh_kw=(align == "Y"))
+                for d in fake_mpi.run(P, pen):
+                    out.update(d)
+        from mpiFFT4py.line import R2C as RefLine
+        N2, L2 = [16, 48], np.array([2 * np.pi, 5.0])
+        out["N_line"], out["L_line"] = np.array(N2), L2
+        for P in (1, 2, 4):
+            def line(rank):
+                return put("line_P%d" % P, rank, RefLine(np.array(N2), L2.copy(), MPI.COMM_WORLD, prec), kvec=False)
+            for d in fake_mpi.run(P, line):
+                out.update(d)
+        np.savez_compressed(os.path.join(OUT, "helpers_%s.npz" % prec), **out)
+    print("helper fixtures written")
+
+
 def main():
     import sys
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "line":
         return line_golden()
+    if len(sys.argv) > 1 and sys.argv[1] == "helpers":
+        return helpers_golden()
+    helpers_golden()
     line_golden()
     with open(os.path.join(OUT, "layouts.json"), "w") as f:
         json.dump(layouts(), f, separators=(",", ":"))

@@ -6,9 +6,9 @@ Starts WORLD ranks on the visible GPU(s) over the IPC transport.  Iteration k tr
 compares the forward result with (k + 1) * the first iteration's result and the round trip with u_k, so a chunk pulled
 before its sender had written it, or after the sender had overwritten it, cannot hide behind identical data.  (The
 per-block factors it prints are of the TRANSFORMED result, in which the x pass has mixed the peers' blocks: they say
-that an iteration went wrong, not which peer's chunk it was.)  MFFT_IPC_STREAM_FLAGS=1 puts the flag operations of the
-"streams" mode on the per-peer streams (round 2's experiment).  8 processes on ONE device take minutes per run in
-that mode."""
+that an iteration went wrong, not which peer's chunk it was.)  (Round 3 also ran it with MFFT_IPC_STREAM_FLAGS=1, the
+round-2 form of the "streams" mode with the flag operations on the per-peer streams; that form was removed in round 4,
+the switch does nothing any more.)"""
 import os
 import subprocess
 import sys
@@ -77,7 +77,7 @@ def main():
     tot = comm.allreduce(float(bad))
     if rank == 0:
         print("IPC_STRESS world=%d pull=%d pipeline=%d iterations=%d flags_on_peer_streams=%s: %d bad blocks"
-              % (P, mode, pipeline, iters, os.environ.get("MFFT_IPC_STREAM_FLAGS", "0"), int(tot)), flush=True)
+              % (P, mode, pipeline, iters, "removed", int(tot)), flush=True)
 
 
 if __name__ == "__main__":

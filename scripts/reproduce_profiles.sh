@@ -29,7 +29,8 @@ run() {
     r02_placement_probe.txt) python scripts/placement_probe.py ;;
     r02_placement_reroll.txt) python scripts/reroll_probe.py ;;
     r02_two_thirds_rule_mask.txt) python scripts/maskprof.py 1024 double; python scripts/maskprof.py 1024 single; python scripts/maskprof_ranks.py 1024 2; python scripts/maskprof_ranks.py 1024 8 ;;
-    r02_ipc_fanout_probe.txt) MFFT_IPC_PULL=streams MFFT_IPC_STREAM_FLAGS=1 python bench.py --gpus 8 --size 128 --steps 3 --warmup 1 --cpu-baseline off --pencil-extra off --transport ipc ;;
+    r02_ipc_fanout_probe.txt) git checkout 292508d -- mpifft4py_amd/csrc/ipc_comm.hip && make -C mpifft4py_amd/csrc -j8 &&   # the per-peer-stream flag form was removed in round 4
+      MFFT_IPC_PULL=streams MFFT_IPC_STREAM_FLAGS=1 python bench.py --gpus 8 --size 128 --steps 3 --warmup 1 --cpu-baseline off --pencil-extra off --transport ipc ;;
     r02_bench_after_two_wg_plan.json|r02_final_bench_1024cubed.json|r03_final_bench_1024cubed.json) python bench.py --steps 10 --warmup 3 ;;
     r03_final_*) bash scripts/profile_r03.sh bench; python scripts/summarize_profiles.py r03_final gpurun_out/prof_r03/trace gpurun_out/prof_r03/fetch gpurun_out/prof_r03/write "bench.py --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off: 1024^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_final gpurun_out/prof_r03/sq1 gpurun_out/prof_r03/sq2 ;;
     r03_720_*) bash scripts/profile_cmd.sh b720 bench.py --size 720 --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off; python scripts/summarize_profiles.py r03_720 gpurun_out/prof_b720/trace gpurun_out/prof_b720/fetch gpurun_out/prof_b720/write "bench.py --size 720: 720^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_720 gpurun_out/prof_b720/sq1 gpurun_out/prof_b720/sq2 ;;
@@ -39,7 +40,7 @@ run() {
     r03_kbench3_quarter_exchange.txt) tools kbench3; tools/build/kbench3 q1536 5 ;;
     r03_cu_mask_probe.txt) tools overlap_probe; tools/build/overlap_probe 8 16 32 ;;
     r03_overlap.txt) for c in "p4_kz4 4 1024 4 1" "p4_rows4 4 1024 -4 1" "p2_kz4 2 1024 4 1" "p4_kz4_copy 4 1024 4 0" "p8_kz4 8 1024 4 1"; do scripts/overlap_trace.sh $c; set -- $c; python scripts/summarize_overlap.py gpurun_out/overlap_$1; done ;;
-    r03_ipc_pull_modes.txt) bash scripts/r03_first_gpu.sh; bash scripts/r03_gpu3.sh; MFFT_IPC_STREAM_FLAGS=1 python scripts/ipc_stress.py 8 2 -4 60 128 ;;
+    r03_ipc_pull_modes.txt) bash scripts/r03_first_gpu.sh; bash scripts/r03_gpu3.sh; MFFT_IPC_STREAM_FLAGS=1 python scripts/ipc_stress.py 8 2 -4 60 128 ;;   # (the switch exists up to commit 292508d only)
     r03_shared_gpu_pipeline_latency.txt) bash scripts/r03_gpu2.sh ;;
     r03_two_thirds_rule_ranks.txt) python scripts/maskprof_ranks.py 1024 8 ;;
     r03_pencil_dealias.txt) for k in X Y; do for p in double single; do python scripts/maskprof.py 1024 $p $k; MFFT_NO_PRUNE=1 python scripts/maskprof.py 1024 $p $k; done; python scripts/padprof.py 512 $k; done; python scripts/padprof.py 512 slab ;;

@@ -48,16 +48,21 @@ def test_version_and_lengths(lib):
     for n in (30, 240, 480, 720, 900, 960, 1200, 1440, 1800, 750, 1500, 1920, 2400, 3000, 3840):   # round 3: 3 and 5 among the factors
         assert lib.mfft_length_supported(n, 0) == 1, n
         assert lib.mfft_length_supported(2 * n, 1) == 1, n
-    assert lib.mfft_length_supported(2100, 0) == 0 and lib.mfft_length_supported(3600, 0) == 0     # no plan, beyond chirp-z
-    for n in (8, 64, 1024, 2048, 8192, 48, 96, 1536, 4000):
+    for n in (14, 28, 56, 112, 224, 448, 896, 1792, 3584, 8192):      # round 4: 7 * 2^a radix plans, 8192
+        assert lib.mfft_length_supported(n, 0) == 1, n
+        assert lib.mfft_length_supported(2 * n, 1) == 1, n
+    for n in (8, 64, 1024, 2048, 8192, 16384, 48, 96, 1536, 4000):
         assert lib.mfft_length_supported(n, 1) == 1, n
-    for n in (7, 11, 13, 17, 36, 1001, 2047):           # chirp-z range: 2n-1 <= 4096
+    # chirp-z range: 2n-1 <= 8192, i.e. EVERY length up to 4096 (numpy_fft.py:25-46: the reference takes any n)
+    for n in (7, 11, 13, 17, 36, 1001, 2047, 2049, 2100, 2688, 3600, 4093, 4095):
         assert lib.mfft_length_supported(n, 0) == 1, n
         assert lib.mfft_length_supported(n, 1) == 1, n
-    for n in (2049, 4097, 5000):
+    assert all(lib.mfft_length_supported(n, 0) == 1 for n in range(1, 4097))
+    assert all(lib.mfft_length_supported(n, 1) == 1 for n in range(2, 4097))
+    for n in (4097, 5000, 8191):
         assert lib.mfft_length_supported(n, 0) == 0, n
-    assert lib.mfft_length_supported(2050, 1) == 1      # even real rows: chirp-z of n/2 complex values
-    assert lib.mfft_length_supported(2051, 1) == 0 and lib.mfft_length_supported(4100, 1) == 0
+    assert lib.mfft_length_supported(4098, 1) == 1 and lib.mfft_length_supported(8190, 1) == 1      # even real rows: chirp-z of n/2 complex values
+    assert lib.mfft_length_supported(4099, 1) == 0 and lib.mfft_length_supported(8194, 1) == 0
 
 
 def test_fails_loudly_without_gpu(lib):
@@ -77,8 +82,8 @@ def test_emulator_passes():
     import glob
     csrc = os.path.join(ROOT, "mpifft4py_amd", "csrc")
     subprocess.check_call(["make", "-C", csrc, "-j", "7", "emu"])
-    parts = sorted(glob.glob(os.path.join(csrc, "build", "emu_test_[0-9]")))
-    assert len(parts) == 10, parts         # the plan list is split over ten binaries (Makefile: EMU_PARTS)
+    parts = sorted(glob.glob(os.path.join(csrc, "build", "emu_test_[0-9]")) + glob.glob(os.path.join(csrc, "build", "emu_test_[0-9][0-9]")))
+    assert len(parts) == 12, parts         # the plan list is split over twelve binaries (Makefile: EMU_PARTS)
     procs = [subprocess.Popen([p], stdout=subprocess.PIPE) for p in parts]
     for p, proc in zip(parts, procs):
         out = proc.communicate()[0].decode()

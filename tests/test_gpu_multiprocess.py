@@ -48,6 +48,8 @@ def _env(transport="mock"):
     env.setdefault("MP_WORKER_VERBOSE", "1")
     if transport == "ipc":
         env["MFFT_TRANSPORT"] = "ipc"
+    elif transport == "rccl":            # the real librccl: needs a device per rank (tests/test_gpu_zz_multidevice.py)
+        env["MFFT_TRANSPORT"] = "rccl"
     else:
         env.update(MFFT_RCCL_LIB=MOCK, MOCK_RCCL_SLOT_KB="2048")
     return env

@@ -364,6 +364,70 @@ def test_two_thirds_rule_edge_masks(kind, P):
         assert np.abs(u - want[rsl]).max() <= 1e-13 * max(np.abs(want).max(), 1e-300), kind     # the oracle's arithmetic
 
 
+@pytest.mark.parametrize("decomp,P", [("slab", 1), ("slab", 4), ("pencilY", 4)])
+def test_two_thirds_rule_filter_edited_in_place(decomp, P):
+    """The reference multiplies by `self.dealias` on every '2/3-rule' call (slab.py:237-245), so an IN-PLACE edit of the
+    filter counts from the next call on.  Here the filter lives on the device: the classes fingerprint the host array at
+    upload and re-upload -- collectively, after a vote -- when it changed.  Only ONE rank's block is edited (the others
+    must follow through the vote), then the lazily built filter is replaced by a bigger one (> 4 MB: the sampled
+    fingerprint) and edited by a band."""
+    from mpifft4py_amd import Pencil_R2C, Slab_R2C
+    N = [32, 64, 128]
+    C = np.fft.rfftn(np.random.default_rng(41).random(N))
+
+    def body(comm):
+        F = (Slab_R2C(np.array(N), L, comm, "double") if decomp == "slab" else
+             Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment="Y"))
+        sl = F.complex_local_slice()
+        c = np.ascontiguousarray(C[sl])
+        out = []
+        u0 = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule").copy()      # builds F.dealias lazily
+        m0 = np.broadcast_to(F.dealias, F.complex_shape()).copy()
+        out.append((u0, m0))
+        assert F.dealias.flags.writeable
+        if comm.Get_rank() == P - 1:
+            F.dealias[:, :, 3:] = 0                                             # in place, on one rank only
+        u1 = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule").copy()
+        out.append((u1, np.broadcast_to(F.dealias, F.complex_shape()).copy()))
+        F.dealias[...] = 1                                                      # "no dealiasing", still in place
+        u2 = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule").copy()
+        out.append((u2, np.broadcast_to(F.dealias, F.complex_shape()).copy()))
+        F.dealias_check = False                                                 # documented opt-out: edits are NOT seen
+        F.dealias[...] = 0
+        u3 = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule").copy()
+        out.append((u3, np.ones(F.complex_shape(), dtype=np.uint8)))
+        F.dealias = F.dealias                                                   # ... until the attribute is assigned
+        u4 = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule").copy()
+        out.append((u4, np.zeros(F.complex_shape(), dtype=np.uint8)))
+        return out, sl, F.real_local_slice()
+    res = run_ranks(P, body)
+    for step in range(5):
+        M = np.zeros(C.shape, dtype=np.uint8)
+        for out, sl, _ in res:
+            M[sl] = out[step][1]
+        want = np.fft.irfftn(C * M, s=N, axes=(0, 1, 2))
+        for out, _, rsl in res:
+            assert np.abs(out[step][0] - want[rsl]).max() <= 1e-13 * max(np.abs(want).max(), 1.0), (step,)
+    assert not np.array_equal(res[0][0][0][0], res[0][0][1][0]) or P == 1      # the other ranks' results changed too
+
+
+def test_two_thirds_rule_large_filter_sampled_fingerprint():
+    """A filter above 4 MB is fingerprinted by 65 536 samples: band and plane edits are seen."""
+    from mpifft4py_amd import Slab_R2C
+    from mpifft4py_amd import SelfComm
+    N = [128, 128, 512]
+    F = Slab_R2C(np.array(N), L, SelfComm(0), "single")
+    assert np.prod(F.complex_shape()) > F._FULL_HASH_BYTES
+    C = np.fft.rfftn(np.random.default_rng(5).random(N)).astype(np.complex64)
+    u0 = F.ifftn(C, np.zeros(F.real_shape(), dtype=np.float32), dealias="2/3-rule").copy()
+    F.dealias[:, 10:20, :] = 0
+    M = np.broadcast_to(F.dealias, F.complex_shape())
+    u1 = F.ifftn(C, np.zeros(F.real_shape(), dtype=np.float32), dealias="2/3-rule").copy()
+    want = np.fft.irfftn(C.astype(np.complex128) * M, s=N, axes=(0, 1, 2))
+    assert orc.rel_l2(u1, want) < 4 * TOL["single"]
+    assert orc.rel_l2(u0, want) > 1e-3
+
+
 @pytest.mark.parametrize("prec", ["double", "single"])
 @pytest.mark.parametrize("decomp,P,pipeline", [("slab", 2, 0), ("pencilX", 4, 1), ("pencilX", 4, 4), ("pencilX", 8, 2), ("pencilX", 1, 1),
                                                ("pencilY", 4, 1), ("pencilY", 4, 4), ("pencilY", 8, 1), ("pencilY", 16, 2)])

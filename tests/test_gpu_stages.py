@@ -17,7 +17,9 @@ LENGTHS = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096,
            18, 36, 72, 144, 288, 576, 1152, 2304, 50, 100, 200, 400, 800, 1600, 250, 500, 1000, 2000,
            # lengths with both 3 and 5 among their factors (plans.h groups L, M: 30 values per thread)
            30, 60, 90, 120, 150, 180, 240, 300, 360, 450, 480, 600, 720, 900, 960, 1200, 1440, 1800,
-           750, 1500, 1920, 2400, 3000, 3840]
+           750, 1500, 1920, 2400, 3000, 3840,
+           # round 4: 7 * 2^a (plans.h group O: 28 values per thread, radix 28 = 7 x 4) and 8192
+           14, 28, 56, 112, 224, 448, 896, 1792, 3584, 8192]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -149,16 +151,18 @@ def test_dealias_filter(prec):
 def test_unsupported_length_raises():
     import mpifft4py_amd as m
     from mpifft4py_amd import _lib
-    with pytest.raises(_lib.MfftError):          # chirp-z needs 2n-1 <= 4096
-        m.fft(np.zeros((2049, 4, 4), dtype=np.complex128), axis=0)
+    with pytest.raises(_lib.MfftError):          # chirp-z needs 2n-1 <= 8192
+        m.fft(np.zeros((4097, 4, 4), dtype=np.complex128), axis=0)
     with pytest.raises(_lib.MfftError):
-        m.rfft(np.zeros((2, 2, 2051)), axis=2)
+        m.rfft(np.zeros((2, 2, 4099)), axis=2)
 
 
 # lengths without a radix plan: chirp-z kernels (csrc/fft_chirpz.h); primes, prime powers, 7-smooth,
 # odd 15-smooth ones, and the range ends of several convolution lengths
 CHIRPZ = [3, 5, 7, 9, 11, 13, 15, 17, 25, 27, 31, 33, 45, 49, 75, 84, 127, 129, 255, 257, 504,
-          675, 729, 1008, 1023, 1025, 1201, 1537, 2047]
+          675, 729, 1008, 1023, 1025, 1201, 1537, 2047,
+          # round 4: convolution length 8192 -- everything up to 4096 (7-smooth meshes like 2688 = 21 * 128, primes, range ends)
+          2049, 2100, 2688, 3125, 3600, 4093, 4095]
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
@@ -177,7 +181,7 @@ def test_c2c_arbitrary_length_every_axis(n, prec):
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("n", CHIRPZ + [14, 22, 30, 126, 258, 1026, 2046, 2050, 3000, 4094])
+@pytest.mark.parametrize("n", CHIRPZ + [22, 126, 258, 1026, 2046, 2050, 4094, 4098, 5000, 8190])
 def test_rfft_irfft_arbitrary_length(n, prec):
     """Real transforms of any length, odd ones included (numpy_fft.py:39-51 with n given by the output)."""
     from mpifft4py_amd import rfft, irfft
