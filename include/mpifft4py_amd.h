@@ -240,6 +240,16 @@ MFFT_API int mfft_ew_axpbz(mfft_plan_t plan, void* y, const void* x, const void*
                            int precision);                                                              /* demo:94-97 */
 MFFT_API int mfft_ew_sumsq(mfft_plan_t plan, const void* x, size_t n_real, int precision, double* result_host);           /* demo:103 */
 
+/* Direct evaluation of up to 16 DFT bins of a distributed field, for checking transforms of meshes that no host
+ * transform can hold (BASELINE config 5, 2048^3): result[2b], result[2b+1] = Re, Im of
+ *   sum over this rank's block u[x][y][z] * exp(-/+ 2 pi i (k0 (start0 + x) / n0 + k1 (start1 + y) / n1 + k2 (start2 + z) / n2)),
+ * bins[3b .. 3b+2] = (k0, k1, k2), sign - for inverse = 0; products and sums in double precision, phase tables exact
+ * (integer reduction mod n, long double).  The global bin is the sum of the ranks' results.  Synchronous.  What the
+ * reference's tests do by comparing with a serial transform of the same data (tests/test_FFT.py:66-91). */
+MFFT_API int mfft_ew_dft_bins(mfft_plan_t plan, const void* u, int is_complex, const int64_t shape[3], const int64_t start[3],
+                              const int64_t n[3], int inverse, int nbins, const int64_t* bins_host, int precision,
+                              double* result_host);
+
 /* ---- HIP-event timers on the default stream (bench.py) ------------------ */
 typedef struct mfft_timer_s* mfft_timer_t;
 MFFT_API int mfft_timer_create(mfft_timer_t* t);

@@ -94,6 +94,8 @@ _SIGNATURES = {
     "mfft_ew_ns_rhs": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_double, c_int], c_int),
     "mfft_ew_axpbz": ([c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_size_t, c_int], c_int),
     "mfft_ew_sumsq": ([c_void_p, c_void_p, c_size_t, c_int, POINTER(c_double)], c_int),
+    "mfft_ew_dft_bins": ([c_void_p, c_void_p, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int, c_int,
+                          POINTER(c_int64), c_int, POINTER(c_double)], c_int),
     "mfft_timer_create": ([POINTER(c_void_p)], c_int),
     "mfft_timer_start": ([c_void_p], c_int),
     "mfft_timer_stop": ([c_void_p, POINTER(c_float)], c_int),

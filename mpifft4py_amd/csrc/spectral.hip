@@ -4,6 +4,8 @@
 // demo/spectral_dns_solver.py:53-80).  All HBM-bound, 16 B per lane where the
 // layout allows.  Fields are (3, n) component-major; wavenumbers are passed as
 // three 1-D device vectors of the local spectral extents.
+#include <math.h>
+#include <vector>
 #include "mfft_internal.h"
 
 using namespace mfft;
@@ -92,9 +94,101 @@ __global__ __launch_bounds__(EW_BLOCK) void sumsq_kernel(const T* __restrict__ x
   }
 }
 
+// Direct evaluation of a few DFT bins of a distributed field (a checker for meshes too large for a host transform):
+//   S[b] = sum over this rank's block of u[x, y, z] * wx_b[x] * wy_b[y] * wz_b[z],  w_b[.] = exp(-/+ 2 pi i k_b g / N)
+// with the three phase tables of every bin evaluated on the host (exact integer reduction of k g mod N, long double)
+// and the products / sums in double precision whatever the field's.  One pass over the block for up to DFT_MAX_BINS bins.
+constexpr int DFT_MAX_BINS = 16;
+template <typename T, bool COMPLEX>
+__global__ __launch_bounds__(EW_BLOCK) void dft_bins_kernel(const void* __restrict__ u, int64_t s0, int64_t s1, int64_t s2,
+                                                           const cx<double>* __restrict__ tab, int nbins, double* out) {
+  __shared__ double part[EW_BLOCK / 64][2 * DFT_MAX_BINS];
+  double ar[DFT_MAX_BINS], ai[DFT_MAX_BINS];
+#pragma unroll
+  for (int b = 0; b < DFT_MAX_BINS; ++b) ar[b] = ai[b] = 0;
+  const size_t n = (size_t)(s0 * s1 * s2);
+  const int64_t per = s0 + s1 + s2;                  // entries of one bin's three tables
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int64_t z = (int64_t)(i % (size_t)s2), y = (int64_t)((i / (size_t)s2) % (size_t)s1), x = (int64_t)(i / (size_t)(s2 * s1));
+    double vr, vi;
+    if constexpr (COMPLEX) { const cx<T> v = static_cast<const cx<T>*>(u)[i]; vr = (double)v.x; vi = (double)v.y; }
+    else { vr = (double)static_cast<const T*>(u)[i]; vi = 0; }
+#pragma unroll
+    for (int b = 0; b < DFT_MAX_BINS; ++b) {
+      if (b >= nbins) break;
+      const cx<double>* t = tab + (size_t)b * per;
+      const cx<double> w = t[x] * t[s0 + y] * t[s0 + s1 + z];
+      ar[b] += vr * w.x - vi * w.y;
+      ai[b] += vr * w.y + vi * w.x;
+    }
+  }
+  for (int b = 0; b < nbins; ++b) {
+    double r = ar[b], m = ai[b];
+    for (int o = 32; o > 0; o >>= 1) { r += __shfl_down(r, o, 64); m += __shfl_down(m, o, 64); }
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][2 * b] = r; part[threadIdx.x >> 6][2 * b + 1] = m; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * nbins) {
+    double t = 0;
+    for (int w = 0; w < EW_BLOCK / 64; ++w) t += part[w][threadIdx.x];
+    atomicAdd(out + threadIdx.x, t);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int mfft_ew_dft_bins(mfft_plan_t plan, const void* u, int is_complex, const int64_t shape[3], const int64_t start[3],
+                     const int64_t n[3], int inverse, int nbins, const int64_t* bins, int precision, double* result_host) {
+  hipStream_t st = plan_stream(plan);
+  if (!u || !shape || !start || !n || !bins || !result_host) return set_error(MFFT_ERR_INVALID, "null argument");
+  if (nbins < 1 || nbins > DFT_MAX_BINS) return set_error(MFFT_ERR_INVALID, "1 .. %d bins per call", DFT_MAX_BINS);
+  for (int a = 0; a < 3; ++a)
+    if (shape[a] < 1 || n[a] < 1 || start[a] < 0 || start[a] + shape[a] > n[a]) return set_error(MFFT_ERR_INVALID, "block outside the mesh");
+  const int64_t per = shape[0] + shape[1] + shape[2];
+  std::vector<cx<double>> tab((size_t)per * nbins);
+  const long double two_pi = 6.283185307179586476925286766559L;
+  for (int b = 0; b < nbins; ++b) {
+    cx<double>* t = tab.data() + (size_t)b * per;
+    for (int a = 0; a < 3; ++a) {
+      const int64_t k = ((bins[3 * b + a] % n[a]) + n[a]) % n[a];
+      for (int64_t i = 0; i < shape[a]; ++i) {
+        const int64_t r = (int64_t)(((__int128)k * (__int128)(start[a] + i)) % (__int128)n[a]);
+        const long double ang = two_pi * (long double)r / (long double)n[a];
+        t[i] = mk<double>((double)cosl(ang), (double)(inverse ? sinl(ang) : -sinl(ang)));
+      }
+      t += shape[a];
+    }
+  }
+  cx<double>* dtab = nullptr;
+  double* dout = nullptr;
+  MFFT_HIP(hipMalloc(reinterpret_cast<void**>(&dtab), tab.size() * sizeof(cx<double>)));
+  if (hipMalloc(reinterpret_cast<void**>(&dout), 2 * DFT_MAX_BINS * sizeof(double)) != hipSuccess) {
+    (void)hipFree(dtab);
+    return set_error(MFFT_ERR_NOMEM, "hipMalloc failed");
+  }
+  hipError_t e = hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(cx<double>), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(dout, 0, 2 * DFT_MAX_BINS * sizeof(double), st);
+  if (e == hipSuccess) {
+    const size_t cnt = (size_t)(shape[0] * shape[1] * shape[2]);
+    const dim3 grid(ew_grid(cnt)), block(EW_BLOCK);
+    if (precision == MFFT_DOUBLE) {
+      if (is_complex) hipLaunchKernelGGL((dft_bins_kernel<double, true>), grid, block, 0, st, u, shape[0], shape[1], shape[2], dtab, nbins, dout);
+      else hipLaunchKernelGGL((dft_bins_kernel<double, false>), grid, block, 0, st, u, shape[0], shape[1], shape[2], dtab, nbins, dout);
+    } else {
+      if (is_complex) hipLaunchKernelGGL((dft_bins_kernel<float, true>), grid, block, 0, st, u, shape[0], shape[1], shape[2], dtab, nbins, dout);
+      else hipLaunchKernelGGL((dft_bins_kernel<float, false>), grid, block, 0, st, u, shape[0], shape[1], shape[2], dtab, nbins, dout);
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(result_host, dout, 2 * (size_t)nbins * sizeof(double), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);        // (tab must outlive the copy out of it)
+  (void)hipFree(dtab);
+  (void)hipFree(dout);
+  if (e != hipSuccess) return set_error(MFFT_ERR_HIP, "mfft_ew_dft_bins: %s", hipGetErrorString(e));
+  return 0;
+}
 
 int mfft_ew_cross(mfft_plan_t plan, const void* a, const void* b, void* out, size_t n, int precision) {
   hipStream_t st = plan_stream(plan);

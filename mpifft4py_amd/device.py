@@ -96,6 +96,15 @@ class DeviceArray(object):
         v._base = self
         return v
 
+    def element(self, flat_index):
+        """One element (by flat C-order index) copied to the host."""
+        i = int(flat_index)
+        if not 0 <= i < self.size:
+            raise IndexError(flat_index)
+        out = np.empty(1, dtype=self.dtype)
+        _lib.call("mfft_memcpy_d2h", out.ctypes.data, self.ptr + i * self.dtype.itemsize, self.dtype.itemsize)
+        return out[0]
+
     def free(self):
         if self._owner and self.ptr:
             _lib.call("mfft_free", self.ptr)

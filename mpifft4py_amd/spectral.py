@@ -60,3 +60,23 @@ def sumsq(FFT, x):
     r = ctypes.c_double(0.0)
     _lib.call("mfft_ew_sumsq", FFT._plan, x.ptr, n_real, _prec(FFT), ctypes.byref(r))
     return r.value
+
+
+def dft_bins(FFT, u, bins, start, is_input=True, inverse=False):
+    """Partial sums of DFT bins over this rank's block of a field (mfft_ew_dft_bins): `u` a DeviceArray holding the
+    block whose first element sits at the global index `start`; bins an (nb, 3) integer array.  Returns a complex
+    vector of length nb; the global bin is the sum over the ranks.  Evaluated by definition in double precision --
+    an independent check of a transform too large for any host FFT."""
+    bins = np.ascontiguousarray(np.asarray(bins, dtype=np.int64).reshape(-1, 3))
+    N = FFT.global_shape() if hasattr(FFT, "global_shape") else FFT.global_real_shape()
+    out = np.zeros(len(bins), dtype=np.complex128)
+    shape = (ctypes.c_int64 * 3)(*[int(x) for x in u.shape])
+    st = (ctypes.c_int64 * 3)(*[int(x) for x in start])
+    n3 = (ctypes.c_int64 * 3)(*[int(x) for x in N])
+    for i in range(0, len(bins), 16):
+        chunk = bins[i:i + 16]
+        res = (ctypes.c_double * (2 * len(chunk)))()
+        _lib.call("mfft_ew_dft_bins", FFT._plan, u.ptr, 1 if u.dtype.kind == "c" else 0, shape, st, n3,
+                  1 if inverse else 0, len(chunk), chunk.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _prec(FFT), res)
+        out[i:i + len(chunk)] = np.array(res[:]).view(np.complex128)
+    return out

@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
 
   /* error path: a length beyond the chirp-z range must fail with a message, not crash */
   mfft_plan_desc bad = d;
-  bad.n[0] = 2051;
+  bad.n[0] = 4099;
   mfft_plan_t p2 = NULL;
   const int rc = mfft_plan_create(comm, &bad, &p2);
   const int err_ok = rc < 0 && strlen(mfft_last_error()) > 0 && p2 == NULL;

@@ -24,7 +24,8 @@ def test_random_configurations_match_the_oracle(seed):
 
 def test_config5_full_size_pencil_c2c(record_property):
     """BASELINE config 5 at its full size, 2048^3 complex64 pencil C2C over 8 ranks (all on this GPU, 275 GB of HBM):
-    Parseval through device-side reductions and the round trip on sampled planes (scripts/config5_full.py).  The
+    Parseval through device-side reductions, the round trip on sampled planes and -- round 4 -- 128 output bins (16 per
+    rank) against the DFT definition evaluated on the device in double precision (scripts/config5_full.py).  The
     script runs in a process of its own (this one's HBM pools do not count against it), prints the size it ran and
     the free HBM it found; on a 288 GB device the size MUST be 2048: nothing shrinks silently."""
     import ctypes
@@ -48,6 +49,9 @@ def test_config5_full_size_pencil_c2c(record_property):
     t = re.search(r"pair time .*: ([0-9.]+) ms", out)
     if t:
         record_property("config5_pair_ms_8_ranks_one_gpu", float(t.group(1)))
+    b = re.search(r"bin check: (\d+) bins .* = ([0-9.e+-]+) ", out)
+    assert b and int(b.group(1)) == 128 and float(b.group(2)) < 1e-5, out[-3000:]
+    record_property("config5_bin_check_max_err_over_rms", float(b.group(2)))
     # a 288 GB part holds the four 8.6 GB buffers of all 8 ranks: anything smaller than 2048^3 there is a FAILURE
     if total.value >= 280e9:
         assert n_ran == 2048, "config 5 ran at %d^3 on a %.0f GB device (free %s GB): it must run at 2048^3" % (

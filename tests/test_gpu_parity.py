@@ -648,6 +648,48 @@ def test_pencil_c2c_extension(P, P1, align, prec):
         assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
 
 
+CONFIG5_MESHES = [[2048, 64, 32], [64, 2048, 32], [32, 64, 2048], [4096, 32, 16]]
+
+
+@pytest.mark.parametrize("N", CONFIG5_MESHES, ids=lambda n: "x".join(map(str, n)))
+@pytest.mark.parametrize("cls,P,P1", [("pencilX", 4, None), ("pencilX", 8, None), ("pencilY", 4, None), ("pencilY", 8, None),
+                                      ("pencilX", 8, 2), ("slab", 1, None), ("slab", 4, None), ("slab", 8, None)])
+def test_config5_kernels_mid_size_vs_dft(cls, P, P1, N):
+    """BASELINE config 5 (2048^3 complex64 pencil C2C) one size class down: meshes with ONE long axis of 2048 / 4096 so that
+    the kernels only that config reaches at scale -- the fp32 strided kernels of length 2048 / 4096 (plans.h
+    MFFT_COLPLANS_F32_C: 32 values per thread, 1024 threads) on whole 128-byte tiles, several tiles per XCD, the nt
+    variants, the contiguous-axis c2c kernels of those lengths -- are compared bin by bin with numpy.fft.fftn of the
+    gathered array (the full-size run checks properties only, a consistent permutation of bins
+    would pass them).  Slab C2C (slab.py:743-772) on the same meshes."""
+    from mpifft4py_amd import Pencil_C2C, Slab_C2C
+    if cls != "slab":
+        lay_p1 = P1 if P1 else {4: 2, 8: 4}[P]
+        p2 = P // lay_p1
+        if N[0] % lay_p1 or N[1] % p2 or ((N[1] % lay_p1 or N[2] % p2) if cls == "pencilX" else (N[0] % p2 or N[2] % lay_p1)):
+            pytest.skip("mesh does not divide over the %dx%d grid" % (lay_p1, p2))
+    elif N[0] % P or N[1] % P:
+        pytest.skip("mesh does not divide")
+    rng = np.random.default_rng(5000 + sum(N) + P)
+    A = (rng.random(N) - 0.5 + 1j * (rng.random(N) - 0.5)).astype(np.complex64)
+    B = np.fft.fftn(A.astype(np.complex128))
+
+    def body(comm):
+        F = (Slab_C2C(np.array(N), L, comm, "single") if cls == "slab" else
+             Pencil_C2C(np.array(N), L, comm, "single", P1=P1, alignment=cls[-1], allow_single=True))
+        a = np.ascontiguousarray(A[F.original_local_slice()])
+        c = F.fftn(a, np.zeros(F.transformed_shape(), dtype=np.complex64))
+        b = F.ifftn(c, np.zeros(F.original_shape(), dtype=np.complex64))
+        return F.transformed_local_slice(), c, F.original_local_slice(), b
+    res = run_ranks(P, body)
+    G = np.zeros(N, dtype=np.complex64)
+    for cs, c, rs, b in res:
+        G[cs] = c
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL["single"]
+    assert orc.rel_l2(G, B) < TOL["single"]
+    # bin level: the largest single-bin deviation, relative to the rms magnitude of the spectrum
+    assert np.abs(G - B).max() < 50 * TOL["single"] * np.sqrt(np.mean(np.abs(B) ** 2))
+
+
 @pytest.mark.parametrize("N,P", [([48, 96, 80], 1), ([48, 96, 80], 2), ([24, 40, 12], 4), ([96, 20, 192], 4),
                                  ([6, 10, 8], 2), ([2, 2, 4], 1), ([2, 2, 4], 2), ([4, 4, 4], 4)])
 def test_slab_non_power_of_two_and_tiny_meshes(N, P):

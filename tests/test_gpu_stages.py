@@ -246,3 +246,26 @@ def test_dct(n, type_):
         assert orc.rel_l2(b, sdct(c.real, type=type_, axis=axis) + 1j * sdct(c.imag, type=type_, axis=axis)) < 1e-12
     with pytest.raises(NotImplementedError):
         dct(np.zeros(8), type=1)
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+def test_dft_bins_checker_against_numpy(prec):
+    """mfft_ew_dft_bins (the bin-level checker of the full-size config-5 run): partial sums over two blocks of a mesh add up
+    to numpy.fft.fftn's bins -- complex and real input, forward and inverse sign, more bins than one launch takes."""
+    from mpifft4py_amd import DeviceArray, SelfComm, Slab_C2C, Slab_R2C, spectral
+    N = [12, 10, 16]
+    rng = np.random.default_rng(8)
+    A = (rng.random(N) - 0.5 + 1j * (rng.random(N) - 0.5)).astype(cdtype(prec))
+    R = (rng.random(N) - 0.5).astype(rdtype(prec))
+    bins = np.stack([rng.integers(0, n, 37) for n in N], axis=1)
+    Fc = Slab_C2C(np.array(N), np.array([1., 1., 1.]), SelfComm(0), prec)
+    Fr = Slab_R2C(np.array(N), np.array([1., 1., 1.]), SelfComm(0), prec)
+    for F, X in ((Fc, A), (Fr, R)):
+        for inverse in (False, True):
+            tot = np.zeros(len(bins), dtype=complex)
+            for (x0, x1) in ((0, 5), (5, 12)):                    # two "ranks": blocks of x planes
+                blk = DeviceArray.from_numpy(np.ascontiguousarray(X[x0:x1]))
+                tot += spectral.dft_bins(F, blk, bins, [x0, 0, 0], inverse=inverse)
+            full = np.fft.ifftn(X.astype(np.complex128)) * np.prod(N) if inverse else np.fft.fftn(X.astype(np.complex128))
+            want = full[bins[:, 0], bins[:, 1], bins[:, 2]]
+            assert np.abs(tot - want).max() < 1e-12 * np.sqrt(np.prod(N)), (prec, inverse)
