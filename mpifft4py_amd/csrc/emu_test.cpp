@@ -39,6 +39,22 @@ void emu_barrier() {
   swapcontext(&e->ctx[e->cur], &e->sched);
 }
 
+// wave shuffle of the kernels' host build (fft_kernels.h wave_shfl): every thread parks its value, all threads meet,
+// every thread reads the slot of lane `src` of its own wave, all threads meet again (the slots are reused)
+static std::vector<double> g_shfl_slot;
+double emu_shfl(double x, int src) {
+  EmuState* e = g_emu;
+  const int tid = e->cur, n = (int)e->ctx.size();
+  if ((int)g_shfl_slot.size() < n) g_shfl_slot.resize(n);
+  g_shfl_slot[tid] = x;
+  emu_barrier();
+  const int from = (tid & ~63) + src;
+  if (src < 0 || src > 63) { fprintf(stderr, "EMU: shuffle from lane %d\n", src); abort(); }
+  const double r = from < n ? g_shfl_slot[from] : 0.0;      // a lane beyond the workgroup: undefined on the device
+  emu_barrier();
+  return r;
+}
+
 static void fibre_entry() {
   EmuState* e = g_emu;
   int tid = e->cur;
@@ -865,6 +881,94 @@ static void test_real_zh(int m) {
   report(name, n, pname<T>(), (double)sqrtl(num / den), 16 * tol_of<T>());
 }
 
+// wave-packed c2r (fft_kernels.h C2RFft WP): plain, column-limited and z-chunked, against the input of the r2c kernels
+template <class S, typename T, int WAVES, bool SPLIT>
+static void test_c2r_wave_packed() {
+  if constexpr (S::TPT < 64 && 64 % S::TPT != 0) {
+    constexpr int RPW = 64 / S::TPT, ROWS = WAVES * RPW;
+    const int M = S::N, N = 2 * M, nrows = 2 * ROWS + 1;       // the last workgroup is ragged, its last wave too
+    std::mt19937_64 rng(99 + N);
+    std::uniform_real_distribution<double> U(-1, 1);
+    const int pin = N + 2, pout = M + 1 + 2;
+    std::vector<T> in((size_t)nrows * pin), back((size_t)nrows * pin, (T)0);
+    std::vector<cx<T>> out((size_t)nrows * pout);
+    for (auto& z : in) z = (T)U(rng);
+    auto tw = build_pass_twiddles<S, T>();
+    auto rtw = build_real_twiddles<T>(N);
+    {
+      typedef R2CFft<S, T, 2, false, false, false, false> K;
+      RealParams<T> P{in.data(), out.data(), tw.data(), rtw.data(), pin, pout, nrows, M + 1, (T)1};
+      emu_launch((nrows + 1) / 2, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    }
+    char name[64];
+    {     // r2c, wave-packed, against the dense kernel's output (and, column-limited, its first bins)
+      std::vector<cx<T>> o2((size_t)nrows * pout, mk<T>((T)7, (T)7)), o3((size_t)nrows * (M / 2 + 1), mk<T>((T)7, (T)7));
+      {
+        typedef R2CFft<S, T, ROWS, false, false, false, SPLIT, true> K;
+        static_assert(K::THREADS == WAVES * 64, "whole waves");
+        RealParams<T> P{in.data(), o2.data(), tw.data(), rtw.data(), pin, pout, nrows, M + 1, (T)1};
+        emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+      }
+      {
+        typedef R2CFft<S, T, ROWS, false, true, false, SPLIT, true> K;
+        RealParams<T> P{in.data(), o3.data(), tw.data(), rtw.data(), pin, M / 2 + 1, nrows, M / 2 + 1, (T)1};
+        emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+      }
+      long double nn = 0, dd = 0, n3 = 0;
+      for (int r = 0; r < nrows; ++r)
+        for (int k = 0; k <= M; ++k) {
+          const cx<T> a = o2[(size_t)r * pout + k], e = out[(size_t)r * pout + k];
+          nn += (long double)(a.x - e.x) * (a.x - e.x) + (long double)(a.y - e.y) * (a.y - e.y);
+          dd += (long double)e.x * e.x + (long double)e.y * e.y;
+          if (k <= M / 2) {
+            const cx<T> c = o3[(size_t)r * (M / 2 + 1) + k];
+            n3 += (long double)(c.x - e.x) * (c.x - e.x) + (long double)(c.y - e.y) * (c.y - e.y);
+          }
+        }
+      snprintf(name, sizeof name, "r2c wave-packed w%d%s", WAVES, SPLIT ? " split" : "");
+      report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
+      snprintf(name, sizeof name, "r2c wave-packed valid<M+1 w%d", WAVES);
+      report(name, N, pname<T>(), (double)sqrtl(n3 / dd), 4 * tol_of<T>());
+    }
+    for (int r = 0; r < nrows; ++r) { out[(size_t)r * pout].y = (T)3.5; out[(size_t)r * pout + M].y = (T)-2.25; }
+    {
+      typedef C2RFft<S, T, ROWS, false, false, false, SPLIT, true> K;
+      static_assert(K::THREADS == WAVES * 64, "whole waves");
+      RealParams<T> P{out.data(), back.data(), tw.data(), rtw.data(), pout, pin, nrows, M + 1, (T)(1.0 / N)};
+      emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    }
+    long double num = 0, den = 0;
+    for (int r = 0; r < nrows; ++r)
+      for (int i = 0; i < N; ++i) {
+        long double d = (long double)back[(size_t)r * pin + i] - in[(size_t)r * pin + i];
+        num += d * d;
+        den += (long double)in[(size_t)r * pin + i] * in[(size_t)r * pin + i];
+      }
+    snprintf(name, sizeof name, "c2r wave-packed w%d%s", WAVES, SPLIT ? " split" : "");
+    report(name, N, pname<T>(), (double)sqrtl(num / den), 4 * tol_of<T>());
+    // column-limited: bins >= valid read as zero
+    const int valid = M / 2 + 1;
+    std::vector<cx<T>> part((size_t)nrows * valid);
+    for (int r = 0; r < nrows; ++r)
+      for (int k = 0; k < valid; ++k) part[(size_t)r * valid + k] = out[(size_t)r * pout + k];
+    std::vector<T> b1((size_t)nrows * pin, (T)0), b2((size_t)nrows * pin, (T)0);
+    {
+      typedef C2RFft<S, T, ROWS, false, true, false, SPLIT, true> K;
+      RealParams<T> P{part.data(), b1.data(), tw.data(), rtw.data(), valid, pin, nrows, valid, (T)(1.0 / N)};
+      emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    }
+    {
+      typedef C2RFft<S, T, 2, false, true, false, false, false> K;      // the unpacked kernel as the reference
+      RealParams<T> P{part.data(), b2.data(), tw.data(), rtw.data(), valid, pin, nrows, valid, (T)(1.0 / N)};
+      emu_launch((nrows + 1) / 2, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    }
+    num = den = 0;
+    for (size_t i = 0; i < b1.size(); ++i) { long double d = (long double)b1[i] - b2[i]; num += d * d; den += (long double)b2[i] * b2[i]; }
+    snprintf(name, sizeof name, "c2r wave-packed valid<M+1 w%d", WAVES);
+    report(name, N, pname<T>(), (double)sqrtl(num / den), 4 * tol_of<T>());
+  }
+}
+
 template <class S> static void test_chirpz_all() {
   const int nmax = (S::N + 1) / 2;
   for (int n : {nmax, nmax - 1, (S::N / 4) + 1, 7}) {
@@ -912,6 +1016,9 @@ template <class S> static void test_spec_all() {
     test_real<S, double, 2, false, true>();
   }
   PadTests<S>::run();
+  test_c2r_wave_packed<S, double, 1, false>();
+  test_c2r_wave_packed<S, float, 2, false>();
+  if constexpr (S::NP > 1 && S::E >= 12) test_c2r_wave_packed<S, double, 2, true>();
 }
 
 // The plan list is split over EMU_PART = 0..5 so that the parts compile (and run) in parallel;

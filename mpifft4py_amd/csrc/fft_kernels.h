@@ -56,6 +56,17 @@ namespace mfft { void emu_barrier(); }
 #define MFFT_BARRIER() ::mfft::emu_barrier()
 #endif
 
+// Value of `x` in lane `src` of the caller's wave (64 lanes).  Device: one cross-lane read.  Host emulator: a round trip
+// through a per-workgroup slot array between two barriers (emu_test.cpp emu_shfl) -- every thread of the workgroup must
+// execute the same sequence of shuffles, which the kernels guarantee (they sit in fully unrolled, uniform loops) -- so
+// that the lane arithmetic of the shuffle paths is checked on the CPU as well.
+#if defined(__HIPCC__)
+template <typename T> __device__ __forceinline__ T wave_shfl(T x, int src) { return __shfl(x, src, 64); }
+#else
+namespace mfft { double emu_shfl(double x, int src_lane); }
+template <typename T> inline T wave_shfl(T x, int src) { return (T)::mfft::emu_shfl((double)x, src); }
+#endif
+
 // nothing is scheduled across it (device code only)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MFFT_NO_R2C_FENCE)
 #define MFFT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -713,11 +724,16 @@ struct RowFft {
 // LIMIT: only the first P.valid complex columns exist in memory (3/2-rule): r2c does not
 // store the others, c2r reads them as zeros.  A template flag so that the regular kernels keep
 // unconditional loads (a runtime test costs the c2r kernel 7 % at 1024^3).
-template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false, bool SPLIT = false>
+// WP: the wave-packed thread layout described at C2RFft (threads per transform that do not divide a wave): the mirrored
+// value Z[M - pos] of the split post-pass comes through a wave shuffle instead of an LDS round trip with three more
+// barriers and E more live registers (the r2c stage of 720^3 / 900^3 took 1.8 x the c2r stage's time, round 3).
+template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false, bool SPLIT = false, bool WP = false>
 struct R2CFft {
   typedef typename RowXch<SPLIT, T, PadSlot<S::R(0)>>::elem XE;
   static constexpr int M = S::N;
-  static constexpr int THREADS = S::TPT * ROWS;
+  static constexpr int RPW = WP ? 64 / S::TPT : 1;
+  static_assert(!WP || (S::TPT < 64 && 64 % S::TPT != 0 && ROWS % (64 / S::TPT) == 0), "wave-packed rows: whole waves of rows");
+  static constexpr int THREADS = WP ? ROWS / RPW * 64 : S::TPT * ROWS;
   static constexpr int PD = S::R(0);
   static constexpr int PLEN = padded_len<M, PD>();
   static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
@@ -726,14 +742,28 @@ struct R2CFft {
 
   static MFFT_D void body(const RealParams<T>& P, int bid, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
-    const int rl = tid / S::TPT;
-    const int j = row_thread_index<S>(tid);
+    int rl, j, lane0 = 0;
+    bool dup = false;
+    if constexpr (WP) {            // see C2RFft
+      const int lane = tid & 63;
+      int lr = lane / S::TPT;
+      dup = lr >= RPW;
+      if (dup) lr = RPW - 1;
+      lane0 = lr * S::TPT;
+      j = dup ? lane - RPW * S::TPT : lane - lane0;
+      if constexpr (S::E % 15 == 0) MFFT_OPAQUE(j);
+      rl = (tid >> 6) * RPW + lr;
+    } else {
+      rl = tid / S::TPT;
+      j = row_thread_index<S>(tid);
+    }
     XE* xch = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
-    const bool active = row < P.nrows;
+    const bool inrange = row < P.nrows;
+    const bool active = inrange && !dup;
     // a row of N reals read as N/2 complex (x[2n], x[2n+1])
     const cx<T>* ip =
-        reinterpret_cast<const cx<T>*>(static_cast<const T*>(P.in) + (active ? row : P.nrows - 1) * P.in_stride);
+        reinterpret_cast<const cx<T>*>(static_cast<const T*>(P.in) + (inrange ? row : P.nrows - 1) * P.in_stride);
     cx<T>* op = static_cast<cx<T>*>(P.out) + row * P.out_stride;
 
     cx<T> v[S::E];
@@ -770,20 +800,15 @@ struct R2CFft {
         put(pos, scale(e + P.rtw[pos] * o, P.scale));
       }
     };
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr bool SHFL = S::TPT <= 64 && (64 % S::TPT) == 0;
-#else
-    constexpr bool SHFL = false;      // host emulator: partner through LDS
-#endif
+    constexpr bool SHFL = WP || (S::TPT <= 64 && (64 % S::TPT) == 0);
     if constexpr (SHFL) {
       // Z[M-pos] of (lane j, register k) is register E-1-k of lane TPT-j of the same row: one
       // wave shuffle instead of an LDS round trip and two barriers (lane 0: its own register E-k)
-#if defined(__HIP_DEVICE_COMPILE__)
-      const int src = (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));
+      const int src = WP ? lane0 + (j == 0 ? 0 : S::TPT - j) : (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {
         const cx<T> give = v[S::E - 1 - k];
-        cx<T> pm = mk<T>(__shfl(give.x, src, 64), __shfl(give.y, src, 64));
+        cx<T> pm = mk<T>(wave_shfl(give.x, src), wave_shfl(give.y, src));
         if (j == 0) pm = v[(S::E - k) % S::E];
         if (active) emit(j + k * S::TPT, v[k], pm);
         // 30 values per thread: keep the scheduler from hoisting every shuffle above the first store (all mirrors live at
@@ -792,7 +817,6 @@ struct R2CFft {
           if (k % 3 == 2) MFFT_SCHED_FENCE();
         }
       }
-#endif
     } else if constexpr (SPLIT) {
       // the mirrored partners through the half-size buffer: real parts, then imaginary parts (the imaginary parts are
       // consumed as they are read: only the real parts of the mirrors are held)
@@ -840,11 +864,19 @@ struct R2CFft {
 // half-complex -> real along the contiguous axis.  S describes M = N/2.
 // out = irfft(in) * N * scale   (scale = 1/N gives numpy's irfft)
 // ---------------------------------------------------------------------------
-template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false, bool SPLIT = false>
+// WP ("wave-packed", round 4): for transforms whose TPT threads do not divide a wave (24, 30, 48, 60 ... threads: the
+// lengths with 3 and 5 among their factors, 9 * 2^a, 125 * 2^a) a wave holds RPW = 64 / TPT whole rows and its last
+// 64 - RPW * TPT lanes DUPLICATE the first threads of its last row (same loads, same LDS writes, same shuffles: harmless,
+// they store nothing).  No row straddles a wave any more, so the mirrored bin X[M - pos] comes through a wave shuffle
+// as it does for the power-of-two thread counts, and every bin is read from memory ONCE (the unpacked layout loaded
+// both bins of a pair: 1.23 x the algorithmic HBM traffic at 720^3, profiles/r03_720_pmc_traffic.json).
+template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false, bool SPLIT = false, bool WP = false>
 struct C2RFft {
   typedef typename RowXch<SPLIT, T, PadSlot<S::R(0)>>::elem XE;
   static constexpr int M = S::N;
-  static constexpr int THREADS = S::TPT * ROWS;
+  static constexpr int RPW = WP ? 64 / S::TPT : 1;                      // rows per wave (wave-packed layout)
+  static_assert(!WP || (S::TPT < 64 && 64 % S::TPT != 0 && ROWS % (64 / S::TPT) == 0), "wave-packed rows: whole waves of rows");
+  static constexpr int THREADS = WP ? ROWS / RPW * 64 : S::TPT * ROWS;
   static constexpr int PD = S::R(0);
   static constexpr int PLEN = padded_len<M, PD>();
   static constexpr int TW_BYTES = TWLDS ? (int)(S::TW * sizeof(cx<T>)) : 0;
@@ -853,18 +885,32 @@ struct C2RFft {
 
   static MFFT_D void body(const RealParams<T>& P, int bid, int tid, char* lds) {
     cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
-    const int rl = tid / S::TPT;
-    const int j = row_thread_index<S>(tid);
+    int rl, j, lane0 = 0;          // row of the workgroup, thread of the row, (WP) lane of the row's thread 0
+    bool dup = false;              // (WP) a lane that duplicates a thread of the wave's last row
+    if constexpr (WP) {
+      const int lane = tid & 63;
+      int lr = lane / S::TPT;
+      dup = lr >= RPW;
+      if (dup) lr = RPW - 1;
+      lane0 = lr * S::TPT;
+      j = dup ? lane - RPW * S::TPT : lane - lane0;
+      if constexpr (S::E % 15 == 0) MFFT_OPAQUE(j);         // see row_thread_index
+      rl = (tid >> 6) * RPW + lr;
+    } else {
+      rl = tid / S::TPT;
+      j = row_thread_index<S>(tid);
+    }
     XE* xch = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
-    const bool active = row < P.nrows;
+    const bool inrange = row < P.nrows;
+    const bool active = inrange && !dup;
     // rows past the end re-read the last row (unconditional loads: see RowFft) and store nothing
-    const cx<T>* ip = static_cast<const cx<T>*>(P.in) + (active ? row : P.nrows - 1) * P.in_stride;
+    const cx<T>* ip = static_cast<const cx<T>*>(P.in) + (inrange ? row : P.nrows - 1) * P.in_stride;
     cx<T>* op = reinterpret_cast<cx<T>*>(static_cast<T*>(P.out) + row * P.out_stride);
 
     // bin `pos` of this row; CHUNK: out of its z chunk, a position the last chunk does not hold (dropped Nyquist
     // column) reads as zero -- the load itself stays unconditional (clamped offset + select), see RowFft
-    const i64 crow = P.row0 + (active ? row : P.nrows - 1);
+    const i64 crow = P.row0 + (inrange ? row : P.nrows - 1);
     auto bin = [&](int pos) -> cx<T> {
       if constexpr (CHUNK) {
         bool ok;
@@ -878,11 +924,7 @@ struct C2RFft {
     // pre-pass: Z[k] = (X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])
     // (twice the textbook value; the factor is folded into the normalisation)
     cx<T> v[S::E];
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr bool SHFL = S::TPT <= 64 && (64 % S::TPT) == 0;
-#else
-    constexpr bool SHFL = false;      // the host emulator has no cross-lane shuffle: it takes the load path
-#endif
+    constexpr bool SHFL = WP || (S::TPT <= 64 && (64 % S::TPT) == 0);
     if constexpr (SHFL) {
       // Every bin is read from memory ONCE.  The mirrored partner X[M-pos] of (lane j, register k)
       // is register E-1-k of lane TPT-j of the same row (all inside one wave), fetched with a
@@ -904,8 +946,8 @@ struct C2RFft {
       }
       cx<T> carry = mk<T>((T)0, (T)0);
       if (j == 0 && (!LIMIT || M < P.valid)) carry = bin(M);
-#if defined(__HIP_DEVICE_COMPILE__)
-      const int src = (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));     // lane of thread TPT-j (mod TPT) of this row
+      // lane of thread TPT-j (mod TPT) of this row
+      const int src = WP ? lane0 + (j == 0 ? 0 : S::TPT - j) : (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));
       auto prepass = [&](cx<T> xk, cx<T> pm, int pos) {
         cx<T> xm = conj(pm);
         if (pos == 0) {              // imaginary parts of the k=0 and k=N/2 bins are ignored
@@ -923,8 +965,8 @@ struct C2RFft {
         const cx<T> a = v[k], b = v[kp];
         const cx<T> give1 = j == 0 ? carry : b;          // partner of position j + k*TPT
         const cx<T> give2 = j == 0 ? v[k + 1] : a;       // partner of position j + kp*TPT (lane 0: its register E-kp = k+1)
-        const cx<T> pm1 = mk<T>(__shfl(give1.x, src, 64), __shfl(give1.y, src, 64));
-        const cx<T> pm2 = mk<T>(__shfl(give2.x, src, 64), __shfl(give2.y, src, 64));
+        const cx<T> pm1 = mk<T>(wave_shfl(give1.x, src), wave_shfl(give1.y, src));
+        const cx<T> pm2 = mk<T>(wave_shfl(give2.x, src), wave_shfl(give2.y, src));
         carry = b;                                       // lane 0's partner register of the next step
         v[k] = prepass(a, pm1, j + k * S::TPT);
         v[kp] = prepass(b, pm2, j + kp * S::TPT);
@@ -932,7 +974,6 @@ struct C2RFft {
           if (k % 3 == 2) MFFT_SCHED_FENCE();
         }
       }
-#endif
     } else {
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {

@@ -18,6 +18,10 @@
 #include "mfft_internal.h"
 #include "relay_plan.h"
 
+#ifndef MFFT_FWD_OOP_DEFAULT
+#define MFFT_FWD_OOP_DEFAULT 0      // one-rank forward y / x passes out of place: see mfft_plan_s::fwd_out_of_place
+#endif
+
 using namespace mfft;
 
 namespace {
@@ -231,6 +235,8 @@ struct mfft_plan_s {
   // z stage with the z-chunk pack / unpack of the pencils fused in (fft_kernels.h, ZSplit): rows [row0, row0 + nrows)
   // of the Pz blocks (rows_total, len_l) that the z-splitting exchange sends / has received
   bool zfuse = false;
+  bool xpad_on = true;          // xplane_pad(): MFFT_NO_XPAD=1 clears it (A/B runs; must be the same on every rank)
+  bool xpass_inplace = false;   // MFFT_XPASS_INPLACE=1: the x pass behind an exchange runs in place on the receive buffer (rounds 1 - 3)
   // the same for the fused 3/2-rule pencil transforms: real length M2, the Nf kept columns split into the z chunks
   bool zfuse_pad() const {
     return getenv("MFFT_NO_ZFUSE") == nullptr && !d.line2d && !d.drop_nyquist && !zc.empty() && zc[0].len < 65536 &&
@@ -470,6 +476,31 @@ struct mfft_plan_s {
   int64_t plane_pad(int64_t stride_elems) const {
     return (stride_elems * (int64_t)es) % 65536 == 0 ? (int64_t)(128 / es) : 0;
   }
+  // The same pad carried THROUGH an exchange (round 4): the strided x pass that follows an exchange reads the received
+  // chunks, whose x rows lie N1/P * Nf (slab), N1/P1 * q (x-aligned pencil, forward) or N1/P2 * q (y-aligned pencil,
+  // inverse) elements apart -- a multiple of 64 KiB for complex data on power-of-two meshes (BASELINE config 5: 4 MiB).
+  // The transform that WRITES the send blocks then leaves one cache line between consecutive x rows (a store-side
+  // pitch costs nothing), every chunk grows by that line per x row (mfft_plan_exchange_schedule reports it: 64 KiB on a
+  // 2 GiB chunk at config 5), and the x pass reads the padded rows and writes the caller's compact array.  Un-pipelined
+  // exchanges only (the pieces of the pipelined ones keep the compact layout); MFFT_NO_XPAD=1 switches it off.
+  int64_t xplane_pad(bool forward) const {
+    if (!xpad_on || P == 1 || npieces() != 1 || d.line2d) return 0;
+    if (d.decomp == MFFT_SLAB) return forward ? plane_pad(Np1 * Nf) : 0;
+    if (d.decomp == MFFT_PENCIL_X) return (forward && P1 > 1) ? plane_pad(N1_1 * q) : 0;
+    return (!forward && P2 > 1) ? plane_pad(N2_1 * q) : 0;
+  }
+  // One-rank forward transform: y and x passes out of place through a work buffer of the size of the spectrum instead
+  // of in place on the result.  MFFT_FWD_OOP=1 / 0 forces it on / off; default: off (measured).
+  // When on by default it would still need room: the buffer exists already (the inverse uses the same one), or a
+  // quarter of the free HBM covers it.
+  bool fwd_out_of_place(size_t cbytes) {
+    static const int mode = getenv("MFFT_FWD_OOP") ? atoi(getenv("MFFT_FWD_OOP")) : MFFT_FWD_OOP_DEFAULT;
+    if (mode <= 0) return false;
+    if (work_bytes[0] >= cbytes) return true;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cbytes <= fr / 4;
+  }
   static RowSpec plain(int64_t stride) { RowSpec r; r.lo = stride; r.hi = 0; r.split = 0; return r; }
   static RowSpec two_level(int64_t split, int64_t hi, int64_t lo) { RowSpec r; r.split = split; r.hi = hi; r.lo = lo; return r; }
 
@@ -611,7 +642,7 @@ int mfft_plan_s::sched(int which, bool forward, bool padded, Sched* o) const {
   if (d.decomp == MFFT_SLAB) {
     if (which != 0) return set_error(MFFT_ERR_INVALID, "slab plans have one exchange");
     const int64_t x = padded ? M0 / P : Np0;
-    equal(world, (size_t)(x * Np1 * Nf) * es);
+    equal(world, (size_t)(x * (Np1 * Nf + (padded ? 0 : xplane_pad(forward)))) * es);
     return 0;
   }
   const bool X = d.decomp == MFFT_PENCIL_X;
@@ -632,8 +663,9 @@ int mfft_plan_s::sched(int which, bool forward, bool padded, Sched* o) const {
     return 0;
   }
   if (which == 1) {
-    if (X) equal(group0, (size_t)(m * N1_1 * q) * es);
-    else   equal(group1, (size_t)(N2_0 * n * q) * es);
+    const int64_t xp = padded ? 0 : xplane_pad(forward);     // one cache line between x rows when they are 64 KiB multiples apart
+    if (X) equal(group0, (size_t)(m * (N1_1 * q + xp)) * es);
+    else   equal(group1, (size_t)(N2_0 * (n * q + xp)) * es);
     return 0;
   }
   return set_error(MFFT_ERR_INVALID, "pencil plans have two exchanges");
@@ -694,23 +726,41 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
       MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Nf, 0, plain(pl), 0, plain(N1 * Nf)); }));
       return 0;
     }
+    if (fwd_out_of_place((size_t)Cb)) {
+      // y transform into the work buffer (the one the inverse uses anyway), x transform out of it into the result: both
+      // passes out of place (MFFT_FWD_OOP, see fwd_out_of_place)
+      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nf) * es));
+      void* A = work[0];
+      MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(fu, A, N1, false, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
+      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
+      return 0;
+    }
     MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(fu, fu, N1, false, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
     MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
     return 0;
   }
   if (nbatch > 1) return slab_forward_rows(u, fu);
   if (nslice > 1) return slab_forward_pipelined(u, fu);
-  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  // x rows of the exchanged layout lie S elements apart: Np1 * Nf, plus one cache line where that is a 64 KiB multiple
+  const int64_t S = Np1 * Nf + xplane_pad(true);
+  const size_t cb = (size_t)std::max(Np0 * N1 * Nf, N0 * S) * es;
   MFFT_TRY(ensure_work(0, cb));
   MFFT_TRY(ensure_work(1, cb));
   void *A = work[0], *B = work[1];
   MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, A, Np0 * N1, N2, Nf); }));
   // y transform writes straight into the packed (P, Np0, Np1, Nf) send layout (slab.py:403)
   MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
-    return col(A, B, N1, false, Np0, Nf, N1 * Nf, plain(Nf), Np1 * Nf, two_level(Np1, Np0 * Np1 * Nf, Nf));
+    return col(A, B, N1, false, Np0, Nf, N1 * Nf, plain(Nf), S, two_level(Np1, Np0 * S, Nf));
   }));
-  MFFT_TRY(stage("fwd_a2a", 0, [&] { return xchg(0, true, false, B, fu); }));
-  MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
+  if (xpass_inplace && S == Np1 * Nf) {           // round 1 - 3: receive into the result, x transform in place
+    MFFT_TRY(stage("fwd_a2a", 0, [&] { return xchg(0, true, false, B, fu); }));
+    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)); }));
+    return 0;
+  }
+  // A is free again (the y transform has read it): the chunks land there and the x transform runs OUT of place into the
+  // result -- no more memory, and an out-of-place pass is the faster one (1024 fp64: 3.19 against 3.35 ms)
+  MFFT_TRY(stage("fwd_a2a", 0, [&] { return xchg(0, true, false, B, A); }));
+  MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, Np1 * Nf, 0, plain(S), 0, plain(Np1 * Nf)); }));
   return 0;
 }
 
@@ -1487,7 +1537,8 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
   // a group of one rank exchanges nothing: its pack / copy steps are skipped altogether
   const bool zsolo = (X ? P2 : P1) == 1 && !d.drop_nyquist, g2solo = (X ? P1 : P2) == 1;
   // largest intermediate of this alignment: X: (m, N1, q) after the z exchange; Y: (N0, n, q) after it
-  const size_t wb = (size_t)std::max(m * n * Nf, X ? m * N1 * q : N0 * n * q) * es;
+  const int64_t SX = N1_1 * q + (X ? xplane_pad(true) : 0);     // x-row pitch of the blocks of the second exchange (X)
+  const size_t wb = (size_t)std::max(m * n * Nf, X ? std::max(m * N1 * q, N0 * SX) : N0 * n * q) * es;
   MFFT_TRY(ensure_work(0, wb));
   MFFT_TRY(ensure_work(1, wb));
   void *W0 = work[0], *W1 = work[1];
@@ -1505,10 +1556,16 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
     // W0 = P2 blocks (m, n, q) -> y transform (gathers y through two-level rows) -> P1 blocks (m, N1_1, q)
     void* ydst = g2solo ? fu : W1;
     MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
-      return col(W0, ydst, N1, false, m, q, n * q, two_level(n, m * n * q, q), N1_1 * q, two_level(N1_1, m * N1_1 * q, q));
+      return col(W0, ydst, N1, false, m, q, n * q, two_level(n, m * n * q, q), SX, two_level(N1_1, m * SX, q));
     }));
-    if (!g2solo) MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W1, fu); }));
-    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
+    if (g2solo || (xpass_inplace && SX == N1_1 * q)) {
+      if (!g2solo) MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W1, fu); }));
+      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
+    } else {
+      // the chunks land in W0 (free: the y transform has read it), rows SX apart; x transform out of place into the result
+      MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W1, W0); }));
+      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, fu, N0, false, 1, N1_1 * q, 0, plain(SX), 0, plain(N1_1 * q)); }));
+    }
   } else {
     // W0 = (N0, n, q): x transform in place, x chunks are contiguous -> exchange -> y transform gathers
     MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, W0, N0, false, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
@@ -1545,7 +1602,8 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
   }
   if (nbatch > 1) return d.decomp == MFFT_PENCIL_X ? pencil_backward_pipelined_x(src, u) : pencil_backward_pipelined_y(src, u);
   // largest intermediate of this alignment: X: (m, N1, q) after the z exchange; Y: (N0, n, q) after it
-  const size_t wb = (size_t)std::max(m * n * Nf, X ? m * N1 * q : N0 * n * q) * es;
+  const int64_t SY = n * q + (X ? 0 : xplane_pad(false));       // x-row pitch of the blocks of the second exchange (Y)
+  const size_t wb = (size_t)std::max(m * n * Nf, X ? m * N1 * q : N0 * SY) * es;
   MFFT_TRY(ensure_work(0, wb));
   MFFT_TRY(ensure_work(1, wb));
   void *W0 = work[0], *W1 = work[1];
@@ -1563,15 +1621,21 @@ int mfft_plan_s::pencil_backward(const void* fu, void* u, bool masked) {
     }));
   } else {
     MFFT_TRY(stage("bwd_y", 2 * Cb, [&] {
-      return col(src, W0, N1, true, N2_0, q, N1 * q, plain(q), n * q, two_level(n, N2_0 * n * q, q));
+      return col(src, W0, N1, true, N2_0, q, N1 * q, plain(q), SY, two_level(n, N2_0 * SY, q));
     }));
     cur = W0;
     if (!g2solo) {
       MFFT_TRY(stage("bwd_a2a_2", 0, [&] { return xchg(1, false, false, W0, W1); }));
       cur = W1;
     }
-    // (N0, n, q): x transform in place; its x chunks are the contiguous blocks of the next exchange
-    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(cur, cur, N0, true, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+    if (g2solo || (xpass_inplace && SY == n * q)) {
+      // (N0, n, q): x transform in place; its x chunks are the contiguous blocks of the next exchange
+      MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(cur, cur, N0, true, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+    } else {
+      // rows SY apart in W1 -> compact (N0, n, q) in W0 (free: the exchange has sent it), out of place
+      MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(W1, W0, N0, true, 1, n * q, 0, plain(SY), 0, plain(n * q)); }));
+      cur = W0;
+    }
   }
   if (!zsolo) {
     void* other = cur == W0 ? W1 : W0;
@@ -1851,6 +1915,8 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   p->Mf = p->r2c ? (int64_t)(ps * p->N2) / 2 + 1 : p->M2;
   p->world.resize(p->P);
   for (int i = 0; i < p->P; ++i) p->world[i] = i;
+  p->xpad_on = !(getenv("MFFT_NO_XPAD") && atoi(getenv("MFFT_NO_XPAD")) != 0);
+  p->xpass_inplace = getenv("MFFT_XPASS_INPLACE") && atoi(getenv("MFFT_XPASS_INPLACE")) != 0;
   const int P = p->P;
   if (p->r2c && p->N2 % 2) return set_error(MFFT_ERR_UNSUPPORTED, "odd N[2]=%lld is not supported for R2C", (long long)p->N2);
   if (desc->decomp == MFFT_SLAB) {

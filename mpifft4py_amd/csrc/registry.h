@@ -240,50 +240,90 @@ template <class S, typename T> constexpr int row_occ_wgs(int threads) {
   return (MFFT_ROW_OCC && sizeof(T) == 8 && S::E % 15 == 0 && S::N >= 120 && threads <= 256) ? 512 / threads : 0;   // shorter: 500+ bytes of scratch
 }
 
+// Round 4: c2r kernels whose threads per transform do not divide a wave (24, 30, 48, 50, 60 ...) run wave-packed
+// (fft_kernels.h C2RFft WP: whole rows per wave, the mirrored bin through a wave shuffle, every bin loaded once) where
+// at least three quarters of the lanes stay busy; 40 threads (one row per wave, 62 %) keep the two loads.
+#ifndef MFFT_C2R_WP
+#define MFFT_C2R_WP 1
+#endif
+template <class S> constexpr bool c2r_wave_packed() {
+  return MFFT_C2R_WP && S::TPT < 64 && 64 % S::TPT != 0 && (64 / S::TPT) * S::TPT * 4 >= 64 * 3;
+}
+template <class S, typename T> constexpr int c2r_rows() {       // rows per workgroup of the c2r kernels
+  constexpr int r = row_rows<S, T, true>();
+  if constexpr (c2r_wave_packed<S>()) {
+    constexpr int rpw = 64 / S::TPT;
+    return r / rpw > 0 ? r / rpw * rpw : rpw;                   // whole waves of rows
+  } else {
+    return r;
+  }
+}
+template <class S, typename T> constexpr int c2r_threads() {
+  if constexpr (c2r_wave_packed<S>()) return c2r_rows<S, T>() / (64 / S::TPT) * 64;
+  else return S::TPT * c2r_rows<S, T>();
+}
+// ... and the r2c kernels (the row c2c kernels have no mirrored partner and keep the dense layout)
+template <class S, typename T> constexpr int r2c_rows() {
+  constexpr int r = row_rows<S, T>();
+  if constexpr (c2r_wave_packed<S>()) {
+    constexpr int rpw = 64 / S::TPT;
+    return r / rpw > 0 ? r / rpw * rpw : rpw;
+  } else {
+    return r;
+  }
+}
+template <class S, typename T> constexpr int r2c_threads() {
+  if constexpr (c2r_wave_packed<S>()) return r2c_rows<S, T>() / (64 / S::TPT) * 64;
+  else return S::TPT * r2c_rows<S, T>();
+}
+
 template <class S, typename T>
 void register_rows(const char* name) {
   auto& reg = kernel_registry();
   constexpr int R = row_rows<S, T>();
   constexpr int WO = row_occ_wgs<S, T>(S::TPT * R);
-  // c2r: only where the mirrored bins come through wave shuffles (threads per transform a power of two up to 64: 12 - 28
-  // bytes of scratch under the cap); the variants that load both bins would spill 470 - 680 bytes per lane (with scheduling
-  // fences every five values as well)
-  constexpr int WOC = (MFFT_ROW_OCC_C2R && S::TPT <= 64 && 64 % S::TPT == 0) ? row_occ_wgs<S, T>(S::TPT * row_rows<S, T, true>()) : 0;
+  constexpr bool WPC = c2r_wave_packed<S>();
+  // c2r: only where the mirrored bins come through wave shuffles (threads per transform a power of two up to 64, or the
+  // wave-packed layout: 12 - 28 bytes of scratch under the cap); the variants that load both bins would spill 470 - 680
+  // bytes per lane (with scheduling fences every five values as well)
+  constexpr int WOC = (MFFT_ROW_OCC_C2R && (WPC || (S::TPT <= 64 && 64 % S::TPT == 0))) ? row_occ_wgs<S, T>(c2r_threads<S, T>()) : 0;
   // the 20-values-per-thread plans in double precision: their column-limited / chunked c2r kernels come out at 256 VGPRs +
   // 10 - 40 AGPRs = one wave per SIMD; capped for two: 1000^3 2/3-rule c2r stage 5.6 -> 4.7 ms (the plain kernel, which reads
   // half as much again, takes 3.3)
-  constexpr int WOV = (MFFT_ROW_OCC_C2R && sizeof(T) == 8 && S::E == 20 && S::N >= 160 && S::TPT * row_rows<S, T, true>() <= 256)
-                          ? 512 / (S::TPT * row_rows<S, T, true>()) : WOC;
+  constexpr int WOV = (MFFT_ROW_OCC_C2R && sizeof(T) == 8 && S::E == 20 && S::N >= 160 && c2r_threads<S, T>() <= 256)
+                          ? 512 / c2r_threads<S, T>() : WOC;
   constexpr bool RT = row_twlds<S, T>();
   constexpr bool SP = row_split<S, T>();
-  constexpr int RC = row_rows<S, T, true>();      // the c2r kernels may differ
+  constexpr int RC = c2r_rows<S, T>();            // the c2r kernels may differ
+  constexpr int RR = r2c_rows<S, T>();            // ... and the r2c kernels (wave-packed layout)
+  constexpr int WOR = row_occ_wgs<S, T>(r2c_threads<S, T>());
   constexpr bool SC = row_split<S, T, true>();
   constexpr bool RTC = row_twlds<S, T, true>();
   reg.push_back(make_entry<RowFft<S, T, R, false, RT, false, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 0, R, name));
   reg.push_back(make_entry<RowFft<S, T, R, true, RT, false, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 1, R, name));
-  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, false, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
-  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, false, SC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
+  reg.push_back(make_entry<R2CFft<S, T, RR, RT, false, false, SP, WPC>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, false, SC, WPC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
   // pencil decompositions: the z-chunk pack / unpack fused into the stores / loads (pad = 4)
   reg.push_back(make_entry<RowFft<S, T, R, false, RT, true, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 0, R, name));
   reg.back().pad = 4;
   reg.push_back(make_entry<RowFft<S, T, R, true, RT, true, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 1, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<R2CFft<S, T, R, RT, false, true, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
+  reg.push_back(make_entry<R2CFft<S, T, RR, RT, false, true, SP, WPC>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, true, SC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, true, SC, WPC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
   reg.back().pad = 4;
   if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
-    reg.push_back(make_entry<R2CFft<S, T, R, RT, true, false, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
+    reg.push_back(make_entry<R2CFft<S, T, RR, RT, true, false, SP, WPC>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
     reg.back().pad = 3;
     // ... and with the kept columns split into the z chunks of the pencils' exchange (pad = 7): the 3/2-rule pencil
     // transforms write / read the exchange blocks themselves (pencil.py:511-632, 758-883 do it in the MPI datatypes)
-    reg.push_back(make_entry<R2CFft<S, T, R, RT, true, true, SP>, RealParams<T>, S, T, WO>(FAM_R2C, 2 * S::N, 0, R, name));
+    reg.push_back(make_entry<R2CFft<S, T, RR, RT, true, true, SP, WPC>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
     reg.back().pad = 7;
-    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, true, SC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, true, SC, WPC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 7;
   }
   if constexpr (S::N >= 4) {                    // column-limited c2r: 3/2-rule lengths and the pruned 2/3-rule (any length)
-    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, false, SC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, false, SC, WPC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 3;
   }
 }

@@ -272,6 +272,77 @@ def pencil(rank, P, N, A, align, P1=None, pipeline=1, relay=False):
     assert orc.rel_l2(back, u) < 1e-13, (align, rank)
 
 
+def c2c_plane_padded_exchanges(rank, P):
+    """Round 4: complex data on power-of-two meshes.  The x rows of the exchange that feeds the strided x pass would lie
+    a multiple of 64 KiB apart; the plan then leaves one cache line (8 complex128) between them INSIDE the exchanged
+    chunks (plan.hip xplane_pad) and the schedule says so.  Here: the slab C2C forward exchange (slab.py:759-766), the
+    second forward exchange of the x-aligned pencil and the second inverse exchange of the y-aligned one, each executed
+    over gloo with the library's byte counts on buffers laid out the way the kernels write / read them; the opposite
+    directions (whose x pass reads the caller's array) must stay compact."""
+    N = [8, 128, 256]
+    rng = np.random.default_rng(2029)
+    A = rng.random(N) + 1j * rng.random(N)
+    B = np.fft.fftn(A)
+    line = 128 // ES
+    # ---- slab C2C ----------------------------------------------------------------------------------------------
+    Np0, Np1, Nz = N[0] // P, N[1] // P, N[2]
+    s = _lib.exchange_schedule(N, P, rank, _lib.SLAB, 0, True, kind=_lib.C2C)
+    S = s["scount"][0] // (Np0 * ES)
+    want_pad = line if (Np1 * Nz * ES) % 65536 == 0 else 0
+    assert S == Np1 * Nz + want_pad and s["sdisp"] == [i * Np0 * S * ES for i in range(P)], (S, s)
+    a = np.fft.fft2(A[rank * Np0:(rank + 1) * Np0], axes=(1, 2))                     # (Np0, N1, N2)
+    send = np.zeros((P, Np0, S), dtype=complex)
+    send[:, :, :Np1 * Nz] = orc.slab_pack(a, P).reshape(P, Np0, Np1 * Nz)            # x rows S apart, the line behind them unused
+    r = exchange(rank, s, send, N[0] * S * ES).reshape(N[0], S)
+    fu = np.fft.fft(r[:, :Np1 * Nz].reshape(N[0], Np1, Nz), axis=0)
+    assert orc.rel_l2(fu, B[:, rank * Np1:(rank + 1) * Np1]) < 1e-13
+    sb = _lib.exchange_schedule(N, P, rank, _lib.SLAB, 0, False, kind=_lib.C2C)
+    assert set(sb["scount"]) == {Np0 * Np1 * Nz * ES}                                 # inverse: compact
+    if P < 4:
+        assert want_pad == line
+        return want_pad
+    # ---- pencils ------------------------------------------------------------------------------------------------
+    lay = orc.PencilC2CLayout(N, P, None, "X")
+    P1, P2 = lay.P1, lay.P2
+    c0, c1 = lay.ranks(rank)
+    m, n, N1_1, N2_0 = N[0] // P1, N[1] // P2, N[1] // P1, N[0] // P2
+    # x-aligned, forward: after the y transform a rank holds (m, N1, q) with q = N2 / P2, sent as P1 blocks (m, N1_1, q)
+    q = N[2] // P2
+    G = np.fft.fft(np.fft.fft(A, axis=2), axis=1)                                     # z and y done, globally
+    mine = G[c0 * m:(c0 + 1) * m, :, c1 * q:(c1 + 1) * q]
+    s1 = _lib.exchange_schedule(N, P, rank, _lib.PENCIL_X, 1, True, kind=_lib.C2C)
+    SX = s1["scount"][0] // (m * ES)
+    padx = line if (N1_1 * q * ES) % 65536 == 0 else 0
+    assert SX == N1_1 * q + padx, (SX, N1_1 * q, padx)
+    send = np.zeros((P1, m, SX), dtype=complex)
+    for l in range(P1):
+        send[l, :, :N1_1 * q] = mine[:, l * N1_1:(l + 1) * N1_1, :].reshape(m, N1_1 * q)
+    r = exchange(rank, s1, send, N[0] * SX * ES).reshape(N[0], SX)
+    fu = np.fft.fft(r[:, :N1_1 * q].reshape(N[0], N1_1, q), axis=0)
+    assert orc.rel_l2(fu, B[lay.complex_local_slice(rank)]) < 1e-13
+    assert set(_lib.exchange_schedule(N, P, rank, _lib.PENCIL_X, 1, False, kind=_lib.C2C)["scount"]) == {m * N1_1 * q * ES}
+    # y-aligned, inverse: after the inverse y transform a rank holds (N2_0, N1, q), q = N2 / P1, sent as P2 blocks (N2_0, n, q)
+    layy = orc.PencilC2CLayout(N, P, None, "Y")
+    qy = N[2] // P1
+    Hy = np.fft.ifft(B, axis=1)                                                       # inverse y done, globally
+    mine = Hy[c1 * N2_0:(c1 + 1) * N2_0, :, c0 * qy:(c0 + 1) * qy]
+    s1b = _lib.exchange_schedule(N, P, rank, _lib.PENCIL_Y, 1, False, kind=_lib.C2C)
+    SY = s1b["scount"][0] // (N2_0 * ES)
+    pady = line if (n * qy * ES) % 65536 == 0 else 0
+    assert SY == n * qy + pady, (SY, n * qy, pady)
+    send = np.zeros((P2, N2_0, SY), dtype=complex)
+    for l in range(P2):
+        send[l, :, :n * qy] = mine[:, l * n:(l + 1) * n, :].reshape(N2_0, n * qy)
+    r = exchange(rank, s1b, send, N[0] * SY * ES).reshape(N[0], SY)
+    got = np.fft.ifft(r[:, :n * qy].reshape(N[0], n, qy), axis=0)                     # inverse x: (N0, n, q) of this rank
+    want = np.fft.ifft(np.fft.ifft(B, axis=1), axis=0)[:, c1 * n:(c1 + 1) * n, c0 * qy:(c0 + 1) * qy]
+    assert orc.rel_l2(got, want) < 1e-13
+    assert set(_lib.exchange_schedule(N, P, rank, _lib.PENCIL_Y, 1, True, kind=_lib.C2C)["scount"]) == {N2_0 * n * qy * ES}
+    assert layy.complex_local_slice(rank)[0] == slice(c1 * N2_0, (c1 + 1) * N2_0, 1)
+    assert want_pad == padx == pady == line
+    return line
+
+
 def main():
     dist.init_process_group("gloo")
     rank, P = dist.get_rank(), dist.get_world_size()
@@ -300,6 +371,8 @@ def main():
             pencil(rank, P, Nr, Ar, align, relay=True)
             if P == 8:
                 pencil(rank, P, Nr, Ar, align, P1=2, relay=True)
+    pad_seen = c2c_plane_padded_exchanges(rank, P)
+    assert pad_seen == 8, pad_seen                     # one 128-byte line of complex128
     dist.barrier()
     if rank == 0:
         print("DIST_OK world=%d" % P)

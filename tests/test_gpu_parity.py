@@ -731,10 +731,10 @@ def test_pencil_non_power_of_two_meshes(N, P, align):
 
 def test_unsupported_mesh_raises_cleanly():
     from mpifft4py_amd import SelfComm, Slab_R2C, _lib
-    with pytest.raises(_lib.MfftError):          # beyond the chirp-z range (2n-1 <= 4096)
-        Slab_R2C(np.array([2050, 8, 8]), L, SelfComm(0), "double")
+    with pytest.raises(_lib.MfftError):          # beyond the chirp-z range (2n-1 <= 8192)
+        Slab_R2C(np.array([4098, 8, 8]), L, SelfComm(0), "double")
     with pytest.raises(_lib.MfftError):
-        Slab_R2C(np.array([8, 8, 4100]), L, SelfComm(0), "double")
+        Slab_R2C(np.array([8, 8, 8196]), L, SelfComm(0), "double")
     with pytest.raises(_lib.MfftError):          # odd real axis
         Slab_R2C(np.array([8, 8, 9]), L, SelfComm(0), "double")
 
