@@ -240,49 +240,51 @@ template <class S, typename T> constexpr int row_occ_wgs(int threads) {
   return (MFFT_ROW_OCC && sizeof(T) == 8 && S::E % 15 == 0 && S::N >= 120 && threads <= 256) ? 512 / threads : 0;   // shorter: 500+ bytes of scratch
 }
 
-// Round 4: c2r kernels whose threads per transform do not divide a wave (24, 30, 48, 50, 60 ...) run wave-packed
-// (fft_kernels.h C2RFft WP: whole rows per wave, the mirrored bin through a wave shuffle, every bin loaded once) where
-// at least three quarters of the lanes stay busy; 40 threads (one row per wave, 62 %) keep the two loads.
-#ifndef MFFT_C2R_WP
-#define MFFT_C2R_WP 1
+// Round 4: real kernels whose threads per transform do not divide a wave (10, 12, 15, 20, 24, 30 ... threads) can run
+// wave-packed (fft_kernels.h R2CFft / C2RFft WP: whole rows per wave, the mirrored bin through a wave shuffle -- r2c without
+// the LDS round trip of its post-pass, c2r with every bin loaded once).  Measured (profiles/r04_wave_packed_real_kernels.txt,
+// z stages of the R2C pair against the dense layout): it pays for the 30-values-per-thread plans, whose dense kernels
+// hold the mirrors in E more registers under a two-wave cap -- r2c at every length (720^3 1.43 -> 1.35 ms, 900^3 3.09 ->
+// 2.69, 1440^3 12.4 -> 11.3; 600 / 1200 unchanged), c2r in single precision (720^3 0.98 -> 0.73, 900^3 1.66 -> 1.51) and in
+// double precision at 10, 12 and 20 threads per transform (600^3 0.77 -> 0.70, 720^3 1.28 -> 1.18, 1200^3 even; 15 and 24
+// threads lose 10 - 13 %: 900^3, 1440^3) -- and LOSES for the 12- and 20-values-per-thread plans (1152^3: r2c 4.65 -> 5.41,
+// c2r 4.75 -> 6.04 ms; 1000^3 r2c 3.31 -> 3.84), which keep the dense layout: their dense kernels run at full occupancy and
+// a quarter of idle lanes costs more than the second load of a mirror pair.
+#ifndef MFFT_REAL_WP
+#define MFFT_REAL_WP 1
 #endif
-template <class S> constexpr bool c2r_wave_packed() {
-  return MFFT_C2R_WP && S::TPT < 64 && 64 % S::TPT != 0 && (64 / S::TPT) * S::TPT * 4 >= 64 * 3;
+template <class S> constexpr bool wave_packable() { return MFFT_REAL_WP && S::TPT < 64 && 64 % S::TPT != 0 && S::E % 15 == 0; }
+template <class S, typename T> constexpr bool r2c_wave_packed() { return wave_packable<S>(); }
+template <class S, typename T> constexpr bool c2r_wave_packed() {
+  return wave_packable<S>() && (sizeof(T) == 4 || S::TPT == 10 || S::TPT == 12 || S::TPT == 20);
 }
-template <class S, typename T> constexpr int c2r_rows() {       // rows per workgroup of the c2r kernels
-  constexpr int r = row_rows<S, T, true>();
-  if constexpr (c2r_wave_packed<S>()) {
+template <class S, typename T, bool C2R> constexpr int real_rows() {       // rows per workgroup of the r2c / c2r kernels
+  constexpr int r = row_rows<S, T, C2R>();
+  constexpr bool wp = C2R ? c2r_wave_packed<S, T>() : r2c_wave_packed<S, T>();
+  if constexpr (wp) {
     constexpr int rpw = 64 / S::TPT;
-    return r / rpw > 0 ? r / rpw * rpw : rpw;                   // whole waves of rows
+    return r / rpw > 0 ? r / rpw * rpw : rpw;                              // whole waves of rows
   } else {
     return r;
   }
 }
-template <class S, typename T> constexpr int c2r_threads() {
-  if constexpr (c2r_wave_packed<S>()) return c2r_rows<S, T>() / (64 / S::TPT) * 64;
-  else return S::TPT * c2r_rows<S, T>();
+template <class S, typename T, bool C2R> constexpr int real_threads() {
+  constexpr bool wp = C2R ? c2r_wave_packed<S, T>() : r2c_wave_packed<S, T>();
+  if constexpr (wp) return real_rows<S, T, C2R>() / (64 / S::TPT) * 64;
+  else return S::TPT * real_rows<S, T, C2R>();
 }
-// ... and the r2c kernels (the row c2c kernels have no mirrored partner and keep the dense layout)
-template <class S, typename T> constexpr int r2c_rows() {
-  constexpr int r = row_rows<S, T>();
-  if constexpr (c2r_wave_packed<S>()) {
-    constexpr int rpw = 64 / S::TPT;
-    return r / rpw > 0 ? r / rpw * rpw : rpw;
-  } else {
-    return r;
-  }
-}
-template <class S, typename T> constexpr int r2c_threads() {
-  if constexpr (c2r_wave_packed<S>()) return r2c_rows<S, T>() / (64 / S::TPT) * 64;
-  else return S::TPT * r2c_rows<S, T>();
-}
+template <class S, typename T> constexpr int c2r_rows() { return real_rows<S, T, true>(); }
+template <class S, typename T> constexpr int c2r_threads() { return real_threads<S, T, true>(); }
+template <class S, typename T> constexpr int r2c_rows() { return real_rows<S, T, false>(); }
+template <class S, typename T> constexpr int r2c_threads() { return real_threads<S, T, false>(); }
 
 template <class S, typename T>
 void register_rows(const char* name) {
   auto& reg = kernel_registry();
   constexpr int R = row_rows<S, T>();
   constexpr int WO = row_occ_wgs<S, T>(S::TPT * R);
-  constexpr bool WPC = c2r_wave_packed<S>();
+  constexpr bool WPC = c2r_wave_packed<S, T>();
+  constexpr bool WPR = r2c_wave_packed<S, T>();
   // c2r: only where the mirrored bins come through wave shuffles (threads per transform a power of two up to 64, or the
   // wave-packed layout: 12 - 28 bytes of scratch under the cap); the variants that load both bins would spill 470 - 680
   // bytes per lane (with scheduling fences every five values as well)
@@ -301,23 +303,23 @@ void register_rows(const char* name) {
   constexpr bool RTC = row_twlds<S, T, true>();
   reg.push_back(make_entry<RowFft<S, T, R, false, RT, false, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 0, R, name));
   reg.push_back(make_entry<RowFft<S, T, R, true, RT, false, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 1, R, name));
-  reg.push_back(make_entry<R2CFft<S, T, RR, RT, false, false, SP, WPC>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
+  reg.push_back(make_entry<R2CFft<S, T, RR, RT, false, false, SP, WPR>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
   reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, false, SC, WPC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
   // pencil decompositions: the z-chunk pack / unpack fused into the stores / loads (pad = 4)
   reg.push_back(make_entry<RowFft<S, T, R, false, RT, true, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 0, R, name));
   reg.back().pad = 4;
   reg.push_back(make_entry<RowFft<S, T, R, true, RT, true, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 1, R, name));
   reg.back().pad = 4;
-  reg.push_back(make_entry<R2CFft<S, T, RR, RT, false, true, SP, WPC>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
+  reg.push_back(make_entry<R2CFft<S, T, RR, RT, false, true, SP, WPR>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
   reg.back().pad = 4;
   reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, true, SC, WPC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
   reg.back().pad = 4;
   if constexpr (S::N % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: column-limited real transforms (pad = 3)
-    reg.push_back(make_entry<R2CFft<S, T, RR, RT, true, false, SP, WPC>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
+    reg.push_back(make_entry<R2CFft<S, T, RR, RT, true, false, SP, WPR>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
     reg.back().pad = 3;
     // ... and with the kept columns split into the z chunks of the pencils' exchange (pad = 7): the 3/2-rule pencil
     // transforms write / read the exchange blocks themselves (pencil.py:511-632, 758-883 do it in the MPI datatypes)
-    reg.push_back(make_entry<R2CFft<S, T, RR, RT, true, true, SP, WPC>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
+    reg.push_back(make_entry<R2CFft<S, T, RR, RT, true, true, SP, WPR>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
     reg.back().pad = 7;
     reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, true, SC, WPC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 7;

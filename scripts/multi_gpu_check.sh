@@ -12,7 +12,7 @@ for P in 2 4 8; do
   for n in 256 512; do
     echo "== parity: $P ranks, $n^3 (slab pipelines 1/2/4/8, pencils X and Y)"
     MP_N=$n timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 \
-      --master-port $((PORT++)) scripts/mp_big_check.py 2>&1 | grep -E "BIG_OK|Error|error|assert" | head -5
+      --master-port $((PORT++)) tests/mp_worker_big.py 2>&1 | grep -E "BIG_OK|Error|error|assert" | head -5
   done
   echo "== IPC transport over real links: every pull mode, CU masks, relay striping (tests/mp_worker.py), then a short soak"
   MFFT_TRANSPORT=ipc timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 \

@@ -105,6 +105,27 @@ def test_process_per_rank_parity(world, transport):
     assert "MP_OK world=%d" % world in out
 
 
+@pytest.mark.parametrize("world,n,transport", [(4, 512, "ipc"), (8, 512, "ipc"), (2, 1024, "ipc"), (4, 512, "mock")])
+def test_process_per_rank_full_size(world, n, transport):
+    """BASELINE config sizes over real PROCESSES and the shipped wire (these ran by hand only): 512^3
+    over 4 and 8 processes, 1024^3 over 2, every pipeline flavour of the slab plan and both pencils, against the host's
+    pocketfft of the whole cube (tests/mp_worker_big.py)."""
+    import subprocess as sp
+    env_extra = {"MP_N": str(n), "MP_WORKERS": str(max(4, (os.cpu_count() or 8) // world))}
+    old = {k: os.environ.get(k) for k in env_extra}
+    os.environ.update(env_extra)
+    try:
+        rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker_big.py")], transport=transport, timeout=870)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert rc == 0, (out[-2000:], err[-4000:])
+    assert "BIG_OK world=%d n=%d" % (world, n) in out
+
+
 @pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("world,launcher", [(2, "torchrun"), (4, "spawn"), (8, "spawn")])
 def test_bench_multi_rank_prints_one_json_line(world, launcher, transport):
