@@ -476,18 +476,43 @@ struct mfft_plan_s {
   int64_t plane_pad(int64_t stride_elems) const {
     return (stride_elems * (int64_t)es) % 65536 == 0 ? (int64_t)(128 / es) : 0;
   }
-  // The same pad carried THROUGH an exchange (round 4): the strided x pass that follows an exchange reads the received
-  // chunks, whose x rows lie N1/P * Nf (slab), N1/P1 * q (x-aligned pencil, forward) or N1/P2 * q (y-aligned pencil,
-  // inverse) elements apart -- a multiple of 64 KiB for complex data on power-of-two meshes (BASELINE config 5: 4 MiB).
-  // The transform that WRITES the send blocks then leaves one cache line between consecutive x rows (a store-side
-  // pitch costs nothing), every chunk grows by that line per x row (mfft_plan_exchange_schedule reports it: 64 KiB on a
-  // 2 GiB chunk at config 5), and the x pass reads the padded rows and writes the caller's compact array.  Un-pipelined
-  // exchanges only (the pieces of the pipelined ones keep the compact layout); MFFT_NO_XPAD=1 switches it off.
-  int64_t xplane_pad(bool forward) const {
-    if (!xpad_on || P == 1 || npieces() != 1 || d.line2d) return 0;
-    if (d.decomp == MFFT_SLAB) return forward ? plane_pad(Np1 * Nf) : 0;
-    if (d.decomp == MFFT_PENCIL_X) return (forward && P1 > 1) ? plane_pad(N1_1 * q) : 0;
-    return (!forward && P2 > 1) ? plane_pad(N2_1 * q) : 0;
+  // The same idea carried THROUGH an exchange (round 4): the strided x pass that follows an exchange reads the received
+  // chunks, whose x rows lie N1/P * Nf (slab; N1/P * kz in the kz-slice pipeline), N1/P1 * q (x-aligned pencil, forward) or
+  // N1/P2 * q (y-aligned pencil, inverse) elements apart.  Measured alone on the device (profiles/r04_xpass_stride_map.txt,
+  // r04_xpass_kernel_ab.txt; 1024 and 2048 rows, out of place, GB/s of algorithmic traffic against ~5000 for a pitch with
+  // one more cache line): a power of two 4100 - 4700; 2^a + 2^(a-7) -- the Nyquist-holding ranks of the 4 x 2 pencil grid at
+  // 1024^3: 512 * 129 elements -- 2100 - 3300 (the memory-channel hash folds address bits seven apart: every row of a tile
+  // lands on the same channels); 2^a + 2^(a-8) 4100 - 4500 (256 * 257 elements); 2^20 + 2^11 (the slab over 8 ranks:
+  // 128 * 513) 4600.  For those pitches the transform that WRITES the send blocks leaves one cache line between
+  // consecutive x rows (a store-side pitch costs nothing), every chunk grows by that line per x row
+  // (mfft_plan_exchange_schedule / _pieces report it: 64 KiB on a 2 GiB chunk at BASELINE config 5), and the x pass reads
+  // the padded rows out of place into the caller's compact array: config 5's x pass 5.52 -> 4.46 ms per rank, the y-aligned
+  // pencil's at 1024^3 0.63 -> 0.47.  MFFT_NO_XPAD=1 switches it off (every rank alike).
+  int64_t slow_pitch_pad(int64_t stride_elems) const {
+    const unsigned long long b = (unsigned long long)stride_elems * (unsigned long long)es;
+    if (b < 65536) return 0;                              // small blocks live in the caches
+    bool slow = b % 65536 == 0;
+    if (!slow && __builtin_popcountll(b) == 2) {
+      const int hi = 63 - __builtin_clzll(b), lo = __builtin_ctzll(b);
+      slow = hi - lo == 7 || hi - lo == 8 || (hi - lo == 9 && hi <= 20);
+    }
+    return slow ? (int64_t)(128 / es) : 0;
+  }
+  int64_t xplane_pad(bool forward) const {                // one pitch for the whole exchange (not the kz-slice pipeline)
+    if (!xpad_on || P == 1 || d.line2d || d.drop_nyquist) return 0;
+    if (d.decomp == MFFT_SLAB) return (forward && nbatch <= 1 && nslice <= 1) ? slow_pitch_pad(Np1 * Nf) : 0;
+    if (d.decomp == MFFT_PENCIL_X) return (forward && P1 > 1) ? slow_pitch_pad(N1_1 * q) : 0;
+    return (!forward && P2 > 1) ? slow_pitch_pad(N2_1 * q) : 0;
+  }
+  // kz-slice pipeline of the slab: x-row pitch of slice s in the exchanged layout, and where the slice starts
+  int64_t slice_pitch(int s, bool forward) const {
+    const int64_t w = Np1 * kslice[s].len;
+    return w + ((forward && xpad_on) ? slow_pitch_pad(w) : 0);
+  }
+  size_t slice_offset(int s, bool forward) const {        // elements of all earlier slices in the send / receive buffers
+    size_t o = 0;
+    for (int t = 0; t < s; ++t) o += (size_t)(P * Np0 * slice_pitch(t, forward));
+    return o;
   }
   // One-rank forward transform: y and x passes out of place through a work buffer of the size of the spectrum instead
   // of in place on the result.  MFFT_FWD_OOP=1 / 0 forces it on / off; default: off (measured).
@@ -692,8 +717,7 @@ int mfft_plan_s::piece_sched(int which, bool forward, int piece, Sched* o) const
       for (int r = 0; r < P; ++r) o->sd[r] = o->rd[r] = (size_t)((r * Np0 + i0) * Np1 * Nf) * es;
       return 0;
     }
-    const int64_t k0 = kslice[piece].start, kz = kslice[piece].len;
-    const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es, chunk = (size_t)(Np0 * Np1 * kz) * es;
+    const size_t boff = slice_offset(piece, forward) * es, chunk = (size_t)(Np0 * slice_pitch(piece, forward)) * es;
     o->peers = world;
     o->sc.assign(P, chunk);
     o->rc = o->sc;
@@ -879,17 +903,18 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
 // the receive layout (N0, Np1, kzs).
 int mfft_plan_s::slab_forward_pipelined(const void* u, void* fu) {
   const double Cb = (double)(N0 * Np1 * Nf) * es, Rb = (double)(Np0 * N1 * N2) * rs;
-  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  // per slice the x rows of the exchanged layout lie slice_pitch() elements apart (Np1 * kz, plus a cache line where that
+  // pitch reads slowly: xplane_pad's rule, slice by slice)
+  const size_t cb = std::max((size_t)(Np0 * N1 * Nf), slice_offset(nslice, true)) * es;
   for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, cb));
   char *A = static_cast<char*>(work[0]), *B = static_cast<char*>(work[1]), *Cr = static_cast<char*>(work[2]);
   char* out = static_cast<char*>(fu);
   MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, A, Np0 * N1, N2, Nf); }));
   for (int s = 0; s < nslice; ++s) {
-    const int64_t k0 = kslice[s].start, kz = kslice[s].len;
-    const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es;
+    const int64_t k0 = kslice[s].start, kz = kslice[s].len, S = slice_pitch(s, true);
+    const size_t boff = slice_offset(s, true) * es;
     MFFT_TRY(stage("fwd_y", 2 * Cb / nslice, [&] {
-      return col(A + (size_t)k0 * es, B + boff, N1, false, Np0, kz, N1 * Nf, plain(Nf), Np1 * kz,
-                 two_level(Np1, Np0 * Np1 * kz, kz));
+      return col(A + (size_t)k0 * es, B + boff, N1, false, Np0, kz, N1 * Nf, plain(Nf), S, two_level(Np1, Np0 * S, kz));
     }));
     MFFT_HIP(hipEventRecord(ev_compute[s], stream));
     MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[s], 0));
@@ -902,10 +927,10 @@ int mfft_plan_s::slab_forward_pipelined(const void* u, void* fu) {
   }
   for (int s = 0; s < nslice; ++s) {
     const int64_t k0 = kslice[s].start, kz = kslice[s].len;
-    const size_t boff = (size_t)(P * Np0 * Np1 * k0) * es;
+    const size_t boff = slice_offset(s, true) * es;
     MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[s], 0));
     MFFT_TRY(stage("fwd_x", 2 * Cb / nslice, [&] {
-      return col(Cr + boff, out + (size_t)k0 * es, N0, false, Np1, kz, kz, plain(Np1 * kz), Nf, plain(Np1 * Nf));
+      return col(Cr + boff, out + (size_t)k0 * es, N0, false, Np1, kz, kz, plain(slice_pitch(s, true)), Nf, plain(Np1 * Nf));
     }));
   }
   return 0;
@@ -1252,22 +1277,24 @@ int mfft_plan_s::sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sch
     // Y alignment, x-chunk exchange over group1 (P2 ranks): rows [i0, i0+mb) of the N2_0 rows of every block
     // [c][x'][j][k] (N2_0, n, q); the send block c is rows c*N2_0.. of (N0, n, q), the receive block c' the same shape
     const int Pg = (int)group1.size();
+    const int64_t SY = n * q + xplane_pad(forward);         // x-row pitch (inverse: padded where the compact one reads slowly)
     o->peers = group1;
-    o->sc.assign(Pg, (size_t)(mb * n * q) * es);
+    o->sc.assign(Pg, (size_t)(mb * SY) * es);
     o->rc = o->sc;
     o->sd.resize(Pg); o->rd.resize(Pg);
-    for (int g = 0; g < Pg; ++g) o->sd[g] = o->rd[g] = (size_t)((g * N2_0 + i0) * n * q) * es;
+    for (int g = 0; g < Pg; ++g) o->sd[g] = o->rd[g] = (size_t)((g * N2_0 + i0) * SY) * es;
     return 0;
   }
   // X alignment, y-chunk exchange over group0 (P1 ranks): P1 blocks (m, N1_1, q) <-> rows of (N0, N1_1, q)
   const int Pg = (int)group0.size();
+  const int64_t SX = N1_1 * q + xplane_pad(forward);        // x-row pitch (forward: padded where the compact one reads slowly)
   o->peers = group0;
-  o->sc.assign(Pg, (size_t)(mb * N1_1 * q) * es);
+  o->sc.assign(Pg, (size_t)(mb * SX) * es);
   o->rc = o->sc;
   o->sd.resize(Pg); o->rd.resize(Pg);
   for (int g = 0; g < Pg; ++g) {
-    const size_t blk = (size_t)(g * m * N1_1 * q + i0 * N1_1 * q) * es;      // [g][i][j'][k]
-    const size_t row = (size_t)((g * m + i0) * N1_1 * q) * es;               // x = g*m + i
+    const size_t blk = (size_t)((g * m + i0) * SX) * es;                     // [g][i][j'][k]
+    const size_t row = (size_t)((g * m + i0) * SX) * es;                     // x = g*m + i
     if (forward) { o->sd[g] = blk; o->rd[g] = row; }
     else         { o->sd[g] = row; o->rd[g] = blk; }
   }
@@ -1292,7 +1319,11 @@ int mfft_plan_s::pencil_forward_pipelined_x(const void* u, void* fu) {
   const int64_t m = N1_0, n = N2_1;
   const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
   const bool zsolo = P2 == 1, g2solo = P1 == 1;
-  const size_t wb = (size_t)std::max(m * n * Nf, m * N1 * q) * es;
+  // x-row pitch of the blocks of the second exchange: N1_1 * q, plus a cache line where that pitch reads slowly
+  // (xplane_pad); then the chunks land in a work buffer and the x transform runs out of place into the result
+  const int64_t SX = N1_1 * q + xplane_pad(true);
+  const bool xoop = SX != N1_1 * q;
+  const size_t wb = (size_t)std::max(std::max(m * n * Nf, m * N1 * q), xoop ? N0 * SX : (int64_t)0) * es;
   for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
   char *W0 = static_cast<char*>(work[0]), *W1 = static_cast<char*>(work[1]), *W2 = static_cast<char*>(work[2]);
   const char* in = static_cast<const char*>(u);
@@ -1327,13 +1358,16 @@ int mfft_plan_s::pencil_forward_pipelined_x(const void* u, void* fu) {
   // this stream) and takes the P1 blocks (m, N1_1, q) that feed the second exchange
   const char* ysrc = zsolo ? W0 : W2;
   char* ydst = g2solo ? out : (zsolo ? W1 : W0);
+  // padded pitch: where the second exchange delivers.  W1 was the send buffer of the z exchanges, all of which are ahead
+  // of every second exchange on the communication stream; on a P1 x 1 grid (no z exchange) W1 is ydst and W2 is unused
+  char* xrecv = xoop ? (zsolo ? W2 : W1) : out;
   for (int b = 0; b < B; ++b) {
     int64_t i0, mb;
     rows(b, &i0, &mb);
     if (!zsolo) MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
     MFFT_TRY(stage("fwd_y", 2 * Cb / B, [&] {
-      return col(ysrc + (size_t)(i0 * n * q) * es, ydst + (size_t)(i0 * N1_1 * q) * es, N1, false, mb, q, n * q,
-                 two_level(n, m * n * q, q), N1_1 * q, two_level(N1_1, m * N1_1 * q, q));
+      return col(ysrc + (size_t)(i0 * n * q) * es, ydst + (size_t)(i0 * SX) * es, N1, false, mb, q, n * q,
+                 two_level(n, m * n * q, q), SX, two_level(N1_1, m * SX, q));
     }));
     if (g2solo) continue;
     MFFT_HIP(hipEventRecord(ev2_compute[b], stream));
@@ -1341,11 +1375,15 @@ int mfft_plan_s::pencil_forward_pipelined_x(const void* u, void* fu) {
     MFFT_TRY(stage_on(cstream, "fwd_a2a_2", 0, [&] {
       Sched sc;
       MFFT_TRY(piece_sched(1, true, b, &sc));
-      return run_sched(sc, ydst, out, cstream);
+      return run_sched(sc, ydst, xrecv, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev2_comm[b], cstream));
   }
   if (!g2solo) MFFT_HIP(hipStreamWaitEvent(stream, ev2_comm[B - 1], 0));     // in order on the comm stream: all batches
+  if (xoop) {
+    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(xrecv, fu, N0, false, 1, N1_1 * q, 0, plain(SX), 0, plain(N1_1 * q)); }));
+    return 0;
+  }
   MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1_1 * q, 0, plain(N1_1 * q), 0, plain(N1_1 * q)); }));
   return 0;
 }
@@ -1485,7 +1523,9 @@ int mfft_plan_s::pencil_forward_pipelined_y(const void* u, void* fu) {
 int mfft_plan_s::pencil_backward_pipelined_y(const void* src, void* u) {
   const int64_t m = N1_0, n = N2_1;
   const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
-  const size_t wb = (size_t)std::max(m * n * Nf, N0 * n * q) * es;
+  const int64_t SY = n * q + xplane_pad(false);        // x-row pitch of the blocks of the x-chunk exchange (see xplane_pad)
+  const bool xoop = SY != n * q;
+  const size_t wb = (size_t)std::max(m * n * Nf, N0 * SY) * es;
   for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, wb));
   char *W0 = static_cast<char*>(work[0]), *W1 = static_cast<char*>(work[1]);
   const char* in = static_cast<const char*>(src);
@@ -1495,8 +1535,8 @@ int mfft_plan_s::pencil_backward_pipelined_y(const void* src, void* u) {
   for (int b = 0; b < B; ++b) {
     const int64_t x0 = N2_0 * b / B, xb = N2_0 * (b + 1) / B - x0;
     MFFT_TRY(stage("bwd_y", 2 * Cb / B, [&] {
-      return col(in + (size_t)(x0 * N1 * q) * es, W0 + (size_t)(x0 * n * q) * es, N1, true, xb, q, N1 * q, plain(q), n * q,
-                 two_level(n, N2_0 * n * q, q));
+      return col(in + (size_t)(x0 * N1 * q) * es, W0 + (size_t)(x0 * SY) * es, N1, true, xb, q, N1 * q, plain(q), SY,
+                 two_level(n, N2_0 * SY, q));
     }));
     MFFT_HIP(hipEventRecord(ev2_compute[b], stream));
     MFFT_HIP(hipStreamWaitEvent(cstream, ev2_compute[b], 0));
@@ -1508,14 +1548,23 @@ int mfft_plan_s::pencil_backward_pipelined_y(const void* src, void* u) {
     MFFT_HIP(hipEventRecord(ev2_comm[b], cstream));
   }
   MFFT_HIP(hipStreamWaitEvent(stream, ev2_comm[B - 1], 0));
-  MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(W1, W1, N0, true, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+  // x transform: in place on the received (N0, n, q), or -- rows SY apart -- out of place into W0, which every x-chunk
+  // exchange has read by now; the z-gathering exchange then goes the other way round
+  char *xsend = W1, *zrecv = W0;
+  if (xoop) {
+    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(W1, W0, N0, true, 1, n * q, 0, plain(SY), 0, plain(n * q)); }));
+    xsend = W0;
+    zrecv = W1;
+  } else {
+    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(W1, W1, N0, true, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+  }
   MFFT_HIP(hipEventRecord(ev_compute[0], stream));
   MFFT_HIP(hipStreamWaitEvent(cstream, ev_compute[0], 0));
   for (int b = 0; b < B; ++b) {
     MFFT_TRY(stage_on(cstream, "bwd_a2a_1", 0, [&] {
       Sched sc;
       MFFT_TRY(piece_sched(0, false, b, &sc));
-      return run_sched(sc, W1, W0, cstream);                                  // W0: every x-chunk exchange has read it
+      return run_sched(sc, xsend, zrecv, cstream);
     }));
     MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
   }
@@ -1523,7 +1572,7 @@ int mfft_plan_s::pencil_backward_pipelined_y(const void* src, void* u) {
     const int64_t i0 = m * b / B, mb = m * (b + 1) / B - i0;
     MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
     MFFT_TRY(stage("bwd_z", (Rb + Cb) / B, [&] {
-      return z_backward_chunked(W0, out + (size_t)(i0 * n * N2) * rs, mb * n, i0 * n, m * n);
+      return z_backward_chunked(zrecv, out + (size_t)(i0 * n * N2) * rs, mb * n, i0 * n, m * n);
     }));
   }
   return 0;

@@ -340,7 +340,52 @@ def c2c_plane_padded_exchanges(rank, P):
     assert set(_lib.exchange_schedule(N, P, rank, _lib.PENCIL_Y, 1, True, kind=_lib.C2C)["scount"]) == {N2_0 * n * qy * ES}
     assert layy.complex_local_slice(rank)[0] == slice(c1 * N2_0, (c1 + 1) * N2_0, 1)
     assert want_pad == padx == pady == line
+    # the same exchange of the x-aligned pencil piece by piece (batches of local x rows, mfft_plan_exchange_pieces): the
+    # pieces address the PADDED buffers
+    pieces = _lib.exchange_pieces(N, P, rank, _lib.PENCIL_X, 1, True, 0, kind=_lib.C2C)
+    assert len(pieces) == min(4, m) and sum(sum(pc["scount"]) for pc in pieces) == N[0] * SX * ES
+    mine = G[c0 * m:(c0 + 1) * m, :, c1 * q:(c1 + 1) * q]
+    send = np.zeros((P1, m, SX), dtype=complex)
+    for l in range(P1):
+        send[l, :, :N1_1 * q] = mine[:, l * N1_1:(l + 1) * N1_1, :].reshape(m, N1_1 * q)
+    r = exchange_pieces(rank, pieces, send, N[0] * SX * ES).reshape(N[0], SX)
+    fu = np.fft.fft(r[:, :N1_1 * q].reshape(N[0], N1_1, q), axis=0)
+    assert orc.rel_l2(fu, B[lay.complex_local_slice(rank)]) < 1e-13
     return line
+
+
+def slab_c2c_kz_slices_padded(rank, P):
+    """The slab's DEFAULT multi-rank path (4 kz slices) on complex data: every slice's x rows lie N1/P * kz elements apart --
+    a power of two here -- so each slice is exchanged with one cache line between its x rows (plan.hip slice_pitch); the
+    piece schedules say where."""
+    N = [8, 256, 512]
+    A = np.random.default_rng(2030).random(N) + 1j * np.random.default_rng(2031).random(N)
+    B = np.fft.fftn(A)
+    Np0, Np1, Nz = N[0] // P, N[1] // P, N[2]
+    fwd = _lib.exchange_pieces(N, P, rank, _lib.SLAB, 0, True, 0, kind=_lib.C2C)
+    bwd = _lib.exchange_pieces(N, P, rank, _lib.SLAB, 0, False, 0, kind=_lib.C2C)
+    assert len(fwd) == 4 and len(bwd) == 4
+    kz = Nz // 4
+    pitch = [pc["scount"][0] // (Np0 * ES) for pc in fwd]
+    assert all(S == Np1 * kz + 8 for S in pitch), (pitch, Np1 * kz)             # (Np1 * kz * 16) % 65536 == 0 at every P
+    assert all(pc["scount"][0] == Np0 * Np1 * kz * ES for pc in bwd)              # the inverse reads the caller's array: compact
+    a = np.fft.fft2(A[rank * Np0:(rank + 1) * Np0], axes=(1, 2))
+    packed = orc.slab_pack(a, P)                                                  # (P, Np0, Np1, Nz)
+    bufs = []
+    for s_, S in enumerate(pitch):
+        blk = np.zeros((P, Np0, S), dtype=complex)
+        blk[:, :, :Np1 * kz] = packed[:, :, :, s_ * kz:(s_ + 1) * kz].reshape(P, Np0, Np1 * kz)
+        bufs.append(blk.ravel())
+        assert fwd[s_]["sdisp"][0] == sum(P * Np0 * t * ES for t in pitch[:s_])
+    total = sum(P * Np0 * S * ES for S in pitch)
+    r = exchange_pieces(rank, fwd, np.concatenate(bufs), total)
+    fu = np.empty((N[0], Np1, Nz), dtype=complex)
+    off = 0
+    for s_, S in enumerate(pitch):
+        rows = r[off:off + N[0] * S].reshape(N[0], S)[:, :Np1 * kz].reshape(N[0], Np1, kz)
+        fu[:, :, s_ * kz:(s_ + 1) * kz] = np.fft.fft(rows, axis=0)
+        off += N[0] * S
+    assert orc.rel_l2(fu, B[:, rank * Np1:(rank + 1) * Np1]) < 1e-13
 
 
 def main():
@@ -373,6 +418,7 @@ def main():
                 pencil(rank, P, Nr, Ar, align, P1=2, relay=True)
     pad_seen = c2c_plane_padded_exchanges(rank, P)
     assert pad_seen == 8, pad_seen                     # one 128-byte line of complex128
+    slab_c2c_kz_slices_padded(rank, P)
     dist.barrier()
     if rank == 0:
         print("DIST_OK world=%d" % P)
