@@ -32,6 +32,15 @@ run() {
     r02_ipc_fanout_probe.txt) git checkout 292508d -- mpifft4py_amd/csrc/ipc_comm.hip && make -C mpifft4py_amd/csrc -j8 &&   # the per-peer-stream flag form was removed in round 4
       MFFT_IPC_PULL=streams MFFT_IPC_STREAM_FLAGS=1 python bench.py --gpus 8 --size 128 --steps 3 --warmup 1 --cpu-baseline off --pencil-extra off --transport ipc ;;
     r02_bench_after_two_wg_plan.json|r02_final_bench_1024cubed.json|r03_final_bench_1024cubed.json) python bench.py --steps 10 --warmup 3 ;;
+    r04_final_bench_1024cubed.json) python bench.py --steps 10 --warmup 3 ;;
+    r04_final_*) bash scripts/profile_r04.sh bench; python scripts/summarize_profiles.py r04_final gpurun_out/prof_r04/trace gpurun_out/prof_r04/fetch gpurun_out/prof_r04/write "bench.py --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off: 1024^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r04_final gpurun_out/prof_r04/sq1 gpurun_out/prof_r04/sq2 ;;
+    r04_720_*) bash scripts/profile_cmd.sh b720 bench.py --size 720 --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off; python scripts/summarize_profiles.py r04_720 gpurun_out/prof_b720/trace gpurun_out/prof_b720/fetch gpurun_out/prof_b720/write "bench.py --size 720: 720^3 fp64 slab R2C forward+inverse on one MI355X" ;;
+    r04_radix7_sweep.txt) bash scripts/r04_gpu1.sh ;;
+    r04_wave_packed_real_kernels.txt) echo '(build with every candidate wave-packed: registry.h wave_packable without the E % 15 / thread-count conditions)'; bash scripts/r04_gpu4.sh ;;
+    r04_xpass_ab.txt) bash scripts/r04_gpu3.sh ;;
+    r04_xpass_kernel_ab.txt) python scripts/xpass_kernel_ab.py ;;
+    r04_xpass_stride_map.txt) (cd scripts && python xpass_stride_map.py 1024 && python xpass_stride_map.py 2048 && python xpass_pad_sweep.py) ;;
+    r04_comm_priority.txt) bash scripts/r04_priority.sh ;;
     r03_final_*) bash scripts/profile_r03.sh bench; python scripts/summarize_profiles.py r03_final gpurun_out/prof_r03/trace gpurun_out/prof_r03/fetch gpurun_out/prof_r03/write "bench.py --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off: 1024^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_final gpurun_out/prof_r03/sq1 gpurun_out/prof_r03/sq2 ;;
     r03_720_*) bash scripts/profile_cmd.sh b720 bench.py --size 720 --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off; python scripts/summarize_profiles.py r03_720 gpurun_out/prof_b720/trace gpurun_out/prof_b720/fetch gpurun_out/prof_b720/write "bench.py --size 720: 720^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_720 gpurun_out/prof_b720/sq1 gpurun_out/prof_b720/sq2 ;;
     r03_512_*) bash scripts/profile_cmd.sh b512 bench.py --size 512 --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off; python scripts/summarize_profiles.py r03_512 gpurun_out/prof_b512/trace gpurun_out/prof_b512/fetch gpurun_out/prof_b512/write "bench.py --size 512: 512^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_512 gpurun_out/prof_b512/sq1 gpurun_out/prof_b512/sq2 ;;
