@@ -648,6 +648,59 @@ def test_pencil_c2c_extension(P, P1, align, prec):
         assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
 
 
+@pytest.mark.parametrize("kind,N", [("c2c", [64, 256, 512]), ("r2c", [64, 256, 1024])])
+@pytest.mark.parametrize("cls,P,pipeline", [("slab", 2, 1), ("slab", 2, 0), ("slab", 4, 0), ("pencilX", 4, 1), ("pencilX", 4, 0),
+                                            ("pencilY", 4, 1), ("pencilY", 4, 0)])
+def test_exchanged_layouts_with_padded_x_rows(cls, P, pipeline, kind, N):
+    """Round 4: where the x rows of an exchanged layout lie a slow pitch apart (a power of two, 2^a + 2^(a-7..9): plan.hip
+    xplane_pad / slice_pitch) the chunks carry one cache line between x rows and the x pass reads them out of place.
+    Meshes on which that is the case for the slab (un-pipelined and kz slices), the x-aligned pencil (forward) and the
+    y-aligned one (inverse), un-pipelined and pipelined, complex and real data -- asserted through the device-free
+    schedule query -- against numpy.fft on the gathered array."""
+    from mpifft4py_amd import Pencil_C2C, Pencil_R2C, Slab_C2C, Slab_R2C, _lib
+    dec = {"slab": _lib.SLAB, "pencilX": _lib.PENCIL_X, "pencilY": _lib.PENCIL_Y}[cls]
+    knd = _lib.C2C if kind == "c2c" else _lib.R2C
+    Nf = N[2] if kind == "c2c" else N[2] // 2 + 1
+    # the pad is there: some chunk of the exchange in front of the x pass is larger than the compact one
+    if cls == "slab":
+        if pipeline == 1:
+            sc = _lib.exchange_schedule(N, P, 0, dec, 0, True, kind=knd)["scount"][0]
+            assert sc == (N[0] // P) * ((N[1] // P) * Nf + 8) * 16
+        else:
+            pcs = _lib.exchange_pieces(N, P, 0, dec, 0, True, 0, kind=knd)
+            assert len(pcs) == 4 and sum(pc["scount"][0] for pc in pcs) > (N[0] // P) * (N[1] // P) * Nf * 16
+    else:
+        fwd = cls == "pencilX"
+        sc = _lib.exchange_schedule(N, P, 0, dec, 1, fwd, kind=knd)["scount"][0]
+        q = Nf // 2
+        rows, plane = (N[0] // 2, (N[1] // 2) * q)
+        assert sc == rows * (plane + 8) * 16, (sc, rows, plane)
+    rng = np.random.default_rng(77 + P)
+    if kind == "c2c":
+        A = rng.random(N) - 0.5 + 1j * (rng.random(N) - 0.5)
+        B = np.fft.fftn(A)
+    else:
+        A = rng.random(N)
+        B = np.fft.rfftn(A)
+
+    def body(comm):
+        if cls == "slab":
+            F = (Slab_C2C if kind == "c2c" else Slab_R2C)(np.array(N), L, comm, "double", pipeline=pipeline)
+        elif kind == "c2c":
+            F = Pencil_C2C(np.array(N), L, comm, "double", alignment=cls[-1], pipeline=pipeline)
+        else:
+            F = Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=cls[-1], pipeline=pipeline)
+        isl = F.original_local_slice() if kind == "c2c" else F.real_local_slice()
+        osl = F.transformed_local_slice() if kind == "c2c" else F.complex_local_slice()
+        a = np.ascontiguousarray(A[isl])
+        c = F.fftn(a, np.zeros(B[osl].shape, dtype=complex))
+        b = F.ifftn(c, np.zeros(a.shape, dtype=a.dtype))
+        c2 = F.fftn(a, np.zeros(B[osl].shape, dtype=complex))            # the work buffers have changed roles once
+        return orc.rel_l2(c, B[osl]), orc.rel_l2(b, a), np.array_equal(c, c2)
+    for e_f, e_b, same in run_ranks(P, body):
+        assert e_f < 1e-10 and e_b < 1e-10 and same, (e_f, e_b, same)
+
+
 CONFIG5_MESHES = [[2048, 64, 32], [64, 2048, 32], [32, 64, 2048], [4096, 32, 16]]
 
 
