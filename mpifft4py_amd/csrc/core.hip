@@ -35,7 +35,8 @@ std::vector<KernelEntry>& kernel_registry() {
 // The registry is complete once the static initialisers of the kernels_*.hip units have run; lookups go
 // through hash maps built on first use (a linear scan of ~2000 entries per launch costs ~0.3 us, visible at 32^3).
 static uint64_t kernel_key(int family, int n, int prec, int inv, int nt, int pad) {
-  return ((uint64_t)(unsigned)n << 12) | ((uint64_t)family << 8) | ((uint64_t)pad << 4) | ((uint64_t)nt << 2) |
+  // pad codes run to 18 (registry.h: 16 + pad for the ColFft3 kernels): six bits
+  return ((uint64_t)(unsigned)n << 16) | ((uint64_t)family << 10) | ((uint64_t)(pad & 63) << 4) | ((uint64_t)nt << 2) |
          ((uint64_t)inv << 1) | (uint64_t)prec;
 }
 
@@ -220,7 +221,8 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   // two); in place only the kernels that run two workgroups per CU gain from it (3.42 -> 3.35 ms; one per CU: 3.57 -> 3.84 ms)
   static const int nt_mode = getenv("MFFT_NT") ? atoi(getenv("MFFT_NT")) : 1;   // 0 never, 1 by that rule, 2 always
   const KernelEntry* ent = nullptr;
-  if (a.allow_nt && nt_mode > 0 && !a.pad && aligned(a.in, a.in_outer, a.in_rows) && aligned(a.out, a.out_outer, a.out_rows)) {
+  const bool nt_ok = a.allow_nt && nt_mode > 0 && !a.pad && aligned(a.in, a.in_outer, a.in_rows) && aligned(a.out, a.out_outer, a.out_rows);
+  if (nt_ok) {
     ent = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1);
     if (ent && a.in == a.out && !(ent->nt_inplace || nt_mode == 2)) ent = nullptr;
   }
@@ -240,6 +242,19 @@ int launch_col(const ColArgs& a, hipStream_t s) {
     if ((a.pad == 1) != a.inverse) return set_error(MFFT_ERR_INVALID, "pad-on-load is an inverse-transform mode, truncate-on-store a forward one");
     e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0, a.pad);
     if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no fused 3/2-rule kernel for length %d", a.n);
+  }
+  // N = 3 L as three sub-transforms per workgroup (fft_col3.h; pad codes 16 + pad), plain and 3/2-rule passes.  Measured at
+  // 1536 (profiles/r04_col3_1536.txt): even with the ColFft plan in double precision (1536^3 pair 75.1 - 81.0 against 76.9 -
+  // 78.1 ms, 3/2-rule pair of 1024^3 45.5 - 47.7 against 47.9 - 48.1), ahead in single precision on the x passes (rows a whole
+  // plane apart: 9.0 -> 7.3 ms inverse, 7.5 -> 6.8 forward) and behind on the y passes (6.9 -> 7.7 - 8.1).  Default: single
+  // precision, passes without an outer batch (the x passes); MFFT_COL3=1 always, MFFT_COL3=0 never.
+  static const int col3_mode = getenv("MFFT_COL3") ? atoi(getenv("MFFT_COL3")) : -1;
+  const bool col3_on = col3_mode > 0 || (col3_mode < 0 && a.prec == MFFT_SINGLE && a.nouter == 1);
+  if (col3_on && !a.mask && !a.band.on) {
+    const KernelEntry* e3 = nullptr;
+    if (nt_ok) e3 = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1, 16);              // same alignment rule, NT build
+    if (!e3) e3 = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0, 16 + a.pad);
+    if (e3) e = e3;
   }
   if (!e && ent) e = ent;
   if (!e) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0);

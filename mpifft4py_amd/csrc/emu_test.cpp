@@ -18,6 +18,7 @@
 
 #include "fft_kernels.h"
 #include "fft_chirpz.h"
+#include "fft_col3.h"
 #include "twiddle.h"
 #include "plans.h"
 
@@ -969,6 +970,118 @@ static void test_c2r_wave_packed() {
   }
 }
 
+// N = 3 L as three sub-transforms (fft_col3.h): plain forward / inverse (in place and out of place, two-level row maps on
+// both sides, ragged last column tile), pad-on-load inverse and truncate-on-store forward with the Nyquist fold, against the
+// long-double DFT of the logical data.
+template <class SL, typename T, int COLS, int SPLIT, int VEC>
+static void test_col3() {
+  constexpr int L = SL::N, N = 3 * L;
+  const int ncols = COLS + COLS / 2 + 1, nouter = 2;         // one full and one ragged tile per outer batch
+  const int pitch = ncols + 3;
+  std::mt19937_64 rng(4242 + N);
+  std::uniform_real_distribution<double> U(-1, 1);
+  auto tw = build_col3_twiddles<SL, T>();
+  char name[96];
+  for (int inv = 0; inv < 2; ++inv) {
+    for (int inplace = 0; inplace < 2; ++inplace) {
+      // rows through a two-level map: row r -> (r / split) * hi + (r % split) * lo
+      const int split = N / 4, lo = pitch, hi = split * pitch + 5 * pitch;
+      const size_t outer_stride = (size_t)4 * hi + 7;
+      std::vector<cx<T>> in(outer_stride * nouter), out(outer_stride * nouter, mk<T>((T)7, (T)7));
+      for (auto& z : in) z = mk<T>((T)U(rng), (T)U(rng));
+      std::vector<cx<T>> src = in;
+      ColParams<T> P;
+      memset(&P, 0, sizeof P);
+      P.in = in.data(); P.out = inplace ? in.data() : out.data(); P.tw = tw.data();
+      P.in_outer = (i64)outer_stride; P.out_outer = (i64)outer_stride;
+      P.in_map = make_rowmap(hi, lo, split, N); P.out_map = make_rowmap(hi, lo, split, N);
+      P.ncols = ncols; P.ntile_c = (ncols + COLS - 1) / COLS; P.nouter = nouter; P.remap = 1; P.scale = (T)(inv ? 1.0 / N : 1.0);
+      auto run = [&](auto k) {
+        typedef decltype(k) K;
+        emu_launch(P.ntile_c * nouter, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+      };
+      if (inv) run(ColFft3<SL, T, COLS, true, true, SPLIT, VEC, false, 0>{});
+      else run(ColFft3<SL, T, COLS, false, false, SPLIT, VEC, false, 0>{});
+      const std::vector<cx<T>>& res = inplace ? in : out;
+      long double num = 0, den = 0;
+      for (int o = 0; o < nouter; ++o)
+        for (int cc = 0; cc < ncols; cc += 3) {
+          lvec x(N);
+          for (int r = 0; r < N; ++r) {
+            const cx<T> z = src[o * outer_stride + (size_t)(r / split) * hi + (size_t)(r % split) * lo + cc];
+            x[r].x = z.x; x[r].y = z.y;
+          }
+          lvec X = naive_dft(x, inv ? +1 : -1);
+          for (int r = 0; r < N; ++r) {
+            const cx<T> g = res[o * outer_stride + (size_t)(r / split) * hi + (size_t)(r % split) * lo + cc];
+            const long double s = inv ? 1.0L / N : 1.0L;
+            num += (g.x - X[r].x * s) * (g.x - X[r].x * s) + (g.y - X[r].y * s) * (g.y - X[r].y * s);
+            den += X[r].x * s * X[r].x * s + X[r].y * s * X[r].y * s;
+          }
+        }
+      snprintf(name, sizeof name, "col3 c%d v%d %s%s%s", COLS, VEC, inv ? "inv" : "fwd", inplace ? " in place" : "", SPLIT ? " split" : "");
+      report(name, N, pname<T>(), (double)sqrtl(num / den), 2 * tol_of<T>());
+    }
+  }
+  // 3/2-rule: inverse with the zero band on input (2L physical rows), forward with the truncated output + Nyquist fold
+  {
+    const int n = 2 * L;
+    std::vector<cx<T>> phys((size_t)n * pitch), big((size_t)N * pitch, mk<T>((T)7, (T)7)), back((size_t)n * pitch, mk<T>((T)7, (T)7));
+    for (auto& z : phys) z = mk<T>((T)U(rng), (T)U(rng));
+    ColParams<T> P;
+    memset(&P, 0, sizeof P);
+    P.in = phys.data(); P.out = big.data(); P.tw = tw.data();
+    P.in_map = make_rowmap(0, pitch, 0, n); P.out_map = make_rowmap(0, pitch, 0, N);
+    P.ncols = ncols; P.ntile_c = (ncols + COLS - 1) / COLS; P.nouter = 1; P.remap = 0; P.scale = (T)1;
+    {
+      typedef ColFft3<SL, T, COLS, true, true, SPLIT, VEC, false, 1> K;
+      emu_launch(P.ntile_c, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+    }
+    long double num = 0, den = 0;
+    for (int cc = 0; cc < ncols; cc += 2) {
+      lvec x(N);
+      for (int r = 0; r < N; ++r) { x[r].x = 0; x[r].y = 0; }
+      for (int r = 0; r < L; ++r) {
+        x[r].x = phys[(size_t)r * pitch + cc].x; x[r].y = phys[(size_t)r * pitch + cc].y;
+        x[2 * L + r].x = phys[(size_t)(L + r) * pitch + cc].x; x[2 * L + r].y = phys[(size_t)(L + r) * pitch + cc].y;
+      }
+      lvec X = naive_dft(x, +1);
+      for (int r = 0; r < N; ++r) {
+        const cx<T> g = big[(size_t)r * pitch + cc];
+        num += (g.x - X[r].x) * (g.x - X[r].x) + (g.y - X[r].y) * (g.y - X[r].y);
+        den += X[r].x * X[r].x + X[r].y * X[r].y;
+      }
+    }
+    snprintf(name, sizeof name, "col3 c%d v%d pad-on-load inv%s", COLS, VEC, SPLIT ? " split" : "");
+    report(name, N, pname<T>(), (double)sqrtl(num / den), 2 * tol_of<T>());
+    for (int fold = 0; fold < 2; ++fold) {
+      std::vector<cx<T>> full((size_t)N * pitch);
+      for (auto& z : full) z = mk<T>((T)U(rng), (T)U(rng));
+      P.in = full.data(); P.out = back.data(); P.in_map = make_rowmap(0, pitch, 0, N); P.out_map = make_rowmap(0, pitch, 0, n);
+      P.fold = fold; P.scale = (T)0.5;
+      {
+        typedef ColFft3<SL, T, COLS, false, false, SPLIT, VEC, false, 2> K;
+        emu_launch(P.ntile_c, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+      }
+      num = den = 0;
+      for (int cc = 0; cc < ncols; cc += 2) {
+        lvec x(N);
+        for (int r = 0; r < N; ++r) { x[r].x = full[(size_t)r * pitch + cc].x; x[r].y = full[(size_t)r * pitch + cc].y; }
+        lvec X = naive_dft(x, -1);
+        for (int r = 0; r < n; ++r) {
+          cx<long double> want = r < L ? X[r] : X[L + r];                  // physical row L + i = logical row 2L + i
+          if (fold && r == L) { want.x += X[L].x; want.y += X[L].y; }
+          const cx<T> g = back[(size_t)r * pitch + cc];
+          num += (g.x - 0.5L * want.x) * (g.x - 0.5L * want.x) + (g.y - 0.5L * want.y) * (g.y - 0.5L * want.y);
+          den += 0.25L * (want.x * want.x + want.y * want.y);
+        }
+      }
+      snprintf(name, sizeof name, "col3 c%d v%d truncate-on-store fwd%s%s", COLS, VEC, fold ? " fold" : "", SPLIT ? " split" : "");
+      report(name, N, pname<T>(), (double)sqrtl(num / den), 2 * tol_of<T>());
+    }
+  }
+}
+
 template <class S> static void test_chirpz_all() {
   const int nmax = (S::N + 1) / 2;
   for (int n : {nmax, nmax - 1, (S::N / 4) + 1, 7}) {
@@ -1056,6 +1169,13 @@ int main() {
 #endif
 #if EMU_HAS(2)
   MFFT_PLANS_D(MFFT_PLAN) MFFT_PLANS_E(MFFT_PLAN) MFFT_COLPLANS_F64_E(MFFT_PLAN)
+  // three sub-transforms per workgroup: small stand-ins for every code path, then the shipped plans
+  test_col3<Spec<16, 4, 4>, double, 4, 0, 1>();
+  test_col3<Spec<16, 4, 4>, float, 8, 1, 2>();
+  test_col3<Spec<32, 8, 4>, double, 2, 1, 1>();
+#define MFFT_COL3(N, L, ...) test_col3<Spec<L, __VA_ARGS__>, double, 4, 0, 1>(); test_col3<Spec<L, __VA_ARGS__>, float, 4, 1, 2>();
+  MFFT_COL3PLANS_E(MFFT_COL3)
+#undef MFFT_COL3
 #endif
 #if EMU_HAS(3)
   MFFT_PLANS_F(MFFT_PLAN) MFFT_PLANS_G(MFFT_PLAN)

@@ -2,5 +2,6 @@
 #define MFFT_TU_PLANS MFFT_PLANS_E
 #define MFFT_TU_ROWPLANS MFFT_ROWPLANS_E
 #define MFFT_TU_COLPLANS MFFT_COLPLANS_F64_E
+#define MFFT_TU_COL3PLANS MFFT_COL3PLANS_E
 #define MFFT_TU_REAL double
 #include "kernels_tu.inc"

@@ -114,6 +114,14 @@ template <typename T> constexpr bool mfft_has_row_override_t(int n) { return mff
 // came out 15 % slower (x / y passes of the 900^3 pair 2.5 / 2.25 -> 3.0 / 2.6 ms, the same for 10x10x3x3, 10x15x6 and
 // 10x6x15), the only length of groups L and M where that happened; the contiguous-axis kernels gain from 15x10x6 like the rest.
 #define MFFT_COLPLANS_F64_M(X) X(900, 5, 5, 3, 3, 2, 2)
+// Round 4: lengths N = 3 L whose strided transforms (plain and 3/2-rule pad / truncate) ALSO exist as three length-L
+// sub-transforms per workgroup (fft_col3.h ColFft3: a third of the exchange buffer): 1536, the 3/2-rule image of 1024.
+// X(N, L, radices of the length-L sub-plan).  The sub-plan holds FOUR values per thread (12 for the three thirds: 48 VGPRs
+// of data in double precision, 1024 threads, no spills under the 128-register cap); with eight (8 x 8 x 8: the 24 values of
+// the ColFft plan) the kernel needs 140+ registers and two workgroups per CU are out of reach (-Rpass-analysis: 22 - 224
+// registers spilled under any cap), and 3072 = 3 x 1024 would need 2048 threads.  The ColFft kernels of the same length
+// stay: they are what double precision and the y passes run (core.hip launch_col has the measurements; MFFT_COL3=0 / 1).
+#define MFFT_COL3PLANS_E(X) X(1536, 512, 4, 4, 4, 4, 2)
 template <typename T> constexpr bool mfft_has_col_override(int n) {
   return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && (n == 1024 || n == 512 || n == 384 || n == 768 || n == 1152 || n == 900));
 }

@@ -5,6 +5,7 @@
 #include <vector>
 #include "fft_kernels.h"
 #include "fft_chirpz.h"
+#include "fft_col3.h"
 #include "twiddle.h"
 #include "plans.h"
 
@@ -224,6 +225,52 @@ void register_col(const char* name) {
     reg.back().nt = 1;
     reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;
   }
+}
+
+// ColFft3 (fft_col3.h): N = 3 L as three sub-transforms of the plan SL.  Registered under pad codes 16 (plain), 17 (pad
+// on load, inverse), 18 (truncate on store, forward): launch_col chooses between them and the ColFft kernels of the same
+// length (MFFT_COL3=0 / 1 force either in the same process).
+template <class SL, typename T>
+void tw3_thunk(void* dst) {
+  auto v = build_col3_twiddles<SL, T>();
+  memcpy(dst, v.data(), v.size() * sizeof(cx<T>));
+}
+template <class K, class SL, typename T, int WGS>
+KernelEntry make_entry3(int inv, int nt, int pad, int tile, const char* name) {
+  KernelEntry e;
+  e.family = FAM_COL;
+  e.n = 3 * SL::N;
+  e.prec = sizeof(T) == 8 ? 1 : 0;
+  e.inv = inv;
+  e.nt = nt;
+  e.nt_inplace = nt;                    // two workgroups per CU (or 1024 threads): non-temporal in place too
+  e.pad = pad;
+  e.tile = tile;
+  e.threads = K::THREADS;
+  e.lds_bytes = K::LDS_BYTES;
+  e.tw_count = K::TW;
+  e.build_tw = &tw3_thunk<SL, T>;
+  e.launch = &launch_thunk<K, ColParams<T>, WGS>;
+  if constexpr (WGS > 1) e.func = reinterpret_cast<const void*>(&mfft_kern_occ<K, ColParams<T>, WGS>);
+  else e.func = reinterpret_cast<const void*>(&mfft_kern<K, ColParams<T>>);
+  e.name = name;
+  return e;
+}
+template <class SL, typename T>
+void register_col3(const char* name) {
+  auto& reg = kernel_registry();
+  constexpr int VEC = (sizeof(T) == 4) ? 2 : 1;                   // 16 bytes per lane
+  constexpr int C = 128 / (int)sizeof(cx<T>);                     // 128-byte tiles
+  constexpr int THR = SL::TPT * (C / VEC);
+  // whole-complex exchange while two workgroups of it (and their twiddles) fit the CU's 160 KB, else real / imaginary parts
+  constexpr int SPL = ((long long)SL::N * C * (int)sizeof(cx<T>) + SL::TW * (int)sizeof(cx<T>) <= 81920) ? 0 : 1;
+  constexpr int W = THR <= 512 ? 2 : 0;                           // register cap for two workgroups per CU
+  reg.push_back(make_entry3<ColFft3<SL, T, C, false, true, SPL, VEC, false, 0>, SL, T, W>(0, 0, 16, C, name));
+  reg.push_back(make_entry3<ColFft3<SL, T, C, true, true, SPL, VEC, false, 0>, SL, T, W>(1, 0, 16, C, name));
+  reg.push_back(make_entry3<ColFft3<SL, T, C, false, true, SPL, VEC, true, 0>, SL, T, W>(0, 1, 16, C, name));
+  reg.push_back(make_entry3<ColFft3<SL, T, C, true, true, SPL, VEC, true, 0>, SL, T, W>(1, 1, 16, C, name));
+  reg.push_back(make_entry3<ColFft3<SL, T, C, true, true, SPL, VEC, false, 1>, SL, T, W>(1, 0, 17, C, name));
+  reg.push_back(make_entry3<ColFft3<SL, T, C, false, true, SPL, VEC, false, 2>, SL, T, W>(0, 0, 18, C, name));
 }
 
 // Register cap of the contiguous-axis kernels: the 30-values-per-thread plans in double precision come out at 256 VGPRs plus
