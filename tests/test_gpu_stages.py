@@ -269,3 +269,44 @@ def test_dft_bins_checker_against_numpy(prec):
             full = np.fft.ifftn(X.astype(np.complex128)) * np.prod(N) if inverse else np.fft.fftn(X.astype(np.complex128))
             want = full[bins[:, 0], bins[:, 1], bins[:, 2]]
             assert np.abs(tot - want).max() < 1e-12 * np.sqrt(np.prod(N)), (prec, inverse)
+
+
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_three_sub_transform_kernels_of_1536(mode):
+    """fft_col3.h ColFft3 (1536 = 3 x 512 per workgroup) forced on (MFFT_COL3=1) and off (=0), in a child process (the
+    switch is read once): c2c of length 1536 on every axis, both precisions, in place and out of place (serialFFT), and the
+    3/2-rule pair of a [1024, 16, 32] mesh, whose padded x axis is 1536 (pad-on-load inverse, truncate-on-store forward)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import mpifft4py_amd as m
+from mpifft4py_amd import Slab_R2C, SelfComm
+rng = np.random.default_rng(3)
+for prec, ct, tol in (("double", np.complex128, 1e-10), ("single", np.complex64, 1e-5)):
+    for axis, shape in ((0, (1536, 3, 40)), (1, (3, 1536, 24)), (0, (1536, 1, 9))):
+        a = (rng.random(shape) - 0.5 + 1j * (rng.random(shape) - 0.5)).astype(ct)
+        for f, g in ((m.fft, np.fft.fft), (m.ifft, np.fft.ifft)):
+            ref = g(a.astype(np.complex128), axis=axis)
+            got = f(a, axis=axis)
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, (prec, axis, shape)
+    N = [1024, 16, 32]
+    F = Slab_R2C(np.array(N), np.array([2 * np.pi] * 3), SelfComm(0), prec)
+    C = np.fft.rfftn(rng.random(N)).astype(ct)
+    C[N[0] // 2] = 0; C[:, N[1] // 2] = 0; C[:, :, -1] = 0
+    up = F.ifftn(C, np.zeros(F.real_shape_padded(), dtype=F.float), dealias="3/2-rule")
+    Cp = np.zeros((1536, 24, 25), dtype=np.complex128)
+    Cp[:512, :8, :17] = C[:512, :8]; Cp[:512, -8:, :17] = C[:512, 8:]
+    Cp[-512:, :8, :17] = C[512:, :8]; Cp[-512:, -8:, :17] = C[512:, 8:]
+    want = np.fft.irfftn(Cp, s=(1536, 24, 48), axes=(0, 1, 2)) * 1.5 ** 3
+    assert np.linalg.norm(up - want) / np.linalg.norm(want) < 4 * tol, prec
+    back = F.fftn(up, np.zeros(F.complex_shape(), dtype=ct), dealias="3/2-rule")
+    assert np.linalg.norm(back - C) / np.linalg.norm(C) < 4 * tol, prec
+print("COL3_OK")
+""" % root
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MFFT_COL3=mode), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"COL3_OK" in p.stdout, p.stdout.decode()[-3000:]
