@@ -289,7 +289,7 @@ static int launch_row_t(const KernelEntry* e, const RowArgs& a, void* tw, hipStr
   P.nrows = a.nrows;
   P.scale = (T)a.scale;
   if constexpr (std::is_same<PT, RowParams<T>>::value) {
-    P.zs = a.zs.nchunk ? make_zsplit(a.zs.q, a.zs.nchunk, a.zs.last_len, a.zs.rows_total) : ZSplit{1, 1, 0, 0, 0};
+    P.zs = a.zs.nchunk ? make_zsplit(a.zs.q, a.zs.nchunk, a.zs.last_len, a.zs.rows_total, a.zs.pitch, a.zs.last_pitch) : ZSplit{1, 1, 0, 0, 0, 1, 0};
     P.row0 = a.zs.row0;
   }
   const int64_t grid = (a.nrows + e->tile - 1) / e->tile;
@@ -360,7 +360,7 @@ static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void
   P.valid = a.valid > 0 ? a.valid : a.n / 2 + 1;
   P.scale = (T)a.scale;
   if constexpr (std::is_same<PT, RealParams<T>>::value) {
-    P.zs = a.zs.nchunk ? make_zsplit(a.zs.q, a.zs.nchunk, a.zs.last_len, a.zs.rows_total) : ZSplit{1, 1, 0, 0, 0};
+    P.zs = a.zs.nchunk ? make_zsplit(a.zs.q, a.zs.nchunk, a.zs.last_len, a.zs.rows_total, a.zs.pitch, a.zs.last_pitch) : ZSplit{1, 1, 0, 0, 0, 1, 0};
     P.row0 = a.zs.row0;
   }
   const int64_t grid = (a.nrows + e->tile - 1) / e->tile;

@@ -604,10 +604,12 @@ static void test_real() {
   // z-chunked complex side (fused pencil pack / unpack): the M + 1 bins of a row go to nch blocks (rows_total, len_l);
   // `drop`: the last block has no room for the Nyquist bin (the 'AlltoallN' mode), which then reads back as zero
   if (M >= 4 && M % 2 == 0) {
-    for (int drop = 0; drop < 2; ++drop) {
+    for (int dp = 0; dp < 3; ++dp) {        // dp == 2: rows of the blocks further apart than their length (ZSplit pitch)
+      const int drop = dp == 1;
       const int nch = 2, q = M / nch, last = q + (drop ? 0 : 1), rows_total = nrows + 3, row0 = 2;
-      const ZSplit zs = make_zsplit(q, nch, last, rows_total);
-      std::vector<cx<T>> blocks((size_t)rows_total * (q * (nch - 1) + last), mk<T>((T)7, (T)7));
+      const int pq = dp == 2 ? q + 3 : q, plast = dp == 2 ? last + 5 : last;
+      const ZSplit zs = dp == 2 ? make_zsplit(q, nch, last, rows_total, pq, plast) : make_zsplit(q, nch, last, rows_total);
+      std::vector<cx<T>> blocks((size_t)rows_total * (pq * (nch - 1) + plast), mk<T>((T)7, (T)7));
       {
         typedef R2CFft<S, T, ROWS, TWLDS, false, true, SPLIT> K;
         RealParams<T> P{in.data(), blocks.data(), tw.data(), rtw.data(), pin, 0, nrows, M + 1, (T)1, zs, row0};
@@ -616,13 +618,13 @@ static void test_real() {
       long double nn = 0, dd = 0;
       for (int r = 0; r < nrows; ++r)
         for (int k = 0; k <= M - drop; ++k) {
-          const int l = std::min(k / q, nch - 1), len = l == nch - 1 ? last : q;
-          cx<T> g = blocks[(size_t)l * rows_total * q + (size_t)(row0 + r) * len + (k - l * q)], e = out[(size_t)r * pout + k];
+          const int l = std::min(k / q, nch - 1), len = l == nch - 1 ? plast : pq;
+          cx<T> g = blocks[(size_t)l * rows_total * pq + (size_t)(row0 + r) * len + (k - l * q)], e = out[(size_t)r * pout + k];
           if (k == 0 || k == M) e.y = 0;
           nn += (g.x - e.x) * (g.x - e.x) + (g.y - e.y) * (g.y - e.y);
           dd += e.x * e.x + e.y * e.y;
         }
-      snprintf(name, sizeof name, "r2c z-chunked%s r%d", drop ? " drop" : "", ROWS);
+      snprintf(name, sizeof name, "r2c z-chunked%s r%d", drop ? " drop" : dp == 2 ? " pitched" : "", ROWS);
       report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
       std::vector<T> b3((size_t)nrows * pin, (T)0);
       {
@@ -646,7 +648,7 @@ static void test_real() {
           dd += e * e;
         }
       }
-      snprintf(name, sizeof name, "c2r z-chunked%s r%d", drop ? " drop" : "", ROWS);
+      snprintf(name, sizeof name, "c2r z-chunked%s r%d", drop ? " drop" : dp == 2 ? " pitched" : "", ROWS);
       report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
     }
   }

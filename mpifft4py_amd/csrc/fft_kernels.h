@@ -120,15 +120,19 @@ struct ZSplit {
   unsigned q, magic;     // chunk length, floor(2^32 / q) + 1
   int nchunk;            // 0: plain rows
   int last_len;
-  i64 block;             // elements between the starts of consecutive blocks: rows_total * q
+  i64 block;             // elements between the starts of consecutive blocks: rows_total * pitch
+  int pitch, last_pitch; // elements between consecutive rows of a block (>= its chunk length; round 4: rows of 129 / 257
+                         // elements start on cache lines for the strided pass that reads them next)
 };
-inline ZSplit make_zsplit(i64 q, int nchunk, i64 last_len, i64 rows_total) {
+inline ZSplit make_zsplit(i64 q, int nchunk, i64 last_len, i64 rows_total, i64 pitch = 0, i64 last_pitch = 0) {
   ZSplit z;
   z.q = (unsigned)q;
   z.magic = (unsigned)(0x100000000ull / (unsigned long long)q + 1ull);
   z.nchunk = nchunk;
   z.last_len = (int)last_len;
-  z.block = rows_total * q;
+  z.pitch = (int)(pitch > 0 ? pitch : q);
+  z.last_pitch = (int)(last_pitch > 0 ? last_pitch : last_len);
+  z.block = rows_total * (i64)z.pitch;
   return z;
 }
 // element offset of (row, k); *ok = the position exists (the last chunk may drop the Nyquist column)
@@ -136,9 +140,9 @@ MFFT_HD i64 zsplit_off(const ZSplit& z, i64 row, int k, bool* ok) {
   int l = (int)fastdiv((unsigned)k, z.magic);
   if (l >= z.nchunk) l = z.nchunk - 1;
   const int kk = k - l * (int)z.q;
-  const int len = l == z.nchunk - 1 ? z.last_len : (int)z.q;
-  *ok = kk < len;
-  return (i64)l * z.block + row * (i64)len + kk;
+  const bool last = l == z.nchunk - 1;
+  *ok = kk < (last ? z.last_len : (int)z.q);
+  return (i64)l * z.block + row * (i64)(last ? z.last_pitch : z.pitch) + kk;
 }
 
 template <typename T>

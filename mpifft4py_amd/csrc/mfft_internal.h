@@ -74,6 +74,7 @@ struct ZSplitArgs {
   int nchunk = 0;
   int64_t q = 0, last_len = 0;       // chunk length; length of the last chunk
   int64_t rows_total = 0, row0 = 0;  // rows of every chunk block; first row of this launch inside them
+  int64_t pitch = 0, last_pitch = 0; // elements between the rows of a block / of the last block; 0 = its chunk length
 };
 
 struct RowArgs {

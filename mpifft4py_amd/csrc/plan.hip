@@ -236,27 +236,47 @@ struct mfft_plan_s {
   // of the Pz blocks (rows_total, len_l) that the z-splitting exchange sends / has received
   bool zfuse = false;
   bool xpad_on = true;          // xplane_pad(): MFFT_NO_XPAD=1 clears it (A/B runs; must be the same on every rank)
+  bool zpitch_on = true;        // zrow_pitch(): MFFT_NO_ZPITCH=1 clears it (likewise)
   bool xpass_inplace = false;   // MFFT_XPASS_INPLACE=1: the x pass behind an exchange runs in place on the receive buffer (rounds 1 - 3)
   // the same for the fused 3/2-rule pencil transforms: real length M2, the Nf kept columns split into the z chunks
   bool zfuse_pad() const {
     return getenv("MFFT_NO_ZFUSE") == nullptr && !d.line2d && !d.drop_nyquist && !zc.empty() && zc[0].len < 65536 &&
            M2 % 2 == 0 && zsplit_limit_supported(M2, prec);
   }
-  ZSplitArgs zsplit(int64_t rows_total, int64_t row0) const {
+  // Row pitch of a z chunk of `len` columns in the blocks of the FORWARD z-splitting exchange (round 4).  The strided pass
+  // that reads the received blocks next (x-aligned: the y pass; y-aligned: the x pass, then the y pass) reads rows of q
+  // elements: with q = 129 or 257 -- the rank that holds the Nyquist column -- they are not line-aligned, and that rank's y
+  // pass ran 28 - 34 % slower than its neighbours' (profiles/r04_rank_shapes.txt: (256, 1024, 257) 0.49 against 0.38 ms), its
+  // x pass (y-aligned, rows 2^20 + 2^13 bytes apart) 37 % slower: the slowest rank sets the pace of the transform.  The z
+  // kernel therefore writes such rows a whole number of cache lines apart (fft_kernels.h ZSplit pitch), the chunk grows by
+  // (pitch - len) / len (2.7 % at 257), and the schedules say so.  Only the fused z kernels, only chunks of 64 columns and
+  // more (small meshes live in the caches), only forward (the inverse z kernel reads contiguous rows: nothing to gain).
+  int64_t zrow_pitch(int64_t len, bool forward) const {
+    if (!forward || !zpitch_on || !zfuse || d.drop_nyquist || zc.size() < 2 || len < 64) return len;
+    const int64_t per_line = (int64_t)(128 / es);
+    return (len + per_line - 1) / per_line * per_line;
+  }
+  int64_t zsend_elems(int64_t rows) const {      // elements of the forward z exchange's send blocks for `rows` rows
+    int64_t t = 0;
+    for (const Chunk& c : zc) t += rows * zrow_pitch(c.len, true);
+    return t;
+  }
+  ZSplitArgs zsplit(int64_t rows_total, int64_t row0, bool forward = false) const {
     ZSplitArgs z;
     z.nchunk = (int)zc.size(); z.q = zc[0].len; z.last_len = zc.back().len; z.rows_total = rows_total; z.row0 = row0;
+    z.pitch = zrow_pitch(z.q, forward); z.last_pitch = zrow_pitch(z.last_len, forward);
     return z;
   }
   int z_forward_chunked(const void* in, void* blocks, int64_t nrows, int64_t row0, int64_t rows_total) {
     if (r2c) {
       RealArgs a;
       a.in = in; a.out = blocks; a.n = (int)N2; a.prec = prec; a.in_stride = N2; a.out_stride = Nf; a.nrows = nrows; a.scale = 1.0;
-      a.zs = zsplit(rows_total, row0);
+      a.zs = zsplit(rows_total, row0, true);
       return launch_r2c(a, stream);
     }
     RowArgs a;
     a.in = in; a.out = blocks; a.n = (int)N2; a.prec = prec; a.inverse = false; a.in_stride = N2; a.out_stride = Nf; a.nrows = nrows;
-    a.scale = 1.0; a.zs = zsplit(rows_total, row0);
+    a.scale = 1.0; a.zs = zsplit(rows_total, row0, true);
     return launch_row(a, stream);
   }
   int z_backward_chunked(const void* blocks, void* out, int64_t nrows, int64_t row0, int64_t rows_total) {
@@ -680,7 +700,9 @@ int mfft_plan_s::sched(int which, bool forward, bool padded, Sched* o) const {
     o->sc.resize(Pz); o->sd.resize(Pz); o->rc.resize(Pz); o->rd.resize(Pz);
     size_t off = 0;
     for (int l = 0; l < Pz; ++l) {
-      const size_t uneven = (size_t)(m * n * zc[l].len) * es, even = (size_t)(m * n * q) * es;
+      // (the fused 3/2-rule transforms have chunked kernels of their own and keep compact rows: padded -> no pitch)
+      const int64_t pl = padded ? zc[l].len : zrow_pitch(zc[l].len, forward), pq = padded ? q : zrow_pitch(q, forward);
+      const size_t uneven = (size_t)(m * n * pl) * es, even = (size_t)(m * n * pq) * es;
       if (forward) { o->sc[l] = uneven; o->sd[l] = off; o->rc[l] = even; o->rd[l] = (size_t)l * even; }
       else         { o->sc[l] = even; o->sd[l] = (size_t)l * even; o->rc[l] = uneven; o->rd[l] = off; }
       off += uneven;
@@ -690,7 +712,7 @@ int mfft_plan_s::sched(int which, bool forward, bool padded, Sched* o) const {
   if (which == 1) {
     const int64_t xp = padded ? 0 : xplane_pad(forward);     // one cache line between x rows when they are 64 KiB multiples apart
     if (X) equal(group0, (size_t)(m * (N1_1 * q + xp)) * es);
-    else   equal(group1, (size_t)(N2_0 * (n * q + xp)) * es);
+    else   equal(group1, (size_t)(N2_0 * (n * (padded ? q : zrow_pitch(q, forward)) + xp)) * es);   // forward: the z kernel's row pitch travels on
     return 0;
   }
   return set_error(MFFT_ERR_INVALID, "pencil plans have two exchanges");
@@ -1264,12 +1286,14 @@ int mfft_plan_s::sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sch
     o->peers = gz;
     o->sc.resize(Pz); o->sd.resize(Pz); o->rc.resize(Pz); o->rd.resize(Pz);
     size_t base = 0;
+    const int64_t pq = zrow_pitch(q, forward);
     for (int l = 0; l < Pz; ++l) {
-      const size_t usz = (size_t)(mb * n * zc[l].len) * es, uoff = base + (size_t)(i0 * n * zc[l].len) * es;
-      const size_t esz = (size_t)(mb * n * q) * es, eoff = (size_t)(l * m * n * q + i0 * n * q) * es;
+      const int64_t pl = zrow_pitch(zc[l].len, forward);
+      const size_t usz = (size_t)(mb * n * pl) * es, uoff = base + (size_t)(i0 * n * pl) * es;
+      const size_t esz = (size_t)(mb * n * pq) * es, eoff = (size_t)(l * m * n * pq + i0 * n * pq) * es;
       if (forward) { o->sc[l] = usz; o->sd[l] = uoff; o->rc[l] = esz; o->rd[l] = eoff; }
       else         { o->sc[l] = esz; o->sd[l] = eoff; o->rc[l] = usz; o->rd[l] = uoff; }
-      base += (size_t)(m * n * zc[l].len) * es;
+      base += (size_t)(m * n * pl) * es;
     }
     return 0;
   }
@@ -1277,7 +1301,8 @@ int mfft_plan_s::sched_rows(int which, bool forward, int64_t i0, int64_t mb, Sch
     // Y alignment, x-chunk exchange over group1 (P2 ranks): rows [i0, i0+mb) of the N2_0 rows of every block
     // [c][x'][j][k] (N2_0, n, q); the send block c is rows c*N2_0.. of (N0, n, q), the receive block c' the same shape
     const int Pg = (int)group1.size();
-    const int64_t SY = n * q + xplane_pad(forward);         // x-row pitch (inverse: padded where the compact one reads slowly)
+    // x-row pitch (inverse: padded where the compact one reads slowly; forward: rows at the z kernel's pitch)
+    const int64_t SY = n * zrow_pitch(q, forward) + xplane_pad(forward);
     o->peers = group1;
     o->sc.assign(Pg, (size_t)(mb * SY) * es);
     o->rc = o->sc;
@@ -1323,7 +1348,8 @@ int mfft_plan_s::pencil_forward_pipelined_x(const void* u, void* fu) {
   // (xplane_pad); then the chunks land in a work buffer and the x transform runs out of place into the result
   const int64_t SX = N1_1 * q + xplane_pad(true);
   const bool xoop = SX != N1_1 * q;
-  const size_t wb = (size_t)std::max(std::max(m * n * Nf, m * N1 * q), xoop ? N0 * SX : (int64_t)0) * es;
+  const int64_t PQ = zrow_pitch(q, true);        // row pitch of the received z blocks (zrow_pitch: q, or whole cache lines)
+  const size_t wb = (size_t)std::max(std::max(std::max(m * n * Nf, zsend_elems(m * n)), m * N1 * PQ), xoop ? N0 * SX : (int64_t)0) * es;
   for (int i = 0; i < 3; ++i) MFFT_TRY(ensure_work(i, wb));
   char *W0 = static_cast<char*>(work[0]), *W1 = static_cast<char*>(work[1]), *W2 = static_cast<char*>(work[2]);
   const char* in = static_cast<const char*>(u);
@@ -1366,8 +1392,8 @@ int mfft_plan_s::pencil_forward_pipelined_x(const void* u, void* fu) {
     rows(b, &i0, &mb);
     if (!zsolo) MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[b], 0));
     MFFT_TRY(stage("fwd_y", 2 * Cb / B, [&] {
-      return col(ysrc + (size_t)(i0 * n * q) * es, ydst + (size_t)(i0 * SX) * es, N1, false, mb, q, n * q,
-                 two_level(n, m * n * q, q), SX, two_level(N1_1, m * SX, q));
+      return col(ysrc + (size_t)(i0 * n * PQ) * es, ydst + (size_t)(i0 * SX) * es, N1, false, mb, q, n * PQ,
+                 two_level(n, m * n * PQ, PQ), SX, two_level(N1_1, m * SX, q));
     }));
     if (g2solo) continue;
     MFFT_HIP(hipEventRecord(ev2_compute[b], stream));
@@ -1477,7 +1503,8 @@ int mfft_plan_s::pencil_backward_pipelined_x(const void* src, void* u) {
 int mfft_plan_s::pencil_forward_pipelined_y(const void* u, void* fu) {
   const int64_t m = N1_0, n = N2_1;
   const double Cb = (double)(m * n * Nf) * es, Rb = (double)(m * n * N2) * rs;
-  const size_t wb = (size_t)std::max(m * n * Nf, N0 * n * q) * es;
+  const int64_t PQ = zrow_pitch(q, true);        // row pitch of the z blocks: it stays through the x pass and the second exchange
+  const size_t wb = (size_t)std::max(std::max(m * n * Nf, zsend_elems(m * n)), N0 * n * PQ) * es;
   for (int i = 0; i < 2; ++i) MFFT_TRY(ensure_work(i, wb));
   char *W0 = static_cast<char*>(work[0]), *W1 = static_cast<char*>(work[1]);
   const char* in = static_cast<const char*>(u);
@@ -1498,7 +1525,7 @@ int mfft_plan_s::pencil_forward_pipelined_y(const void* u, void* fu) {
     MFFT_HIP(hipEventRecord(ev_comm[b], cstream));
   }
   MFFT_HIP(hipStreamWaitEvent(stream, ev_comm[B - 1], 0));                    // in order on the comm stream: all batches
-  MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, W0, N0, false, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+  MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, W0, N0, false, 1, n * PQ, 0, plain(n * PQ), 0, plain(n * PQ)); }));
   MFFT_HIP(hipEventRecord(ev2_compute[0], stream));
   MFFT_HIP(hipStreamWaitEvent(cstream, ev2_compute[0], 0));
   for (int b = 0; b < B; ++b) {
@@ -1513,8 +1540,8 @@ int mfft_plan_s::pencil_forward_pipelined_y(const void* u, void* fu) {
     const int64_t x0 = N2_0 * b / B, xb = N2_0 * (b + 1) / B - x0;
     MFFT_HIP(hipStreamWaitEvent(stream, ev2_comm[b], 0));
     MFFT_TRY(stage("fwd_y", 2 * Cb / B, [&] {
-      return col(W1 + (size_t)(x0 * n * q) * es, out + (size_t)(x0 * N1 * q) * es, N1, false, xb, q, n * q,
-                 two_level(n, N2_0 * n * q, q), N1 * q, plain(q));
+      return col(W1 + (size_t)(x0 * n * PQ) * es, out + (size_t)(x0 * N1 * q) * es, N1, false, xb, q, n * PQ,
+                 two_level(n, N2_0 * n * PQ, PQ), N1 * q, plain(q));
     }));
   }
   return 0;
@@ -1587,7 +1614,9 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
   const bool zsolo = (X ? P2 : P1) == 1 && !d.drop_nyquist, g2solo = (X ? P1 : P2) == 1;
   // largest intermediate of this alignment: X: (m, N1, q) after the z exchange; Y: (N0, n, q) after it
   const int64_t SX = N1_1 * q + (X ? xplane_pad(true) : 0);     // x-row pitch of the blocks of the second exchange (X)
-  const size_t wb = (size_t)std::max(m * n * Nf, X ? std::max(m * N1 * q, N0 * SX) : N0 * n * q) * es;
+  // row pitch of the received z blocks: q, or whole cache lines where the fused z kernel wrote them so (zrow_pitch)
+  const int64_t PQ = (!zsolo && zfuse) ? zrow_pitch(q, true) : q;
+  const size_t wb = (size_t)std::max(std::max(m * n * Nf, zsend_elems(m * n)), X ? std::max(m * N1 * PQ, N0 * SX) : N0 * n * PQ) * es;
   MFFT_TRY(ensure_work(0, wb));
   MFFT_TRY(ensure_work(1, wb));
   void *W0 = work[0], *W1 = work[1];
@@ -1605,7 +1634,7 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
     // W0 = P2 blocks (m, n, q) -> y transform (gathers y through two-level rows) -> P1 blocks (m, N1_1, q)
     void* ydst = g2solo ? fu : W1;
     MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
-      return col(W0, ydst, N1, false, m, q, n * q, two_level(n, m * n * q, q), SX, two_level(N1_1, m * SX, q));
+      return col(W0, ydst, N1, false, m, q, n * PQ, two_level(n, m * n * PQ, PQ), SX, two_level(N1_1, m * SX, q));
     }));
     if (g2solo || (xpass_inplace && SX == N1_1 * q)) {
       if (!g2solo) MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W1, fu); }));
@@ -1617,14 +1646,14 @@ int mfft_plan_s::pencil_forward(const void* u, void* fu) {
     }
   } else {
     // W0 = (N0, n, q): x transform in place, x chunks are contiguous -> exchange -> y transform gathers
-    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, W0, N0, false, 1, n * q, 0, plain(n * q), 0, plain(n * q)); }));
+    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(W0, W0, N0, false, 1, n * PQ, 0, plain(n * PQ), 0, plain(n * PQ)); }));
     void* ysrc = W0;
     if (!g2solo) {
       MFFT_TRY(stage("fwd_a2a_2", 0, [&] { return xchg(1, true, false, W0, W1); }));
       ysrc = W1;
     }
     MFFT_TRY(stage("fwd_y", 2 * Cb, [&] {
-      return col(ysrc, fu, N1, false, N2_0, q, n * q, two_level(n, N2_0 * n * q, q), N1 * q, plain(q));
+      return col(ysrc, fu, N1, false, N2_0, q, n * PQ, two_level(n, N2_0 * n * PQ, PQ), N1 * q, plain(q));
     }));
   }
   return 0;
@@ -1966,6 +1995,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   for (int i = 0; i < p->P; ++i) p->world[i] = i;
   p->xpad_on = !(getenv("MFFT_NO_XPAD") && atoi(getenv("MFFT_NO_XPAD")) != 0);
   p->xpass_inplace = getenv("MFFT_XPASS_INPLACE") && atoi(getenv("MFFT_XPASS_INPLACE")) != 0;
+  p->zpitch_on = !(getenv("MFFT_NO_ZPITCH") && atoi(getenv("MFFT_NO_ZPITCH")) != 0);
   const int P = p->P;
   if (p->r2c && p->N2 % 2) return set_error(MFFT_ERR_UNSUPPORTED, "odd N[2]=%lld is not supported for R2C", (long long)p->N2);
   if (desc->decomp == MFFT_SLAB) {

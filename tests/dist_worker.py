@@ -225,27 +225,41 @@ def pencil(rank, P, N, A, align, P1=None, pipeline=1, relay=False):
     a = np.fft.rfft(u, axis=2)
     s0 = _lib.exchange_schedule(N, P, rank, dec, 0, True, p1=P1 or 0)
     assert s0["peers"] == (lay.comm1_members(rank) if align == "X" else lay.comm0_members(rank))
-    # z chunks: lengths follow from the byte counts
-    lens = [c // (m * n * ES) for c in s0["scount"]]
+    # z chunks: the pencils' rule (N2 / Pz / 2 columns each, the Nyquist column on the last rank: pencil.py:197, 908); in
+    # the FORWARD exchange the rows of a block of 64 columns and more lie a whole number of cache lines apart (plan.hip
+    # zrow_pitch: the byte counts say how far), the rest of the row is unused
+    Pz = len(s0["peers"])
+    lens = [N[2] // Pz // 2] * Pz
+    lens[-1] += 1
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
-    send = np.concatenate([a[:, :, st:st + ln].ravel() for ln, st in zip(lens, starts)])
-    q = s0["rcount"][0] // (m * n * ES)
-    assert q == lay.complex_shape(rank)[2]
+    pitch = [c // (m * n * ES) for c in s0["scount"]]
+    for ln, pt in zip(lens, pitch):
+        assert pt == (ln if ln < 64 else -(-ln // 8) * 8), (ln, pt)
+    bufs = []
+    for ln, st, pt in zip(lens, starts, pitch):
+        blk = np.zeros((m, n, pt), dtype=complex)
+        blk[:, :, :ln] = a[:, :, st:st + ln]
+        bufs.append(blk.ravel())
+    send = np.concatenate(bufs)
+    q = lay.complex_shape(rank)[2]
+    qp = s0["rcount"][0] // (m * n * ES)                       # row pitch of the received blocks
+    assert qp == (q if q < 64 else -(-q // 8) * 8) and all(c == m * n * qp * ES for c in s0["rcount"])
     r = exchange(rank, s0, send, sum(s0["rcount"]), 0, True)
-    blocks = r.reshape(len(lens), m, n, q)
+    blocks = r.reshape(len(lens), m, n, qp)
     s1 = _lib.exchange_schedule(N, P, rank, dec, 1, True, p1=P1 or 0)
     if align == "X":
-        b = np.fft.fft(np.concatenate(list(blocks), axis=1), axis=1)              # (m, N1, q)
+        b = np.fft.fft(np.concatenate(list(blocks[..., :q]), axis=1), axis=1)     # (m, N1, q): the y pass reads the pitched rows
         assert s1["peers"] == lay.comm0_members(rank)
         send = np.concatenate([b[:, l * N1_1:(l + 1) * N1_1, :].ravel() for l in range(lay.P1)])
         r = exchange(rank, s1, send, sum(s1["rcount"]), 1, True)
         fu = np.fft.fft(r.reshape(N[0], N1_1, q), axis=0)
     else:
-        b = np.fft.fft(np.concatenate(list(blocks), axis=0), axis=0)              # (N0, n, q)
-        assert s1["peers"] == lay.comm1_members(rank)
+        # the x pass runs in place on (N0, n, qp) -- the unused columns ride along -- and the pitch travels on
+        b = np.fft.fft(np.concatenate(list(blocks), axis=0), axis=0)              # (N0, n, qp)
+        assert s1["peers"] == lay.comm1_members(rank) and set(s1["scount"]) == {N2_0 * n * qp * ES}
         r = exchange(rank, s1, b, sum(s1["rcount"]), 1, True)
-        blocks = r.reshape(lay.P2, N2_0, n, q)
-        fu = np.fft.fft(np.concatenate(list(blocks), axis=1), axis=1)              # (N2_0, N1, q)
+        blocks = r.reshape(lay.P2, N2_0, n, qp)
+        fu = np.fft.fft(np.concatenate(list(blocks[..., :q]), axis=1), axis=1)    # (N2_0, N1, q)
     assert fu.shape == lay.complex_shape(rank)
     assert orc.rel_l2(fu, want[rank]) < 1e-13, (align, rank)
     # inverse: mirror
@@ -409,6 +423,12 @@ def main():
         if P == 8:
             for align in ("X", "Y"):
                 pencil(rank, P, N, A, align, P1=2)
+        # chunks of 64 columns and more: the forward z exchange carries line-aligned rows (129 -> 136, 65 -> 72 columns)
+        Nq = [16, 32, 512]
+        Aq = np.random.default_rng(2032).random(Nq)
+        for align in ("X", "Y"):
+            for pipeline in (1, 0):
+                pencil(rank, P, Nq, Aq, align, pipeline=pipeline)
         # relay striping of the sub-group exchanges (IPC transport): two-hop schedule executed over gloo
         Nr = [32, 64, 128]                                 # messages large enough for 4 KiB stripes
         Ar = np.random.default_rng(2028).random(Nr)

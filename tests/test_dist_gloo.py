@@ -46,26 +46,34 @@ def test_schedule_matches_reference_message_sizes():
     call sites).  The exchanges whose receiver runs a strided x pass out of the chunks carry one cache line (8 complex128)
     between x rows where the compact pitch reads slowly (plan.hip xplane_pad, round 4): 128 * 513 elements (slab over 8
     ranks, forward), 256 * 257 (x-aligned pencil, forward, the ranks that hold the Nyquist column), 512 * 128 / 512 * 129
-    (y-aligned pencil, inverse); the opposite directions have the reference's sizes exactly."""
+    (y-aligned pencil, inverse); the forward z-splitting exchange carries the rows of the Nyquist-holding rank's chunk (129,
+    257 columns) a whole number of cache lines apart (zrow_pitch: 136, 264); the opposite directions have the
+    reference's sizes exactly."""
     from mpifft4py_amd import _lib
     N = [1024] * 3
     s = _lib.exchange_schedule(N, 8, 0, _lib.SLAB, forward=False)
     assert set(s["scount"]) == {128 * 128 * 513 * 16}                     # slab.py:281
     s = _lib.exchange_schedule(N, 8, 0, _lib.SLAB, forward=True)
     assert set(s["scount"]) == {128 * (128 * 513 + 8) * 16}               # slab.py:406 + 128 B per x row
-    # R2CY first exchange over comm0 (P1 = 4): 256*512*128*16, 129 columns on the last rank
-    s = _lib.exchange_schedule(N, 8, 0, _lib.PENCIL_Y, which=0)
+    # R2CY first exchange over comm0 (P1 = 4): 256*512*128*16, 129 columns on the last rank (forward: its rows 136 apart)
+    s = _lib.exchange_schedule(N, 8, 0, _lib.PENCIL_Y, which=0, forward=False)
     assert s["peers"] == [0, 1, 2, 3]
-    assert s["scount"] == [256 * 512 * 128 * 16] * 3 + [256 * 512 * 129 * 16]
+    assert s["rcount"] == [256 * 512 * 128 * 16] * 3 + [256 * 512 * 129 * 16]
+    s = _lib.exchange_schedule(N, 8, 0, _lib.PENCIL_Y, which=0)
+    assert s["scount"] == [256 * 512 * 128 * 16] * 3 + [256 * 512 * 136 * 16]
     s = _lib.exchange_schedule(N, 8, 0, _lib.PENCIL_Y, which=1)            # comm1 (P2 = 2), stride P1
     assert s["peers"] == [0, 4] and set(s["scount"]) == {512 * 512 * 128 * 16}
+    s = _lib.exchange_schedule(N, 8, 3, _lib.PENCIL_Y, which=1)            # rank 3: 129 columns, rows 136 apart all the way
+    assert set(s["scount"]) == {512 * 512 * 136 * 16}
     s = _lib.exchange_schedule(N, 8, 0, _lib.PENCIL_Y, which=1, forward=False)
     assert set(s["scount"]) == {512 * (512 * 128 + 8) * 16}
     s = _lib.exchange_schedule(N, 8, 3, _lib.PENCIL_Y, which=1, forward=False)      # rank 3 holds kz 384..512: 129 columns
     assert set(s["scount"]) == {512 * (512 * 129 + 8) * 16}
     # R2CX: comm1 first (256 | 257 columns), then comm0
+    s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=0, forward=False)
+    assert s["peers"] == [1, 5] and s["rcount"] == [256 * 512 * 256 * 16, 256 * 512 * 257 * 16]
     s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=0)
-    assert s["peers"] == [1, 5] and s["scount"] == [256 * 512 * 256 * 16, 256 * 512 * 257 * 16]
+    assert s["scount"] == [256 * 512 * 256 * 16, 256 * 512 * 264 * 16]    # rows of 257 columns start on cache lines
     s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=1, forward=False)
     assert s["peers"] == [4, 5, 6, 7] and set(s["scount"]) == {256 * 256 * 257 * 16}
     s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=1, forward=True)
@@ -77,6 +85,9 @@ def test_schedule_matches_reference_message_sizes():
             "assert set(_lib.exchange_schedule([1024] * 3, 8, 0, _lib.SLAB)['scount']) == {128 * 128 * 513 * 16}\n"
             "assert set(_lib.exchange_schedule([1024] * 3, 8, 5, _lib.PENCIL_X, which=1)['scount']) == {256 * 256 * 257 * 16}\n" % ROOT)
     subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, MFFT_NO_XPAD="1"))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom mpifft4py_amd import _lib\n"
+            "assert _lib.exchange_schedule([1024] * 3, 8, 5, _lib.PENCIL_X, which=0)['scount'] == [256 * 512 * 256 * 16, 256 * 512 * 257 * 16]\n" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, MFFT_NO_ZPITCH="1"))
 
 
 def test_file_rendezvous_two_processes(tmp_path):

@@ -701,6 +701,39 @@ def test_exchanged_layouts_with_padded_x_rows(cls, P, pipeline, kind, N):
         assert e_f < 1e-10 and e_b < 1e-10 and same, (e_f, e_b, same)
 
 
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("align,P,P1,pipeline", [("X", 4, None, 1), ("X", 4, None, 0), ("X", 8, None, 0), ("X", 8, 2, 1),
+                                                 ("Y", 4, None, 1), ("Y", 4, None, 0), ("Y", 8, None, 0), ("Y", 8, 2, 1)])
+def test_pencil_forward_z_blocks_with_line_aligned_rows(align, P, P1, pipeline, prec):
+    """Round 4: in the forward z-splitting exchange the rows of a chunk of 64 columns and more lie a whole number of cache
+    lines apart (plan.hip zrow_pitch, fft_kernels.h ZSplit pitch): the rank that holds the Nyquist column (129 / 65 columns
+    here) no longer reads unaligned rows in its y pass -- and, y-aligned, carries the pitch through its x pass and the
+    second exchange.  [32, 64, 512]: Nf = 257; asserted through the schedule query; against numpy.fft."""
+    from mpifft4py_amd import Pencil_R2C, _lib
+    N = [32, 64, 512]
+    dec = _lib.PENCIL_X if align == "X" else _lib.PENCIL_Y
+    s0 = _lib.exchange_schedule(N, P, P - 1, dec, 0, True, p1=P1 or 0, precision=prec)
+    lay = orc.PencilLayout(N, P, P1, align)
+    m, n = int(lay.N1[0]), int(lay.N2[1])
+    es = 16 if prec == "double" else 8
+    q_last = lay.complex_shape(P - 1)[2]
+    per_line = 128 // es
+    assert q_last % 2 == 1 and s0["rcount"][0] == m * n * (-(-q_last // per_line) * per_line) * es, (q_last, s0)
+    rng = np.random.default_rng(31 + P)
+    A = rng.random(N).astype(rdtype(prec))
+    B = np.fft.rfftn(A.astype(np.float64))
+
+    def body(comm):
+        F = Pencil_R2C(np.array(N), L, comm, prec, P1=P1, communication="Alltoallw", alignment=align, pipeline=pipeline)
+        a = np.ascontiguousarray(A[F.real_local_slice()])
+        c = F.fftn(a, np.zeros(F.complex_shape(), dtype=F.complex))
+        b = F.ifftn(c, np.zeros(F.real_shape(), dtype=F.float))
+        c2 = F.fftn(a, np.zeros(F.complex_shape(), dtype=F.complex))
+        return orc.rel_l2(c, B[F.complex_local_slice()]), orc.rel_l2(b, a), np.array_equal(c, c2)
+    for e_f, e_b, same in run_ranks(P, body):
+        assert e_f < TOL[prec] and e_b < 4 * TOL[prec] and same, (e_f, e_b, same)
+
+
 CONFIG5_MESHES = [[2048, 64, 32], [64, 2048, 32], [32, 64, 2048], [4096, 32, 16]]
 
 
