@@ -207,6 +207,10 @@ MFFT_API int mfft_plan_timing_get(mfft_plan_t plan, int max_stages, char names[]
  * current device, default stream; synchronous w.r.t. the host on return. */
 MFFT_API int mfft_c2c_axis(const void* in, void* out, const int64_t shape[3], int axis,
                            int inverse, int precision);                 /* fft / ifft  (ifft scaled 1/n) */
+/* the same along a strided axis with every stride spelled out (a non-contiguous view in numpy's terms): `nouter` batches
+ * in_outer / out_outer elements apart, each `ncols` contiguous columns wide, rows in_pitch / out_pitch elements apart */
+MFFT_API int mfft_c2c_strided(const void* in, void* out, int64_t n, int64_t nouter, int64_t ncols, int64_t in_outer,
+                              int64_t in_pitch, int64_t out_outer, int64_t out_pitch, int inverse, int precision);
 MFFT_API int mfft_r2c_last(const void* in, void* out, const int64_t real_shape[3], int precision);    /* rfft axis=2 */
 MFFT_API int mfft_c2r_last(const void* in, void* out, const int64_t real_shape[3], int precision);    /* irfft axis=2, scaled 1/n */
 /* slab pack / unpack (slab.py:403; cython/maths.pyx:21-31 transpose_Uc) */

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "mfft_plan_timing_reset": ([c_void_p], c_int),
     "mfft_plan_timing_get": ([c_void_p, c_int, c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)], c_int),
     "mfft_c2c_axis": ([c_void_p, c_void_p, POINTER(c_int64), c_int, c_int, c_int], c_int),
+    "mfft_c2c_strided": ([c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int], c_int),
     "mfft_r2c_last": ([c_void_p, c_void_p, POINTER(c_int64), c_int], c_int),
     "mfft_c2r_last": ([c_void_p, c_void_p, POINTER(c_int64), c_int], c_int),
     "mfft_slab_pack": ([c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int], c_int),

@@ -186,6 +186,25 @@ int mfft_c2c_axis(const void* in, void* out, const int64_t shape[3], int axis, i
   return 0;
 }
 
+// The strided transform with every stride spelled out (the "advanced" layout of a stage-level call: what numpy does for a
+// non-contiguous view, numpy_fft.py:25-37): nouter batches in_outer / out_outer elements apart, each ncols contiguous
+// columns wide, rows in_pitch / out_pitch elements apart.
+int mfft_c2c_strided(const void* in, void* out, int64_t n, int64_t nouter, int64_t ncols, int64_t in_outer, int64_t in_pitch,
+                     int64_t out_outer, int64_t out_pitch, int inverse, int precision) {
+  if (!in || !out) return set_error(MFFT_ERR_INVALID, "null argument");
+  if (n < 1 || nouter < 1 || ncols < 1 || in_pitch < ncols || out_pitch < ncols)
+    return set_error(MFFT_ERR_INVALID, "bad extents: n %lld, %lld batches of %lld columns, pitches %lld / %lld", (long long)n,
+                     (long long)nouter, (long long)ncols, (long long)in_pitch, (long long)out_pitch);
+  ColArgs a;
+  a.in = in; a.out = out; a.n = (int)n; a.prec = precision; a.inverse = inverse != 0;
+  a.scale = inverse ? 1.0 / (double)n : 1.0;
+  a.nouter = nouter; a.ncols = ncols; a.in_outer = in_outer; a.out_outer = out_outer;
+  a.in_rows.lo = in_pitch; a.out_rows.lo = out_pitch;
+  MFFT_TRY(launch_col(a, nullptr));
+  MFFT_HIP(hipStreamSynchronize(nullptr));
+  return 0;
+}
+
 int mfft_r2c_last(const void* in, void* out, const int64_t rshape[3], int precision) {
   if (!in || !out || !rshape) return set_error(MFFT_ERR_INVALID, "null argument");
   RealArgs a;

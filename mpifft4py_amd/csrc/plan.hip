@@ -243,16 +243,20 @@ struct mfft_plan_s {
     return getenv("MFFT_NO_ZFUSE") == nullptr && !d.line2d && !d.drop_nyquist && !zc.empty() && zc[0].len < 65536 &&
            M2 % 2 == 0 && zsplit_limit_supported(M2, prec);
   }
-  // Row pitch of a z chunk of `len` columns in the blocks of the FORWARD z-splitting exchange (round 4).  The strided pass
-  // that reads the received blocks next (x-aligned: the y pass; y-aligned: the x pass, then the y pass) reads rows of q
-  // elements: with q = 129 or 257 -- the rank that holds the Nyquist column -- they are not line-aligned, and that rank's y
-  // pass ran 28 - 34 % slower than its neighbours' (profiles/r04_rank_shapes.txt: (256, 1024, 257) 0.49 against 0.38 ms), its
-  // x pass (y-aligned, rows 2^20 + 2^13 bytes apart) 37 % slower: the slowest rank sets the pace of the transform.  The z
-  // kernel therefore writes such rows a whole number of cache lines apart (fft_kernels.h ZSplit pitch), the chunk grows by
-  // (pitch - len) / len (2.7 % at 257), and the schedules say so.  Only the fused z kernels, only chunks of 64 columns and
-  // more (small meshes live in the caches), only forward (the inverse z kernel reads contiguous rows: nothing to gain).
+  // Row pitch of a z chunk of `len` columns in the blocks of the FORWARD z-splitting exchange of the Y-ALIGNED pencil
+  // (round 4).  The rank that holds the Nyquist column has q = 129 (257 ...) columns; its x pass -- in place on the received
+  // (N0, N1/P2, q) -- then reads rows N1/P2 * q elements apart: 512 * 129 * 16 bytes = 2^20 + 2^13 at 1024^3 on the 4 x 2 grid,
+  // the slowest pitch there is (xplane_pad: 0.64 against 0.47 ms, profiles/r04_rank_shapes.txt), and the slowest rank sets
+  // the pace of the transform.  The z kernel therefore writes such rows a whole number of cache lines apart (fft_kernels.h
+  // ZSplit pitch: 129 -> 136 columns, the chunk of that one destination grows by 5 %), the x pass runs over N1/P2 * 136
+  // columns (the unused ones ride along), the pitch stays through the second exchange and the y pass reads it.
+  // NOT for the x-aligned pencil: there only the y pass would see the pitch, and a strided pass that reads line-aligned
+  // rows but must write compact ones is SLOWER than compact -> compact (scripts/ypass_pitch_ab.py, profiles/r04_ypass_pitch.txt:
+  // (256, 1024, 257) 0.49 -> 0.56 ms; aligned on both sides it would be 0.41, but the result's layout is the caller's) --
+  // the y-aligned plan pays the same 0.04 ms in its y pass and wins 0.17 in the x pass.  Only the fused z kernels, only
+  // chunks of 64 columns and more, only forward.
   int64_t zrow_pitch(int64_t len, bool forward) const {
-    if (!forward || !zpitch_on || !zfuse || d.drop_nyquist || zc.size() < 2 || len < 64) return len;
+    if (!forward || !zpitch_on || d.decomp != MFFT_PENCIL_Y || !zfuse || d.drop_nyquist || zc.size() < 2 || len < 64) return len;
     const int64_t per_line = (int64_t)(128 / es);
     return (len + per_line - 1) / per_line * per_line;
   }

@@ -227,14 +227,14 @@ def pencil(rank, P, N, A, align, P1=None, pipeline=1, relay=False):
     assert s0["peers"] == (lay.comm1_members(rank) if align == "X" else lay.comm0_members(rank))
     # z chunks: the pencils' rule (N2 / Pz / 2 columns each, the Nyquist column on the last rank: pencil.py:197, 908); in
     # the FORWARD exchange the rows of a block of 64 columns and more lie a whole number of cache lines apart (plan.hip
-    # zrow_pitch: the byte counts say how far), the rest of the row is unused
+    # zrow_pitch: y-aligned plans; the byte counts say how far), the rest of the row is unused
     Pz = len(s0["peers"])
     lens = [N[2] // Pz // 2] * Pz
     lens[-1] += 1
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
     pitch = [c // (m * n * ES) for c in s0["scount"]]
-    for ln, pt in zip(lens, pitch):
-        assert pt == (ln if ln < 64 else -(-ln // 8) * 8), (ln, pt)
+    for ln, pt in zip(lens, pitch):                           # (y-aligned only: plan.hip zrow_pitch says why)
+        assert pt == (ln if ln < 64 or align == "X" else -(-ln // 8) * 8), (ln, pt)
     bufs = []
     for ln, st, pt in zip(lens, starts, pitch):
         blk = np.zeros((m, n, pt), dtype=complex)
@@ -243,7 +243,7 @@ def pencil(rank, P, N, A, align, P1=None, pipeline=1, relay=False):
     send = np.concatenate(bufs)
     q = lay.complex_shape(rank)[2]
     qp = s0["rcount"][0] // (m * n * ES)                       # row pitch of the received blocks
-    assert qp == (q if q < 64 else -(-q // 8) * 8) and all(c == m * n * qp * ES for c in s0["rcount"])
+    assert qp == (q if q < 64 or align == "X" else -(-q // 8) * 8) and all(c == m * n * qp * ES for c in s0["rcount"])
     r = exchange(rank, s0, send, sum(s0["rcount"]), 0, True)
     blocks = r.reshape(len(lens), m, n, qp)
     s1 = _lib.exchange_schedule(N, P, rank, dec, 1, True, p1=P1 or 0)

@@ -46,9 +46,9 @@ def test_schedule_matches_reference_message_sizes():
     call sites).  The exchanges whose receiver runs a strided x pass out of the chunks carry one cache line (8 complex128)
     between x rows where the compact pitch reads slowly (plan.hip xplane_pad, round 4): 128 * 513 elements (slab over 8
     ranks, forward), 256 * 257 (x-aligned pencil, forward, the ranks that hold the Nyquist column), 512 * 128 / 512 * 129
-    (y-aligned pencil, inverse); the forward z-splitting exchange carries the rows of the Nyquist-holding rank's chunk (129,
-    257 columns) a whole number of cache lines apart (zrow_pitch: 136, 264); the opposite directions have the
-    reference's sizes exactly."""
+    (y-aligned pencil, inverse); the forward z-splitting exchange of the y-aligned pencil carries the rows of the
+    Nyquist-holding rank's chunk (129 columns) a whole number of cache lines apart (zrow_pitch: 136); the opposite
+    directions have the reference's sizes exactly."""
     from mpifft4py_amd import _lib
     N = [1024] * 3
     s = _lib.exchange_schedule(N, 8, 0, _lib.SLAB, forward=False)
@@ -73,7 +73,7 @@ def test_schedule_matches_reference_message_sizes():
     s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=0, forward=False)
     assert s["peers"] == [1, 5] and s["rcount"] == [256 * 512 * 256 * 16, 256 * 512 * 257 * 16]
     s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=0)
-    assert s["scount"] == [256 * 512 * 256 * 16, 256 * 512 * 264 * 16]    # rows of 257 columns start on cache lines
+    assert s["scount"] == [256 * 512 * 256 * 16, 256 * 512 * 257 * 16]    # x-aligned: compact (a pitch would only slow its y pass)
     s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=1, forward=False)
     assert s["peers"] == [4, 5, 6, 7] and set(s["scount"]) == {256 * 256 * 257 * 16}
     s = _lib.exchange_schedule(N, 8, 5, _lib.PENCIL_X, which=1, forward=True)
@@ -86,7 +86,7 @@ def test_schedule_matches_reference_message_sizes():
             "assert set(_lib.exchange_schedule([1024] * 3, 8, 5, _lib.PENCIL_X, which=1)['scount']) == {256 * 256 * 257 * 16}\n" % ROOT)
     subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, MFFT_NO_XPAD="1"))
     code = ("import sys; sys.path.insert(0, %r)\nfrom mpifft4py_amd import _lib\n"
-            "assert _lib.exchange_schedule([1024] * 3, 8, 5, _lib.PENCIL_X, which=0)['scount'] == [256 * 512 * 256 * 16, 256 * 512 * 257 * 16]\n" % ROOT)
+            "assert _lib.exchange_schedule([1024] * 3, 8, 0, _lib.PENCIL_Y, which=0)['scount'] == [256 * 512 * 128 * 16] * 3 + [256 * 512 * 129 * 16]\n" % ROOT)
     subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, MFFT_NO_ZPITCH="1"))
 
 

@@ -706,9 +706,9 @@ def test_exchanged_layouts_with_padded_x_rows(cls, P, pipeline, kind, N):
                                                  ("Y", 4, None, 1), ("Y", 4, None, 0), ("Y", 8, None, 0), ("Y", 8, 2, 1)])
 def test_pencil_forward_z_blocks_with_line_aligned_rows(align, P, P1, pipeline, prec):
     """Round 4: in the forward z-splitting exchange the rows of a chunk of 64 columns and more lie a whole number of cache
-    lines apart (plan.hip zrow_pitch, fft_kernels.h ZSplit pitch): the rank that holds the Nyquist column (129 / 65 columns
-    here) no longer reads unaligned rows in its y pass -- and, y-aligned, carries the pitch through its x pass and the
-    second exchange.  [32, 64, 512]: Nf = 257; asserted through the schedule query; against numpy.fft."""
+    lines apart in the y-aligned plans (plan.hip zrow_pitch, fft_kernels.h ZSplit pitch): the rank that holds the Nyquist
+    column (129 / 65 columns here) runs its x pass off the 2^a + 2^(a-7) pitch and carries the row pitch through the second
+    exchange; the x-aligned plans keep compact rows (same test, same meshes).  [32, 64, 512]: Nf = 257; asserted through the schedule query; against numpy.fft."""
     from mpifft4py_amd import Pencil_R2C, _lib
     N = [32, 64, 512]
     dec = _lib.PENCIL_X if align == "X" else _lib.PENCIL_Y
@@ -718,7 +718,8 @@ def test_pencil_forward_z_blocks_with_line_aligned_rows(align, P, P1, pipeline, 
     es = 16 if prec == "double" else 8
     q_last = lay.complex_shape(P - 1)[2]
     per_line = 128 // es
-    assert q_last % 2 == 1 and s0["rcount"][0] == m * n * (-(-q_last // per_line) * per_line) * es, (q_last, s0)
+    want_pitch = -(-q_last // per_line) * per_line if align == "Y" else q_last      # y-aligned plans only (plan.hip zrow_pitch)
+    assert q_last % 2 == 1 and s0["rcount"][0] == m * n * want_pitch * es, (q_last, s0)
     rng = np.random.default_rng(31 + P)
     A = rng.random(N).astype(rdtype(prec))
     B = np.fft.rfftn(A.astype(np.float64))

@@ -310,3 +310,27 @@ print("COL3_OK")
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MFFT_COL3=mode), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0 and b"COL3_OK" in p.stdout, p.stdout.decode()[-3000:]
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+def test_c2c_strided_entry_point(prec):
+    """mfft_c2c_strided: the strided transform with every stride spelled out (rows further apart than the columns they
+    hold, different pitches on the two sides, in place and out of place) against numpy.fft on the same views."""
+    from mpifft4py_amd import DeviceArray, _lib
+    rng = np.random.default_rng(21)
+    ct = cdtype(prec)
+    for n, nouter, ncols, ip, op in ((96, 3, 33, 40, 33), (128, 2, 65, 65, 72), (60, 1, 500, 512, 500), (1024, 2, 129, 136, 129)):
+        A = (rng.random((nouter, n, ip)) - 0.5 + 1j * (rng.random((nouter, n, ip)) - 0.5)).astype(ct)
+        dA = DeviceArray.from_numpy(A)
+        dB = DeviceArray.zeros((nouter, n, op), ct)
+        for inverse in (0, 1):
+            _lib.call("mfft_c2c_strided", dA.ptr, dB.ptr, n, nouter, ncols, n * ip, ip, n * op, op, inverse, _lib.precision_code(prec))
+            f = np.fft.ifft if inverse else np.fft.fft
+            want = f(A[:, :, :ncols].astype(np.complex128), axis=1)
+            assert orc.rel_l2(dB.get()[:, :, :ncols], want) < TOL[prec], (n, inverse)
+        _lib.call("mfft_c2c_strided", dA.ptr, dA.ptr, n, nouter, ncols, n * ip, ip, n * ip, ip, 0, _lib.precision_code(prec))
+        got = dA.get()
+        assert orc.rel_l2(got[:, :, :ncols], np.fft.fft(A[:, :, :ncols].astype(np.complex128), axis=1)) < TOL[prec]
+        assert np.array_equal(got[:, :, ncols:], A[:, :, ncols:])          # the columns between the rows are not touched
+    with pytest.raises(_lib.MfftError):
+        _lib.call("mfft_c2c_strided", dA.ptr, dA.ptr, 8, 1, 16, 0, 8, 0, 16, 0, 1)
