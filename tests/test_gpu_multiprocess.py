@@ -261,6 +261,34 @@ def test_bench_ranks_stay_together_when_rank0_cannot_make_an_id():
     assert "first transport unavailable" in err
 
 
+@pytest.mark.parametrize("cus", [16, -1])
+def test_ipc_survivor_of_a_killed_peer(cus):
+    """with CU-masked (= blocking) plan streams the host-side release of a hung exchange queued behind
+    the very wait kernel it must release, so a dead peer meant a permanent hang.  Two IPC processes, rank 1 SIGKILLed between
+    two transforms: rank 0 gets an error within the transport's timeout and can still free its plan and communicator
+    (tests/mp_worker_peer_dies.py); with CU masks and without."""
+    import time
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(_env("ipc"), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MFFT_LOCAL_TIMEOUT="10", PEER_DIES_CUS=str(cus))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker_peer_dies.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT))
+    t0 = time.time()
+    try:
+        out0, err0 = procs[0].communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        for q in procs:
+            q.kill()
+        out0, err0 = procs[0].communicate(timeout=10)
+        raise AssertionError("the survivor hung; stderr tail:\n" + err0.decode()[-3000:])
+    procs[1].wait(timeout=30)
+    assert procs[1].returncode != 0                      # it was killed
+    assert procs[0].returncode == 0 and b"SURVIVOR_OK" in out0, (out0.decode()[-2000:], err0.decode()[-3000:])
+    assert time.time() - t0 < 200
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_mpi4py_like_communicator_is_wrapped(world):
     """INTEGRATION.md route A with the caller's own communicator object: the constructors accept anything with
