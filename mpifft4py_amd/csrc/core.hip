@@ -184,7 +184,8 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.ncols = (int)a.ncols;
   P.ntile_c = (int)((a.ncols + e->tile - 1) / e->tile);
   P.nouter = (int)a.nouter;
-  P.remap = a.remap;
+  static const int remap_env = getenv("MFFT_REMAP") ? atoi(getenv("MFFT_REMAP")) : -1;      // experiments: 0 none, 1 XCD-aware, 2 skewed
+  P.remap = remap_env >= 0 ? remap_env : a.remap;
   P.fold = a.fold ? 1 : 0;
   P.scale = (T)a.scale;
   P.nblocks = 0;
