@@ -17,7 +17,8 @@ def ypass(label, nouter, n, q, dtype):
     A = DeviceArray.random((nouter, n, qp), dtype, seed=1)
     B = DeviceArray.empty((nouter, n, qp), dtype)
     res = []
-    for name, ip, op in (("compact -> compact", q, q), ("aligned -> compact", qp, q), ("aligned -> aligned", qp, qp)):
+    for name, ip, op in (("compact -> compact", q, q), ("aligned -> compact", qp, q), ("aligned -> aligned", qp, qp),
+                         ("compact -> aligned", q, qp)):
         fn = lambda: _lib.call("mfft_c2c_strided", A.ptr, B.ptr, n, nouter, q, n * ip, ip, n * op, op, 0, prec)
         fn()
         mn, _ = timed(fn)
@@ -34,3 +35,7 @@ if __name__ == "__main__":
     ypass("reference: (256, 1024, 256)", 256, 1024, 256, c128)
     ypass("slab 8 ranks kz slice: (128, 1024, 129)", 128, 1024, 129, c128)
     ypass("one rank: (1024, 1024, 513)", 1024, 1024, 513, c128)
+    # the x pass of the one-rank inverse if the y pass went first and left rows of 520: in place over 1024 * 520 columns
+    from xpass_kernel_ab import run
+    run("one rank x pass over (1024, 1024*520)", 1024, 1024 * 520, c128)
+    run("one rank x pass over (1024, 1024*513)", 1024, 1024 * 513, c128)
