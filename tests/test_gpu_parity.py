@@ -735,6 +735,28 @@ def test_pencil_forward_z_blocks_with_line_aligned_rows(align, P, P1, pipeline, 
         assert e_f < TOL[prec] and e_b < 4 * TOL[prec] and same, (e_f, e_b, same)
 
 
+@pytest.mark.parametrize("pipeline", [1, 0])
+def test_pencil_c2c_y_with_pitched_z_chunks(pipeline):
+    """The y-aligned pencil's row pitch (plan.hip zrow_pitch) on COMPLEX data: chunks of 72 complex64 columns (576 bytes)
+    travel 80 apart; the contiguous-axis c2c kernel writes them (RowFft CHUNK through ZSplit)."""
+    from mpifft4py_amd import Pencil_C2C, _lib
+    N, P = [32, 64, 144], 4
+    s0 = _lib.exchange_schedule(N, P, 0, _lib.PENCIL_Y, 0, True, kind=_lib.C2C, precision="single")
+    assert s0["scount"][0] == (32 // 2) * (64 // 2) * 80 * 8, s0
+    rng = np.random.default_rng(12)
+    A = (rng.random(N) - 0.5 + 1j * (rng.random(N) - 0.5)).astype(np.complex64)
+    B = np.fft.fftn(A.astype(np.complex128))
+
+    def body(comm):
+        F = Pencil_C2C(np.array(N), L, comm, "single", alignment="Y", pipeline=pipeline)
+        a = np.ascontiguousarray(A[F.original_local_slice()])
+        c = F.fftn(a, np.zeros(F.transformed_shape(), dtype=np.complex64))
+        b = F.ifftn(c, np.zeros(F.original_shape(), dtype=np.complex64))
+        return orc.rel_l2(c, B[F.transformed_local_slice()]), orc.rel_l2(b, a)
+    for e_f, e_b in run_ranks(P, body):
+        assert e_f < TOL["single"] and e_b < 4 * TOL["single"], (e_f, e_b)
+
+
 CONFIG5_MESHES = [[2048, 64, 32], [64, 2048, 32], [32, 64, 2048], [4096, 32, 16]]
 
 
