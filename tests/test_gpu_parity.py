@@ -735,6 +735,40 @@ def test_pencil_forward_z_blocks_with_line_aligned_rows(align, P, P1, pipeline, 
         assert e_f < TOL[prec] and e_b < 4 * TOL[prec] and same, (e_f, e_b, same)
 
 
+@pytest.mark.parametrize("kind", ["r2c", "c2c"])
+@pytest.mark.parametrize("align,P1,pipeline", [("X", 4, 1), ("X", 4, 0), ("X", 1, 1), ("X", 1, 0), ("Y", 1, 1), ("Y", 1, 0), ("Y", 4, 1), ("Y", 4, 0)])
+def test_one_dimensional_process_grids_with_padded_layouts(align, P1, pipeline, kind):
+    """P x 1 and 1 x P grids (the C ABI takes them; bench.py times them) on meshes where the padded exchange layouts of
+    round 4 are active: a group of one rank exchanges nothing, so the buffers change roles differently (plan.hip:
+    zsolo / g2solo) -- x-aligned 4 x 1: no z exchange but a padded second one; y-aligned 1 x 4: a z exchange with pitched
+    rows and no second one; and the two grids on which neither pad applies."""
+    from mpifft4py_amd import Pencil_C2C, Pencil_R2C
+    N = [64, 256, 1024] if kind == "r2c" else [64, 256, 512]
+    P = 4
+    rng = np.random.default_rng(5 + P1)
+    if kind == "c2c":
+        A = rng.random(N) - 0.5 + 1j * (rng.random(N) - 0.5)
+        B = np.fft.fftn(A)
+    else:
+        A = rng.random(N)
+        B = np.fft.rfftn(A)
+
+    def body(comm):
+        if kind == "c2c":
+            F = Pencil_C2C(np.array(N), L, comm, "double", P1=P1, alignment=align, pipeline=pipeline, allow_odd_grid=True)
+            isl, osl = F.original_local_slice(), F.transformed_local_slice()
+        else:
+            F = Pencil_R2C(np.array(N), L, comm, "double", P1=P1, communication="Alltoallw", alignment=align, pipeline=pipeline,
+                           allow_odd_grid=True)
+            isl, osl = F.real_local_slice(), F.complex_local_slice()
+        a = np.ascontiguousarray(A[isl])
+        c = F.fftn(a, np.zeros(B[osl].shape, dtype=complex))
+        b = F.ifftn(c, np.zeros(a.shape, dtype=a.dtype))
+        return orc.rel_l2(c, B[osl]), orc.rel_l2(b, a)
+    for e_f, e_b in run_ranks(P, body):
+        assert e_f < 1e-10 and e_b < 1e-10, (e_f, e_b)
+
+
 @pytest.mark.parametrize("pipeline", [1, 0])
 def test_pencil_c2c_y_with_pitched_z_chunks(pipeline):
     """The y-aligned pencil's row pitch (plan.hip zrow_pitch) on COMPLEX data: chunks of 72 complex64 columns (576 bytes)
