@@ -16,6 +16,13 @@ _DEALIAS = {None: _lib.DEALIAS_NONE, "None": _lib.DEALIAS_NONE,
             "2/3-rule": _lib.DEALIAS_2_3, "3/2-rule": _lib.DEALIAS_3_2}
 
 
+try:                       # a 64-bit hash at memory speed where the module exists; zlib's adler32 (~3 GB/s) otherwise
+    from xxhash import xxh3_64_intdigest as _hash_bytes
+except ImportError:        # pragma: no cover
+    def _hash_bytes(buf):
+        return zlib.adler32(buf)
+
+
 def default_planner_effort():
     return defaultdict(lambda: "FFTW_MEASURE")
 
@@ -48,15 +55,18 @@ class DistFFTBase(object):
     # The reference reads `self.dealias` on every '2/3-rule' call (slab.py:237-245, pencil.py:455-462), so a caller may
     # replace the filter, or edit it in place, at any time.  Here the filter lives on the device.  Assigning to `dealias`
     # marks the device copy stale.  In-place edits are found by a fingerprint taken at upload and compared on every
-    # '2/3-rule' call (`dealias_check`, on by default): the whole array up to 4 MB, above that 65 536 elements at fixed
-    # pseudo-random positions (an edit of a fraction f of a large mask goes unnoticed with probability (1 - f)^65536:
-    # planes, bands and blocks are always seen, a single changed element of a 500 MB mask is not -- re-assign then).
+    # '2/3-rule' call (`dealias_check`, on by default).  It has to stay far below the transform it guards -- 50 us at 128^3,
+    # 0.2 ms at 256^3 -- so it hashes the whole array only up to 256 KiB (a 64^3 filter: ~10 us) and above that 8192
+    # elements at fixed pseudo-random positions (~40 us at 128^3, ~0.15 ms for the 540 MB filter of 1024^3; the first
+    # version hashed 4 MB / 65 536 samples: 0.4 - 1 ms per call, several times the transform between 128^3 and 256^3).
+    # An edit of a fraction f of a large mask goes unnoticed with probability (1 - f)^8192: planes, bands and blocks
+    # are always seen (one plane of 1024: 3e-4), a single changed element is not -- re-assign then.
     # The upload is COLLECTIVE for plans over more than one rank (mfft_plan_set_dealias_mask), so the ranks vote on
     # "somebody's filter changed" with one small host all-reduce per '2/3-rule' call; `F.dealias_check = False` (on
     # every rank) switches fingerprint and vote off, and only assignment re-uploads.
     dealias_check = True
-    _FULL_HASH_BYTES = 4 << 20
-    _SAMPLES = 1 << 16
+    _FULL_HASH_BYTES = 256 << 10
+    _SAMPLES = 1 << 13
     _sample_index = {}
 
     @property
@@ -77,7 +87,7 @@ class DistFFTBase(object):
                 idx = np.sort(np.random.default_rng(0x6d666674).integers(0, flat.size, self._SAMPLES))
                 DistFFTBase._sample_index = {flat.size: idx}
             flat = flat[idx]
-        return (a.shape, a.dtype.str, zlib.adler32(np.ascontiguousarray(flat).view(np.uint8)))
+        return (a.shape, a.dtype.str, _hash_bytes(np.ascontiguousarray(flat).view(np.uint8)))
 
     def _describe(self, kind, decomp, mesh=None, p1=0, pipeline=0, drop_nyquist=False, line2d=False):
         """Fill the plan descriptor and ask the library -- on the host, no device involved (mfft_layout_query) -- for

@@ -538,6 +538,18 @@ struct mfft_plan_s {
     for (int t = 0; t < s; ++t) o += (size_t)(P * Np0 * slice_pitch(t, forward));
     return o;
   }
+  // One-rank real transforms (experiment, MFFT_ALIGNED: 1 both directions, 2 inverse only, 3 forward only): the intermediate
+  // between the passes is ours, so its z rows can start on cache lines (Nf = N2/2 + 1 bins never fill whole lines).
+  // Returns the row pitch in bins, 0 = compact route.
+  int64_t aligned_route(bool forward) const {
+    static const int mode = getenv("MFFT_ALIGNED") ? atoi(getenv("MFFT_ALIGNED")) : 0;
+    if (mode <= 0 || !r2c || d.line2d || d.decomp != MFFT_SLAB) return 0;
+    if (mode == 2 && forward) return 0;
+    if (mode == 3 && !forward) return 0;
+    const int64_t per_line = (int64_t)(128 / es);
+    if (Nf % per_line == 0 || Nf < 2 * per_line) return 0;
+    return (Nf + per_line - 1) / per_line * per_line;
+  }
   // One-rank forward transform: y and x passes out of place through a work buffer of the size of the spectrum instead
   // of in place on the result.  MFFT_FWD_OOP=1 / 0 forces it on / off; default: off (measured).
   // When on by default it would still need room: the buffer exists already (the inverse uses the same one), or a
@@ -766,8 +778,8 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
   const double Cb = (double)(N0 * Np1 * Nf) * es;            // local complex bytes
   const double Rb = (double)(Np0 * N1 * N2) * rs;            // local real-space bytes
   if (P == 1) {
-    MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Nf); }));
     if (const int64_t xpad = plane_pad(N1 * Nf)) {
+      MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Nf); }));
       // power-of-two plane stride: the y transform writes planes one cache line apart from that, the x transform reads them
       const int64_t pl = N1 * Nf + xpad;
       MFFT_TRY(ensure_work(0, (size_t)(N0 * pl) * es));
@@ -776,6 +788,17 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
       MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Nf, 0, plain(pl), 0, plain(N1 * Nf)); }));
       return 0;
     }
+    if (const int64_t Nfp = aligned_route(true)) {
+      // line-aligned intermediate (aligned_route): r2c writes rows of Nfp bins, the y pass runs in place on whole private
+      // cache lines, the x pass reads them and writes the caller's compact rows
+      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nfp) * es));
+      void* A = work[0];
+      MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return r2c_rows(u, A, N0 * N1, N2, N2, Nfp); }));
+      MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(A, A, N1, false, N0, Nf, N1 * Nfp, plain(Nfp), N1 * Nfp, plain(Nfp)); }));
+      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, N1, Nf, Nfp, plain(N1 * Nfp), Nf, plain(N1 * Nf)); }));
+      return 0;
+    }
+    MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Nf); }));
     if (fwd_out_of_place((size_t)Cb)) {
       // y transform into the work buffer (the one the inverse uses anyway), x transform out of it into the result: both
       // passes out of place (MFFT_FWD_OOP, see fwd_out_of_place)
@@ -903,6 +926,16 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
   MFFT_TRY(ensure_work(0, cb));
   void* A = work[0];
   if (P == 1) {
+    if (const int64_t Nfp = aligned_route(false)) {
+      // line-aligned intermediate: the x pass reads the caller's compact rows and writes rows of Nfp bins, the y pass runs in
+      // place on whole private cache lines, c2r reads them
+      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nfp) * es));
+      A = work[0];
+      MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, N1, Nf, Nf, plain(N1 * Nf), Nfp, plain(N1 * Nfp)); }));
+      MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(A, A, N1, true, N0, Nf, N1 * Nfp, plain(Nfp), N1 * Nfp, plain(Nfp)); }));
+      MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return c2r_rows(A, u, N0 * N1, N2, Nfp, N2, 1.0 / (double)N2); }));
+      return 0;
+    }
     MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
     MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(A, A, N1, true, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
     MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A, u, N0 * N1, N2, Nf); }));

@@ -412,7 +412,7 @@ def test_two_thirds_rule_filter_edited_in_place(decomp, P):
 
 
 def test_two_thirds_rule_large_filter_sampled_fingerprint():
-    """A filter above 4 MB is fingerprinted by 65 536 samples: band and plane edits are seen."""
+    """A filter above 256 KiB is fingerprinted by 8192 samples: band and plane edits are seen."""
     from mpifft4py_amd import Slab_R2C
     from mpifft4py_amd import SelfComm
     N = [128, 128, 512]
