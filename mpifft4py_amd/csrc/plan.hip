@@ -923,14 +923,13 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(u, u, N0 * N1, N2, Nf); }));
     return 0;
   }
-  MFFT_TRY(ensure_work(0, cb));
+  const int64_t Nfp = P == 1 ? aligned_route(false) : 0;
+  MFFT_TRY(ensure_work(0, Nfp ? (size_t)(N0 * N1 * Nfp) * es : cb));
   void* A = work[0];
   if (P == 1) {
-    if (const int64_t Nfp = aligned_route(false)) {
+    if (Nfp) {
       // line-aligned intermediate: the x pass reads the caller's compact rows and writes rows of Nfp bins, the y pass runs in
       // place on whole private cache lines, c2r reads them
-      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nfp) * es));
-      A = work[0];
       MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, N1, Nf, Nf, plain(N1 * Nf), Nfp, plain(N1 * Nfp)); }));
       MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(A, A, N1, true, N0, Nf, N1 * Nfp, plain(Nfp), N1 * Nfp, plain(Nfp)); }));
       MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return c2r_rows(A, u, N0 * N1, N2, Nfp, N2, 1.0 / (double)N2); }));
