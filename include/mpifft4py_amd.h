@@ -192,7 +192,8 @@ MFFT_API int mfft_plan_set_dealias_mask(mfft_plan_t plan, const uint8_t* mask_ho
 /* What a plan decided, by key: "pruned_route" (after mfft_plan_set_dealias_mask: 0 = the mask is applied on load,
  * 1 = pruned passes and a smaller exchange, 2 = the same with every ky of THIS rank removed), "comm_cus" (CUs set aside
  * for the communication stream, 0 = no masks), "kz_slices", "row_batches" (pieces of the exchange pipeline), "zfuse"
- * (pencils: z-chunk pack fused into the z transform), "ranks".  Unknown keys are MFFT_ERR_INVALID. */
+ * (pencils: z-chunk pack fused into the z transform), "ranks", "plane_pad" (one-rank slab plans: elements added to the
+ * plane pitch of the intermediate because the mesh's own plane pitch is one the strided x pass reads slowly).  Unknown keys are MFFT_ERR_INVALID. */
 MFFT_API int mfft_plan_get_info(mfft_plan_t plan, const char* key, int64_t* value);
 
 /* per-stage timing with HIP events on the plan's own streams (bench roofline) */

@@ -204,7 +204,8 @@ class DistFFTBase(object):
         return dst
 
     def plan_info(self, key):
-        """What the plan decided (mfft_plan_get_info): "pruned_route", "comm_cus", "kz_slices", "row_batches", "zfuse"."""
+        """What the plan decided (mfft_plan_get_info): "pruned_route", "comm_cus", "kz_slices", "row_batches", "zfuse",
+        "plane_pad"."""
         v = ctypes.c_int64(0)
         _lib.call("mfft_plan_get_info", self._plan, key.encode(), ctypes.byref(v))
         return int(v.value)

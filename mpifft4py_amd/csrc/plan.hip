@@ -19,6 +19,7 @@
 #include "relay_plan.h"
 
 #ifndef MFFT_FWD_OOP_DEFAULT
+#define MFFT_P1_XPAD_DEFAULT 0      // one-rank real transforms: cache lines added to slow plane pitches of the intermediate (p1_plane_pad; measured: no gain)
 #define MFFT_FWD_OOP_DEFAULT 0      // one-rank forward y / x passes out of place: see mfft_plan_s::fwd_out_of_place
 #endif
 
@@ -512,6 +513,22 @@ struct mfft_plan_s {
   // (mfft_plan_exchange_schedule / _pieces report it: 64 KiB on a 2 GiB chunk at BASELINE config 5), and the x pass reads
   // the padded rows out of place into the caller's compact array: config 5's x pass 5.52 -> 4.46 ms per rank, the y-aligned
   // pencil's at 1024^3 0.63 -> 0.47.  MFFT_NO_XPAD=1 switches it off (every rank alike).
+  // One rank (round 4): the x rows (planes) of a rank's own spectrum lie N1 * Nf elements apart -- for a power-of-two mesh
+  // N * (N/2 + 1) * es = 2^a + 2^(a - log2 N + 1) bytes, which for N = 256 and 512 (N = 1024 in single precision) is one of
+  // the pitches the strided x pass reads slowly (slow_pitch_pad).  The caller's array keeps its layout, so the route puts the
+  // pass that READS it first or last and gives the intermediate planes `lines` cache lines more: forward y out of place into
+  // padded planes, x out of them into the result; inverse y first (it reads rows, the plane pitch does not matter to it)
+  // into padded planes, x out of them.  Complex data with power-of-two planes took this route since round 2 (plane_pad) and
+  // keeps it.  For real data it is OFF: the x pass alone gains 4 - 10 % from the pad when it is timed by itself
+  // (profiles/r04_xpass_stride_map.txt), inside the transform the pairs of 256^3, 512^3 (fp64, fp32) and 1024^3 fp32 come
+  // out the same to +-1 % with 0 - 3 lines (profiles/r04_p1_xpad_ab.txt) -- the y pass that has to go first / out of place
+  // gives back what the x pass wins.  MFFT_P1_XPAD = lines switches it on (read when a plan is created).
+  int p1_xpad_lines = MFFT_P1_XPAD_DEFAULT;     // read when the plan is created
+  int64_t p1_plane_pad() const {
+    if (const int64_t c = r2c ? 0 : plane_pad(N1 * Nf)) return c;
+    if (p1_xpad_lines <= 0 || d.line2d) return 0;
+    return slow_pitch_pad(N1 * Nf) ? (int64_t)p1_xpad_lines * (int64_t)(128 / es) : 0;
+  }
   int64_t slow_pitch_pad(int64_t stride_elems) const {
     const unsigned long long b = (unsigned long long)stride_elems * (unsigned long long)es;
     if (b < 65536) return 0;                              // small blocks live in the caches
@@ -778,7 +795,7 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
   const double Cb = (double)(N0 * Np1 * Nf) * es;            // local complex bytes
   const double Rb = (double)(Np0 * N1 * N2) * rs;            // local real-space bytes
   if (P == 1) {
-    if (const int64_t xpad = plane_pad(N1 * Nf)) {
+    if (const int64_t xpad = p1_plane_pad()) {
       MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Nf); }));
       // power-of-two plane stride: the y transform writes planes one cache line apart from that, the x transform reads them
       const int64_t pl = N1 * Nf + xpad;
@@ -905,7 +922,7 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
   }
   if (masked) {
     bool fused = false;
-    MFFT_TRY(fuse_mask(fu, (P == 1 && !r2c && plane_pad(N1 * Nf)) ? N1 : N0, &fused));
+    MFFT_TRY(fuse_mask(fu, (P == 1 && p1_plane_pad()) ? N1 : N0, &fused));
     if (!fused) {
       void* m = nullptr;
       MFFT_TRY(stage("bwd_mask", 2 * Cb, [&] { return apply_mask_copy(fu, &m); }));
@@ -913,14 +930,20 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     }
   }
   const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
-  if (const int64_t xpad = (P == 1 && !r2c) ? plane_pad(N1 * Nf) : 0) {
-    // complex data, power-of-two plane stride: y first (into padded planes), x out of them, z in place in the result
+  if (const int64_t xpad = P == 1 ? p1_plane_pad() : 0) {
+    // slow plane stride (p1_plane_pad): y first (into padded planes), x out of them -- complex data: into the result, z in
+    // place there; real data: into a second work buffer that c2r reads
     const int64_t pl = N1 * Nf + xpad;
     MFFT_TRY(ensure_work(0, (size_t)(N0 * pl) * es));
     void* Ap = work[0];
+    void* X = u;
+    if (r2c) {
+      MFFT_TRY(ensure_work(1, cb));
+      X = work[1];
+    }
     MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(src, Ap, N1, true, N0, Nf, N1 * Nf, plain(Nf), pl, plain(Nf)); }));
-    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(Ap, u, N0, true, 1, N1 * Nf, 0, plain(pl), 0, plain(N1 * Nf)); }));
-    MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(u, u, N0 * N1, N2, Nf); }));
+    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(Ap, X, N0, true, 1, N1 * Nf, 0, plain(pl), 0, plain(N1 * Nf)); }));
+    MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(X, u, N0 * N1, N2, Nf); }));
     return 0;
   }
   const int64_t Nfp = P == 1 ? aligned_route(false) : 0;
@@ -2031,6 +2054,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   for (int i = 0; i < p->P; ++i) p->world[i] = i;
   p->xpad_on = !(getenv("MFFT_NO_XPAD") && atoi(getenv("MFFT_NO_XPAD")) != 0);
   p->xpass_inplace = getenv("MFFT_XPASS_INPLACE") && atoi(getenv("MFFT_XPASS_INPLACE")) != 0;
+  if (getenv("MFFT_P1_XPAD")) p->p1_xpad_lines = atoi(getenv("MFFT_P1_XPAD"));
   p->zpitch_on = !(getenv("MFFT_NO_ZPITCH") && atoi(getenv("MFFT_NO_ZPITCH")) != 0);
   const int P = p->P;
   if (p->r2c && p->N2 % 2) return set_error(MFFT_ERR_UNSUPPORTED, "odd N[2]=%lld is not supported for R2C", (long long)p->N2);
@@ -2445,6 +2469,7 @@ int mfft_plan_get_info(mfft_plan_t p, const char* key, int64_t* value) {
   else if (k == "row_batches") *value = p->nbatch;
   else if (k == "zfuse") *value = p->zfuse ? 1 : 0;
   else if (k == "ranks") *value = p->P;
+  else if (k == "plane_pad") *value = (p->P == 1 && p->d.decomp == MFFT_SLAB) ? p->p1_plane_pad() : 0;   // elements added to the intermediate's plane pitch
   else return set_error(MFFT_ERR_INVALID, "mfft_plan_get_info: unknown key '%s'", key);
   return 0;
 }

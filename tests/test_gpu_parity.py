@@ -222,6 +222,43 @@ def test_padded_long_axes(N, prec):
         assert orc.rel_l2(a, want_a[0]) < 4 * TOL[prec], "backward"
 
 
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("N", [[16, 256, 256], [12, 512, 512]])
+def test_one_rank_padded_planes(N, prec, monkeypatch):
+    """One rank, real data, a mesh whose own plane pitch N1 * (N2/2 + 1) elements is one the strided x pass reads slowly
+    (2^a + 2^(a-7), 2^a + 2^(a-8): the power-of-two meshes 256 and 512; plan.hip p1_plane_pad, a switch: MFFT_P1_XPAD): the
+    intermediate's planes lie some cache lines further apart, the forward x pass reads them out of place, the inverse starts with the y pass.
+    Route asserted, results against numpy.fft (slab.py:366-370, 247-249), the 2/3-rule with the reference's filter
+    (pruned passes) and with an arbitrary one (mask applied by the y pass, now the first one)."""
+    from mpifft4py_amd import Slab_R2C, SelfComm
+    rng = np.random.default_rng(77)
+    ct, rt = cdtype(prec), rdtype(prec)
+    monkeypatch.setenv("MFFT_P1_XPAD", "2")
+    F = Slab_R2C(np.array(N), L, SelfComm(0), prec)
+    assert F.plan_info("plane_pad") == 2 * 128 // np.dtype(ct).itemsize
+    A = rng.random(N).astype(rt)
+    fu = F.fftn(A, np.zeros(F.complex_shape(), dtype=ct))
+    want = np.fft.rfftn(A.astype(np.float64), axes=(0, 1, 2))
+    assert orc.rel_l2(fu, want) < 4 * TOL[prec], orc.rel_l2(fu, want)
+    C = want.astype(ct)
+    c_in = C.copy()
+    u = F.ifftn(C, np.zeros(F.real_shape(), dtype=rt))
+    assert np.array_equal(C, c_in)
+    assert orc.rel_l2(u, A) < 4 * TOL[prec], orc.rel_l2(u, A)
+    # the reference's own filter: pruned passes (they do not take the padded route, nothing to pad in rows that are skipped)
+    u23 = F.ifftn(C, np.zeros(F.real_shape(), dtype=rt), dealias="2/3-rule")
+    mask = np.broadcast_to(F.get_dealias_filter(), F.complex_shape())
+    w23 = np.fft.irfftn(want * mask, s=N, axes=(0, 1, 2))
+    assert orc.rel_l2(u23, w23) < 4 * TOL[prec], orc.rel_l2(u23, w23)
+    # an arbitrary filter: applied while the FIRST inverse pass loads -- here the y pass
+    M = (rng.random(F.complex_shape()) < 0.6).astype(np.uint8)
+    F.dealias = M
+    um = F.ifftn(C, np.zeros(F.real_shape(), dtype=rt), dealias="2/3-rule")
+    assert np.array_equal(C, c_in)
+    wm = np.fft.irfftn(want * M, s=N, axes=(0, 1, 2))
+    assert orc.rel_l2(um, wm) < 4 * TOL[prec], orc.rel_l2(um, wm)
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("prec", ["double", "single"])
 @pytest.mark.parametrize("decomp,P,pipeline", [("slab", 1, 0), ("slab", 2, 1), ("slab", 4, 2), ("slab", 4, -2), ("pencilX", 4, 1),
