@@ -195,7 +195,7 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.tile_list = a.band.on ? a.band.tile_list : nullptr;
   P.ntiles_listed = a.band.ntiles_listed;
   P.b_gzero = a.band.on ? a.band.g_zero : 0;
-  const int64_t grid = P.tile_list ? (int64_t)P.ntiles_listed : (int64_t)P.ntile_c * a.nouter;
+  const int64_t grid = P.tile_list ? (int64_t)P.ntiles_listed : (int64_t)P.ntile_c * a.nouter * (e->grid_mult > 1 ? e->grid_mult : 1);
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large (%lld tiles)", (long long)grid);
   e->launch(&P, (int)grid, s);
@@ -203,6 +203,9 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   return 0;
 }
 
+#ifndef MFFT_COL3S_DEFAULT
+#define MFFT_COL3S_DEFAULT 1
+#endif
 int launch_col(const ColArgs& a, hipStream_t s) {
   if (a.n == 1) {   // a length-1 transform is a (scaled) copy of its single row
     if (a.in == a.out && a.in_outer == a.out_outer && a.scale == 1.0) return 0;
@@ -256,6 +259,15 @@ int launch_col(const ColArgs& a, hipStream_t s) {
     if (nt_ok) e3 = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1, 16);              // same alignment rule, NT build
     if (!e3) e3 = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0, 16 + a.pad);
     if (e3) e = e3;
+  }
+  // The pad-on-load inverse with one third of a tile's transform per workgroup (fft_col3.h ColFft3S, pad code 33): out of
+  // place only (its passes are).  3/2-rule ifftn + fftn pair of 1024^3 (profiles/r04_col3s_ab.txt): double precision x pass
+  // 5.31 -> 5.16 ms, y pass 8.47 -> 9.17 (not taken); single precision x 2.99 -> 2.54, y 4.98 -> 4.35.  Default on; MFFT_COL3S=0 never.
+  static const int col3s_mode = getenv("MFFT_COL3S") ? atoi(getenv("MFFT_COL3S")) : MFFT_COL3S_DEFAULT;
+  // double precision: the passes without an outer batch only (y pass 8.4 -> 9.1 ms with it); MFFT_COL3S=2: every pass
+  if (col3s_mode > 0 && a.pad == 1 && a.inverse && a.in != a.out && !a.mask && !a.band.on &&
+      (col3s_mode > 1 || a.prec == MFFT_SINGLE || a.nouter == 1)) {
+    if (const KernelEntry* es = find_kernel(FAM_COL, a.n, a.prec, 1, 0, 33)) e = es;
   }
   if (!e && ent) e = ent;
   if (!e) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0);

@@ -1056,6 +1056,24 @@ static void test_col3() {
     }
     snprintf(name, sizeof name, "col3 c%d v%d pad-on-load inv%s", COLS, VEC, SPLIT ? " split" : "");
     report(name, N, pname<T>(), (double)sqrtl(num / den), 2 * tol_of<T>());
+    // the same with one third of a tile's transform per workgroup (ColFft3S): three times the workgroups, XCD-aware order
+    // and plain order, against the kernel above (same arithmetic up to the order of the radix-3 step's sums)
+    for (int remap = 0; remap < 2; ++remap) {
+      std::vector<cx<T>> big2((size_t)N * pitch, mk<T>((T)7, (T)7));
+      P.out = big2.data(); P.remap = remap;
+      typedef ColFft3S<SL, T, COLS, true, true, SPLIT, VEC, false, 1> K;
+      emu_launch(3 * P.ntile_c, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+      num = den = 0;
+      for (int r = 0; r < N; ++r)
+        for (int cc = 0; cc < pitch; ++cc) {
+          const cx<T> g = big2[(size_t)r * pitch + cc], w0 = big[(size_t)r * pitch + cc];
+          num += (long double)(g.x - w0.x) * (g.x - w0.x) + (long double)(g.y - w0.y) * (g.y - w0.y);
+          den += (long double)w0.x * w0.x + (long double)w0.y * w0.y;
+        }
+      snprintf(name, sizeof name, "col3s c%d v%d pad-on-load inv, a third per workgroup%s%s", COLS, VEC, remap ? " remap" : "", SPLIT ? " split" : "");
+      report(name, N, pname<T>(), (double)sqrtl(num / den), 2 * tol_of<T>());
+    }
+    P.out = big.data(); P.remap = 0;
     for (int fold = 0; fold < 2; ++fold) {
       std::vector<cx<T>> full((size_t)N * pitch);
       for (auto& z : full) z = mk<T>((T)U(rng), (T)U(rng));

@@ -47,9 +47,13 @@ struct ColFft3 {
   typedef typename Base::GPack GPack;
   typedef typename Base::Slot Slot;
 
-  // load VEC columns of one row (zeros beyond the array), swapped for inverse transforms
+  // load VEC columns of one row (zeros beyond the array), swapped for inverse transforms.  FULL: all VEC columns of this
+  // thread exist -- one unconditional 16-byte load.  The callers branch ONCE per thread on that, around their whole load
+  // phase: with the test inside (once per row) hipcc waits for every row's load inside its branch, i.e. the rows of a tile
+  // come in one after the other (single precision, VEC = 2: 12 of 24 loads serialised, found in round 4 in the ISA).
+  template <bool FULL>
   static MFFT_D void load_row(const cx<T>* src, int nact, cx<T> (&dst)[VEC]) {
-    if (nact >= VEC) {
+    if constexpr (FULL) {
       const GPack g = Base::load_pack(src);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) dst[i] = INV ? swapri(g.e[i]) : g.e[i];
@@ -62,6 +66,8 @@ struct ColFft3 {
       }
     }
   }
+  struct FullLanes { static constexpr bool value = true; };
+  struct RaggedLanes { static constexpr bool value = false; };
   static MFFT_D void store_row(cx<T>* dst, int nact, const cx<T> (&val)[VEC], T s) {
     if (nact >= VEC) {
       GPack g;
@@ -112,14 +118,18 @@ struct ColFft3 {
   template <int R>
   static MFFT_D void dit_third(const ColParams<T>& P, cx<T> (&w)[3][VEC][EL], int j, int c, int nact, const cx<T>* ip,
                                const cx<T>* ltw, char* xbuf) {
+    auto loads = [&](auto lanes) {
 #pragma unroll
-    for (int k = 0; k < EL; ++k) {
-      const unsigned row = 3u * (unsigned)(j + k * SL::TPT) + (unsigned)R;
-      cx<T> x[VEC];
-      load_row(ip + row_off(P.in_map, row), nact, x);
+      for (int k = 0; k < EL; ++k) {
+        const unsigned row = 3u * (unsigned)(j + k * SL::TPT) + (unsigned)R;
+        cx<T> x[VEC];
+        load_row<decltype(lanes)::value>(ip + row_off(P.in_map, row), nact, x);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) w[R][i][k] = x[i];
-    }
+        for (int i = 0; i < VEC; ++i) w[R][i][k] = x[i];
+      }
+    };
+    if (nact >= VEC) loads(FullLanes{});
+    else loads(RaggedLanes{});
     if constexpr (TWLDS) sub_transform(w[R], j, ltw, xbuf, c);
     else sub_transform(w[R], j, P.tw, xbuf, c);
   }
@@ -145,23 +155,28 @@ struct ColFft3 {
     if constexpr (PAD != 2) {
       // ---- DIF: rows p, p + L, p + 2L -> radix-3 butterfly -> twiddles -> three sub-transforms -> rows 3 q + r --------
       // all loads first, straight into the registers the butterflies work on (as ColFft does: no second copy of the tile)
+      auto loads = [&](auto lanes) {
+        constexpr bool FULL = decltype(lanes)::value;
 #pragma unroll
-      for (int k = 0; k < EL; ++k) {
-        const unsigned p = (unsigned)(j + k * SL::TPT);
-        cx<T> x[VEC];
-        load_row(ip + row_off(P.in_map, p), nact, x);
+        for (int k = 0; k < EL; ++k) {
+          const unsigned p = (unsigned)(j + k * SL::TPT);
+          cx<T> x[VEC];
+          load_row<FULL>(ip + row_off(P.in_map, p), nact, x);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) w[0][i][k] = x[i];
-        if constexpr (PAD != 1) {                   // PAD == 1: logical rows [L, 2L) are the zero band, never loaded
-          load_row(ip + row_off(P.in_map, p + (unsigned)L), nact, x);
+          for (int i = 0; i < VEC; ++i) w[0][i][k] = x[i];
+          if constexpr (PAD != 1) {                   // PAD == 1: logical rows [L, 2L) are the zero band, never loaded
+            load_row<FULL>(ip + row_off(P.in_map, p + (unsigned)L), nact, x);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) w[1][i][k] = x[i];
+            for (int i = 0; i < VEC; ++i) w[1][i][k] = x[i];
+          }
+          // (PAD == 1: logical row 2L + p is physical row L + p)
+          load_row<FULL>(ip + row_off(P.in_map, p + (PAD == 1 ? 1u : 2u) * (unsigned)L), nact, x);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) w[2][i][k] = x[i];
         }
-        // (PAD == 1: logical row 2L + p is physical row L + p)
-        load_row(ip + row_off(P.in_map, p + (PAD == 1 ? 1u : 2u) * (unsigned)L), nact, x);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) w[2][i][k] = x[i];
-      }
+      };
+      if (nact >= VEC) loads(FullLanes{});
+      else loads(RaggedLanes{});
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
         const unsigned p = (unsigned)(j + k * SL::TPT);
@@ -201,6 +216,83 @@ struct ColFft3 {
         store_row(op + row_off(P.out_map, p), nact, lo, P.scale);
         store_row(op + row_off(P.out_map, p + (unsigned)L), nact, hi, P.scale);
       }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ColFft3S: the pad-on-load inverse (PAD == 1) with its three sub-transforms in THREE WORKGROUPS (round 4).
+//
+// The zero band makes the radix-3 step of the DIF form a two-term sum, X[3 q + r] = FFT_L{ (x[p] + w3^(2r) x[2L + p]) W_N^(r p) }[q],
+// so third r needs nothing of the other two.  One workgroup per (tile, r): it reads the 2 L physical rows of its tile --
+// the three workgroups of a tile are neighbours in the XCD-aware order, so two of the three reads are L2 hits --, holds
+// E_L values per thread instead of 3 E_L (1536 in double precision: 4 instead of the 24 of the ColFft plan), exchanges L
+// rows through LDS, and runs at the occupancy of the length-L kernel (two 1024-thread workgroups per CU at L = 512)
+// where the ColFft plan of 1536 -- and ColFft3 with its 12 values per thread -- stay at one.  Output rows 3 q + r: every
+// workgroup writes its own rows, so the kernel is for OUT-OF-PLACE passes only (which the pad-on-load passes are: their
+// output has more rows than their input).  Launch: 3 x the tiles (KernelEntry::grid_mult).  Same twiddle table as ColFft3.
+template <class SL, typename T, int COLS, bool INV, bool TWLDS, int SPLIT = 0, int VEC = 1, bool NT = false, int PAD = 1>
+struct ColFft3S {
+  static_assert(PAD == 1 && INV, "one third per workgroup: the pad-on-load inverse");
+  typedef ColFft3<SL, T, COLS, INV, TWLDS, SPLIT, VEC, NT, PAD> Sib;      // its row load / store and its sub-transform
+  static constexpr int L = SL::N, N = 3 * SL::N, EL = SL::E;
+  static constexpr int CG = COLS / VEC;
+  static constexpr int THREADS = Sib::THREADS;
+  static constexpr int LDS_BYTES = Sib::LDS_BYTES;
+  static constexpr int TW_BYTES = Sib::TW_BYTES;
+  static constexpr int TW = Sib::TW;
+  static constexpr int GRID_MULT = 3;
+
+  static MFFT_D void body(const ColParams<T>& P, int bid_raw, int tid, char* lds) {
+    cx<T>* ltw = reinterpret_cast<cx<T>*>(lds);
+    const int nt3 = 3 * P.ntile_c * P.nouter;
+    const int v = P.remap ? xcd_remap(bid_raw, nt3) : bid_raw;      // consecutive v on one XCD: the three thirds of a tile
+    const int bid = v / 3;
+    const int r = v - 3 * bid;
+    const int outer = bid / P.ntile_c;
+    const int tc = bid - outer * P.ntile_c;
+    const int c = tid % CG;
+    const int j = tid / CG;
+    const int col = tc * COLS + c * VEC;
+    const int nact = P.ncols - col;
+    const cx<T>* ip = P.in + (i64)outer * P.in_outer + col;
+    cx<T>* op = P.out + (i64)outer * P.out_outer + col;
+    const cx<T>* twr = P.tw + SL::TW + (r == 2 ? L : 0);          // W_N^(r p), r = 1, 2
+    char* xbuf = lds + TW_BYTES;
+    if constexpr (TWLDS && SL::NP > 1) stage_twiddles<SL, T>(ltw, P.tw, tid, THREADS);      // (the first exchange's barrier publishes it)
+    // w3^(2r) with w3 = exp(-2 pi i / 3): 1, (-1/2, +sqrt(3)/2), (-1/2, -sqrt(3)/2)
+    const T h = (T)0.86602540378443864676372317075294L;
+    const cx<T> coef = r == 0 ? mk<T>((T)1, (T)0) : mk<T>((T)-0.5, r == 1 ? h : -h);
+
+    cx<T> w[VEC][EL];
+    auto loads = [&](auto lanes) {
+      constexpr bool FULL = decltype(lanes)::value;
+      cx<T> a[EL][VEC], b[EL][VEC];
+#pragma unroll
+      for (int k = 0; k < EL; ++k) {
+        const unsigned p = (unsigned)(j + k * SL::TPT);
+        Sib::template load_row<FULL>(ip + row_off(P.in_map, p), nact, a[k]);
+        Sib::template load_row<FULL>(ip + row_off(P.in_map, p + (unsigned)L), nact, b[k]);      // logical row 2L + p is physical row L + p
+      }
+#pragma unroll
+      for (int k = 0; k < EL; ++k) {
+        const unsigned p = (unsigned)(j + k * SL::TPT);
+        const cx<T> t = keep_bits(twr[p], r != 0) + mk<T>(r == 0 ? (T)1 : (T)0, (T)0);           // W_N^(r p); 1 for r = 0
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) w[i][k] = (a[k][i] + coef * b[k][i]) * t;
+      }
+    };
+    if (nact >= VEC) loads(typename Sib::FullLanes{});
+    else loads(typename Sib::RaggedLanes{});
+    if constexpr (TWLDS) Sib::sub_transform(w, j, (const cx<T>*)ltw, xbuf, c);
+    else Sib::sub_transform(w, j, P.tw, xbuf, c);
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      const unsigned row = 3u * (unsigned)(j + k * SL::TPT) + (unsigned)r;
+      cx<T> val[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) val[i] = w[i][k];
+      Sib::store_row(op + row_off(P.out_map, row), nact, val, P.scale);
     }
   }
 };

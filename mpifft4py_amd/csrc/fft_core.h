@@ -22,6 +22,7 @@
 //    (sum over passes of Ns*(R-1) entries, < N) that the kernels stage in LDS.
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define MFFT_HD __host__ __device__ __forceinline__
@@ -49,6 +50,28 @@ template <typename T> MFFT_HD cx<T> conj(cx<T> a) { return mk<T>(a.x, -a.y); }
 template <typename T> MFFT_HD cx<T> mul_mi(cx<T> a) { return mk<T>(a.y, -a.x); }   // a * (-i)
 template <typename T> MFFT_HD cx<T> mul_pi(cx<T> a) { return mk<T>(-a.y, a.x); }   // a * (+i)
 template <typename T> MFFT_HD cx<T> swapri(cx<T> a) { return mk<T>(a.y, a.x); }
+
+// `a` if keep, +0 otherwise -- as an AND on the bit pattern, not a select.  For values that come out of an UNCONDITIONAL load of
+// a clamped address ("this position does not exist: read position 0 instead and drop it"): hipcc turns `keep ? load : 0` into
+// a branch around the load and then waits for every such load on its own inside its branch -- the loads of a thread, meant
+// to be in flight together, become round trips to HBM one after the other (found in round 4 in the column-limited and the
+// z-chunked c2r kernels: 12 - 32 serialised loads per thread, single precision 1024^3 3/2-rule c2r 7.7 ms -> see DESIGN.md).
+// An AND cannot be turned into control flow, and unlike a multiplication by 0 it also drops a NaN / Inf at the clamped position.
+MFFT_HD float keep_bits(float a, bool keep) {
+  uint32_t u;
+  memcpy(&u, &a, sizeof u);
+  u &= keep ? 0xFFFFFFFFu : 0u;
+  memcpy(&a, &u, sizeof u);
+  return a;
+}
+MFFT_HD double keep_bits(double a, bool keep) {
+  uint64_t u;
+  memcpy(&u, &a, sizeof u);
+  u &= keep ? 0xFFFFFFFFFFFFFFFFull : 0ull;
+  memcpy(&a, &u, sizeof u);
+  return a;
+}
+template <typename T> MFFT_HD cx<T> keep_bits(cx<T> a, bool keep) { return mk<T>(keep_bits(a.x, keep), keep_bits(a.y, keep)); }
 
 // ---------------------------------------------------------------------------
 // compile-time constants: cos/sin(2*pi*k/32), k = 0..8 (first octant+), the

@@ -920,7 +920,8 @@ struct C2RFft {
         bool ok;
         const i64 o = zsplit_off(P.zs, crow, pos, &ok);
         const cx<T> x = static_cast<const cx<T>*>(P.in)[ok ? o : (i64)0];
-        return ok ? x : mk<T>((T)0, (T)0);
+        if constexpr (sizeof(T) == 4) return keep_bits(x, ok);      // not a select: hipcc made a branch of it and serialised the loads
+        else return ok ? x : mk<T>((T)0, (T)0);                     // (double precision: measured as it was, see LIMIT below)
       } else {
         return ip[pos];
       }
@@ -941,7 +942,17 @@ struct C2RFft {
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {
         const int pos = j + k * S::TPT;
-        if constexpr (LIMIT) {
+        if constexpr (LIMIT && sizeof(T) == 4) {
+          // columns >= valid read as zero.  Single precision: the load stays UNCONDITIONAL (position 0 instead, a cache hit,
+          // and keep_bits).  With a branch around it hipcc waits for every load on its own inside its branch -- twelve round
+          // trips to HBM one after the other: c2r of the 1024^3 3/2-rule pair 7.7 ms against 5.1 for r2c with the same
+          // bytes; 5.2 now (profiles/r04_serialised_loads.txt)
+          const bool ok = pos < P.valid;
+          v[k] = keep_bits(bin(ok ? pos : 0), ok);
+        } else if constexpr (LIMIT) {
+          // double precision: the branches compile to predicated loads that are all in flight together, and the loads of
+          // the missing columns are skipped: 9.2 ms; the unconditional form compiles for fewer registers and then waits for
+          // every (cached) twiddle load of the pre-pass on its own: 10.1 ms
           v[k] = mk<T>((T)0, (T)0);
           if (pos < P.valid) v[k] = bin(pos);
         } else {
@@ -985,9 +996,10 @@ struct C2RFft {
         cx<T> z;
         {
           cx<T> xk, xm;
-          if constexpr (LIMIT) {
-            xk = pos < P.valid ? bin(pos) : mk<T>((T)0, (T)0);
-            xm = (M - pos) < P.valid ? conj(bin(M - pos)) : mk<T>((T)0, (T)0);
+          if constexpr (LIMIT) {          // unconditional loads of clamped positions + selects (see the shuffle path)
+            const bool okk = pos < P.valid, okm = (M - pos) < P.valid;
+            xk = keep_bits(bin(okk ? pos : 0), okk);
+            xm = conj(keep_bits(bin(okm ? M - pos : 0), okm));
           } else {
             xk = bin(pos);
             xm = conj(bin(M - pos));

@@ -31,6 +31,7 @@ struct KernelEntry {
   int threads;
   int lds_bytes;
   int tw_count;     // entries of the inter-pass twiddle table
+  int grid_mult;    // COL: workgroups per tile (3 for ColFft3S, fft_col3.h: one third of a tile's transform each)
   void (*build_tw)(void* host_dst);
   void (*launch)(const void* params, int grid, hipStream_t s);
   const void* func;
@@ -175,6 +176,7 @@ KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
   e.threads = K::THREADS;
   e.lds_bytes = K::LDS_BYTES;
   e.tw_count = S::TW;
+  e.grid_mult = 1;
   e.build_tw = &tw_thunk<S, T>;
   e.launch = &launch_thunk<K, P, WGS>;
   if constexpr (WGS > 1) e.func = reinterpret_cast<const void*>(&mfft_kern_occ<K, P, WGS>);
@@ -249,6 +251,7 @@ KernelEntry make_entry3(int inv, int nt, int pad, int tile, const char* name) {
   e.threads = K::THREADS;
   e.lds_bytes = K::LDS_BYTES;
   e.tw_count = K::TW;
+  e.grid_mult = 1;
   e.build_tw = &tw3_thunk<SL, T>;
   e.launch = &launch_thunk<K, ColParams<T>, WGS>;
   if constexpr (WGS > 1) e.func = reinterpret_cast<const void*>(&mfft_kern_occ<K, ColParams<T>, WGS>);
@@ -271,6 +274,10 @@ void register_col3(const char* name) {
   reg.push_back(make_entry3<ColFft3<SL, T, C, true, true, SPL, VEC, true, 0>, SL, T, W>(1, 1, 16, C, name));
   reg.push_back(make_entry3<ColFft3<SL, T, C, true, true, SPL, VEC, false, 1>, SL, T, W>(1, 0, 17, C, name));
   reg.push_back(make_entry3<ColFft3<SL, T, C, false, true, SPL, VEC, false, 2>, SL, T, W>(0, 0, 18, C, name));
+  // pad code 33: the pad-on-load inverse with one third of a tile's transform per workgroup (ColFft3S), registers capped for
+  // two workgroups per CU (1024 threads at L = 512: 64 VGPRs, what the length-L ColFft kernel runs with)
+  reg.push_back(make_entry3<ColFft3S<SL, T, C, true, true, SPL, VEC, false, 1>, SL, T, 2>(1, 0, 33, C, name));
+  reg.back().grid_mult = 3;
 }
 
 // Register cap of the contiguous-axis kernels: the 30-values-per-thread plans in double precision come out at 256 VGPRs plus
