@@ -571,8 +571,12 @@ struct mfft_plan_s {
   // of in place on the result.  MFFT_FWD_OOP=1 / 0 forces it on / off; default: off (measured).
   // When on by default it would still need room: the buffer exists already (the inverse uses the same one), or a
   // quarter of the free HBM covers it.
-  bool fwd_out_of_place(size_t cbytes) {
+  static int fwd_oop_mode() {
     static const int mode = getenv("MFFT_FWD_OOP") ? atoi(getenv("MFFT_FWD_OOP")) : MFFT_FWD_OOP_DEFAULT;
+    return mode;
+  }
+  bool fwd_out_of_place(size_t cbytes) {
+    const int mode = fwd_oop_mode();
     if (mode <= 0) return false;
     if (work_bytes[0] >= cbytes) return true;
     size_t fr = 0, tot = 0;
@@ -813,6 +817,15 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
       MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return r2c_rows(u, A, N0 * N1, N2, N2, Nfp); }));
       MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(A, A, N1, false, N0, Nf, N1 * Nfp, plain(Nfp), N1 * Nfp, plain(Nfp)); }));
       MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, N1, Nf, Nfp, plain(N1 * Nfp), Nf, plain(N1 * Nf)); }));
+      return 0;
+    }
+    if (fwd_oop_mode() == 2 && fwd_out_of_place((size_t)Cb)) {
+      // z transform into the work buffer, y in place there, ONLY the x transform out of place, into the result
+      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nf) * es));
+      void* A = work[0];
+      MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, A, N0 * N1, N2, Nf); }));
+      MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(A, A, N1, false, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
+      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
       return 0;
     }
     MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Nf); }));
