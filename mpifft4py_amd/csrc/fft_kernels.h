@@ -793,7 +793,7 @@ struct R2CFft {
         op[pos] = val;
       }
     };
-    auto emit = [&](int pos, cx<T> zk, cx<T> zpartner) {
+    auto emit_w = [&](int pos, cx<T> zk, cx<T> zpartner, cx<T> w) {
       if (pos == 0) {
         put(0, mk<T>((zk.x + zk.y) * P.scale, (T)0));
         if (!LIMIT || M < P.valid) put(M, mk<T>((zk.x - zk.y) * P.scale, (T)0));
@@ -801,19 +801,33 @@ struct R2CFft {
         const cx<T> zm = conj(zpartner);
         const cx<T> e = scale(zk + zm, half);
         const cx<T> o = mul_mi(scale(zk - zm, half));
-        put(pos, scale(e + P.rtw[pos] * o, P.scale));
+        put(pos, scale(e + w * o, P.scale));
       }
     };
+    auto emit = [&](int pos, cx<T> zk, cx<T> zpartner) { emit_w(pos, zk, zpartner, P.rtw[pos]); };
     constexpr bool SHFL = WP || (S::TPT <= 64 && (64 % S::TPT) == 0);
     if constexpr (SHFL) {
       // Z[M-pos] of (lane j, register k) is register E-1-k of lane TPT-j of the same row: one
       // wave shuffle instead of an LDS round trip and two barriers (lane 0: its own register E-k)
       const int src = WP ? lane0 + (j == 0 ? 0 : S::TPT - j) : (tid & 63) - j + ((S::TPT - j) & (S::TPT - 1));
+      // The post-pass twiddles exp(-2 pi i pos / N), loaded BEFORE the loop where the plan is small (<= 128 bytes of them per
+      // thread).  Left inside `if (active)`, hipcc loads each one right before its use and waits for it with
+      // s_waitcnt vmcnt(0) -- which on gfx9 also waits for the previous step's STORE to be acknowledged: the eight steps
+      // of the single-precision kernel of 1024 ran one memory round trip after the other (read in the ISA, round 4)
+      constexpr bool RTW_EARLY = S::E * (int)sizeof(cx<T>) <= 128;
+      cx<T> rt[RTW_EARLY ? S::E : 1];
+      if constexpr (RTW_EARLY) {
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) rt[k] = P.rtw[j + k * S::TPT];
+      }
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {
         const cx<T> give = v[S::E - 1 - k];
         cx<T> pm = mk<T>(wave_shfl(give.x, src), wave_shfl(give.y, src));
         if (j == 0) pm = v[(S::E - k) % S::E];
+        if constexpr (RTW_EARLY) {
+          if (active) emit_w(j + k * S::TPT, v[k], pm, rt[k]);
+        } else
         if (active) emit(j + k * S::TPT, v[k], pm);
         // 30 values per thread: keep the scheduler from hoisting every shuffle above the first store (all mirrors live at
         // once = 120 more registers in double precision, one wave per SIMD)
