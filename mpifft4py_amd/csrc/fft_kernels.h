@@ -814,7 +814,7 @@ struct R2CFft {
       // thread).  Left inside `if (active)`, hipcc loads each one right before its use and waits for it with
       // s_waitcnt vmcnt(0) -- which on gfx9 also waits for the previous step's STORE to be acknowledged: the eight steps
       // of the single-precision kernel of 1024 ran one memory round trip after the other (read in the ISA, round 4)
-      constexpr bool RTW_EARLY = S::E * (int)sizeof(cx<T>) <= 128;
+      constexpr bool RTW_EARLY = S::E * (int)sizeof(cx<T>) <= 128;      // 192 measured: no gain at 768 / 1536, fewer waves
       cx<T> rt[RTW_EARLY ? S::E : 1];
       if constexpr (RTW_EARLY) {
 #pragma unroll
