@@ -337,8 +337,13 @@ class Tuner:
         # device (functional runs) they add seven more queues per process, stream memory operations are spinning
         # kernels, and the hardware scheduler's time slices are all that gets measured (seconds per pair,
         # profiles/r03_ipc_pull_modes.txt) -- and the streams, once created, slow every later candidate down.
+        # Round 4: the streams mode is not swept by default at all any more (MFFT_BENCH_PULL_STREAMS=1 adds it when every rank
+        # owns a device): in the closing suite of the round one 4-process run of it stalled beyond the transport's 180 s on
+        # a shared device, and a candidate that stalls costs the whole line (watchdog, exit code 3) for a mode that has
+        # never been the fastest anywhere it could be measured.
         own_device = int(_lib.device_count()) >= self.world
-        pulls = ((1, 2, 0) if own_device else (1, 0)) if self.c.get_option("ipc_pull") >= 0 else (None,)
+        streams = own_device and os.environ.get("MFFT_BENCH_PULL_STREAMS", "0") == "1"
+        pulls = ((1, 2, 0) if streams else (1, 0)) if self.c.get_option("ipc_pull") >= 0 else (None,)
         best = None
         for pull in pulls:
             tc = tuning.setdefault(cand_label(self.c, pull), {})

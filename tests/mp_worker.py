@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from mpifft4py_amd import DeviceArray, Pencil_R2C, Slab_C2C, Slab_R2C, from_env  # noqa: E402
+from mpifft4py_amd import DeviceArray, Pencil_R2C, Slab_C2C, Slab_R2C, from_env, _lib  # noqa: E402
 from oracle import mpifft_oracle as orc  # noqa: E402
 
 L = np.array([2 * np.pi] * 3)
@@ -44,11 +44,19 @@ def main():
     # other) x CU-masked streams or not must give the SAME bits; the other transports have one mode
     ipc = comm.get_option("ipc_pull") >= 0
     modes = [(m, cus) for m in (1, 2, 0) for cus in (-1, 16)] if ipc else [(None, 0)]
-    if ipc and P > 4:
+    shared = int(_lib.device_count()) < P          # several ranks on one device (this pool's one-GPU boxes)
+    if ipc and shared and P > 4:
         # 8 processes on ONE device: the per-peer streams (seven more queues per process) and extra masked streams
         # push the device's hardware scheduler into time-slicing so hard that runs take minutes and one in five did
         # not finish at all; those variants are covered at 2 and 4 processes, here the default and the copy mode
         modes = [(1, -1), (0, -1)]
+    elif ipc and shared and P > 2:
+        # 4 processes on ONE device: the per-peer streams mode (its waits are spinning kernels on three more queues per
+        # process) is at the mercy of the same time-slicing -- 2 s per iteration in the round-4 soak, one run of six
+        # stalled beyond the transport's 180 s (profiles/r04_ipc_soak.txt) -- a property of sharing a device, which
+        # bench.py's tuner does not try there either.  It stays covered at 2 processes here and, with a GPU per
+        # rank, at every size (test_gpu_zz_multidevice.py).
+        modes = [(m, cus) for m in (1, 0) for cus in (-1, 16)]
     first = {}
     for mode, cus in modes:
         stage("slab pull mode %s comm_cus %s" % (mode, cus))
