@@ -41,6 +41,18 @@ run() {
     r04_xpass_kernel_ab.txt) python scripts/xpass_kernel_ab.py ;;
     r04_xpass_stride_map.txt) (cd scripts && python xpass_stride_map.py 1024 && python xpass_stride_map.py 2048 && python xpass_pad_sweep.py) ;;
     r04_comm_priority.txt) bash scripts/r04_priority.sh ;;
+    r04_size_sweep.txt) bash scripts/size_sweep.sh ;;
+    r04_rank_shapes.txt) python scripts/rank_shapes.py ;;
+    r04_ypass_pitch.txt) python scripts/ypass_pitch_ab.py ;;
+    r04_col3_1536.txt) bash scripts/r04_col3.sh ;;
+    r04_aligned_route_ab.txt) bash scripts/aligned_ab.sh ;;
+    r04_p1_xpad_ab.txt) bash scripts/p1_xpad_ab.sh ;;
+    r04_fwd_oop_ab.txt) bash scripts/fwd_oop_ab.sh ;;
+    r04_small_mesh_overhead.txt) python scripts/small_mesh_overhead.py ;;
+    r04_ipc_soak.txt) bash scripts/r04_soak.sh ;;
+    r04_col3s_ab.txt) bash scripts/col3s_ab.sh ;;
+    r04_pad_pmc_traffic.txt) bash scripts/pad_pmc.sh ;;
+    r04_serialised_loads.txt) echo '(per translation unit: hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --offload-device-only mpifft4py_amd/csrc/kernels_X_Y.hip -o /tmp/X_Y.s; python scripts/isa_scan.py /tmp/*.s)'; bash scripts/col3s_f32.sh; bash scripts/r04_c2r_check.sh ;;
     r03_final_*) bash scripts/profile_r03.sh bench; python scripts/summarize_profiles.py r03_final gpurun_out/prof_r03/trace gpurun_out/prof_r03/fetch gpurun_out/prof_r03/write "bench.py --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off: 1024^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_final gpurun_out/prof_r03/sq1 gpurun_out/prof_r03/sq2 ;;
     r03_720_*) bash scripts/profile_cmd.sh b720 bench.py --size 720 --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off; python scripts/summarize_profiles.py r03_720 gpurun_out/prof_b720/trace gpurun_out/prof_b720/fetch gpurun_out/prof_b720/write "bench.py --size 720: 720^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_720 gpurun_out/prof_b720/sq1 gpurun_out/prof_b720/sq2 ;;
     r03_512_*) bash scripts/profile_cmd.sh b512 bench.py --size 512 --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off; python scripts/summarize_profiles.py r03_512 gpurun_out/prof_b512/trace gpurun_out/prof_b512/fetch gpurun_out/prof_b512/write "bench.py --size 512: 512^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r03_512 gpurun_out/prof_b512/sq1 gpurun_out/prof_b512/sq2 ;;
