@@ -101,6 +101,11 @@ def _spawn(nproc, script_args, timeout=600, transport="mock"):
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_process_per_rank_parity(world, transport):
     rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker.py")], transport=transport)
+    if rc != 0:         # the whole story where a failed run can be read afterwards (pytest shortens the message below)
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "mp_worker_failure_%d_%s.txt" % (world, transport)), "w") as f:
+            f.write("==== stdout\n" + out + "\n==== stderr\n" + err)
     assert rc == 0, (out[-2000:], err[-4000:])
     assert "MP_OK world=%d" % world in out
 
