@@ -271,11 +271,14 @@ def test_dft_bins_checker_against_numpy(prec):
             assert np.abs(tot - want).max() < 1e-12 * np.sqrt(np.prod(N)), (prec, inverse)
 
 
-@pytest.mark.parametrize("mode", ["1", "0"])
-def test_three_sub_transform_kernels_of_1536(mode):
+@pytest.mark.parametrize("mode,third", [("1", "0"), ("0", "0"), ("0", "2"), ("1", "1")])
+def test_three_sub_transform_kernels_of_1536(mode, third):
     """fft_col3.h ColFft3 (1536 = 3 x 512 per workgroup) forced on (MFFT_COL3=1) and off (=0), in a child process (the
     switch is read once): c2c of length 1536 on every axis, both precisions, in place and out of place (serialFFT), and the
-    3/2-rule pair of a [1024, 16, 32] mesh, whose padded x axis is 1536 (pad-on-load inverse, truncate-on-store forward)."""
+    3/2-rule pairs of a [1024, 16, 32] and a [16, 1024, 32] mesh, whose padded x / y axis is 1536 (pad-on-load inverse,
+    truncate-on-store forward).  `third`: MFFT_COL3S -- the pad-on-load inverse with one third of a tile's transform per
+    workgroup (ColFft3S) never (0: the ColFft / ColFft3 kernels it replaces by default stay covered), by default (1), on
+    every pass (2: also the y pass, an outer batch, in double precision)."""
     import os
     import subprocess
     import sys
@@ -293,21 +296,22 @@ for prec, ct, tol in (("double", np.complex128, 1e-10), ("single", np.complex64,
             ref = g(a.astype(np.complex128), axis=axis)
             got = f(a, axis=axis)
             assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, (prec, axis, shape)
-    N = [1024, 16, 32]
-    F = Slab_R2C(np.array(N), np.array([2 * np.pi] * 3), SelfComm(0), prec)
-    C = np.fft.rfftn(rng.random(N)).astype(ct)
-    C[N[0] // 2] = 0; C[:, N[1] // 2] = 0; C[:, :, -1] = 0
-    up = F.ifftn(C, np.zeros(F.real_shape_padded(), dtype=F.float), dealias="3/2-rule")
-    Cp = np.zeros((1536, 24, 25), dtype=np.complex128)
-    Cp[:512, :8, :17] = C[:512, :8]; Cp[:512, -8:, :17] = C[:512, 8:]
-    Cp[-512:, :8, :17] = C[512:, :8]; Cp[-512:, -8:, :17] = C[512:, 8:]
-    want = np.fft.irfftn(Cp, s=(1536, 24, 48), axes=(0, 1, 2)) * 1.5 ** 3
-    assert np.linalg.norm(up - want) / np.linalg.norm(want) < 4 * tol, prec
-    back = F.fftn(up, np.zeros(F.complex_shape(), dtype=ct), dealias="3/2-rule")
-    assert np.linalg.norm(back - C) / np.linalg.norm(C) < 4 * tol, prec
+    for N in ([1024, 16, 32], [16, 1024, 32]):
+        F = Slab_R2C(np.array(N), np.array([2 * np.pi] * 3), SelfComm(0), prec)
+        C = np.fft.rfftn(rng.random(N)).astype(ct)
+        C[N[0] // 2] = 0; C[:, N[1] // 2] = 0; C[:, :, -1] = 0
+        up = F.ifftn(C, np.zeros(F.real_shape_padded(), dtype=F.float), dealias="3/2-rule")
+        M0, M1, h0, h1 = 3 * N[0] // 2, 3 * N[1] // 2, N[0] // 2, N[1] // 2
+        Cp = np.zeros((M0, M1, 25), dtype=np.complex128)
+        Cp[:h0, :h1, :17] = C[:h0, :h1]; Cp[:h0, -h1:, :17] = C[:h0, h1:]
+        Cp[-h0:, :h1, :17] = C[h0:, :h1]; Cp[-h0:, -h1:, :17] = C[h0:, h1:]
+        want = np.fft.irfftn(Cp, s=(M0, M1, 48), axes=(0, 1, 2)) * 1.5 ** 3
+        assert np.linalg.norm(up - want) / np.linalg.norm(want) < 4 * tol, (prec, N)
+        back = F.fftn(up, np.zeros(F.complex_shape(), dtype=ct), dealias="3/2-rule")
+        assert np.linalg.norm(back - C) / np.linalg.norm(C) < 4 * tol, (prec, N)
 print("COL3_OK")
 """ % root
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MFFT_COL3=mode), stdout=subprocess.PIPE,
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MFFT_COL3=mode, MFFT_COL3S=third), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0 and b"COL3_OK" in p.stdout, p.stdout.decode()[-3000:]
 
