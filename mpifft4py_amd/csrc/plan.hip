@@ -19,8 +19,10 @@
 #include "relay_plan.h"
 
 #ifndef MFFT_FWD_OOP_DEFAULT
-#define MFFT_P1_XPAD_DEFAULT 0      // one-rank real transforms: cache lines added to slow plane pitches of the intermediate (p1_plane_pad; measured: no gain)
 #define MFFT_FWD_OOP_DEFAULT 0      // one-rank forward y / x passes out of place: see mfft_plan_s::fwd_out_of_place
+#endif
+#ifndef MFFT_P1_XPAD_DEFAULT
+#define MFFT_P1_XPAD_DEFAULT 0      // one-rank real transforms: cache lines added to slow plane pitches of the intermediate (p1_plane_pad; measured: no gain)
 #endif
 
 using namespace mfft;
