@@ -1,0 +1,42 @@
+"""The compiled kernels keep a thread's global loads in flight TOGETHER (round 4).
+
+hipcc turned `cond ? load : 0` and per-row `if (columns exist) load` into branches with `s_waitcnt vmcnt(0)` inside:
+every load a round trip to HBM of its own (single precision: the column-limited and z-chunked c2r kernels, ColFft3;
+profiles/r04_serialised_loads.txt).  The sources now avoid the pattern (fft_core.h keep_bits, one branch around a whole
+load phase); this test reads the ISA hipcc produces here and fails if it comes back in the kernels of the BASELINE
+configurations (group B, double precision: 512 / 1024) or in the kernels that had it (group E, single precision).
+No GPU needed: hipcc cross-compiles."""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _asm(unit, tmp):
+    out = os.path.join(tmp, unit + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I/opt/rocm/include", "-S", "--offload-device-only",
+           os.path.join(ROOT, "mpifft4py_amd", "csrc", unit + ".hip"), "-o", out]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_no_serialised_loads_in_the_baseline_and_the_repaired_kernels(tmp_path):
+    import isa_scan
+    with ThreadPoolExecutor(2) as ex:
+        b_d, e_s = ex.map(lambda u: _asm(u, str(tmp_path)), ["kernels_b_d", "kernels_e_s"])
+    # group B, double precision: every kernel family of 512 / 1024 except chirp-z, and except the z-chunked / column-limited
+    # c2r of complex length 1024 (real 2048), whose four cached pre-pass twiddle loads are waited for (not a BASELINE path)
+    bad = [r for r in isa_scan.scan(b_d) if not r[0].endswith("Z") and not (r[0] == "C2RFft" and r[1] == 1024 and r[4] <= 4)]
+    assert not bad, bad
+    # group E, single precision: the kernels that had it
+    bad = [r for r in isa_scan.scan(e_s) if r[0] in ("C2RFft", "ColFft3", "ColFft3S", "R2CFft", "RowFft", "ColFft")]
+    assert not bad, bad
