@@ -557,28 +557,12 @@ struct mfft_plan_s {
     for (int t = 0; t < s; ++t) o += (size_t)(P * Np0 * slice_pitch(t, forward));
     return o;
   }
-  // One-rank real transforms (experiment, MFFT_ALIGNED: 1 both directions, 2 inverse only, 3 forward only): the intermediate
-  // between the passes is ours, so its z rows can start on cache lines (Nf = N2/2 + 1 bins never fill whole lines).
-  // Returns the row pitch in bins, 0 = compact route.
-  int64_t aligned_route(bool forward) const {
-    static const int mode = getenv("MFFT_ALIGNED") ? atoi(getenv("MFFT_ALIGNED")) : 0;
-    if (mode <= 0 || !r2c || d.line2d || d.decomp != MFFT_SLAB) return 0;
-    if (mode == 2 && forward) return 0;
-    if (mode == 3 && !forward) return 0;
-    const int64_t per_line = (int64_t)(128 / es);
-    if (Nf % per_line == 0 || Nf < 2 * per_line) return 0;
-    return (Nf + per_line - 1) / per_line * per_line;
-  }
   // One-rank forward transform: y and x passes out of place through a work buffer of the size of the spectrum instead
   // of in place on the result.  MFFT_FWD_OOP=1 / 0 forces it on / off; default: off (measured).
   // When on by default it would still need room: the buffer exists already (the inverse uses the same one), or a
   // quarter of the free HBM covers it.
-  static int fwd_oop_mode() {
-    static const int mode = getenv("MFFT_FWD_OOP") ? atoi(getenv("MFFT_FWD_OOP")) : MFFT_FWD_OOP_DEFAULT;
-    return mode;
-  }
   bool fwd_out_of_place(size_t cbytes) {
-    const int mode = fwd_oop_mode();
+    static const int mode = getenv("MFFT_FWD_OOP") ? atoi(getenv("MFFT_FWD_OOP")) : MFFT_FWD_OOP_DEFAULT;
     if (mode <= 0) return false;
     if (work_bytes[0] >= cbytes) return true;
     size_t fr = 0, tot = 0;
@@ -811,25 +795,6 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
       MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Nf, 0, plain(pl), 0, plain(N1 * Nf)); }));
       return 0;
     }
-    if (const int64_t Nfp = aligned_route(true)) {
-      // line-aligned intermediate (aligned_route): r2c writes rows of Nfp bins, the y pass runs in place on whole private
-      // cache lines, the x pass reads them and writes the caller's compact rows
-      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nfp) * es));
-      void* A = work[0];
-      MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return r2c_rows(u, A, N0 * N1, N2, N2, Nfp); }));
-      MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(A, A, N1, false, N0, Nf, N1 * Nfp, plain(Nfp), N1 * Nfp, plain(Nfp)); }));
-      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, N1, Nf, Nfp, plain(N1 * Nfp), Nf, plain(N1 * Nf)); }));
-      return 0;
-    }
-    if (fwd_oop_mode() == 2 && fwd_out_of_place((size_t)Cb)) {
-      // z transform into the work buffer, y in place there, ONLY the x transform out of place, into the result
-      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nf) * es));
-      void* A = work[0];
-      MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, A, N0 * N1, N2, Nf); }));
-      MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(A, A, N1, false, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
-      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
-      return 0;
-    }
     MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Nf); }));
     if (fwd_out_of_place((size_t)Cb)) {
       // y transform into the work buffer (the one the inverse uses anyway), x transform out of it into the result: both
@@ -961,18 +926,13 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(X, u, N0 * N1, N2, Nf); }));
     return 0;
   }
-  const int64_t Nfp = P == 1 ? aligned_route(false) : 0;
-  MFFT_TRY(ensure_work(0, Nfp ? (size_t)(N0 * N1 * Nfp) * es : cb));
+  MFFT_TRY(ensure_work(0, cb));
   void* A = work[0];
   if (P == 1) {
-    if (Nfp) {
-      // line-aligned intermediate: the x pass reads the caller's compact rows and writes rows of Nfp bins, the y pass runs in
-      // place on whole private cache lines, c2r reads them
-      MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, N1, Nf, Nf, plain(N1 * Nf), Nfp, plain(N1 * Nfp)); }));
-      MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(A, A, N1, true, N0, Nf, N1 * Nfp, plain(Nfp), N1 * Nfp, plain(Nfp)); }));
-      MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return c2r_rows(A, u, N0 * N1, N2, Nfp, N2, 1.0 / (double)N2); }));
-      return 0;
-    }
+    // (Round 4 measured two more one-rank routes and removed them again -- a line-aligned intermediate (rows of N2/2 + 1 bins
+    // rounded up to whole cache lines: one per cent at 1024^3 for the inverse, a loss forward and at 512^3) and a forward
+    // transform whose x pass alone runs out of place (gains only at 2048^3 in single precision): profiles/r04_aligned_route_ab.txt,
+    // r04_fwd_oop_ab.txt; the last commit that has the switches MFFT_ALIGNED / MFFT_FWD_OOP=2 is a7fb791.)
     MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
     MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(A, A, N1, true, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
     MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A, u, N0 * N1, N2, Nf); }));

@@ -45,9 +45,9 @@ run() {
     r04_rank_shapes.txt) python scripts/rank_shapes.py ;;
     r04_ypass_pitch.txt) python scripts/ypass_pitch_ab.py ;;
     r04_col3_1536.txt) bash scripts/r04_col3.sh ;;
-    r04_aligned_route_ab.txt) bash scripts/aligned_ab.sh ;;
+    r04_aligned_route_ab.txt) echo '(the switch MFFT_ALIGNED exists up to commit a7fb791 only)'; bash scripts/aligned_ab.sh ;;
     r04_p1_xpad_ab.txt) bash scripts/p1_xpad_ab.sh ;;
-    r04_fwd_oop_ab.txt) bash scripts/fwd_oop_ab.sh ;;
+    r04_fwd_oop_ab.txt) echo '(MFFT_FWD_OOP=2 exists up to commit a7fb791 only)'; bash scripts/fwd_oop_ab.sh ;;
     r04_small_mesh_overhead.txt) python scripts/small_mesh_overhead.py ;;
     r04_ipc_soak.txt) bash scripts/r04_soak.sh ;;
     r04_col3s_ab.txt) bash scripts/col3s_ab.sh ;;
