@@ -404,7 +404,8 @@ def tune_in_children(comm, other, args, world, rank, timeout_s=300.0, task="slab
         os.unlink(path)
     path = comm.bcast(path, root=0)
     env = {k: v for k, v in os.environ.items() if k not in ("MFFT_TRANSPORT",)}
-    env.update(MFFT_RENDEZVOUS_FILE=path, MFFT_LOCAL_TIMEOUT="60")
+    # a child whose peer died waits this long for it (less if the caller's environment says so: the tests)
+    env.update(MFFT_RENDEZVOUS_FILE=path, MFFT_LOCAL_TIMEOUT=str(min(60, int(os.environ.get("MFFT_LOCAL_TIMEOUT", "60") or 60))))
     cmd = [sys.executable, os.path.abspath(__file__), "--tune-child", other, "--child-task", task, "--gpus", str(world),
            "--size", str(args.n), "--precision", args.precision]
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)

@@ -1,6 +1,7 @@
 """Shared machinery of the slab / pencil classes: plan handle, host<->device
 marshalling, dealias handling.  All arithmetic happens in libmpifft4py_amd.so."""
 import ctypes
+import threading
 import zlib
 from collections import defaultdict
 
@@ -45,6 +46,11 @@ class DistFFTBase(object):
         self.planner_effort = planner_effort    # accepted, unused (FFTW knob)
         self._mask_set = False
         self._mask_fp = None
+        self._mask_whole_fp = None
+        self._mask_calls = 0
+        self._mask_pending = False
+        self._mask_serial = 0
+        self._whole_job = None
         self.dealias = np.zeros(0)
         self.work_arrays = work_arrays()
         self._plan = None
@@ -53,21 +59,37 @@ class DistFFTBase(object):
             self._comm_cus = 0
 
     # The reference reads `self.dealias` on every '2/3-rule' call (slab.py:237-245, pencil.py:455-462), so a caller may
-    # replace the filter, or edit it in place, at any time.  Here the filter lives on the device.  Assigning to `dealias`
-    # marks the device copy stale.  In-place edits are found by a fingerprint taken at upload and compared on every
-    # '2/3-rule' call (`dealias_check`, on by default).  It has to stay far below the transform it guards -- 50 us at 128^3,
-    # 0.2 ms at 256^3 -- so it hashes the whole array only up to 256 KiB (a 64^3 filter: ~10 us) and above that 8192
-    # elements at fixed pseudo-random positions (~40 us at 128^3, ~0.15 ms for the 540 MB filter of 1024^3; the first
-    # version hashed 4 MB / 65 536 samples: 0.4 - 1 ms per call, several times the transform between 128^3 and 256^3).
-    # An edit of a fraction f of a large mask goes unnoticed with probability (1 - f)^8192: planes, bands and blocks
-    # are always seen (one plane of 1024: 3e-4), a single changed element is not -- re-assign then.
-    # The upload is COLLECTIVE for plans over more than one rank (mfft_plan_set_dealias_mask), so the ranks vote on
-    # "somebody's filter changed" with one small host all-reduce per '2/3-rule' call; `F.dealias_check = False` (on
-    # every rank) switches fingerprint and vote off, and only assignment re-uploads.
+    # replace the filter, or edit it in place, at any time.  Here the filter lives on the device; what keeps the two equal:
+    #   * ASSIGNING to `dealias` marks the device copy stale: the next '2/3-rule' call uploads.
+    #   * IN-PLACE edits are found by fingerprints of the host array, taken at upload and compared later
+    #     (`dealias_check`):
+    #       True / "sampled" (default)  every '2/3-rule' call compares a CHEAP fingerprint -- the whole array up to 256 KiB
+    #                 (a 64^3 filter: ~10 us), above that 8192 elements at fixed pseudo-random positions (~40 us at 128^3,
+    #                 ~50 us for the 540 MB filter of 1024^3; it must stay far below the transform it guards) -- which sees
+    #                 planes, bands and blocks at once (an edit of a fraction f goes unnoticed with probability
+    #                 (1 - f)^8192: one plane of 1024: 3e-4) but NOT a single changed element of a large mask.  That blind
+    #                 spot is closed by a hash of the WHOLE array every `dealias_full_every`-th call (64), computed by a
+    #                 background thread (the hash functions release the GIL) and compared when it is ready, at the latest
+    #                 at the next such call: ANY edit counts after at most 2 x dealias_full_every (+ dealias_vote_every
+    #                 over several ranks) further calls; `F.dealias = F.dealias` makes it count at once.
+    #       "full"    every call hashes the whole array (3 - 15 GB/s: 0.3 - 1 ms per 4 MB): every edit counts at the next
+    #                 call, as in the reference.
+    #       False     no fingerprints, no vote: only assignment uploads (on every rank).
+    #     Nothing is copied to take a fingerprint unless the array is not C-contiguous (a broadcast view, a slice), and
+    #     then only for the whole-array hashes.
+    #   * The upload is COLLECTIVE for plans over more than one rank (mfft_plan_set_dealias_mask: the ranks agree on the
+    #     pruned route), and an edit may touch one rank's block only, so the ranks VOTE on "somebody's filter changed" with
+    #     one small host all-reduce.  Where that stays on the host (the IPC and in-process transports: two shared-memory
+    #     barriers, ~5 us, no device stream involved) they vote on every '2/3-rule' call; over RCCL the all-reduce is a
+    #     copy + ncclAllReduce + stream synchronisation that ends the host's asynchronous run-ahead, so there the vote is
+    #     taken every 16th call only (`dealias_vote_every`; a locally found edit waits for it) and ASSIGNMENT must happen
+    #     on every rank at the same point of the program (as SPMD codes do).
     dealias_check = True
+    dealias_full_every = 64
+    dealias_vote_every = None             # None: 1 where host collectives stay on the host, 16 over RCCL
     _FULL_HASH_BYTES = 256 << 10
     _SAMPLES = 1 << 13
-    _sample_index = {}
+    _sample_index = {}                    # element count -> sorted flat positions; shape -> the same as an index tuple
 
     @property
     def dealias(self):
@@ -78,16 +100,59 @@ class DistFFTBase(object):
         self._dealias = value
         self._mask_set = False
 
-    def _mask_fingerprint(self):
+    @classmethod
+    def _samples(cls, a):
+        idx = cls._sample_index.get(a.size)
+        if idx is None:
+            idx = np.sort(np.random.default_rng(0x6d666674).integers(0, a.size, cls._SAMPLES))
+            cls._sample_index[a.size] = idx
+        if a.flags.c_contiguous:
+            return a.reshape(-1)[idx]                      # a view, then a gather of 8192 elements
+        key = ("nd",) + a.shape
+        tup = cls._sample_index.get(key)
+        if tup is None:
+            tup = np.unravel_index(idx, a.shape)
+            cls._sample_index[key] = tup
+        return a[tup]                                      # any strides (broadcast views too), nothing else is touched
+
+    @staticmethod
+    def _whole_hash(a):
+        """Hash of every element (no copy for C-contiguous arrays)."""
+        a = np.asarray(a)
+        if not a.flags.c_contiguous:
+            a = np.ascontiguousarray(a)
+        return _hash_bytes(a.reshape(-1).view(np.uint8))
+
+    def _mask_fingerprint(self, whole=False):
         a = np.asarray(self._dealias)
-        flat = a.reshape(-1)
-        if flat.nbytes > self._FULL_HASH_BYTES:
-            idx = DistFFTBase._sample_index.get(flat.size)
-            if idx is None:
-                idx = np.sort(np.random.default_rng(0x6d666674).integers(0, flat.size, self._SAMPLES))
-                DistFFTBase._sample_index = {flat.size: idx}
-            flat = flat[idx]
-        return (a.shape, a.dtype.str, _hash_bytes(np.ascontiguousarray(flat).view(np.uint8)))
+        if whole or a.nbytes <= self._FULL_HASH_BYTES:
+            return (a.shape, a.dtype.str, "whole", self._whole_hash(a))
+        return (a.shape, a.dtype.str, "sampled", _hash_bytes(np.ascontiguousarray(self._samples(a)).view(np.uint8)))
+
+    def _large_mask(self):
+        return np.asarray(self._dealias).nbytes > self._FULL_HASH_BYTES
+
+    def _whole_hash_start(self):
+        """Hash the whole filter in a background thread; `_whole_hash_poll` compares it with the upload's."""
+        a = np.asarray(self._dealias)
+        job = {"done": threading.Event(), "value": None, "serial": self._mask_serial}
+
+        def work():
+            try:
+                job["value"] = (a.shape, a.dtype.str, "whole", self._whole_hash(a))
+            finally:
+                job["done"].set()
+        threading.Thread(target=work, daemon=True).start()
+        self._whole_job = job
+
+    def _whole_hash_poll(self, wait):
+        """True when a finished background hash differs from the one taken at upload."""
+        job = self._whole_job
+        if job is None or not (wait or job["done"].is_set()):
+            return False
+        job["done"].wait()
+        self._whole_job = None
+        return job["serial"] == self._mask_serial and job["value"] != self._mask_whole_fp
 
     def _describe(self, kind, decomp, mesh=None, p1=0, pipeline=0, drop_nyquist=False, line2d=False):
         """Fill the plan descriptor and ask the library -- on the host, no device involved (mfft_layout_query) -- for
@@ -169,19 +234,42 @@ class DistFFTBase(object):
     def _ensure_mask(self):
         if np.shape(self.dealias) == (0,):
             self.dealias = self.get_dealias_filter()
-        stale = not self._mask_set
+        mode = self.dealias_check
+        self._mask_calls += 1
+        changed = False
         fp = None
-        if self.dealias_check:
-            fp = self._mask_fingerprint()
-            stale = stale or fp != self._mask_fp
-            if self.num_processes > 1:
-                stale = self.comm.allreduce(1.0 if stale else 0.0, MAX) > 0
+        if mode:
+            whole = mode == "full"
+            fp = self._mask_fingerprint(whole)
+            changed = self._mask_set and fp != self._mask_fp
+            if not whole and self._mask_set and self._large_mask() and self.dealias_full_every:
+                due = self._mask_calls % int(self.dealias_full_every) == 0
+                changed = self._whole_hash_poll(wait=due) or changed
+                if due and not changed:
+                    self._whole_hash_start()
+        stale = not self._mask_set
+        if mode and self.num_processes > 1:
+            every = self.dealias_vote_every or (1 if self.comm.get_option("host_collectives") == 1 else 16)
+            self._mask_pending = self._mask_pending or changed
+            if every <= 1:
+                stale = self.comm.allreduce(1.0 if (stale or self._mask_pending) else 0.0, MAX) > 0
+            elif self._mask_calls % every == 0:         # assignment (stale) is SPMD here: no vote needed for it
+                stale = self.comm.allreduce(1.0 if self._mask_pending else 0.0, MAX) > 0 or stale
+        else:
+            stale = stale or changed
         if not stale:
             return
         m = np.ascontiguousarray(np.broadcast_to(self.dealias, self.complex_shape()), dtype=np.uint8)
         _lib.call("mfft_plan_set_dealias_mask", self._plan, m.ctypes.data, m.size)
         self._mask_set = True
-        self._mask_fp = fp
+        self._mask_pending = False
+        self._mask_serial += 1
+        self._whole_job = None
+        if mode:
+            self._mask_fp = fp
+            self._mask_whole_fp = self._mask_fingerprint(True) if (mode != "full" and self._large_mask()) else None
+        else:
+            self._mask_fp = self._mask_whole_fp = None
 
     def _run(self, forward, src, dst, dealias, src_shape, src_dtype, dst_shape, dst_dtype):
         assert dealias in ('3/2-rule', '2/3-rule', 'None', None)

@@ -15,7 +15,9 @@
 int mfft_comm_s::work_alloc(void** p, size_t bytes) { return mfft::dev_alloc(p, bytes); }
 int mfft_comm_s::work_free(void* p) { return mfft::dev_free(p); }
 int mfft_comm_s::set_option(const char* key, long long) { return mfft::set_error(MFFT_ERR_INVALID, "this transport has no option '%s'", key); }
-long long mfft_comm_s::get_option(const char*) { return -1; }
+// "host_collectives": 1 when barrier / bcast_host / allreduce_host stay on the host (shared memory, condition variables) and
+// never touch a device stream -- every transport but RCCL, whose host collectives are a copy + ncclAllReduce + stream sync
+long long mfft_comm_s::get_option(const char* key) { return key && !strcmp(key, "host_collectives") ? 1 : -1; }
 
 int mfft_comm_s::selftest(size_t bytes_per_peer, int timeout_ms) {
   using namespace mfft;
@@ -179,6 +181,7 @@ struct RcclComm : mfft_comm_s {
     }
     return 0;
   }
+  long long get_option(const char* key) override { return key && !strcmp(key, "host_collectives") ? 0 : mfft_comm_s::get_option(key); }
   int barrier() override {
     double v = 0;
     return allreduce_host(&v, 1, 0);

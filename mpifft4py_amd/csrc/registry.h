@@ -290,8 +290,14 @@ void register_col3(const char* name) {
 #ifndef MFFT_ROW_OCC
 #define MFFT_ROW_OCC 1
 #endif
+// Round 5: the 28-values-per-thread plans (7 * 2^a) as well.  Their c2r kernels sat at 242 - 248 VGPRs when radix 7 was
+// measured (896^3 bwd_z 2.05 ms, profiles/r04_radix7_sweep.txt) and came out at 262 - 287 (256 + AGPRs = ONE wave per
+// SIMD) after an unrelated edit of C2RFft two commits later: 4.2 ms in every sweep since, found by the bisect of
+// profiles/r05_radix7_c2r_bisect.txt.  Capped, 448 / 896 / 1792 spill 20 - 100 bytes of scratch per lane; the short
+// lengths (56 ... 224 with LDS twiddles) would spill 370: not capped.
 template <class S, typename T> constexpr int row_occ_wgs(int threads) {
-  return (MFFT_ROW_OCC && sizeof(T) == 8 && S::E % 15 == 0 && S::N >= 120 && threads <= 256) ? 512 / threads : 0;   // shorter: 500+ bytes of scratch
+  return (MFFT_ROW_OCC && sizeof(T) == 8 && ((S::E % 15 == 0 && S::N >= 120) || (S::E % 7 == 0 && S::N >= 448)) && threads <= 256)
+             ? 512 / threads : 0;   // shorter: 500+ bytes of scratch
 }
 
 // Round 4: real kernels whose threads per transform do not divide a wave (10, 12, 15, 20, 24, 30 ... threads) can run

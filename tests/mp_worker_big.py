@@ -20,7 +20,7 @@ def rel(x, r):
 def main():
     import faulthandler
     import scipy.fft as sfft
-    faulthandler.dump_traceback_later(int(os.environ.get("MP_WORKER_DUMP_AFTER", "840")), exit=True)
+    faulthandler.dump_traceback_later(int(os.environ.get("MP_WORKER_DUMP_AFTER", "200")), exit=True)
     comm = from_env()
     rank, P = comm.Get_rank(), comm.Get_size()
     n = int(os.environ.get("MP_N", "512"))

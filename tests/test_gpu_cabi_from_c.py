@@ -33,6 +33,6 @@ def test_c_program_roundtrip(tmp_path, mesh):
     if not have_gpu():
         pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
     exe = _build(tmp_path)
-    p = subprocess.run([exe] + [str(m) for m in mesh], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    p = subprocess.run([exe] + [str(m) for m in mesh], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
     out = p.stdout.decode()
     assert p.returncode == 0 and "C_ABI_ROUNDTRIP_OK" in out, out

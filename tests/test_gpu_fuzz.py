@@ -17,7 +17,7 @@ def test_random_configurations_match_the_oracle(seed):
     if not have_gpu():
         pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "60", str(seed)],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
     out = p.stdout.decode()
     assert p.returncode == 0 and "60 cases, 0 failures" in out, out[-3000:]
 
@@ -36,7 +36,7 @@ def test_config5_full_size_pencil_c2c(record_property):
     free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
     hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "config5_full.py"), "auto", "8"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
     out = p.stdout.decode()
     print(out)                                     # shown with -rA / on failure: which size ran, free / total HBM
     m = re.search(r"CONFIG5_SIZE n=(\d+) free_hbm_gb=([0-9.]+) total_hbm_gb=([0-9.]+)", out)
@@ -65,6 +65,6 @@ def test_random_serialfft_calls_match_numpy():
     if not have_gpu():
         pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_stages.py"), "200", "5"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
     out = p.stdout.decode()
     assert p.returncode == 0 and "200 cases, 0 failures" in out, out[-3000:]

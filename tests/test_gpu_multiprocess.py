@@ -46,6 +46,9 @@ def _env(transport="mock"):
     env = {k: v for k, v in os.environ.items() if k not in ("MFFT_TRANSPORT", "MFFT_RCCL_LIB")}
     env["OMP_NUM_THREADS"] = "1"
     env.setdefault("MP_WORKER_VERBOSE", "1")
+    # a rank that waits for a peer gives up after 30 s (the transports' default is 180 s) and every subprocess below is
+    # cut off after at most 240 s: a stall is a named failure well inside the driver's step limit
+    env.setdefault("MFFT_LOCAL_TIMEOUT", "30")
     if transport == "ipc":
         env["MFFT_TRANSPORT"] = "ipc"
     elif transport == "rccl":            # the real librccl: needs a device per rank (tests/test_gpu_zz_multidevice.py)
@@ -58,7 +61,7 @@ def _env(transport="mock"):
 TRANSPORTS = ["ipc", "mock"]
 
 
-def _torchrun(nproc, script_args, timeout=900, transport="mock"):
+def _torchrun(nproc, script_args, timeout=240, transport="mock"):
     """The driver's launch line (python -m torch.distributed.run ...)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
@@ -66,7 +69,7 @@ def _torchrun(nproc, script_args, timeout=900, transport="mock"):
     return p.returncode, p.stdout.decode(), p.stderr.decode()
 
 
-def _spawn(nproc, script_args, timeout=600, transport="mock"):
+def _spawn(nproc, script_args, timeout=240, transport="mock"):
     """Same environment contract (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) without the launcher's
     own start-up cost: one python process per rank started directly."""
     port = _free_port()
@@ -120,7 +123,7 @@ def test_process_per_rank_full_size(world, n, transport):
     old = {k: os.environ.get(k) for k in env_extra}
     os.environ.update(env_extra)
     try:
-        rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker_big.py")], transport=transport, timeout=870)
+        rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker_big.py")], transport=transport, timeout=240)
     finally:
         for k, v in old.items():
             if v is None:
@@ -131,8 +134,11 @@ def test_process_per_rank_full_size(world, n, transport):
     assert "BIG_OK world=%d n=%d" % (world, n) in out
 
 
-@pytest.mark.parametrize("transport", TRANSPORTS)
-@pytest.mark.parametrize("world,launcher", [(2, "torchrun"), (4, "spawn"), (8, "spawn")])
+# 8 processes x two transports (the second one in child processes) x every candidate x every pencil grid on ONE device
+# takes 90 s: `slow`; the 8-rank line over the IPC transport alone (30 s) and both transports at 2 and 4 ranks stay.
+@pytest.mark.parametrize("world,launcher,transport", [
+    (2, "torchrun", "ipc"), (2, "torchrun", "mock"), (4, "spawn", "ipc"), (4, "spawn", "mock"), (8, "spawn", "ipc"),
+    pytest.param(8, "spawn", "mock", marks=pytest.mark.slow)])
 def test_bench_multi_rank_prints_one_json_line(world, launcher, transport):
     run = _torchrun if launcher == "torchrun" else _spawn
     # "mock": --transport auto, i.e. the (mocked) RCCL path first and the IPC transport as the second candidate, the
@@ -181,7 +187,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher(world, transport):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "128", "--steps", "3",
                         "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off", "--transport",
                         "ipc" if transport == "ipc" else "auto"], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+                       stderr=subprocess.PIPE, timeout=240, cwd=ROOT)
     out, err = p.stdout.decode(), p.stderr.decode()
     assert p.returncode == 0, (out[-2000:], err[-4000:])
     lines = [l for l in out.splitlines() if l.strip()]
@@ -198,7 +204,7 @@ def test_bench_falls_back_when_rccl_refuses():
                                                              "MFFT_TRANSPORT", "MFFT_RCCL_LIB")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "128", "--steps", "3",
                         "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off"], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+                       stderr=subprocess.PIPE, timeout=240, cwd=ROOT)
     out, err = p.stdout.decode(), p.stderr.decode()
     assert p.returncode == 0, (out[-2000:], err[-4000:])
     lines = [l for l in out.splitlines() if l.strip()]
@@ -217,7 +223,7 @@ def test_bench_measures_relay_striping_in_children():
     env["MFFT_BENCH_RELAY"] = "force"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--size", "128", "--steps", "2",
                         "--warmup", "1", "--cpu-baseline", "off", "--transport", "ipc", "--pipeline", "1"], env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=ROOT)
     out, err = p.stdout.decode(), p.stderr.decode()
     assert p.returncode == 0, (out[-2000:], err[-4000:])
     d = json.loads([l for l in out.splitlines() if l.strip()][0])
@@ -233,9 +239,10 @@ def test_bench_survives_a_second_transport_that_faults():
     the failure recorded in the tuning table."""
     env = {k: v for k, v in _env("mock").items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["MFFT_BENCH_CHILD_FAULT"] = "1"               # rank 1's child aborts right after the communicator is built
+    env["MFFT_LOCAL_TIMEOUT"] = "10"                  # ... and rank 0's child gives up waiting for it after this long
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--steps", "2",
                         "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off"], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+                       stderr=subprocess.PIPE, timeout=240, cwd=ROOT)
     out, err = p.stdout.decode(), p.stderr.decode()
     assert p.returncode == 0, (out[-2000:], err[-4000:])
     lines = [l for l in out.splitlines() if l.strip()]
@@ -257,7 +264,7 @@ def test_bench_ranks_stay_together_when_rank0_cannot_make_an_id():
     t0 = time.time()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--steps", "2",
                         "--warmup", "1", "--cpu-baseline", "off", "--pencil-extra", "off", "--pipeline", "1"], env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=ROOT)
     out, err = p.stdout.decode(), p.stderr.decode()
     assert p.returncode == 0, (out[-2000:], err[-4000:])
     assert time.time() - t0 < 150, "the ranks waited for each other's time-outs"

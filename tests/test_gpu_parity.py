@@ -306,9 +306,21 @@ def test_two_thirds_rule_mask_on_load(decomp, P, pipeline, prec, fused, monkeypa
         assert orc.rel_l2(u, want[rsl]) < 4 * TOL[prec], orc.rel_l2(u, want[rsl])
 
 
-@pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("P,pipeline", [(1, 1), (2, 1), (4, 1), (2, 0), (4, 2), (4, 3), (2, -2), (4, -3), (8, 1), (8, 0), (8, -2)])
-@pytest.mark.parametrize("N", [[32, 32, 32], [48, 20, 36], [64, 128, 256], [16, 24, 10], [100, 36, 50], [8, 8, 8], [12, 6, 4], [32, 16, 512]])
+def _pruned_cases():
+    """Every (mesh, ranks, pipeline, precision) of the round-3 matrix: two meshes keep all of it (the one whose ranks 3 and 4
+    own nothing but removed ky, and the large one), the others keep one case per rank count; the rest (96 of 176) is
+    `slow` (tests/conftest.py: MFFT_TEST_SLOW=1)."""
+    out = []
+    for N in ([32, 32, 32], [48, 20, 36], [64, 128, 256], [16, 24, 10], [100, 36, 50], [8, 8, 8], [12, 6, 4], [32, 16, 512]):
+        for P, pipeline in [(1, 1), (2, 1), (4, 1), (2, 0), (4, 2), (4, 3), (2, -2), (4, -3), (8, 1), (8, 0), (8, -2)]:
+            for prec in ("double", "single"):
+                full = N in ([32, 32, 32], [64, 128, 256]) or (P, pipeline) in [(1, 1), (2, 1), (8, 1)]
+                out.append(pytest.param(N, P, pipeline, prec, marks=() if full else pytest.mark.slow,
+                                        id="%s-%d-%d-%s" % ("x".join(map(str, N)), P, pipeline, prec)))
+    return out
+
+
+@pytest.mark.parametrize("N,P,pipeline,prec", _pruned_cases())
 def test_two_thirds_rule_pruned(N, P, pipeline, prec, monkeypatch):
     """Real data, the reference's own dealias filter (three 1-D band conditions).  One GPU: the inverse does not load
     the removed rows, skips the tiles of removed columns and reads only the kept bins of every z row; P ranks: the x pass
@@ -463,6 +475,58 @@ def test_two_thirds_rule_large_filter_sampled_fingerprint():
     want = np.fft.irfftn(C.astype(np.complex128) * M, s=N, axes=(0, 1, 2))
     assert orc.rel_l2(u1, want) < 4 * TOL["single"]
     assert orc.rel_l2(u0, want) > 1e-3
+
+
+@pytest.mark.parametrize("P", [1, 2])
+@pytest.mark.parametrize("mode", ["sampled", "full"])
+def test_two_thirds_rule_one_element_of_a_large_filter(mode, P):
+    """ONE element of a 4 MB filter flipped in place (slab.py:237-245 reads the array on every call): the 8192-sample
+    fingerprint cannot see it, the whole-array hash of every `dealias_full_every`-th call does -- the new result arrives
+    within 2 x dealias_full_every (+ the vote period) further calls, with `dealias_check = "full"` at the next call, and
+    on every rank although one rank's block was edited."""
+    from mpifft4py_amd import DeviceArray, Slab_R2C
+    from mpifft4py_amd._base import DistFFTBase
+    N = [128 * P, 128, 512]
+    C = np.fft.rfftn(np.random.default_rng(77).random(N)).astype(np.complex64)
+    every = 8
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, "single")
+        F.dealias_check = mode
+        F.dealias_full_every = every
+        sl = F.complex_local_slice()
+        c = DeviceArray.from_numpy(np.ascontiguousarray(C[sl]))
+        u = DeviceArray.empty(F.real_shape(), F.float)
+        F.ifftn(c, u, dealias="2/3-rule")
+        F.dealias = np.ascontiguousarray(np.broadcast_to(F.dealias, F.complex_shape())).astype(np.uint8)
+        assert F.dealias.nbytes > 4 << 20 and F.dealias.nbytes > F._FULL_HASH_BYTES
+        F.ifftn(c, u, dealias="2/3-rule")
+        u0 = u.get().copy()
+        m = F.dealias
+        taken = set(DistFFTBase._samples(np.arange(m.size)).tolist())
+        flat = m.reshape(-1)
+        pos = next(i for i in range(5 * 257 + 3, m.size) if i not in taken and flat[i])   # a kept mode no sample looks at
+        if comm.Get_rank() == P - 1:
+            flat[pos] = 0
+        calls = 0
+        bound = 1 if mode == "full" else 2 * every + 1
+        M = np.broadcast_to(F.dealias, F.complex_shape()).copy()
+        while calls < bound:
+            F.ifftn(c, u, dealias="2/3-rule")
+            calls += 1
+            if not np.array_equal(u.get(), u0):
+                break
+        return u.get().copy(), u0, M, sl, F.real_local_slice(), calls
+    res = run_ranks(P, body)
+    M = np.zeros(C.shape, dtype=np.uint8)
+    for _, _, m, sl, _, _ in res:
+        M[sl] = m
+    assert M.size - int(M.sum()) > 0
+    want = np.fft.irfftn(C.astype(np.complex128) * M, s=N, axes=(0, 1, 2))
+    for u1, u0, _, _, rsl, calls in res:
+        assert orc.rel_l2(u1, want[rsl]) < 4 * TOL["single"], (mode, calls)
+        assert not np.array_equal(u1, u0), (mode, calls)
+        assert calls <= (1 if mode == "full" else 2 * every + 1)
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
@@ -1464,9 +1528,15 @@ def test_other_pad_factors(kind, N, P, ps):
         assert e1 < 1e-10 and e2 < 1e-10
 
 
-@pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("depth", [2, 3, 4, 16])
-@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2), (16, None)])
+def _pipeline_cases(grids):
+    """grids x depths x precisions; sixteen virtual ranks on one device take a second per case: depths 3 and 16 of the
+    16-rank grid are `slow` (they run at 4 and 8 ranks), depths 2 and 4 stay."""
+    return [pytest.param(P, P1, depth, prec, marks=pytest.mark.slow if (P == 16 and depth in (3, 16)) else (),
+                         id="%d-%s-%d-%s" % (P, P1, depth, prec))
+            for (P, P1) in grids for depth in (2, 3, 4, 16) for prec in ("double", "single")]
+
+
+@pytest.mark.parametrize("P,P1,depth,prec", _pipeline_cases([(4, None), (8, None), (8, 2), (16, None)]))
 def test_pencil_y_exchange_pipeline(P, P1, depth, prec):
     """Exchange pipeline of the y-aligned pencil (the reference class's default alignment; pencil.py:730-754, 483-507):
     z stage and z-splitting exchange in batches of local x rows, then the x transform, then the x-chunk exchange and the
@@ -1504,9 +1574,7 @@ def test_pencil_y_exchange_pipeline(P, P1, depth, prec):
         assert orc.rel_l2(piped[4], piped[7]) < 4 * TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("depth", [2, 3, 4, 16])
-@pytest.mark.parametrize("P,P1", [(4, None), (8, None), (8, 2), (16, None), (2, 1), (4, 1), (8, 1), (2, 2), (4, 4)])
+@pytest.mark.parametrize("P,P1,depth,prec", _pipeline_cases([(4, None), (8, None), (8, 2), (16, None), (2, 1), (4, 1), (8, 1), (2, 2), (4, 4)]))
 def test_pencil_x_exchange_pipeline(P, P1, depth, prec):
     """Opt-in exchange pipeline of the x-aligned pencil (batches of local x rows through both exchanges, compute and
     communication streams): same numbers as the un-pipelined path, R2C plain / 2/3-rule and C2C.  The 1 x P2, P1 x 1

@@ -17,7 +17,7 @@ def test_bench_one_gpu_line():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "256", "--steps", "5", "--warmup", "2",
-                        "--cpu-baseline", "off"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+                        "--cpu-baseline", "off"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=root)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines

@@ -312,7 +312,7 @@ for prec, ct, tol in (("double", np.complex128, 1e-10), ("single", np.complex64,
 print("COL3_OK")
 """ % root
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MFFT_COL3=mode, MFFT_COL3S=third), stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, timeout=600)
+                       stderr=subprocess.STDOUT, timeout=240)
     assert p.returncode == 0 and b"COL3_OK" in p.stdout, p.stdout.decode()[-3000:]
 
 

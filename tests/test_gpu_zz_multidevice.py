@@ -7,7 +7,15 @@ on its own GPU, so that `pytest -m gpu` itself moves bytes over xGMI where the l
   * RcclComm:   the real librccl (it refuses two ranks on one device, so this is the only place it runs with P > 1)
 
 The file sorts last on purpose: the rest of the suite (whose virtual ranks are spread over the devices too once
-gpu_util.peer_probe passes) reports first.  Mirrors the reference's own rank-count gating (tests/test_FFT.py:27-34)."""
+gpu_util.peer_probe passes) reports first.  Mirrors the reference's own rank-count gating (tests/test_FFT.py:27-34).
+
+Nothing here has run yet (the pool leases one GPU).  Extra time on an 8-GPU box, ESTIMATED from the same workers on one
+shared device (tests/test_gpu_multiprocess.py: mp_worker.py takes 1 / 6 / 21 s at 2 / 4 / 8 processes over IPC, 1 / 2.5 /
+9 s over the stand-in for RCCL; a dedicated device per rank can only be faster, real RCCL adds a few seconds of
+communicator set-up per world size): test_one_process_per_device 2 x (1 + 6 + 21) = under 60 s, the two LocalGroup tests
+(virtual ranks, no process start) under 15 s, relay striping under 30 s -- about 100 s, against a limit of 240 s per
+subprocess and MFFT_LOCAL_TIMEOUT = 30 s per wait.  Only modes that have run clean everywhere are swept: the per-peer
+streams pull mode (`ipc_pull = 2`, stalled twice in round 4) needs MP_WORKER_STREAMS=1."""
 import os
 
 import numpy as np
@@ -74,11 +82,11 @@ def test_local_group_one_rank_per_device(prec):
 
 @pytest.mark.parametrize("transport", ["ipc", "rccl"])
 def test_one_process_per_device(transport):
-    """tests/mp_worker.py (selftest, slab x every IPC pull mode x CU masks, padded / masked paths, C2C, pencils with and
+    """tests/mp_worker.py (selftest, slab x the shipped IPC pull modes -- pull kernel, copy engines -- x CU masks, padded / masked paths, C2C, pencils with and
     without relay striping, all against the oracle and bit-identical between modes) with LOCAL_RANK = rank, i.e. every
     process on its own GPU (comm.from_env); "rccl" = the real library."""
     from test_gpu_multiprocess import _spawn
     for world in worlds():
-        rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker.py")], transport=transport, timeout=900)
+        rc, out, err = _spawn(world, [os.path.join(ROOT, "tests", "mp_worker.py")], transport=transport, timeout=240)
         assert rc == 0, (transport, world, out[-2000:], err[-4000:])
         assert "MP_OK world=%d" % world in out

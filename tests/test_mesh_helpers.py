@@ -139,3 +139,44 @@ def test_work_arrays_contract():
         w[((3,), float, 0, 1)]
     with pytest.raises(TypeError):
         w.values()
+
+
+def test_dealias_fingerprints_without_copies_and_per_size_cache():
+    """`F.dealias` fingerprints (slab.py:237-245 reads the attribute on every call; _base.py compares fingerprints instead):
+    the whole-array hash is the same for equal content whatever the strides, the sampled one reads 8192 elements through
+    the array's own strides (a broadcast view is not expanded), the sample positions are cached per size -- two plans of
+    different sizes do not evict each other -- and a single changed element is seen by the whole hash."""
+    from mpifft4py_amd._base import DistFFTBase
+    F = Slab_R2C(np.array([32, 32, 32]), np.array([2 * np.pi] * 3), LayoutComm(1, 0), "double")
+    DistFFTBase._sample_index.clear()
+    a = np.ones((96, 96, 49), dtype=np.uint8)                         # 451 584 B > 256 KiB: sampled
+    b = np.ones((128, 64, 65), dtype=bool)
+    row = np.ones((1, 1, 49), dtype=np.uint8)
+    view = np.broadcast_to(row, a.shape)                               # strides (0, 0, 1): 49 bytes of memory
+    F._dealias = a
+    fa = F._mask_fingerprint()
+    assert fa[2] == "sampled"
+    F._dealias = b
+    fb = F._mask_fingerprint()
+    assert a.size in DistFFTBase._sample_index and b.size in DistFFTBase._sample_index
+    idx_a = DistFFTBase._sample_index[a.size]
+    F._dealias = a
+    assert F._mask_fingerprint() == fa and DistFFTBase._sample_index[a.size] is idx_a
+    F._dealias = view
+    fv = F._mask_fingerprint()
+    assert fv == fa                                                    # same content, other strides
+    assert ("nd",) + a.shape in DistFFTBase._sample_index
+    assert F._mask_fingerprint(True)[3] == DistFFTBase._whole_hash(a)
+    # one element of the large array, at a position the samples do not hold
+    taken = set(idx_a.tolist())
+    pos = next(i for i in range(a.size) if i not in taken)
+    a.reshape(-1)[pos] = 0
+    F._dealias = a
+    assert F._mask_fingerprint() == fa                                 # the documented blind spot of the cheap fingerprint
+    assert F._mask_fingerprint(True)[3] != DistFFTBase._whole_hash(np.ones_like(a))
+    a.reshape(-1)[int(idx_a[0])] = 0
+    assert F._mask_fingerprint() != fa
+    small = np.ones((8, 8, 5))
+    F._dealias = small
+    assert F._mask_fingerprint()[2] == "whole"
+    assert fb[2] == "sampled"
