@@ -211,29 +211,51 @@ def cpu_baseline(n_full, seconds_budget=30.0):
                       % (ns, cores, t_s, err, n_full, scale)}
 
 
-def cpu_baseline_cached(n_full, world):
+def cpu_baseline_cached(n_full, world, max_age_s=6 * 3600):
     """The host timing does not depend on the number of GPUs: the N = 1 run measures it (the full cube when time and
-    memory allow) and leaves it in a file of this user's temp directory; a run with N > 1 on the same box reports that
-    measurement next to its own number (`sample` says so), or -- no N = 1 run before it -- times the bounded 512^3 sample
-    on rank 0 alone (about a second; the other ranks wait at the final barrier)."""
-    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mfft-cpu-baseline-%d-%d.json" % (os.getuid(), n_full))
+    memory allow) and leaves it in this user's PRIVATE cache directory (mode 0700; the file is written under a random name
+    and renamed); a run with N > 1 on the same box reports that measurement next to its own number -- marked `"cached":
+    true`, with its age in `sample` -- when it was taken on this host, with this core count, numpy and scipy, less than
+    `max_age_s` ago; otherwise it times the bounded 512^3 sample on rank 0 alone (about a second; the other ranks wait at
+    the final barrier)."""
+    import tempfile
+    import time
+    d_cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mfft-%d" % os.getuid())
+    path = os.path.join(d_cache, "cpu-baseline-%d.json" % n_full)
+
+    def stamp():
+        import numpy
+        try:
+            import scipy
+            sv = scipy.__version__
+        except Exception:  # noqa: BLE001
+            sv = None
+        return {"host": os.uname().nodename, "ncpu": os.cpu_count() or 1, "numpy": numpy.__version__, "scipy": sv}
     if world > 1:
         try:
-            with open(path) as f:
-                d = json.load(f)
-            if d.get("host") == os.uname().nodename and d.get("cores") == (os.cpu_count() or 1):
-                d.pop("host")
-                d["sample"] = "measured by this box's --gpus 1 run: " + d["sample"]
-                return d
-        except (OSError, ValueError):
+            st = os.lstat(d_cache)
+            import stat as _stat
+            if _stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o077):
+                with open(path) as f:
+                    d = json.load(f)
+                meta = d.pop("_meta", {})
+                age = time.time() - float(meta.get("time", 0))
+                if {k: meta.get(k) for k in ("host", "ncpu", "numpy", "scipy")} == stamp() and 0 <= age < max_age_s:
+                    d["cached"] = True
+                    d["sample"] = "measured %.0f min ago by this box's --gpus 1 run: %s" % (age / 60.0, d["sample"])
+                    return d
+        except (OSError, ValueError, TypeError):
             pass
         return cpu_baseline(n_full, seconds_budget=0.0)
     d = cpu_baseline(n_full)
     try:
-        tmp = path + ".%d" % os.getpid()
-        with open(tmp, "w") as f:
-            json.dump(dict(d, host=os.uname().nodename), f)
-        os.replace(tmp, path)
+        os.makedirs(d_cache, mode=0o700, exist_ok=True)
+        st = os.lstat(d_cache)
+        if st.st_uid == os.getuid() and not (st.st_mode & 0o077):
+            fd, tmp = tempfile.mkstemp(prefix="cpu-baseline-", dir=d_cache)
+            with os.fdopen(fd, "w") as f:
+                json.dump(dict(d, _meta=dict(stamp(), time=time.time())), f)
+            os.replace(tmp, path)
     except OSError:
         pass
     return d
@@ -469,6 +491,9 @@ def main():
         else:
             F = Pencil_R2C(N, L, comm, args.precision, communication="Alltoallw", alignment="X",
                            allow_single=True, pipeline=pipeline, comm_cus=comm_cus)
+        # placement probe (profiles/r05_alloc_shift_probe.txt): a dummy allocation of this many MiB ahead of the arrays
+        shift_mb = int(os.environ.get("MFFT_BENCH_ALLOC_SHIFT_MB", "0") or 0)
+        shift_buf = DeviceArray.empty((shift_mb << 20,), np.uint8) if shift_mb > 0 else None      # noqa: F841 (kept alive)
         u = DeviceArray.random(F.real_shape(), F.float, seed=1234 + rank)
         fu = DeviceArray.empty(F.complex_shape(), F.complex)
         u2 = DeviceArray.empty(F.real_shape(), F.float)

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "mfft_slab_unpack": ([c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int], c_int),
     "mfft_dealias_filter": ([c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_length_supported": ([c_int64, c_int], c_int),
+    "mfft_length_route": ([c_int64, c_int], c_int),
     "mfft_kernel_name": ([c_int, c_int64, c_int, c_int, c_int, c_void_p, c_size_t], c_int),
     "mfft_ew_cross": ([c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_ew_curl_hat": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int], c_int),
@@ -104,7 +105,7 @@ _SIGNATURES = {
 }
 
 # functions whose int result is a count, not a status
-_COUNT_RESULT = {"mfft_version", "mfft_length_supported", "mfft_plan_timing_get"}
+_COUNT_RESULT = {"mfft_version", "mfft_length_supported", "mfft_length_route", "mfft_plan_timing_get"}
 
 _lib = None
 

@@ -68,9 +68,21 @@ bool length_supported(int64_t n, bool real_transform) {
   if (n <= 0 || n > (1 << 20)) return false;
   if (real_transform)
     return find_kernel(FAM_R2C, (int)n, MFFT_DOUBLE, 0) != nullptr || find_chirpz(FAM_R2CZ, (int)n, MFFT_DOUBLE, 0) != nullptr ||
-           (n % 2 == 0 && n >= 4 && find_chirpz(FAM_R2CZH, (int)(n / 2), MFFT_DOUBLE, 0) != nullptr);
+           (n % 2 == 0 && n >= 4 && find_chirpz(FAM_R2CZH, (int)(n / 2), MFFT_DOUBLE, 0) != nullptr) || big_length_ok(n);
   return n == 1 || find_kernel(FAM_COL, (int)n, MFFT_DOUBLE, 0) != nullptr ||
-         find_chirpz(FAM_COLZ, (int)n, MFFT_DOUBLE, 0) != nullptr;
+         find_chirpz(FAM_COLZ, (int)n, MFFT_DOUBLE, 0) != nullptr || big_length_ok(n);
+}
+// 1: a radix plan, 2: the one-workgroup chirp-z kernels, 3: the scratch-buffer fallback (bigfft.hip), 0: none
+int length_route(int64_t n, bool real_transform) {
+  if (n <= 0 || n > (1 << 20)) return 0;
+  if (real_transform) {
+    if (find_kernel(FAM_R2C, (int)n, MFFT_DOUBLE, 0)) return 1;
+    if (find_chirpz(FAM_R2CZ, (int)n, MFFT_DOUBLE, 0) || (n % 2 == 0 && n >= 4 && find_chirpz(FAM_R2CZH, (int)(n / 2), MFFT_DOUBLE, 0))) return 2;
+  } else {
+    if (n == 1 || find_kernel(FAM_COL, (int)n, MFFT_DOUBLE, 0)) return 1;
+    if (find_chirpz(FAM_COLZ, (int)n, MFFT_DOUBLE, 0)) return 2;
+  }
+  return big_length_ok(n) ? 3 : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -195,6 +207,12 @@ static int launch_col_t(const KernelEntry* e, const ColArgs& a, void* tw, hipStr
   P.tile_list = a.band.on ? a.band.tile_list : nullptr;
   P.ntiles_listed = a.band.ntiles_listed;
   P.b_gzero = a.band.on ? a.band.g_zero : 0;
+  if constexpr (std::is_same<PT, ColParams<T>>::value) {
+    P.in_wrap = (int)a.in_wrap;
+    P.in_wrap_gap = (int)a.in_wrap_gap;
+  } else {
+    if (a.in_wrap > 0) return set_error(MFFT_ERR_UNSUPPORTED, "wrapped input columns need a radix kernel (length %d has none)", a.n);
+  }
   const int64_t grid = P.tile_list ? (int64_t)P.ntiles_listed : (int64_t)P.ntile_c * a.nouter * (e->grid_mult > 1 ? e->grid_mult : 1);
   if (grid <= 0) return 0;
   if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large (%lld tiles)", (long long)grid);
@@ -253,7 +271,7 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   // plane apart: 9.0 -> 7.3 ms inverse, 7.5 -> 6.8 forward) and behind on the y passes (6.9 -> 7.7 - 8.1).  Default: single
   // precision, passes without an outer batch (the x passes); MFFT_COL3=1 always, MFFT_COL3=0 never.
   static const int col3_mode = getenv("MFFT_COL3") ? atoi(getenv("MFFT_COL3")) : -1;
-  const bool col3_on = col3_mode > 0 || (col3_mode < 0 && a.prec == MFFT_SINGLE && a.nouter == 1);
+  const bool col3_on = col3_mode > 0 || (col3_mode < 0 && a.prec == MFFT_SINGLE && (a.nouter == 1 || a.thirds > 0));
   if (col3_on && !a.mask && !a.band.on) {
     const KernelEntry* e3 = nullptr;
     if (nt_ok) e3 = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 1, 16);              // same alignment rule, NT build
@@ -265,8 +283,8 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   // 5.31 -> 5.16 ms, y pass 8.47 -> 9.17 (not taken); single precision x 2.99 -> 2.54, y 4.98 -> 4.35.  Default on; MFFT_COL3S=0 never.
   static const int col3s_mode = getenv("MFFT_COL3S") ? atoi(getenv("MFFT_COL3S")) : MFFT_COL3S_DEFAULT;
   // double precision: the passes without an outer batch only (y pass 8.4 -> 9.1 ms with it); MFFT_COL3S=2: every pass
-  if (col3s_mode > 0 && a.pad == 1 && a.inverse && a.in != a.out && !a.mask && !a.band.on &&
-      (col3s_mode > 1 || a.prec == MFFT_SINGLE || a.nouter == 1)) {
+  if (col3s_mode > 0 && a.thirds != 0 && a.pad == 1 && a.inverse && a.in != a.out && !a.mask && !a.band.on &&
+      (col3s_mode > 1 || a.thirds > 0 || a.prec == MFFT_SINGLE || a.nouter == 1)) {
     if (const KernelEntry* es = find_kernel(FAM_COL, a.n, a.prec, 1, 0, 33)) e = es;
   }
   if (!e && ent) e = ent;
@@ -274,7 +292,8 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   void* tw = nullptr;
   if (!e) {   // no radix plan for this length: chirp-z on the next compiled length >= 2n-1
     e = find_chirpz(FAM_COLZ, a.n, a.prec, a.inverse ? 1 : 0);
-    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d (maximum 4096 for lengths without a radix plan: plans.h)", a.n);
+    if (!e && big_length_ok(a.n)) return big_col(a, s);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d", a.n);
     void *chirp = nullptr, *bhat = nullptr;
     MFFT_TRY(prepare_kernel(e, &tw));
     MFFT_TRY(chirpz_tables(a.n, e->n, a.prec, &chirp, &bhat));
@@ -343,7 +362,8 @@ int launch_row(const RowArgs& a, hipStream_t s) {
   void* tw = nullptr;
   if (!e) {
     e = find_chirpz(FAM_ROWZ, a.n, a.prec, a.inverse ? 1 : 0);
-    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d (maximum 4096 for lengths without a radix plan: plans.h)", a.n);
+    if (!e && big_length_ok(a.n)) return big_row(a, s);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a complex transform of length %d", a.n);
     void *chirp = nullptr, *bhat = nullptr;
     MFFT_TRY(prepare_kernel(e, &tw));
     MFFT_TRY(chirpz_tables(a.n, e->n, a.prec, &chirp, &bhat));
@@ -408,7 +428,8 @@ static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
     const bool half = a.n % 2 == 0 && a.n >= 4 && real_stride % 2 == 0;
     const int nz = half ? a.n / 2 : a.n;
     e = find_chirpz(half ? (r2c ? FAM_R2CZH : FAM_C2RZH) : (r2c ? FAM_R2CZ : FAM_C2RZ), nz, a.prec, r2c ? 0 : 1);
-    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a real transform of length %d (maximum 4096 for lengths without a radix plan: plans.h)", a.n);
+    if (!e && big_length_ok(a.n)) return big_real(!r2c, a, s);
+    if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no kernel for a real transform of length %d", a.n);
     void *chirp = nullptr, *bhat = nullptr;
     MFFT_TRY(prepare_kernel(e, &tw));
     MFFT_TRY(chirpz_tables(nz, e->n, a.prec, &chirp, &bhat));

@@ -237,6 +237,40 @@ static void test_col(bool two_level) {
   report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
 }
 
+// Wrapped input columns (ColParams::in_wrap, round 5): the same truncating forward kernel on a compact input and on one whose
+// columns sit in rows of W columns at a pitch of W + 3 (W odd, so that a lane's VEC columns straddle the end of a row
+// somewhere) must store the same bits.  K: any strided kernel type whose output has `nout` rows.
+template <class K, typename T>
+static void test_wrapped_columns(const char* what, int N, int nout, const cx<T>* tw, int cols_per_tile) {
+  const int W = 5, G = 2 * cols_per_tile / W + 3, ncols = W * G, Wp = W + 3;
+  const int pin_a = ncols + 1, pin_b = G * Wp + 2, pout = ncols + 2;
+  std::mt19937_64 rng(4321 + N);
+  std::uniform_real_distribution<double> U(-1, 1);
+  std::vector<cx<T>> a((size_t)N * pin_a), b((size_t)N * pin_b, mk<T>((T)99, (T)99));
+  for (int r = 0; r < N; ++r)
+    for (int c = 0; c < ncols; ++c) {
+      const cx<T> z = mk<T>((T)U(rng), (T)U(rng));
+      a[(size_t)r * pin_a + c] = z;
+      b[(size_t)r * pin_b + (size_t)(c / W) * Wp + c % W] = z;
+    }
+  std::vector<cx<T>> out_a((size_t)nout * pout, mk<T>((T)5, (T)5)), out_b = out_a;
+  for (int wrapped = 0; wrapped < 2; ++wrapped) {
+    ColParams<T> P;
+    memset(&P, 0, sizeof P);
+    P.in = wrapped ? b.data() : a.data(); P.out = wrapped ? out_b.data() : out_a.data(); P.tw = tw;
+    P.in_map = make_rowmap(0, wrapped ? pin_b : pin_a, 0, N); P.out_map = make_rowmap(0, pout, 0, nout);
+    P.ncols = ncols; P.ntile_c = (ncols + cols_per_tile - 1) / cols_per_tile; P.nouter = 1; P.remap = wrapped; P.fold = 1;
+    P.scale = (T)0.5;
+    if (wrapped) { P.in_wrap = W; P.in_wrap_gap = Wp - W; }
+    emu_launch(P.ntile_c, K::THREADS, K::LDS_BYTES, [&](int bb, int t, char* lds) { K::body(P, bb, t, lds); });
+  }
+  size_t bad = 0;
+  for (size_t i = 0; i < out_a.size(); ++i) bad += memcmp(&out_a[i], &out_b[i], sizeof(cx<T>)) != 0;
+  bool any = false;
+  for (int c = 0; c < ncols; ++c) any = any || out_a[c].x != (T)5;
+  report(what, N, pname<T>(), (bad == 0 && any) ? 0.0 : 1.0, tol_of<T>());
+}
+
 // 3/2-rule fusion: PAD == 1 (inverse, zero band on load) and PAD == 2 (forward, truncate on store,
 // with and without the Nyquist fold) against explicit pad / truncate around a plain DFT
 template <class S, typename T, int COLS, int VEC>
@@ -314,6 +348,13 @@ static void test_col_pad() {
     char name[64];
     snprintf(name, sizeof name, "col c%d v%d trunc-on-store%s", COLS, VEC, fold ? " fold" : "");
     report(name, N, pname<T>(), (double)sqrtl(num / den), tol_of<T>());
+  }
+  {
+    char name[64];
+    snprintf(name, sizeof name, "col c%d v%d trunc-on-store, wrapped input columns", COLS, VEC);
+    test_wrapped_columns<ColFft<S, T, COLS, false, false, false, VEC, false, 2>, T>(name, N, n, tw.data(), COLS);
+    snprintf(name, sizeof name, "col c%d v%d plain fwd, wrapped input columns", COLS, VEC);
+    test_wrapped_columns<ColFft<S, T, COLS, false, false, false, VEC, false, 0>, T>(name, N, N, tw.data(), COLS);
   }
 }
 
@@ -1099,6 +1140,10 @@ static void test_col3() {
       snprintf(name, sizeof name, "col3 c%d v%d truncate-on-store fwd%s%s", COLS, VEC, fold ? " fold" : "", SPLIT ? " split" : "");
       report(name, N, pname<T>(), (double)sqrtl(num / den), 2 * tol_of<T>());
     }
+    snprintf(name, sizeof name, "col3 c%d v%d truncate-on-store fwd, wrapped input columns%s", COLS, VEC, SPLIT ? " split" : "");
+    test_wrapped_columns<ColFft3<SL, T, COLS, false, false, SPLIT, VEC, false, 2>, T>(name, N, n, tw.data(), COLS);
+    snprintf(name, sizeof name, "col3 c%d v%d plain fwd, wrapped input columns%s", COLS, VEC, SPLIT ? " split" : "");
+    test_wrapped_columns<ColFft3<SL, T, COLS, false, false, SPLIT, VEC, false, 0>, T>(name, N, N, tw.data(), COLS);
   }
 }
 

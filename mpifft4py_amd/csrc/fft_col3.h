@@ -51,8 +51,10 @@ struct ColFft3 {
   // thread exist -- one unconditional 16-byte load.  The callers branch ONCE per thread on that, around their whole load
   // phase: with the test inside (once per row) hipcc waits for every row's load inside its branch, i.e. the rows of a tile
   // come in one after the other (single precision, VEC = 2: 12 of 24 loads serialised, found in round 4 in the ISA).
+  // (wrapped input columns, ColParams::in_wrap: a lane whose VEC columns straddle the end of an input row takes the ragged
+  // path with `first` = its columns before the wrap and `gap` = the distance the others lie further)
   template <bool FULL>
-  static MFFT_D void load_row(const cx<T>* src, int nact, cx<T> (&dst)[VEC]) {
+  static MFFT_D void load_row(const cx<T>* src, int nact, cx<T> (&dst)[VEC], int first = VEC, int gap = 0) {
     if constexpr (FULL) {
       const GPack g = Base::load_pack(src);
 #pragma unroll
@@ -61,7 +63,7 @@ struct ColFft3 {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         cx<T> x = mk<T>((T)0, (T)0);
-        if (i < nact) x = src[i];
+        if (i < nact) x = src[i + (i >= first ? gap : 0)];
         dst[i] = INV ? swapri(x) : x;
       }
     }
@@ -117,18 +119,18 @@ struct ColFft3 {
   // third R of the DIT form: its rows 3 q + R of the input, then its sub-transform
   template <int R>
   static MFFT_D void dit_third(const ColParams<T>& P, cx<T> (&w)[3][VEC][EL], int j, int c, int nact, const cx<T>* ip,
-                               const cx<T>* ltw, char* xbuf) {
+                               const cx<T>* ltw, char* xbuf, int first) {
     auto loads = [&](auto lanes) {
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
         const unsigned row = 3u * (unsigned)(j + k * SL::TPT) + (unsigned)R;
         cx<T> x[VEC];
-        load_row<decltype(lanes)::value>(ip + row_off(P.in_map, row), nact, x);
+        load_row<decltype(lanes)::value>(ip + row_off(P.in_map, row), nact, x, first, P.in_wrap_gap);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) w[R][i][k] = x[i];
       }
     };
-    if (nact >= VEC) loads(FullLanes{});
+    if (nact >= VEC && first == VEC) loads(FullLanes{});
     else loads(RaggedLanes{});
     if constexpr (TWLDS) sub_transform(w[R], j, ltw, xbuf, c);
     else sub_transform(w[R], j, P.tw, xbuf, c);
@@ -144,7 +146,14 @@ struct ColFft3 {
     const int j = tid / CG;
     const int col = tc * COLS + c * VEC;
     const int nact = P.ncols - col;
-    const cx<T>* ip = P.in + (i64)outer * P.in_outer + col;
+    i64 icol = col;
+    int first = VEC;                                 // wrapped input columns (ColParams::in_wrap), as in ColFft
+    if (P.in_wrap > 0) {
+      const int q = col / P.in_wrap;
+      icol += (i64)q * P.in_wrap_gap;
+      if (VEC > 1 && col - q * P.in_wrap + VEC > P.in_wrap) first = P.in_wrap - (col - q * P.in_wrap);
+    }
+    const cx<T>* ip = P.in + (i64)outer * P.in_outer + icol;
     cx<T>* op = P.out + (i64)outer * P.out_outer + col;
     const cx<T>* tw1 = P.tw + SL::TW;               // W_N^p
     const cx<T>* tw2 = tw1 + L;                      // W_N^{2p}
@@ -161,21 +170,21 @@ struct ColFft3 {
         for (int k = 0; k < EL; ++k) {
           const unsigned p = (unsigned)(j + k * SL::TPT);
           cx<T> x[VEC];
-          load_row<FULL>(ip + row_off(P.in_map, p), nact, x);
+          load_row<FULL>(ip + row_off(P.in_map, p), nact, x, first, P.in_wrap_gap);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) w[0][i][k] = x[i];
           if constexpr (PAD != 1) {                   // PAD == 1: logical rows [L, 2L) are the zero band, never loaded
-            load_row<FULL>(ip + row_off(P.in_map, p + (unsigned)L), nact, x);
+            load_row<FULL>(ip + row_off(P.in_map, p + (unsigned)L), nact, x, first, P.in_wrap_gap);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) w[1][i][k] = x[i];
           }
           // (PAD == 1: logical row 2L + p is physical row L + p)
-          load_row<FULL>(ip + row_off(P.in_map, p + (PAD == 1 ? 1u : 2u) * (unsigned)L), nact, x);
+          load_row<FULL>(ip + row_off(P.in_map, p + (PAD == 1 ? 1u : 2u) * (unsigned)L), nact, x, first, P.in_wrap_gap);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) w[2][i][k] = x[i];
         }
       };
-      if (nact >= VEC) loads(FullLanes{});
+      if (nact >= VEC && first == VEC) loads(FullLanes{});
       else loads(RaggedLanes{});
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
@@ -197,9 +206,9 @@ struct ColFft3 {
       dif_third<2>(P, w, j, c, nact, op, ltw, xbuf);
     } else {
       // ---- DIT: rows 3 q + r -> three sub-transforms -> twiddles -> radix-3 butterfly -> rows k1 and (2L + k1 -> L + k1) ---
-      dit_third<0>(P, w, j, c, nact, ip, ltw, xbuf);
-      dit_third<1>(P, w, j, c, nact, ip, ltw, xbuf);
-      dit_third<2>(P, w, j, c, nact, ip, ltw, xbuf);
+      dit_third<0>(P, w, j, c, nact, ip, ltw, xbuf, first);
+      dit_third<1>(P, w, j, c, nact, ip, ltw, xbuf, first);
+      dit_third<2>(P, w, j, c, nact, ip, ltw, xbuf, first);
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
         const unsigned p = (unsigned)(j + k * SL::TPT);

@@ -60,9 +60,18 @@ namespace mfft { void emu_barrier(); }
 // through a per-workgroup slot array between two barriers (emu_test.cpp emu_shfl) -- every thread of the workgroup must
 // execute the same sequence of shuffles, which the kernels guarantee (they sit in fully unrolled, uniform loops) -- so
 // that the lane arithmetic of the shuffle paths is checked on the CPU as well.
+// WAVE_SHFL_DIRECT: the same on the device WITHOUT the function in between.  Through the `__forceinline__` template wrapper the
+// shuffles of the dense c2r kernels compiled to 13 - 45 more VGPRs for the 28-values plans -- 263 / 287 instead of 250 / 242,
+// i.e. one wave per SIMD instead of two and twice the time (896^3 bwd_z 2.05 -> 4.2 ms from round 4's commit d98a6c4 on; found
+// in round 5 by reverting that commit's hunks one at a time, profiles/r05_radix7_c2r_bisect.txt) -- while the wave-packed
+// kernels, which were tuned with the wrapper, lose registers the other way round (fp32 c2r of 1200 / 1500 / 1800: 163 -> 200
+// VGPRs with the direct form).  So: the dense c2r kernels call the builtin directly, everything else keeps the wrapper;
+// scripts/kernel_regs.py --diff shows such moves before they reach a GPU.
 #if defined(__HIPCC__)
+#define WAVE_SHFL_DIRECT(x, src) __shfl((x), (src), 64)
 template <typename T> __device__ __forceinline__ T wave_shfl(T x, int src) { return __shfl(x, src, 64); }
 #else
+#define WAVE_SHFL_DIRECT(x, src) wave_shfl((x), (src))
 namespace mfft { double emu_shfl(double x, int src_lane); }
 template <typename T> inline T wave_shfl(T x, int src) { return (T)::mfft::emu_shfl((double)x, src); }
 #endif
@@ -170,6 +179,11 @@ struct ColParams {
                          // zeros): for outputs that somebody reads whole, e.g. a chunk that goes through an exchange;
                          // 2 = the same for the columns of a removed z too, and no tile is skipped: the output is complete
                          // (the pencils' first inverse pass: the band parameters instead of one mask byte per element)
+  // Round 5, wrapped INPUT columns: the tiles follow the (compact) output, whose ncols columns are contiguous, while the
+  // input keeps in_wrap columns per row of a pitched buffer: column c is read from c + (c / in_wrap) * in_wrap_gap.  The pass
+  // that leaves a line-aligned intermediate (rows of 520 instead of 513 bins) for the caller's compact spectrum stores
+  // whole cache lines this way (its loads straddle lines instead, which costs little).  0: plain columns.
+  int in_wrap = 0, in_wrap_gap = 0;
 };
 
 template <typename T>
@@ -506,7 +520,14 @@ struct ColFft {
     const int j = tid / CG;
     const int col = tc * COLS + c * VEC;
     const int nact = P.ncols - col;                // columns of this thread inside the array (may be <= 0)
-    const cx<T>* ip = P.in + (i64)outer * P.in_outer + col;
+    i64 icol = col;
+    int first = VEC;                               // wrapped input: columns i >= first of this lane lie in_wrap_gap further
+    if (P.in_wrap > 0) {
+      const int q = col / P.in_wrap;
+      icol += (i64)q * P.in_wrap_gap;
+      if (VEC > 1 && col - q * P.in_wrap + VEC > P.in_wrap) first = P.in_wrap - (col - q * P.in_wrap);
+    }
+    const cx<T>* ip = P.in + (i64)outer * P.in_outer + icol;
     cx<T>* op = P.out + (i64)outer * P.out_outer + col;
     bool tile_zero = false;                        // b_gzero == 2: a tile of removed columns only is written as zeros
     if constexpr (PAD == 4) {                      // nothing downstream reads the columns the mask removes
@@ -569,7 +590,7 @@ struct ColFft {
         zero_row = zero_col || ((int)r >= P.b_row_lo && (int)r < P.b_row_hi);
         if (zero_row) src = ip + row_off(P.in_map, 0u);
       }
-      if (nact >= VEC) {
+      if (nact >= VEC && first == VEC) {
         const GPack g = load_pack(src);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) v[i][k] = INV ? swapri(g.e[i]) : g.e[i];
@@ -577,7 +598,7 @@ struct ColFft {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           cx<T> x = mk<T>((T)0, (T)0);
-          if (i < nact) x = src[i];
+          if (i < nact) x = src[i + (i >= first ? P.in_wrap_gap : 0)];
           v[i][k] = INV ? swapri(x) : x;
         }
       }
@@ -994,8 +1015,14 @@ struct C2RFft {
         const cx<T> a = v[k], b = v[kp];
         const cx<T> give1 = j == 0 ? carry : b;          // partner of position j + k*TPT
         const cx<T> give2 = j == 0 ? v[k + 1] : a;       // partner of position j + kp*TPT (lane 0: its register E-kp = k+1)
-        const cx<T> pm1 = mk<T>(wave_shfl(give1.x, src), wave_shfl(give1.y, src));
-        const cx<T> pm2 = mk<T>(wave_shfl(give2.x, src), wave_shfl(give2.y, src));
+        cx<T> pm1, pm2;
+        if constexpr (WP) {
+          pm1 = mk<T>(wave_shfl(give1.x, src), wave_shfl(give1.y, src));
+          pm2 = mk<T>(wave_shfl(give2.x, src), wave_shfl(give2.y, src));
+        } else {
+          pm1 = mk<T>(WAVE_SHFL_DIRECT(give1.x, src), WAVE_SHFL_DIRECT(give1.y, src));
+          pm2 = mk<T>(WAVE_SHFL_DIRECT(give2.x, src), WAVE_SHFL_DIRECT(give2.y, src));
+        }
         carry = b;                                       // lane 0's partner register of the next step
         v[k] = prepass(a, pm1, j + k * S::TPT);
         v[kp] = prepass(b, pm2, j + kp * S::TPT);

@@ -36,6 +36,7 @@
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
+#include <future>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -351,7 +352,7 @@ struct IpcComm : mfft_comm_s {
     // plan streams are covered by the channels' last_issue events
     hipError_t e = hipEventRecord(ev, nullptr);
     const auto t0 = std::chrono::steady_clock::now();
-    bool released = false;
+    bool released = false, stuck = false;
     auto pending = [&]() {
       if (e == hipSuccess && hipEventQuery(ev) == hipErrorNotReady) return true;
       for (int ch = 0; ch < IPC_MAX_CH; ++ch)
@@ -366,18 +367,46 @@ struct IpcComm : mfft_comm_s {
         rescue();
         released = true;
       }
-      if (released && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(ipc_timeout_s() + 30)) break;
+      if (released && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(ipc_timeout_s() + 30)) {
+        stuck = true;
+        break;
+      }
     }
     (void)hipGetLastError();
     (void)hipEventDestroy(ev);
-    if (!released) MFFT_HIP(hipDeviceSynchronize());      // nothing of mine is waiting on a peer: cheap, and covers every stream
+    if (stuck)      // the caller must not reuse what in-flight work may still touch (work_free keeps the block)
+      return set_error(MFFT_ERR_HIP, "ipc transport: work of a broken group is still pending %d s after its waits were released", (int)(ipc_timeout_s() + 30));
+    if (!released) {
+      MFFT_HIP(hipDeviceSynchronize());      // nothing of mine is waiting on a peer: cheap, and covers every stream
+      return 0;
+    }
+    // Released path: the events above cover the exchanges and what was queued BEFORE them; a transform kernel queued after
+    // the last exchange on a plan's non-blocking compute stream (the out-of-place x pass reads the work buffers) is covered
+    // by neither.  Every wait of mine has been released, so the device drains -- wait for that, bounded all the same.
+    if (!bounded_device_sync(30))
+      return set_error(MFFT_ERR_HIP, "ipc transport: the device did not drain within 30 s after the waits of a broken group were released");
     return 0;
+  }
+  // hipDeviceSynchronize with a time limit: run by a helper thread (detached if it never returns)
+  static bool bounded_device_sync(int seconds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    auto done = std::make_shared<std::promise<bool>>();
+    std::future<bool> fut = done->get_future();
+    std::thread([done, dev] {
+      bool ok = hipSetDevice(dev) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+      (void)hipGetLastError();
+      done->set_value(ok);
+    }).detach();
+    return fut.wait_for(std::chrono::seconds(seconds)) == std::future_status::ready && fut.get();
   }
   int work_free(void* p) override {
     if (!p) return 0;
     // As safe as the hipFree it stands in for: the block may be handed to another plan (another stream) at once, while
     // transforms of the plan that owned it are still in flight and peers still pull from it (their "done" flags are
     // awaited in-stream only).  Once this device is idle every such wait of mine has been satisfied.  Growth is rare.
+    // If the device cannot be shown idle (quiesce fails: a broken group whose work never drains) the block is NOT returned
+    // to the arena -- it leaks, which nothing can reuse under in-flight kernels -- and the error goes to the caller.
     if (sh && sh->broken.load()) rescue();
     MFFT_TRY(quiesce());
     for (Seg& s : segs) {

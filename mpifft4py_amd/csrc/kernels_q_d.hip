@@ -1,0 +1,5 @@
+// gfx950 instantiations: plan group Q, double precision
+#define MFFT_TU_PLANS MFFT_PLANS_Q
+#define MFFT_TU_ROWPLANS MFFT_ROWPLANS_Q
+#define MFFT_TU_REAL double
+#include "kernels_tu.inc"

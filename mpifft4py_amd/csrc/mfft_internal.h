@@ -49,6 +49,10 @@ struct ColArgs {
   bool allow_nt = true;  // use the non-temporal variant when the layout is 128-byte aligned
   int pad = 0;           // 1: input has 2n/3 physical rows (zero band skipped); 2: output truncated to 2n/3 rows
   bool fold = false;     // pad == 2: sum the two Nyquist rows (R2C convention)
+  int64_t in_wrap = 0, in_wrap_gap = 0;   // wrapped input columns (fft_kernels.h ColParams::in_wrap): column c is read from
+                                          // c + (c / in_wrap) * in_wrap_gap; radix kernels only
+  int thirds = -1;       // pad == 1 inverse: one third of a tile's transform per workgroup (ColFft3S)?  -1: launch_col's rule
+                         // (single precision, or a pass without an outer batch), 1: yes where the kernel exists, 0: no
   const uint8_t* mask = nullptr;   // inverse transforms: one byte per element of `in` (same element offsets), 0 = reads as zero
                                    // (the 2/3-rule `fu * dealias` of slab.py:237-245 without a masked copy of the spectrum)
   // inverse transforms, 2/3-rule mask of band form (fft_kernels.h ColParams b_*): rows [row_lo, row_hi) are zero and
@@ -123,6 +127,14 @@ int launch_scale(void* data, size_t count_real, double scale, int prec, hipStrea
 int launch_fill_uniform(void* data, size_t count, int prec, uint64_t seed, hipStream_t s);
 
 bool length_supported(int64_t n, bool real_transform);
+int length_route(int64_t n, bool real_transform);   // 1 radix plan, 2 one-workgroup chirp-z, 3 bigfft.hip, 0 none
+// bigfft.hip: any length up to MFFT_BIG_MAX_LENGTH through Bluestein's convolution over a four-step power-of-two transform in
+// a scratch buffer (the fallback behind the radix plans and the one-workgroup chirp-z kernels); plain transforms only
+#define MFFT_BIG_MAX_LENGTH (1 << 20)
+bool big_length_ok(int64_t n);
+int big_col(const ColArgs& a, hipStream_t s);
+int big_row(const RowArgs& a, hipStream_t s);
+int big_real(bool c2r, const RealArgs& a, hipStream_t s);
 bool zsplit_supported(int64_t n, int prec, bool real_transform);   // radix kernels with fused z-chunk pack exist for n
 bool zsplit_limit_supported(int64_t n, int prec);                  // ... that are column-limited as well (3/2-rule pencils)
 hipStream_t plan_stream(mfft_plan_t plan);   // the plan's compute stream (nullptr plan -> default stream)

@@ -240,6 +240,7 @@ struct mfft_plan_s {
   bool zfuse = false;
   bool xpad_on = true;          // xplane_pad(): MFFT_NO_XPAD=1 clears it (A/B runs; must be the same on every rank)
   bool zpitch_on = true;        // zrow_pitch(): MFFT_NO_ZPITCH=1 clears it (likewise)
+  bool pad_align = true;        // pad_pitch(): MFFT_PAD_ALIGN=0 clears it
   bool xpass_inplace = false;   // MFFT_XPASS_INPLACE=1: the x pass behind an exchange runs in place on the receive buffer (rounds 1 - 3)
   // the same for the fused 3/2-rule pencil transforms: real length M2, the Nf kept columns split into the z chunks
   bool zfuse_pad() const {
@@ -490,12 +491,26 @@ struct mfft_plan_s {
     return 0;
   }
   int col_pad(const void* in, void* out, int64_t n, bool inv, int pad, bool fold, int64_t nouter, int64_t ncols,
-              int64_t in_outer, RowSpec in_rows, int64_t out_outer, RowSpec out_rows, double scale) {
+              int64_t in_outer, RowSpec in_rows, int64_t out_outer, RowSpec out_rows, double scale, int64_t in_wrap = 0,
+              int64_t in_wrap_gap = 0, int thirds = -1) {
     ColArgs a;
     a.in = in; a.out = out; a.n = (int)n; a.prec = prec; a.inverse = inv; a.nouter = nouter; a.ncols = ncols;
     a.in_outer = in_outer; a.out_outer = out_outer; a.in_rows = in_rows; a.out_rows = out_rows;
     a.scale = scale; a.pad = pad; a.fold = fold;
+    a.in_wrap = in_wrap; a.in_wrap_gap = in_wrap_gap; a.thirds = thirds;
     return launch_col(a, stream);
+  }
+  // One-rank fused 3/2-rule transforms (round 5): the two intermediates belong to the plan, so their z rows get a pitch of
+  // whole cache lines (513 bins -> 520 in double precision: rows of 8208 bytes never start on a line, and a 128-byte tile
+  // row then costs two lines on either side of the y pass).  The plain transform measured the same idea in round 4
+  // (profiles/r04_ypass_pitch.txt: y pass 3.46 -> 2.96 ms with rows of 520 on both sides) and could not use it -- it has
+  // one work buffer less and its x passes touch the caller's compact array on the wrong side; here the inverse x pass
+  // stores whole lines per y row (its loads straddle), the y pass and the real transform see aligned rows, and the
+  // forward x pass tiles the compact OUTPUT and wraps its input columns (ColParams::in_wrap).  MFFT_PAD_ALIGN=0: compact.
+  int64_t pad_pitch() const {
+    if (!pad_align || P != 1) return Nf;
+    const int64_t line = 128 / (int64_t)es;
+    return (Nf + line - 1) / line * line;
   }
   // A strided pass whose rows lie a multiple of 64 KiB apart reads 12 - 30 % slower than one whose rows are one 128-byte
   // line further apart (every row of a tile meets the same memory channels; profiles/r02_power_of_two_stride.txt);
@@ -1158,6 +1173,19 @@ bool mfft_plan_s::can_fuse_pad() const {
 int mfft_plan_s::slab_backward_padded_fused(const void* fu, void* u) {
   const double sc3 = padscale();
   const int64_t Mp0 = M0 / P;
+  if (const int64_t Za = pad_pitch(); Za != Nf) {          // one rank, line-aligned z rows in both intermediates
+    MFFT_TRY(ensure_work(0, (size_t)(M0 * N1 * Za) * es));
+    MFFT_TRY(ensure_work(2, (size_t)(M0 * M1 * Za) * es));
+    void *W0 = work[0], *W2 = work[2];
+    MFFT_TRY(stage("bwd_x", 0, [&] {     // one outer batch per y row: compact rows in, pitched rows out
+      return col_pad(fu, W0, M0, true, 1, false, N1, Nf, Nf, plain(N1 * Nf), Za, plain(N1 * Za), sc3 / (double)M0, 0, 0, 1);
+    }));
+    MFFT_TRY(stage("bwd_y", 0, [&] {
+      return col_pad(W0, W2, M1, true, 1, false, M0, Nf, N1 * Za, plain(Za), M1 * Za, plain(Za), 1.0 / (double)M1);
+    }));
+    MFFT_TRY(stage("bwd_z", 0, [&] { return c2r_rows(W2, u, M0 * M1, M2, Za, M2, 1.0 / (double)M2, (int)Nf); }));
+    return 0;
+  }
   MFFT_TRY(ensure_work(0, (size_t)(M0 * Np1 * Nf) * es));
   MFFT_TRY(ensure_work(1, (size_t)(M0 * Np1 * Nf) * es));
   MFFT_TRY(ensure_work(2, (size_t)(Mp0 * M1 * Nf) * es));
@@ -1183,6 +1211,19 @@ int mfft_plan_s::slab_backward_padded_fused(const void* fu, void* u) {
 int mfft_plan_s::slab_forward_padded_fused(const void* u, void* fu) {
   const double isc3 = 1.0 / padscale();
   const int64_t Mp0 = M0 / P;
+  if (const int64_t Za = pad_pitch(); Za != Nf) {          // one rank, line-aligned z rows in both intermediates
+    MFFT_TRY(ensure_work(0, (size_t)(M0 * N1 * Za) * es));
+    MFFT_TRY(ensure_work(2, (size_t)(M0 * M1 * Za) * es));
+    void *W0 = work[0], *W2 = work[2];
+    MFFT_TRY(stage("fwd_z", 0, [&] { return r2c_rows(u, W2, M0 * M1, M2, M2, Za, 1.0, (int)Nf); }));
+    MFFT_TRY(stage("fwd_y", 0, [&] {
+      return col_pad(W2, W0, M1, false, 2, true, M0, Nf, M1 * Za, plain(Za), N1 * Za, plain(Za), 1.0);
+    }));
+    MFFT_TRY(stage("fwd_x", 0, [&] {     // tiles of the compact result; input column c = (y, z) sits at y * Za + z
+      return col_pad(W0, fu, M0, false, 2, true, 1, N1 * Nf, 0, plain(N1 * Za), 0, plain(N1 * Nf), isc3, Nf, Za - Nf);
+    }));
+    return 0;
+  }
   MFFT_TRY(ensure_work(0, (size_t)(M0 * Np1 * Nf) * es));
   MFFT_TRY(ensure_work(1, (size_t)(M0 * Np1 * Nf) * es));
   MFFT_TRY(ensure_work(2, (size_t)(Mp0 * M1 * Nf) * es));
@@ -2031,6 +2072,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   p->xpass_inplace = getenv("MFFT_XPASS_INPLACE") && atoi(getenv("MFFT_XPASS_INPLACE")) != 0;
   if (getenv("MFFT_P1_XPAD")) p->p1_xpad_lines = atoi(getenv("MFFT_P1_XPAD"));
   p->zpitch_on = !(getenv("MFFT_NO_ZPITCH") && atoi(getenv("MFFT_NO_ZPITCH")) != 0);
+  if (getenv("MFFT_PAD_ALIGN")) p->pad_align = atoi(getenv("MFFT_PAD_ALIGN")) != 0;
   const int P = p->P;
   if (p->r2c && p->N2 % 2) return set_error(MFFT_ERR_UNSUPPORTED, "odd N[2]=%lld is not supported for R2C", (long long)p->N2);
   if (desc->decomp == MFFT_SLAB) {
@@ -2104,7 +2146,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   // every transform length must have a kernel
   auto need = [&](int64_t n, bool real) -> int {
     if (n == 1 && !real) return 0;
-    if (!length_supported(n, real)) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %lld%s has no kernel (radix plans: 2^a <= 8192, 3*2^a, 5*2^a, 7*2^a, 9*2^a, 15*2^a, 25*2^a, 45*2^a, 75*2^a, 125*2^a, 225*2^a, 375*2^a; any other length up to 4096, even real lengths up to 8192)", (long long)n, real ? " (real)" : "");
+    if (!length_supported(n, real)) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %lld%s is not supported (lengths run from 1 to 2^20: include/mpifft4py_amd.h mfft_length_route)", (long long)n, real ? " (real)" : "");
     return 0;
   };
   MFFT_TRY(need(p->N0, false));

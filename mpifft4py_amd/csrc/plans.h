@@ -50,6 +50,10 @@
 // Group P (round 4): 8192, first of all as the convolution length M of the chirp-z kernels, which makes EVERY length up to
 // 4096 a supported one (2 n - 1 <= 8192), as it is for numpy / FFTW (numpy_fft.py:25-46); real rows up to 16384.
 #define MFFT_PLANS_P(X) X(8192, 32, 16, 16)
+// Group Q (round 5): the 3-, 5-, 7- and 9-smooth lengths between 4096 and 8192 -- 4608, 5120, 6144, 7168 are ordinary FFTW /
+// numpy sizes (numpy_fft.py:25-46 takes every n) and were MFFT_ERR_UNSUPPORTED as complex lengths (their real rows already
+// worked through the half-length plans); 192 / 128 / 256 / 256 threads per transform, strided tiles of 2 - 4 columns.
+#define MFFT_PLANS_Q(X) X(4608, 24, 24, 8) X(5120, 40, 8, 4, 4) X(6144, 24, 8, 8, 4) X(7168, 28, 4, 4, 4, 4)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -69,6 +73,7 @@
 #define MFFT_ROWPLANS_N(X)
 #define MFFT_ROWPLANS_O(X)
 #define MFFT_ROWPLANS_P(X)
+#define MFFT_ROWPLANS_Q(X)
 #define MFFT_ROWPLANS_A(X)
 #define MFFT_ROWPLANS_B(X)
 #define MFFT_ROWPLANS_C(X)
@@ -129,4 +134,4 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
   MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X) MFFT_PLANS_N(X) \
-  MFFT_PLANS_O(X) MFFT_PLANS_P(X)
+  MFFT_PLANS_O(X) MFFT_PLANS_P(X) MFFT_PLANS_Q(X)

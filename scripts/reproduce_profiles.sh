@@ -29,8 +29,12 @@ run() {
     r02_placement_probe.txt) python scripts/placement_probe.py ;;
     r02_placement_reroll.txt) python scripts/reroll_probe.py ;;
     r02_two_thirds_rule_mask.txt) python scripts/maskprof.py 1024 double; python scripts/maskprof.py 1024 single; python scripts/maskprof_ranks.py 1024 2; python scripts/maskprof_ranks.py 1024 8 ;;
-    r02_ipc_fanout_probe.txt) git checkout 292508d -- mpifft4py_amd/csrc/ipc_comm.hip && make -C mpifft4py_amd/csrc -j8 &&   # the per-peer-stream flag form was removed in round 4
-      MFFT_IPC_PULL=streams MFFT_IPC_STREAM_FLAGS=1 python bench.py --gpus 8 --size 128 --steps 3 --warmup 1 --cpu-baseline off --pencil-extra off --transport ipc ;;
+    r02_ipc_fanout_probe.txt)   # the per-peer-stream flag form was removed in round 4: the old revision is built in a throw-away worktree
+      # (its own sources, objects and library; this tree and its libmpifft4py_amd.so are not touched)
+      wt=$(mktemp -d /tmp/mfft-r02-fanout.XXXXXX) && git worktree add --detach "$wt" 292508d >/dev/null &&
+      make -C "$wt/mpifft4py_amd/csrc" -j8 >/dev/null &&
+      (cd "$wt" && MFFT_IPC_PULL=streams MFFT_IPC_STREAM_FLAGS=1 python bench.py --gpus 8 --size 128 --steps 3 --warmup 1 --cpu-baseline off --pencil-extra off --transport ipc);
+      git worktree remove --force "$wt" 2>/dev/null ;;
     r02_bench_after_two_wg_plan.json|r02_final_bench_1024cubed.json|r03_final_bench_1024cubed.json) python bench.py --steps 10 --warmup 3 ;;
     r04_final_bench_1024cubed.json) python bench.py --steps 10 --warmup 3 ;;
     r04_final_*) bash scripts/profile_r04.sh bench; python scripts/summarize_profiles.py r04_final gpurun_out/prof_r04/trace gpurun_out/prof_r04/fetch gpurun_out/prof_r04/write "bench.py --steps 10 --warmup 3 --cpu-baseline off --pencil-extra off: 1024^3 fp64 slab R2C forward+inverse on one MI355X"; python scripts/summarize_profiles.py sq r04_final gpurun_out/prof_r04/sq1 gpurun_out/prof_r04/sq2 ;;

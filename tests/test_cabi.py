@@ -59,10 +59,19 @@ def test_version_and_lengths(lib):
         assert lib.mfft_length_supported(n, 1) == 1, n
     assert all(lib.mfft_length_supported(n, 0) == 1 for n in range(1, 4097))
     assert all(lib.mfft_length_supported(n, 1) == 1 for n in range(2, 4097))
-    for n in (4097, 5000, 8191):
-        assert lib.mfft_length_supported(n, 0) == 0, n
-    assert lib.mfft_length_supported(4098, 1) == 1 and lib.mfft_length_supported(8190, 1) == 1      # even real rows: chirp-z of n/2 complex values
-    assert lib.mfft_length_supported(4099, 1) == 0 and lib.mfft_length_supported(8194, 1) == 0
+    # round 5: radix plans between 4096 and 8192, and EVERY other length up to 2^20 through the scratch-buffer fallback
+    # (csrc/bigfft.hip) -- numpy_fft.py:25-46 takes any n
+    for n in (4608, 5120, 6144, 7168):
+        assert lib.mfft_length_route(n, 0) == 1 and lib.mfft_length_route(2 * n, 1) == 1, n
+    assert all(lib.mfft_length_supported(n, 0) == 1 for n in range(1, 8193))
+    assert all(lib.mfft_length_supported(n, 1) == 1 for n in range(2, 16385))
+    for n in (4097, 5000, 8191, 10007, 65536, 100000, 1 << 20):
+        assert lib.mfft_length_supported(n, 0) == 1 and lib.mfft_length_supported(n, 1) == 1, n
+        assert lib.mfft_length_route(n, 0) == 3, n
+    assert lib.mfft_length_route(4098, 1) == 2 and lib.mfft_length_route(8190, 1) == 2      # even real rows: chirp-z of n/2 complex values
+    assert lib.mfft_length_route(4099, 1) == 3 and lib.mfft_length_route(8194, 1) == 3
+    assert lib.mfft_length_route(1024, 0) == 1 and lib.mfft_length_route(1001, 0) == 2
+    assert lib.mfft_length_supported((1 << 20) + 1, 0) == 0 and lib.mfft_length_route(0, 0) == 0
 
 
 def test_fails_loudly_without_gpu(lib):

@@ -134,6 +134,35 @@ def test_slab_padded(P, prec):
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("N", [[32, 64, 128], [64, 32, 1024], [16, 1024, 16], [1024, 8, 48], [20, 12, 44]])
+def test_slab_padded_one_rank_line_aligned_intermediates(N, prec, monkeypatch):
+    """One rank, fused 3/2-rule transforms (slab.py:250-268, 372-386): the plan's two intermediates keep their z rows on
+    cache lines (plan.hip pad_pitch: 513 -> 520 bins), the inverse x pass writes pitched rows per y row, the forward x pass
+    tiles the compact result and wraps its input columns (ColParams::in_wrap; [64,32,1024] and [1024,8,48] through the
+    three-sub-transform kernels of 1536 in single precision).  Against the oracle, and bit for bit against the compact
+    route (MFFT_PAD_ALIGN=0): same arithmetic per column, other addresses."""
+    from mpifft4py_amd import SelfComm, Slab_R2C
+    A = np.random.default_rng(sum(N)).random(N)
+    C0 = np.fft.rfftn(A).astype(cdtype(prec))
+    C0[N[0] // 2] = 0
+    C0[:, N[1] // 2] = 0
+    C0[:, :, -1] = 0
+    want = orc.slab_r2c_backward_padded(orc.scatter_complex(C0, orc.SlabLayout(N, 1)), N, prec)[0]
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MFFT_PAD_ALIGN", mode)
+        F = Slab_R2C(np.array(N), L, SelfComm(0), prec)
+        c = C0.copy()
+        up = F.ifftn(c, np.zeros(F.real_shape_padded(), dtype=rdtype(prec)), "3/2-rule")
+        assert np.array_equal(c, C0)
+        fu = F.fftn(up.copy(), np.zeros(F.complex_shape(), dtype=cdtype(prec)), "3/2-rule")
+        assert orc.rel_l2(up, want) < 4 * TOL[prec], (mode, orc.rel_l2(up, want))
+        assert orc.rel_l2(fu, C0) < 4 * TOL[prec], (mode, orc.rel_l2(fu, C0))
+        got[mode] = (up.copy(), fu.copy())
+    assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
 @pytest.mark.parametrize("align", ["X", "Y"])
 @pytest.mark.parametrize("P", [4, 8])
 def test_pencil_padded(P, align, prec):
@@ -1467,6 +1496,37 @@ def test_slab_padded_arbitrary_lengths(N, P):
     for r, (up, fu) in enumerate(run_ranks(P, body)):
         assert orc.rel_l2(up, want_up[r]) < 1e-10
         assert orc.rel_l2(fu, want_fu[r]) < 1e-10
+
+
+@pytest.mark.parametrize("N,P,decomp", [([4100, 8, 6], 1, "slab"), ([8, 5000, 6], 2, "slab"), ([8, 4, 8194], 2, "slab"),
+                                        ([8, 4, 8190], 1, "slab"), ([16, 4104, 12], 4, "pencilY"), ([4098, 8, 12], 4, "pencilX"),
+                                        ([6, 10, 9001], 1, "slab"), ([4608, 4, 6], 1, "slab"), ([4, 6144, 10240], 2, "slab")])
+def test_meshes_with_an_axis_beyond_the_radix_plans(N, P, decomp):
+    """numpy / FFTW take every mesh (numpy_fft.py:25-107); axes of 4100, 5000, 8194 (real), 9001 (real, odd) points go through
+    the scratch-buffer fallback (csrc/bigfft.hip) inside the slab and pencil plans -- plain transforms, the 2/3-rule through the
+    masked copy and the 3/2-rule through the copy-based pad --, 4608 / 6144 / 10240 (real) through the radix plans of round 5."""
+    from mpifft4py_amd import Pencil_R2C, Slab_R2C
+    A = np.random.default_rng(sum(N)).random(N)
+    B = np.fft.rfftn(A)
+
+    def body(comm):
+        F = (Slab_R2C(np.array(N), L, comm, "double") if decomp == "slab" else
+             Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment=decomp[-1]))
+        a = np.ascontiguousarray(A[F.real_local_slice()])
+        c = F.fftn(a, np.zeros(F.complex_shape(), dtype=complex))
+        b = F.ifftn(c, np.zeros(F.real_shape()))
+        m = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule")
+        mask = np.broadcast_to(F.dealias, F.complex_shape()).copy()
+        return F.complex_local_slice(), c, F.real_local_slice(), b, m, mask
+    res = run_ranks(P, body)
+    M = np.zeros(B.shape, dtype=np.uint8)
+    for cs, c, rs, b, m, mask in res:
+        M[cs] = mask
+    want_m = np.fft.irfftn(B * M, s=N, axes=(0, 1, 2))
+    for cs, c, rs, b, m, mask in res:
+        assert orc.rel_l2(c, B[cs]) < 1e-10, orc.rel_l2(c, B[cs])
+        assert orc.rel_l2(b, A[rs]) < 1e-10
+        assert orc.rel_l2(m, want_m[rs]) < 1e-10
 
 
 @pytest.mark.parametrize("N,P", [([1, 8, 8], 1), ([8, 1, 8], 1), ([1, 1, 8], 1), ([2, 1, 4], 1), ([1, 16, 2], 1),

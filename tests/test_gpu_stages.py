@@ -19,7 +19,9 @@ LENGTHS = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096,
            30, 60, 90, 120, 150, 180, 240, 300, 360, 450, 480, 600, 720, 900, 960, 1200, 1440, 1800,
            750, 1500, 1920, 2400, 3000, 3840,
            # round 4: 7 * 2^a (plans.h group O: 28 values per thread, radix 28 = 7 x 4) and 8192
-           14, 28, 56, 112, 224, 448, 896, 1792, 3584, 8192]
+           14, 28, 56, 112, 224, 448, 896, 1792, 3584, 8192,
+           # round 5: the radix plans between 4096 and 8192 (plans.h group Q)
+           4608, 5120, 6144, 7168]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -163,6 +165,63 @@ CHIRPZ = [3, 5, 7, 9, 11, 13, 15, 17, 25, 27, 31, 33, 45, 49, 75, 84, 127, 129, 
           675, 729, 1008, 1023, 1025, 1201, 1537, 2047,
           # round 4: convolution length 8192 -- everything up to 4096 (7-smooth meshes like 2688 = 21 * 128, primes, range ends)
           2049, 2100, 2688, 3125, 3600, 4093, 4095]
+
+
+# round 5: lengths without a radix plan beyond the one-workgroup chirp-z range (complex n > 4096, odd real n > 4096, anything
+# above 8192): Bluestein over a four-step power-of-two transform in a scratch buffer (csrc/bigfft.hip, route 3 of
+# mfft_length_route) -- primes, range ends, composite lengths, M = 16384 ... 2^18
+BIG = [4097, 4099, 5000, 6561, 8191, 8193, 10000, 16385, 30011, 65537, 100003]
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("n", BIG)
+def test_c2c_lengths_through_the_scratch_buffer_fallback(n, prec):
+    """numpy_fft.py:25-37 takes every n: so does mfft_c2c_axis, along every axis, forward and inverse."""
+    from mpifft4py_amd import _lib, fft, ifft
+    assert _lib.load().mfft_length_route(n, 0) == 3
+    rng = np.random.default_rng(n)
+    for axis in (0, 1, 2):
+        shape = [2, 3, 5]
+        shape[axis] = n
+        a = (rng.random(shape) - 0.5 + 1j * (rng.random(shape) - 0.5)).astype(cdtype(prec))
+        got = fft(a, axis=axis)
+        assert orc.rel_l2(got, np.fft.fft(a.astype(np.complex128), axis=axis)) < 2 * TOL[prec], (n, axis)
+        goti = ifft(a, axis=axis)
+        assert orc.rel_l2(goti, np.fft.ifft(a.astype(np.complex128), axis=axis)) < 2 * TOL[prec], (n, axis)
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("n", [4099, 8193, 8194, 10000, 16386, 20001, 65538, 131071])
+def test_rfft_irfft_lengths_through_the_scratch_buffer_fallback(n, prec):
+    from mpifft4py_amd import _lib, rfft, irfft
+    assert _lib.load().mfft_length_route(n, 1) == 3
+    rng = np.random.default_rng(n + 1)
+    a = (rng.random((2, 3, n)) - 0.5).astype(rdtype(prec))
+    ref = np.fft.rfft(a.astype(np.float64), axis=2)
+    got = rfft(a, axis=2)
+    assert got.shape == ref.shape
+    assert orc.rel_l2(got, ref) < 2 * TOL[prec]
+    c = ref.astype(cdtype(prec)).copy()
+    c[..., 0] += 1j * 0.7                      # ignored by c2r
+    if n % 2 == 0:
+        c[..., -1] -= 1j * 0.3
+    back = irfft(c, np.zeros(a.shape, dtype=a.dtype), axis=2)
+    assert orc.rel_l2(back, np.fft.irfft(c.astype(np.complex128), n=n, axis=2)) < 2 * TOL[prec]
+    assert orc.rel_l2(back, a) < 4 * TOL[prec]
+
+
+def test_many_vectors_through_the_scratch_buffer_fallback_in_chunks():
+    """More vectors than the 256 MiB scratch buffer holds at once (M = 16384, 16 bytes: 1024 vectors per chunk): rows in
+    several chunks, and strided columns of one batch wider than the buffer (runs of columns) and of many batches."""
+    from mpifft4py_amd import fft
+    rng = np.random.default_rng(8)
+    n = 4100
+    a = (rng.random((40, 30, n)) - 0.5 + 1j * (rng.random((40, 30, n)) - 0.5))            # 1200 rows
+    assert orc.rel_l2(fft(a, axis=2), np.fft.fft(a, axis=2)) < 2e-10
+    b = np.ascontiguousarray(np.moveaxis(a, 2, 0))                                        # (n, 40, 30): one batch of 1200 columns
+    assert orc.rel_l2(fft(b, axis=0), np.fft.fft(b, axis=0)) < 2e-10
+    c = np.ascontiguousarray(np.moveaxis(a, 2, 1))                                        # (40, n, 30): 40 batches of 30 columns
+    assert orc.rel_l2(fft(c, axis=1), np.fft.fft(c, axis=1)) < 2e-10
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])

@@ -211,3 +211,41 @@ def test_get_subarrays_match_the_reference(golden_dir):
             lists, cds = got[:4], got[4:]
         assert [[list(map(list, b.args())) for b in lst] for lst in lists] == rec["lists"], rec
         assert [[list(c[0]), list(c[1])] for c in cds] == rec["counts_displs"], rec
+
+
+def test_bench_cpu_baseline_cache_is_private_dated_and_versioned(tmp_path, monkeypatch):
+    """bench.py cpu_baseline_cached: the N = 1 run's host timing is reused by an N > 1 run only from this
+    user's 0700 directory, on the same host / core count / numpy / scipy and younger than the limit -- and says so."""
+    import json
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    calls = []
+
+    def fake(n_full, seconds_budget=30.0):
+        calls.append(seconds_budget)
+        return {"value": 0.25 if seconds_budget else 0.2, "unit": "pairs/s", "cores": 8, "kind": "port", "sample": "fake"}
+    monkeypatch.setattr(bench, "cpu_baseline", fake)
+    d1 = bench.cpu_baseline_cached(64, 1)
+    assert d1["value"] == 0.25 and "cached" not in d1
+    cache_dir = os.path.join(str(tmp_path), "mfft-%d" % os.getuid())
+    assert (os.stat(cache_dir).st_mode & 0o777) == 0o700
+    path = os.path.join(cache_dir, "cpu-baseline-64.json")
+    assert os.path.exists(path)
+    d2 = bench.cpu_baseline_cached(64, 8)
+    assert d2["cached"] is True and d2["value"] == 0.25 and "min ago" in d2["sample"] and "_meta" not in d2
+    # too old, another numpy, a directory others can write: each falls back to the bounded sample on rank 0
+    raw = json.load(open(path))
+    for tamper in ({"time": time.time() - 7 * 3600}, {"numpy": "0.0"}):
+        json.dump(dict(raw, _meta=dict(raw["_meta"], **tamper)), open(path, "w"))
+        d3 = bench.cpu_baseline_cached(64, 8)
+        assert "cached" not in d3 and d3["value"] == 0.2 and calls[-1] == 0.0
+    json.dump(raw, open(path, "w"))
+    os.chmod(cache_dir, 0o755)
+    assert "cached" not in bench.cpu_baseline_cached(64, 8)
+    os.chmod(cache_dir, 0o700)
+    assert bench.cpu_baseline_cached(64, 8)["cached"] is True
