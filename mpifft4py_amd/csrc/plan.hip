@@ -240,7 +240,8 @@ struct mfft_plan_s {
   bool zfuse = false;
   bool xpad_on = true;          // xplane_pad(): MFFT_NO_XPAD=1 clears it (A/B runs; must be the same on every rank)
   bool zpitch_on = true;        // zrow_pitch(): MFFT_NO_ZPITCH=1 clears it (likewise)
-  bool pad_align = true;        // pad_pitch(): MFFT_PAD_ALIGN=0 clears it
+  int pad_align = -1;           // pad_pitch(): MFFT_PAD_ALIGN = 0 never, 1 always, unset: where it was measured to pay
+  int pad_align_inv = 1;        // inverse flavour of that route (MFFT_PAD_ALIGN_INV = 1 | 2 | 3, see slab_backward_padded_fused)
   bool xpass_inplace = false;   // MFFT_XPASS_INPLACE=1: the x pass behind an exchange runs in place on the receive buffer (rounds 1 - 3)
   // the same for the fused 3/2-rule pencil transforms: real length M2, the Nf kept columns split into the z chunks
   bool zfuse_pad() const {
@@ -259,10 +260,18 @@ struct mfft_plan_s {
   // (256, 1024, 257) 0.49 -> 0.56 ms; aligned on both sides it would be 0.41, but the result's layout is the caller's) --
   // the y-aligned plan pays the same 0.04 ms in its y pass and wins 0.17 in the x pass.  Only the fused z kernels, only
   // chunks of 64 columns and more, only forward.
+  // Round 5, the x-aligned pencil after all -- for the one case where its y pass gains: chunks whose rows are a multiple of 2^13
+  // bytes (BASELINE config 5: 1024 complex64 columns per rank of the 4 x 2 grid).  Such rows are line-aligned already; what
+  // hurts is that the 2048 rows a y transform gathers then lie a power of two apart (the memory-channel hash folds them onto
+  // few channels): (512, 2048, 1024) axis 1 takes 4.10 ms per rank, 3.82 with the rows one cache line further apart
+  // (profiles/r04_rank_shapes.txt).  The z kernel leaves that line between its rows, the chunk grows by 1.6 %, the y pass
+  // reads the pitch and writes the compact blocks of the second exchange as before (a store-side pitch costs nothing).
   int64_t zrow_pitch(int64_t len, bool forward) const {
-    if (!forward || !zpitch_on || d.decomp != MFFT_PENCIL_Y || !zfuse || d.drop_nyquist || zc.size() < 2 || len < 64) return len;
+    if (!forward || !zpitch_on || !zfuse || d.drop_nyquist || zc.size() < 2 || len < 64) return len;
     const int64_t per_line = (int64_t)(128 / es);
-    return (len + per_line - 1) / per_line * per_line;
+    if (d.decomp == MFFT_PENCIL_Y) return (len + per_line - 1) / per_line * per_line;
+    if (d.decomp == MFFT_PENCIL_X && (len * (int64_t)es) % 8192 == 0) return len + per_line;
+    return len;
   }
   int64_t zsend_elems(int64_t rows) const {      // elements of the forward z exchange's send blocks for `rows` rows
     int64_t t = 0;
@@ -507,8 +516,12 @@ struct mfft_plan_s {
   // one work buffer less and its x passes touch the caller's compact array on the wrong side; here the inverse x pass
   // stores whole lines per y row (its loads straddle), the y pass and the real transform see aligned rows, and the
   // forward x pass tiles the compact OUTPUT and wraps its input columns (ColParams::in_wrap).  MFFT_PAD_ALIGN=0: compact.
+  // Measured (profiles/r05_pad_align_ab.txt, 3/2-rule pair): 1024^3 fp64 45.3 -> 43.9 ms (y passes 8.7 / 7.8 -> 6.9 / 7.0 ms, the x
+  // passes give part of it back: their misaligned side costs 0.3 - 1.1 ms); 768^3 fp64 even; 512^3 fp64 and 1024^3 fp32 LOSE
+  // 2 - 3 % (rows of 4 KiB: the y pass gains less than the x pass pays).  Default: double precision, rows of 8 KiB and more.
   int64_t pad_pitch() const {
-    if (!pad_align || P != 1) return Nf;
+    if (pad_align == 0 || P != 1) return Nf;
+    if (pad_align < 0 && !(prec == MFFT_DOUBLE && Nf * (int64_t)es >= 8192)) return Nf;
     const int64_t line = 128 / (int64_t)es;
     return (Nf + line - 1) / line * line;
   }
@@ -1177,12 +1190,22 @@ int mfft_plan_s::slab_backward_padded_fused(const void* fu, void* u) {
     MFFT_TRY(ensure_work(0, (size_t)(M0 * N1 * Za) * es));
     MFFT_TRY(ensure_work(2, (size_t)(M0 * M1 * Za) * es));
     void *W0 = work[0], *W2 = work[2];
-    MFFT_TRY(stage("bwd_x", 0, [&] {     // one outer batch per y row: compact rows in, pitched rows out
-      return col_pad(fu, W0, M0, true, 1, false, N1, Nf, Nf, plain(N1 * Nf), Za, plain(N1 * Za), sc3 / (double)M0, 0, 0, 1);
-    }));
-    MFFT_TRY(stage("bwd_y", 0, [&] {
-      return col_pad(W0, W2, M1, true, 1, false, M0, Nf, N1 * Za, plain(Za), M1 * Za, plain(Za), 1.0 / (double)M1);
-    }));
+    if (pad_align_inv == 3) {            // the y pass converts: x compact -> compact, y compact -> pitched
+      MFFT_TRY(stage("bwd_x", 0, [&] {
+        return col_pad(fu, W0, M0, true, 1, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf), sc3 / (double)M0);
+      }));
+      MFFT_TRY(stage("bwd_y", 0, [&] {
+        return col_pad(W0, W2, M1, true, 1, false, M0, Nf, N1 * Nf, plain(Nf), M1 * Za, plain(Za), 1.0 / (double)M1);
+      }));
+    } else {
+      MFFT_TRY(stage("bwd_x", 0, [&] {     // one outer batch per y row: compact rows in, pitched rows out
+        return col_pad(fu, W0, M0, true, 1, false, N1, Nf, Nf, plain(N1 * Nf), Za, plain(N1 * Za), sc3 / (double)M0, 0, 0,
+                       pad_align_inv == 2 ? -1 : 1);
+      }));
+      MFFT_TRY(stage("bwd_y", 0, [&] {
+        return col_pad(W0, W2, M1, true, 1, false, M0, Nf, N1 * Za, plain(Za), M1 * Za, plain(Za), 1.0 / (double)M1);
+      }));
+    }
     MFFT_TRY(stage("bwd_z", 0, [&] { return c2r_rows(W2, u, M0 * M1, M2, Za, M2, 1.0 / (double)M2, (int)Nf); }));
     return 0;
   }
@@ -2072,7 +2095,8 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   p->xpass_inplace = getenv("MFFT_XPASS_INPLACE") && atoi(getenv("MFFT_XPASS_INPLACE")) != 0;
   if (getenv("MFFT_P1_XPAD")) p->p1_xpad_lines = atoi(getenv("MFFT_P1_XPAD"));
   p->zpitch_on = !(getenv("MFFT_NO_ZPITCH") && atoi(getenv("MFFT_NO_ZPITCH")) != 0);
-  if (getenv("MFFT_PAD_ALIGN")) p->pad_align = atoi(getenv("MFFT_PAD_ALIGN")) != 0;
+  if (getenv("MFFT_PAD_ALIGN")) p->pad_align = atoi(getenv("MFFT_PAD_ALIGN")) != 0 ? 1 : 0;
+  if (getenv("MFFT_PAD_ALIGN_INV")) p->pad_align_inv = atoi(getenv("MFFT_PAD_ALIGN_INV"));
   const int P = p->P;
   if (p->r2c && p->N2 % 2) return set_error(MFFT_ERR_UNSUPPORTED, "odd N[2]=%lld is not supported for R2C", (long long)p->N2);
   if (desc->decomp == MFFT_SLAB) {

@@ -233,8 +233,15 @@ def pencil(rank, P, N, A, align, P1=None, pipeline=1, relay=False):
     lens[-1] += 1
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
     pitch = [c // (m * n * ES) for c in s0["scount"]]
-    for ln, pt in zip(lens, pitch):                           # (y-aligned only: plan.hip zrow_pitch says why)
-        assert pt == (ln if ln < 64 or align == "X" else -(-ln // 8) * 8), (ln, pt)
+
+    def zpitch(ln):       # plan.hip zrow_pitch: y-aligned: whole lines; x-aligned (round 5): one more line for rows of k * 8 KiB
+        if ln < 64:
+            return ln
+        if align == "Y":
+            return -(-ln // 8) * 8
+        return ln + 8 if (ln * ES) % 8192 == 0 else ln
+    for ln, pt in zip(lens, pitch):
+        assert pt == zpitch(ln), (ln, pt)
     bufs = []
     for ln, st, pt in zip(lens, starts, pitch):
         blk = np.zeros((m, n, pt), dtype=complex)
@@ -243,16 +250,20 @@ def pencil(rank, P, N, A, align, P1=None, pipeline=1, relay=False):
     send = np.concatenate(bufs)
     q = lay.complex_shape(rank)[2]
     qp = s0["rcount"][0] // (m * n * ES)                       # row pitch of the received blocks
-    assert qp == (q if q < 64 or align == "X" else -(-q // 8) * 8) and all(c == m * n * qp * ES for c in s0["rcount"])
+    assert qp == zpitch(q) and all(c == m * n * qp * ES for c in s0["rcount"])
     r = exchange(rank, s0, send, sum(s0["rcount"]), 0, True)
     blocks = r.reshape(len(lens), m, n, qp)
     s1 = _lib.exchange_schedule(N, P, rank, dec, 1, True, p1=P1 or 0)
     if align == "X":
         b = np.fft.fft(np.concatenate(list(blocks[..., :q]), axis=1), axis=1)     # (m, N1, q): the y pass reads the pitched rows
         assert s1["peers"] == lay.comm0_members(rank)
-        send = np.concatenate([b[:, l * N1_1:(l + 1) * N1_1, :].ravel() for l in range(lay.P1)])
-        r = exchange(rank, s1, send, sum(s1["rcount"]), 1, True)
-        fu = np.fft.fft(r.reshape(N[0], N1_1, q), axis=0)
+        SX = s1["scount"][0] // (m * ES)                      # x-row pitch of the blocks: N1_1 * q (+ a line: plan.hip xplane_pad)
+        assert SX in (N1_1 * q, N1_1 * q + 8)
+        blk = np.zeros((lay.P1, m, SX), dtype=complex)
+        for l in range(lay.P1):
+            blk[l, :, :N1_1 * q] = b[:, l * N1_1:(l + 1) * N1_1, :].reshape(m, N1_1 * q)
+        r = exchange(rank, s1, blk.ravel(), sum(s1["rcount"]), 1, True)
+        fu = np.fft.fft(r.reshape(N[0], SX)[:, :N1_1 * q].reshape(N[0], N1_1, q), axis=0)
     else:
         # the x pass runs in place on (N0, n, qp) -- the unused columns ride along -- and the pitch travels on
         b = np.fft.fft(np.concatenate(list(blocks), axis=0), axis=0)              # (N0, n, qp)
@@ -429,6 +440,12 @@ def main():
         for align in ("X", "Y"):
             for pipeline in (1, 0):
                 pencil(rank, P, Nq, Aq, align, pipeline=pipeline)
+        # x-aligned, chunks whose rows are 8 KiB (512 complex128 columns): one cache line between the rows (BASELINE config 5's
+        # y pass reads rows a power of two apart otherwise); the Nyquist-holding rank's 513 columns stay compact
+        Nz = [16, 32, 2048]
+        Az = np.random.default_rng(2033).random(Nz)
+        for pipeline in (1, 0):
+            pencil(rank, P, Nz, Az, "X", pipeline=pipeline)
         # relay striping of the sub-group exchanges (IPC transport): two-hop schedule executed over gloo
         Nr = [32, 64, 128]                                 # messages large enough for 4 KiB stripes
         Ar = np.random.default_rng(2028).random(Nr)

@@ -149,7 +149,7 @@ def test_slab_padded_one_rank_line_aligned_intermediates(N, prec, monkeypatch):
     C0[:, :, -1] = 0
     want = orc.slab_r2c_backward_padded(orc.scatter_complex(C0, orc.SlabLayout(N, 1)), N, prec)[0]
     got = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "0"):                         # forced on (the default takes it for double precision rows of 8 KiB only) / off
         monkeypatch.setenv("MFFT_PAD_ALIGN", mode)
         F = Slab_R2C(np.array(N), L, SelfComm(0), prec)
         c = C0.copy()

@@ -151,12 +151,13 @@ def test_dealias_filter(prec):
 
 
 def test_unsupported_length_raises():
+    """Lengths run to 2^20 (include/mpifft4py_amd.h mfft_length_route); beyond that the call fails loudly."""
     import mpifft4py_amd as m
     from mpifft4py_amd import _lib
-    with pytest.raises(_lib.MfftError):          # chirp-z needs 2n-1 <= 8192
-        m.fft(np.zeros((4097, 4, 4), dtype=np.complex128), axis=0)
     with pytest.raises(_lib.MfftError):
-        m.rfft(np.zeros((2, 2, 4099)), axis=2)
+        m.fft(np.zeros(((1 << 20) + 1, 1, 1), dtype=np.complex64), axis=0)
+    with pytest.raises(_lib.MfftError):
+        m.rfft(np.zeros((1, 1, (1 << 20) + 2), dtype=np.float32), axis=2)
 
 
 # lengths without a radix plan: chirp-z kernels (csrc/fft_chirpz.h); primes, prime powers, 7-smooth,
