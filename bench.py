@@ -537,6 +537,35 @@ def main():
     def cand_name(c, pull):
         return comm_name(c) + (PULL_NAMES.get(pull, "") if pull is not None else "")
 
+    def link_model(n_, esz_, P_, decomp_):
+        """What the node's point-to-point links allow for ONE cube over P GPUs ("What to expect"): every
+        transform sends (P - 1) / P of a rank's C / P bytes, 1 / P of it to each peer over that pair's own link -- the slab
+        (or an 8 x 1 pencil grid) all P - 1 links at once, the reference's default 4 x 2 pencil grid inside groups of 4 and 2
+        (one link carries half of a rank's spectrum).  With the assumed rate per link and direction and the transforms at
+        1 / P of the measured one-GPU pair: the speed-up over one GPU with the exchange fully hidden behind the transforms,
+        and with nothing hidden.  BASELINE's north star asks for >= 6 x at 8 GPUs on the pencil path: at 1024^3 these
+        links hold about 5.6 x for the slab and less for the 4 x 2 grid, whatever the software does -- reported here so that
+        a scaling curve is read against it."""
+        if P_ <= 1:
+            return None
+        link_gbs, t1_ms = 77.0, {"f64": 19.6, "f32": 10.2}["f64" if esz_ == 8 else "f32"] * (n_ / 1024.0) ** 3
+        Cb = 2.0 * esz_ * n_ * n_ * (n_ // 2 + 1)
+        per_peer = Cb / P_ / P_
+        if decomp_ == "slab":
+            busiest = per_peer                                   # every link carries one peer's chunk
+        else:
+            p1 = {2: 1, 4: 2, 8: 4, 16: 4}.get(P_, 1)
+            p2 = P_ // p1
+            # two exchanges one after the other, each inside its group: one peer's share of each (no relay striping)
+            busiest = (Cb / P_ / p1 if p1 > 1 else 0.0) + (Cb / P_ / p2 if p2 > 1 else 0.0)
+        xchg_ms = 2.0 * busiest / (link_gbs * 1e9) * 1e3          # forward + inverse
+        fft_ms = t1_ms / P_
+        return {"assumed_GBps_per_link_and_direction": link_gbs, "one_gpu_pair_ms": t1_ms,
+                "bytes_over_busiest_link_per_transform": busiest, "exchange_ms_per_pair": xchg_ms,
+                "transform_ms_per_pair_per_rank": fft_ms,
+                "speedup_ceiling_exchange_hidden": t1_ms / max(fft_ms, xchg_ms),
+                "speedup_ceiling_nothing_hidden": t1_ms / (fft_ms + xchg_ms)}
+
     def headline(mres, tuning):
         dt, stages, rt_err = mres["dt"], mres["stages"], mres["rt_err"]
         esz = 8 if args.precision == "double" else 4
@@ -571,7 +600,8 @@ def main():
                        "whole_path_hbm_GBs_per_gpu": alg_pair / world / (ms * 1e-3) / 1e9,
                        "whole_path_frac_of_8TBs": alg_pair / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "whole_path_frac_of_6.29TBs_copy_ceiling": alg_pair / world / (ms * 1e-3) / 1e9 / 6290.0,
-                       "stage_ms": {k_: v[0] / max(v[1], 1) for k_, v in sorted(stages.items())}},
+                       "stage_ms": {k_: v[0] / max(v[1], 1) for k_, v in sorted(stages.items())},
+                       "xgmi_link_model": link_model(n, esz, world, args.decomp)},
             "roofline": {"bound": "hbm", "kernel": "col_fft (strided-axis c2c, stages *_x/*_y)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

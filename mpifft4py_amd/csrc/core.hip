@@ -232,7 +232,8 @@ int launch_col(const ColArgs& a, hipStream_t s) {
     b.elem = (int)elem_bytes(a.prec, true); b.scale = a.scale; b.prec = a.prec;
     return launch_box_copy(b, s);
   }
-  if (a.n >= 65536) return set_error(MFFT_ERR_UNSUPPORTED, "transform length %d too large", a.n);
+  if (a.n >= 65536)      // beyond the radix kernels' 16-bit row arithmetic: the scratch-buffer fallback or nothing
+    return big_length_ok(a.n) ? big_col(a, s) : set_error(MFFT_ERR_UNSUPPORTED, "transform length %d too large", a.n);
   if (a.ncols >= (1ll << 31)) return set_error(MFFT_ERR_UNSUPPORTED, "too many columns");
   // non-temporal variant only when every row segment of the tile is a whole, private L2 line
   const int64_t per_line = 128 / (int64_t)elem_bytes(a.prec, true);

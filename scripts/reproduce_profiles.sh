@@ -46,6 +46,12 @@ run() {
     r04_xpass_stride_map.txt) (cd scripts && python xpass_stride_map.py 1024 && python xpass_stride_map.py 2048 && python xpass_pad_sweep.py) ;;
     r04_comm_priority.txt) bash scripts/r04_priority.sh ;;
     r04_size_sweep.txt) bash scripts/size_sweep.sh ;;
+    r05_size_sweep.txt) bash scripts/r05_final.sh gate ;;
+    r05_final_*) bash scripts/r05_final.sh prof ;;
+    r05_radix7_c2r_bisect.txt|r05_r03_vs_head_ab.txt) echo "(needs reduced libraries of old commits under _bisect/: see the header of scripts/r05_gpu1.sh)" ;;
+    r05_alloc_shift_probe.txt) bash scripts/r05_gpu2.sh ;;
+    r05_pad_align_ab.txt|r05_pad_align_bits.txt) bash scripts/r05_gpu3.sh; bash scripts/r05_gpu4.sh ;;
+    r05_config5_zpitch.txt) python scripts/config5_full.py; MFFT_NO_ZPITCH=1 python scripts/config5_full.py ;;
     r04_rank_shapes.txt) python scripts/rank_shapes.py ;;
     r04_ypass_pitch.txt) python scripts/ypass_pitch_ab.py ;;
     r04_col3_1536.txt) bash scripts/r04_col3.sh ;;

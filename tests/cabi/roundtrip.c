@@ -8,7 +8,7 @@
  *   - the spectrum against the analytic coefficients of the plane waves (numpy's unnormalised convention),
  *   - the round trip against the input,
  *   - that the input array was not modified,
- *   - the error path (unsupported length -> negative status + message).
+ *   - the error path (unsupported length, beyond 2^20 -> negative status + message).
  */
 #include <math.h>
 #include <stdio.h>
@@ -97,9 +97,9 @@ int main(int argc, char** argv) {
   printf("mesh %lld x %lld x %lld: max |spectrum - analytic| / N = %.3e, max |roundtrip - u| = %.3e, input untouched: %s\n",
          (long long)n0, (long long)n1, (long long)n2, worst / ntot, rt, untouched ? "yes" : "NO");
 
-  /* error path: a length beyond the chirp-z range must fail with a message, not crash */
+  /* error path: a length beyond the supported range (1 ... 2^20, mfft_length_route) must fail with a message, not crash */
   mfft_plan_desc bad = d;
-  bad.n[0] = 4099;
+  bad.n[0] = (1 << 20) + 2;
   mfft_plan_t p2 = NULL;
   const int rc = mfft_plan_create(comm, &bad, &p2);
   const int err_ok = rc < 0 && strlen(mfft_last_error()) > 0 && p2 == NULL;

@@ -159,7 +159,13 @@ def test_slab_padded_one_rank_line_aligned_intermediates(N, prec, monkeypatch):
         assert orc.rel_l2(up, want) < 4 * TOL[prec], (mode, orc.rel_l2(up, want))
         assert orc.rel_l2(fu, C0) < 4 * TOL[prec], (mode, orc.rel_l2(fu, C0))
         got[mode] = (up.copy(), fu.copy())
-    assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])
+    if prec == "double":
+        assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])
+    else:
+        # single precision: the two routes put different columns into the kernels' ragged-lanes path (per-element loads and
+        # stores for the last, partial tile of a row), which hipcc contracts into fused multiply-adds differently from the
+        # full-lanes path: 1-ulp differences in some rows ([32,64,128]: 12 of 48 x rows, max 3.6e-7; the other meshes: none)
+        assert orc.rel_l2(got["1"][0], got["0"][0]) < 1e-6 and orc.rel_l2(got["1"][1], got["0"][1]) < 1e-6
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
@@ -1004,10 +1010,10 @@ def test_pencil_non_power_of_two_meshes(N, P, align):
 
 def test_unsupported_mesh_raises_cleanly():
     from mpifft4py_amd import SelfComm, Slab_R2C, _lib
-    with pytest.raises(_lib.MfftError):          # beyond the chirp-z range (2n-1 <= 8192)
-        Slab_R2C(np.array([4098, 8, 8]), L, SelfComm(0), "double")
+    with pytest.raises(_lib.MfftError):          # beyond the supported lengths (1 ... 2^20: mfft_length_route)
+        Slab_R2C(np.array([(1 << 20) + 2, 2, 2]), L, SelfComm(0), "double")
     with pytest.raises(_lib.MfftError):
-        Slab_R2C(np.array([8, 8, 8196]), L, SelfComm(0), "double")
+        Slab_R2C(np.array([2, 2, (1 << 21) + 4]), L, SelfComm(0), "double")
     with pytest.raises(_lib.MfftError):          # odd real axis
         Slab_R2C(np.array([8, 8, 9]), L, SelfComm(0), "double")
 
