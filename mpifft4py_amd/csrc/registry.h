@@ -124,17 +124,34 @@ template <class S, typename T, bool SPLIT, bool C2R = false> constexpr int row_r
 template <class S, typename T, bool C2R = false> constexpr int row_rows() { return row_rows_n<S, T, row_split<S, T, C2R>(), C2R>(); }
 template <class S, typename T, bool C2R = false> constexpr bool row_twlds() { return S::NP > 1 && !row_lean<S, T, C2R>(); }
 
+#ifndef MFFT_COL_OCC_R5
+#define MFFT_COL_OCC_R5 1
+#endif
 // Workgroups per CU the strided kernel's REGISTER allocation must leave room for (0: whatever the compiler takes).
 // 1152 in double precision runs 768 threads with ~88 VGPRs: one register more than two workgroups per CU allow
 // (6 waves per SIMD x 85); capped, both fit (LDS 2 x 72 KiB) and one's loads overlap the other's passes.
 // Single precision (kbench3 f32long, profiles/r02_kbench3_long_lengths.txt): 1152 (8x8x3x3x2, 768 threads) with the cap
 // for two workgroups 3.7 - 3.9 -> 2.9 - 3.0 ms per pass; 1536 as 64-byte tiles (8 columns, 512 threads, 48 KiB) with the
 // cap for three 7.9 - 8.7 -> 7.3 - 7.8 ms (the same tiling changes nothing in double precision).
+// Round 5: scripts/kernel_regs.py over every strided kernel -- which plans hold fewer workgroups per CU by REGISTERS than their
+// LDS would admit, and by how little?  Capped and measured against the uncapped library in one session
+// (profiles/r05_col_occupancy_caps.txt, pairs):  single precision 720 (30 values per thread, 384 threads: 110 -> 94 VGPRs, no
+// scratch, THREE workgroups) 4.22 / 4.27 -> 4.13 / 3.97 ms;  single precision 2304 (768 threads: 84 -> 80, 16 bytes of scratch,
+// two workgroups) 170.7 -> 163.6 ms (y passes 29.6 / 32.3 -> 26.7 / 27.3): kept.  1200 / 2400 (30 values, 320 / 640 threads: 178
+// -> 168 VGPRs in double precision with 36 bytes of scratch, 115 -> 89 in single with none; two workgroups fit their 75 KiB
+// of split exchange): double precision 42.7 / 43.0 -> 43.3 / 42.0 (nothing), single precision 24.6 / 23.9 -> 24.8 / 25.4 and
+// 281 -> 288 (worse): NOT kept -- a second workgroup does not help these five-pass kernels, whatever it is they wait for.
+// (768 and 750 looked the same but their LDS twiddle tables leave room for two workgroups only, which their registers
+// allow already; 1440 / 1536 / 1792 need the four-round exchange for a second workgroup, which costs 450 - 560 bytes of
+// scratch under the cap: round 3's result stands.)
 template <class S, typename T> constexpr int col_wgs() {
   if (sizeof(T) == 8) return ((S::N == 1152 && S::E == 12) || (S::N == 512 && S::E == 4)) ? 2 : 0;
-  return (S::N == 1152 && S::E == 24) ? 2 : (S::N == 1536 && S::E == 24) ? 3 : 0;
+  if (S::N == 1152 && S::E == 24) return 2;
+  if (S::N == 1536 && S::E == 24) return 3;
+  if (MFFT_COL_OCC_R5 && S::N == 2304 && S::E == 24) return 2;
+  if (MFFT_COL_OCC_R5 && S::N == 720 && S::E == 30) return 3;
+  return 0;
 }
-
 // ---- generic __global__ wrapper + launch thunks ------------------------------
 template <class K, class P>
 __global__ __launch_bounds__(K::THREADS) void mfft_kern(P p) {
@@ -185,10 +202,18 @@ KernelEntry make_entry(int family, int n, int inv, int tile, const char* name) {
   return e;
 }
 
+// (the masked-load / pruned 2/3-rule variants of the plans capped in round 5 hold 10 - 40 registers more than the plain
+// kernels: under the same cap they would spill 100 - 170 bytes, so they keep the compiler's allocation)
+template <class S, typename T> constexpr int col_wgs_mask() {
+  constexpr bool r5 = sizeof(T) == 4 && ((S::N == 720 && S::E == 30) || (S::N == 2304 && S::E == 24));
+  return r5 ? 0 : col_wgs<S, T>();
+}
+
 template <class S, typename T>
 void register_col(const char* name) {
   auto& reg = kernel_registry();
   constexpr int W = col_wgs<S, T>();
+  constexpr int WM = col_wgs_mask<S, T>();
   constexpr int C = (sizeof(T) == 4 && S::N == 1536 && W == 3) ? 8 : col_cols<S, T>();      // see col_wgs
   constexpr bool CT = col_twlds<S, T>();
   constexpr bool CS = col_split<S, T>() || (W > 1 && (long long)S::N * C * (int)sizeof(cx<T>) * W > 163840);
@@ -202,19 +227,19 @@ void register_col(const char* name) {
     reg.back().pad = 2;
   }
   // 2/3-rule: inverse transform with the dealias mask applied on load (pad = 5)
-  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 3>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
+  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 3>, ColParams<T>, S, T, WM>(FAM_COL, S::N, 1, C, name));
   reg.back().pad = 5;
   if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {
-    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 3>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
+    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 3>, ColParams<T>, S, T, WM>(FAM_COL, S::N, 1, C, name));
     reg.back().pad = 5;
     reg.back().nt = 1;
     reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;
   }
   // pruned 2/3-rule passes (pad = 6)
-  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 4>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
+  reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 4>, ColParams<T>, S, T, WM>(FAM_COL, S::N, 1, C, name));
   reg.back().pad = 6;
   if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {
-    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 4>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
+    reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 4>, ColParams<T>, S, T, WM>(FAM_COL, S::N, 1, C, name));
     reg.back().pad = 6;
     reg.back().nt = 1;
     reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;
@@ -338,11 +363,31 @@ template <class S, typename T> constexpr int c2r_threads() { return real_threads
 template <class S, typename T> constexpr int r2c_rows() { return real_rows<S, T, false>(); }
 template <class S, typename T> constexpr int r2c_threads() { return real_threads<S, T, false>(); }
 
+// Round 5, the census of scripts/kernel_regs.py applied to the contiguous-axis kernels: plans whose PLAIN kernels sit one to
+// fourteen registers above the next occupancy step while their LDS admits the extra workgroup, and which compile under the
+// cap with little or no scratch.  Candidates (family: 0 c2c rows, 1 r2c, 2 c2r): single precision c2r of real 2048 (130 ->
+// 128 VGPRs, no scratch: four workgroups of 256 threads instead of three), c2c rows of 720 / 1200 in single precision (172 -
+// 178 -> 168, none: five workgroups of 120 threads instead of four), rows and r2c of 500 in double precision (182 -> 168: none /
+// 20 bytes, six instead of four), the 20-values rows of 800 / 2000 in double precision (130 - 132 -> 128: 12 - 16 bytes, four
+// instead of three).  Measured: profiles/r05_row_occupancy_caps.txt; MFFT_ROW_OCC_R5=0 builds without them.
+#ifndef MFFT_ROW_OCC_R5
+#define MFFT_ROW_OCC_R5 1
+#endif
+template <class S, typename T, int FAM> constexpr int row_occ_r5(int threads) {
+  if (!MFFT_ROW_OCC_R5) return 0;
+  if (sizeof(T) == 4 && FAM == 2 && S::N == 1024 && S::E == 16) return 1024 / threads;
+  if (sizeof(T) == 4 && FAM == 0 && (S::N == 720 || S::N == 1200) && S::E == 30) return 768 / threads;       // three waves per SIMD
+  if (sizeof(T) == 8 && FAM != 2 && S::N == 500 && S::E == 20) return 768 / threads;
+  if (sizeof(T) == 8 && FAM == 0 && (S::N == 800 || S::N == 2000) && S::E == 20) return 1024 / threads;
+  return 0;
+}
+
 template <class S, typename T>
 void register_rows(const char* name) {
   auto& reg = kernel_registry();
   constexpr int R = row_rows<S, T>();
   constexpr int WO = row_occ_wgs<S, T>(S::TPT * R);
+  constexpr int WO5 = row_occ_r5<S, T, 0>(S::TPT * R) ? row_occ_r5<S, T, 0>(S::TPT * R) : WO;      // the plain kernels only
   constexpr bool WPC = c2r_wave_packed<S, T>();
   constexpr bool WPR = r2c_wave_packed<S, T>();
   // c2r: only where the mirrored bins come through wave shuffles (threads per transform a power of two up to 64, or the
@@ -359,12 +404,14 @@ void register_rows(const char* name) {
   constexpr int RC = c2r_rows<S, T>();            // the c2r kernels may differ
   constexpr int RR = r2c_rows<S, T>();            // ... and the r2c kernels (wave-packed layout)
   constexpr int WOR = row_occ_wgs<S, T>(r2c_threads<S, T>());
+  constexpr int WOR5 = row_occ_r5<S, T, 1>(r2c_threads<S, T>()) ? row_occ_r5<S, T, 1>(r2c_threads<S, T>()) : WOR;
+  constexpr int WOC5 = row_occ_r5<S, T, 2>(c2r_threads<S, T>());       // plain c2r only
   constexpr bool SC = row_split<S, T, true>();
   constexpr bool RTC = row_twlds<S, T, true>();
-  reg.push_back(make_entry<RowFft<S, T, R, false, RT, false, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 0, R, name));
-  reg.push_back(make_entry<RowFft<S, T, R, true, RT, false, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 1, R, name));
-  reg.push_back(make_entry<R2CFft<S, T, RR, RT, false, false, SP, WPR>, RealParams<T>, S, T, WOR>(FAM_R2C, 2 * S::N, 0, RR, name));
-  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, false, SC, WPC>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
+  reg.push_back(make_entry<RowFft<S, T, R, false, RT, false, SP>, RowParams<T>, S, T, WO5>(FAM_ROW, S::N, 0, R, name));
+  reg.push_back(make_entry<RowFft<S, T, R, true, RT, false, SP>, RowParams<T>, S, T, WO5>(FAM_ROW, S::N, 1, R, name));
+  reg.push_back(make_entry<R2CFft<S, T, RR, RT, false, false, SP, WPR>, RealParams<T>, S, T, WOR5>(FAM_R2C, 2 * S::N, 0, RR, name));
+  reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, false, SC, WPC>, RealParams<T>, S, T, (WOC5 ? WOC5 : WOC)>(FAM_C2R, 2 * S::N, 1, RC, name));
   // pencil decompositions: the z-chunk pack / unpack fused into the stores / loads (pad = 4)
   reg.push_back(make_entry<RowFft<S, T, R, false, RT, true, SP>, RowParams<T>, S, T, WO>(FAM_ROW, S::N, 0, R, name));
   reg.back().pad = 4;
