@@ -17,7 +17,10 @@
 //     X[k]   = z[k] c[k] scale                                                                   scatter kernel
 //
 // -- 8 launches and ~10 passes over the scratch per batch of vectors, against 1 launch and 2 passes of a radix plan: a
-// completeness path (0.05 - 0.1 of the roofline), not a fast one.  Real transforms go through the complex one (r2c: imaginary
+// completeness path (0.05 - 0.1 of the roofline), not a fast one.
+// COMPOSITE lengths n = n1 n2 whose factors both have radix plans (16384 = 128 x 128, 10000 = 80 x 125, 65536, 2^20 ...) skip
+// Bluestein: gather, the three launches of the four-step transform at length n itself (table W_n^(m2 k1)), and a scatter
+// that reads bin k1 + n1 k2 from [k1][k2] -- 5 launches, ~6 passes.  Real transforms go through the complex one (r2c: imaginary
 // parts zero, the first n/2 + 1 bins stored; c2r: Hermitian extension on load, real parts stored; the imaginary parts of
 // bins 0 and n/2 are ignored as numpy's irfft ignores them).  Inverse transforms use the swap identity of fft_core.h.
 // Not offered here: the fused 3/2-rule / 2/3-rule passes and the z-chunked real kernels (their callers ask
@@ -81,20 +84,24 @@ __global__ void bz_gather(const void* in, cx<T>* scratch, const cx<T>* chirp, Ve
       x = static_cast<const cx<T>*>(in)[vec_off(map, v, m)];
     }
     if (INV) x = swapri(x);
-    x = x * chirp[m];
+    if (chirp) x = x * chirp[m];
   }
   scratch[v * (i64)M + m] = x;
 }
 
 // out(v, k) = scratch[v][k] * chirp[k] * scale
+// (perm1 > 0: the composite route -- bin k = k1 + perm1 * k2 sits at [k1][k2] = k1 * (M / perm1) + k2; no chirp there)
 template <typename T, int MODE, bool INV>
 __global__ void bz_scatter(const cx<T>* scratch, void* out, const cx<T>* chirp, VecMap map, i64 nvec, int n, int M, int nout,
-                           T scale, bool vfast) {
+                           T scale, bool vfast, int perm1) {
   const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nvec * (i64)nout) return;
   i64 v, k;
   bz_index(t, nvec, nout, vfast, &v, &k);
-  cx<T> x = scratch[v * (i64)M + k] * chirp[k];
+  i64 src = k;
+  if (perm1 > 0) { const i64 k2 = k / perm1, k1 = k - k2 * perm1; src = k1 * (M / perm1) + k2; }
+  cx<T> x = scratch[v * (i64)M + src];
+  if (chirp) x = x * chirp[k];
   if (INV) x = swapri(x);
   x = mfft::scale(x, scale);
   if constexpr (MODE == BZ_C2R) static_cast<T*>(out)[vec_off(map, v, k)] = x.x;
@@ -112,6 +119,7 @@ __global__ void bz_mul(cx<T>* z, const cx<T>* table, i64 count, int M) {
 }
 
 struct BigTables {
+  bool composite = false;    // M = n = M1 * M2 with radix plans for both factors: no chirp, no filter
   int M = 0, M1 = 0, M2 = 0;
   void* chirp = nullptr;     // c[m], m < n
   void* step = nullptr;      // W_M^(m2 k1) at [k1 * M2 + m2]
@@ -155,8 +163,36 @@ int big_forward(void* z, i64 nvec, const BigTables& t, int prec, bool inverse, h
   return 0;
 }
 
+// n = n1 * n2 with a strided radix plan of length n1 and a contiguous one of length n2 (the most balanced such pair), or 0
+int composite_split(int n, int prec) {
+  int best = 0;
+  for (int n2 = 2; (long long)n2 * n2 <= (long long)n * 8192 && n2 <= 8192; ++n2) {
+    if (n % n2) continue;
+    const int n1 = n / n2;
+    if (n1 < 2 || n1 > 8192 || !radix_plan_exists(0, n1, prec) || !radix_plan_exists(1, n2, prec)) continue;
+    auto skew = [](int a, int b) { return a > b ? (double)a / b : (double)b / a; };
+    if (!best || skew(n1, n2) < skew(n / best, best)) best = n2;
+  }
+  return best;
+}
+
 template <typename T>
 int build_tables(int n, int prec, BigTables* t) {
+  const long double pi = 3.141592653589793238462643383279503L;
+  if (const int n2 = composite_split(n, prec)) {
+    t->composite = true;
+    t->M = n; t->M2 = n2; t->M1 = n / n2;
+    std::vector<cx<T>> step((size_t)n);
+    for (int k1 = 0; k1 < t->M1; ++k1)
+      for (int m2 = 0; m2 < t->M2; ++m2) {
+        const long long q = ((long long)k1 * m2) % n;
+        const long double a = 2.0L * pi * (long double)q / (long double)n;
+        step[(size_t)k1 * t->M2 + m2] = mk<T>((T)cosl(a), (T)(-sinl(a)));
+      }
+    MFFT_HIP(hipMalloc(&t->step, step.size() * sizeof(cx<T>)));
+    MFFT_HIP(hipMemcpy(t->step, step.data(), step.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+    return 0;
+  }
   int M = 2;
   while (M < 2 * n - 1) M *= 2;
   int lg = 0;
@@ -164,7 +200,6 @@ int build_tables(int n, int prec, BigTables* t) {
   t->M = M;
   t->M1 = 1 << ((lg + 1) / 2);
   t->M2 = M / t->M1;
-  const long double pi = 3.141592653589793238462643383279503L;
   auto c = build_chirp<T>(n);
   std::vector<cx<T>> step((size_t)M), b((size_t)M, mk<T>((T)0, (T)0));
   for (int k1 = 0; k1 < t->M1; ++k1)
@@ -258,13 +293,16 @@ int run_big_t(const void* in, void* out, const VecMap& imap, const VecMap& omap,
       hipLaunchKernelGGL((bz_gather<T, MODE, false>), dim3(nblocks(gcount)), dim3(256), 0, s, inp, static_cast<cx<T>*>(z), chirp, im, nv, n, t.M, valid, vfast);
     MFFT_HIP(hipGetLastError());
     MFFT_TRY(big_forward(z, nv, t, prec, false, s));
-    hipLaunchKernelGGL((bz_mul<T, false>), dim3(nblocks(gcount)), dim3(256), 0, s, static_cast<cx<T>*>(z), static_cast<const cx<T>*>(t.bhat), gcount, t.M);
-    MFFT_HIP(hipGetLastError());
-    MFFT_TRY(big_forward(z, nv, t, prec, true, s));
+    if (!t.composite) {
+      hipLaunchKernelGGL((bz_mul<T, false>), dim3(nblocks(gcount)), dim3(256), 0, s, static_cast<cx<T>*>(z), static_cast<const cx<T>*>(t.bhat), gcount, t.M);
+      MFFT_HIP(hipGetLastError());
+      MFFT_TRY(big_forward(z, nv, t, prec, true, s));
+    }
+    const int perm1 = t.composite ? t.M1 : 0;
     if (inverse)
-      hipLaunchKernelGGL((bz_scatter<T, MODE, true>), dim3(nblocks(scount)), dim3(256), 0, s, static_cast<const cx<T>*>(z), outp, chirp, om, nv, n, t.M, nout, (T)scale, vfast);
+      hipLaunchKernelGGL((bz_scatter<T, MODE, true>), dim3(nblocks(scount)), dim3(256), 0, s, static_cast<const cx<T>*>(z), outp, chirp, om, nv, n, t.M, nout, (T)scale, vfast, perm1);
     else
-      hipLaunchKernelGGL((bz_scatter<T, MODE, false>), dim3(nblocks(scount)), dim3(256), 0, s, static_cast<const cx<T>*>(z), outp, chirp, om, nv, n, t.M, nout, (T)scale, vfast);
+      hipLaunchKernelGGL((bz_scatter<T, MODE, false>), dim3(nblocks(scount)), dim3(256), 0, s, static_cast<const cx<T>*>(z), outp, chirp, om, nv, n, t.M, nout, (T)scale, vfast, perm1);
     MFFT_HIP(hipGetLastError());
   }
   return 0;
@@ -289,9 +327,9 @@ bool big_length_ok(int64_t n) { return n >= 2 && n <= MFFT_BIG_MAX_LENGTH; }
 int big_col(const ColArgs& a, hipStream_t s) {
   if (a.pad || a.mask || a.band.on || a.in_wrap)
     return set_error(MFFT_ERR_UNSUPPORTED, "length %d has no radix plan: the fused 3/2-rule / 2/3-rule passes are not available for it", a.n);
-  int M = 2;
-  while (M < 2 * a.n - 1) M *= 2;
-  const size_t per_vec = (size_t)M * elem_bytes(a.prec, true);
+  BigTables tb;
+  MFFT_TRY(tables_for(a.n, a.prec, &tb));
+  const size_t per_vec = (size_t)tb.M * elem_bytes(a.prec, true);
   const i64 per_outer = a.ncols;
   i64 outers = std::max<i64>(1, (i64)(BIG_SCRATCH_BYTES / per_vec) / per_outer);     // whole outer batches per call
   for (i64 o0 = 0; o0 < a.nouter; o0 += outers) {

@@ -72,6 +72,10 @@ bool length_supported(int64_t n, bool real_transform) {
   return n == 1 || find_kernel(FAM_COL, (int)n, MFFT_DOUBLE, 0) != nullptr ||
          find_chirpz(FAM_COLZ, (int)n, MFFT_DOUBLE, 0) != nullptr || big_length_ok(n);
 }
+bool radix_plan_exists(int contiguous, int64_t n, int prec) {
+  if (n < 2 || n >= 65536) return false;
+  return find_kernel(contiguous ? FAM_ROW : FAM_COL, (int)n, prec, 0) != nullptr && find_kernel(contiguous ? FAM_ROW : FAM_COL, (int)n, prec, 1) != nullptr;
+}
 // 1: a radix plan, 2: the one-workgroup chirp-z kernels, 3: the scratch-buffer fallback (bigfft.hip), 0: none
 int length_route(int64_t n, bool real_transform) {
   if (n <= 0 || n > (1 << 20)) return 0;

@@ -365,13 +365,16 @@ template <class S, typename T> constexpr int r2c_threads() { return real_threads
 
 // Round 5, the census of scripts/kernel_regs.py applied to the contiguous-axis kernels: plans whose PLAIN kernels sit one to
 // fourteen registers above the next occupancy step while their LDS admits the extra workgroup, and which compile under the
-// cap with little or no scratch.  Candidates (family: 0 c2c rows, 1 r2c, 2 c2r): single precision c2r of real 2048 (130 ->
-// 128 VGPRs, no scratch: four workgroups of 256 threads instead of three), c2c rows of 720 / 1200 in single precision (172 -
-// 178 -> 168, none: five workgroups of 120 threads instead of four), rows and r2c of 500 in double precision (182 -> 168: none /
-// 20 bytes, six instead of four), the 20-values rows of 800 / 2000 in double precision (130 - 132 -> 128: 12 - 16 bytes, four
-// instead of three).  Measured: profiles/r05_row_occupancy_caps.txt; MFFT_ROW_OCC_R5=0 builds without them.
+// cap with little or no scratch (family: 0 c2c rows, 1 r2c, 2 c2r): single precision c2r of real 2048 (130 -> 128 VGPRs, no
+// scratch: four workgroups of 256 threads instead of three), c2c rows of 720 / 1200 in single precision (172 - 178 -> 168,
+// none: five workgroups instead of four), rows and r2c of 500 in double precision (182 -> 168: none / 20 bytes, six instead
+// of four), the 20-values rows of 800 / 2000 in double precision (130 - 132 -> 128: 12 - 16 bytes, four instead of three).
+// MEASURED against the library without them, alternating, one session (profiles/r05_row_occupancy_caps.txt, z stages in ms):
+// 2048^3 fp32 c2r 13.9 / 13.8 -> 14.1 / 13.7, 1000^3 fp64 r2c 3.32 / 3.30 -> 3.31 / 3.32, C2C rows 1200 fp32 6.5 - 6.6 -> the
+// same, 800 fp64 3.0 - 3.1 -> the same, 500 fp64 0.70 - 0.72 -> 0.72 - 0.74, 720 fp32 1.13 - 1.17 -> 1.22 - 1.23 (6 % WORSE):
+// nothing gained anywhere -- the extra workgroup is not what these kernels wait for.  OFF; MFFT_ROW_OCC_R5=1 builds them.
 #ifndef MFFT_ROW_OCC_R5
-#define MFFT_ROW_OCC_R5 1
+#define MFFT_ROW_OCC_R5 0
 #endif
 template <class S, typename T, int FAM> constexpr int row_occ_r5(int threads) {
   if (!MFFT_ROW_OCC_R5) return 0;

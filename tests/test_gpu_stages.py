@@ -171,11 +171,18 @@ CHIRPZ = [3, 5, 7, 9, 11, 13, 15, 17, 25, 27, 31, 33, 45, 49, 75, 84, 127, 129, 
 # round 5: lengths without a radix plan beyond the one-workgroup chirp-z range (complex n > 4096, odd real n > 4096, anything
 # above 8192): Bluestein over a four-step power-of-two transform in a scratch buffer (csrc/bigfft.hip, route 3 of
 # mfft_length_route) -- primes, range ends, composite lengths, M = 16384 ... 2^18
-BIG = [4097, 4099, 5000, 6561, 8191, 8193, 10000, 16385, 30011, 65537, 100003]
+BIG = [4097, 4099, 5000, 6561, 8191, 8193, 10000, 16385, 30011, 65537, 100003,
+       # composite lengths n = n1 * n2 with radix plans for both factors: the four-step transform at length n itself, no Bluestein
+       6400, 12288, 16384, 20000, 65536, 1 << 20]
+
+
+def _slow_above(lengths, limit):
+    """the longest lengths (host FFTs of 15 - 30 million points per case) only with MFFT_TEST_SLOW=1 (tests/conftest.py)"""
+    return [pytest.param(n, marks=pytest.mark.slow) if n > limit else n for n in lengths]
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("n", BIG)
+@pytest.mark.parametrize("n", _slow_above(BIG, 65537))
 def test_c2c_lengths_through_the_scratch_buffer_fallback(n, prec):
     """numpy_fft.py:25-37 takes every n: so does mfft_c2c_axis, along every axis, forward and inverse."""
     from mpifft4py_amd import _lib, fft, ifft
@@ -192,7 +199,7 @@ def test_c2c_lengths_through_the_scratch_buffer_fallback(n, prec):
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("n", [4099, 8193, 8194, 10000, 16386, 20001, 65538, 131071])
+@pytest.mark.parametrize("n", _slow_above([4099, 8193, 8194, 10000, 16386, 20001, 65538, 131071, 12800, 32768, 200000], 65538))
 def test_rfft_irfft_lengths_through_the_scratch_buffer_fallback(n, prec):
     from mpifft4py_amd import _lib, rfft, irfft
     assert _lib.load().mfft_length_route(n, 1) == 3
