@@ -65,7 +65,8 @@ namespace mfft { void emu_barrier(); }
 // i.e. one wave per SIMD instead of two and twice the time (896^3 bwd_z 2.05 -> 4.2 ms from round 4's commit d98a6c4 on; found
 // in round 5 by reverting that commit's hunks one at a time, profiles/r05_radix7_c2r_bisect.txt) -- while the wave-packed
 // kernels, which were tuned with the wrapper, lose registers the other way round (fp32 c2r of 1200 / 1500 / 1800: 163 -> 200
-// VGPRs with the direct form).  So: the dense c2r kernels call the builtin directly, everything else keeps the wrapper;
+// VGPRs with the direct form), and so does one dense 20-values plan (c2r of 640: 248 -> 170 VGPRs and 11 % slower).  So: the
+// dense c2r kernels of the 28-values plans call the builtin directly, everything else keeps the wrapper;
 // scripts/kernel_regs.py --diff shows such moves before they reach a GPU.
 #if defined(__HIPCC__)
 #define WAVE_SHFL_DIRECT(x, src) __shfl((x), (src), 64)
@@ -1016,7 +1017,9 @@ struct C2RFft {
         const cx<T> give1 = j == 0 ? carry : b;          // partner of position j + k*TPT
         const cx<T> give2 = j == 0 ? v[k + 1] : a;       // partner of position j + kp*TPT (lane 0: its register E-kp = k+1)
         cx<T> pm1, pm2;
-        if constexpr (WP) {
+        // (direct form for the 28-values plans only: with it the c2r of 640 complex points -- 20 values, 248 -> 170 VGPRs --
+        // came out 11 % SLOWER, 1280^3 bwd_z 6.17 -> 6.86 ms in the round-5 sweep; every other plan keeps round 4's code)
+        if constexpr (WP || S::E % 7 != 0) {
           pm1 = mk<T>(wave_shfl(give1.x, src), wave_shfl(give1.y, src));
           pm2 = mk<T>(wave_shfl(give2.x, src), wave_shfl(give2.y, src));
         } else {

@@ -176,13 +176,15 @@ BIG = [4097, 4099, 5000, 6561, 8191, 8193, 10000, 16385, 30011, 65537, 100003,
        6400, 12288, 16384, 20000, 65536, 1 << 20]
 
 
-def _slow_above(lengths, limit):
-    """the longest lengths (host FFTs of 15 - 30 million points per case) only with MFFT_TEST_SLOW=1 (tests/conftest.py)"""
-    return [pytest.param(n, marks=pytest.mark.slow) if n > limit else n for n in lengths]
+def _slow_above(lengths, limit, also=()):
+    """the longest lengths (host FFTs of 15 - 30 million points per case) and some of the others only with MFFT_TEST_SLOW=1
+    (tests/conftest.py): every mechanism -- Bluestein at M = 2^14 ... 2^18, the composite route, primes, range ends -- keeps
+    cases in the default run"""
+    return [pytest.param(n, marks=pytest.mark.slow) if (n > limit or n in also) else n for n in lengths]
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("n", _slow_above(BIG, 65537))
+@pytest.mark.parametrize("n", _slow_above(BIG, 65537, also=(4099, 6561, 8193, 16385, 30011, 12288, 20000)))
 def test_c2c_lengths_through_the_scratch_buffer_fallback(n, prec):
     """numpy_fft.py:25-37 takes every n: so does mfft_c2c_axis, along every axis, forward and inverse."""
     from mpifft4py_amd import _lib, fft, ifft
@@ -199,7 +201,7 @@ def test_c2c_lengths_through_the_scratch_buffer_fallback(n, prec):
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("n", _slow_above([4099, 8193, 8194, 10000, 16386, 20001, 65538, 131071, 12800, 32768, 200000], 65538))
+@pytest.mark.parametrize("n", _slow_above([4099, 8193, 8194, 10000, 16386, 20001, 65538, 131071, 12800, 32768, 200000], 65538, also=(8193, 16386, 20001)))
 def test_rfft_irfft_lengths_through_the_scratch_buffer_fallback(n, prec):
     from mpifft4py_amd import _lib, rfft, irfft
     assert _lib.load().mfft_length_route(n, 1) == 3
