@@ -113,7 +113,8 @@ def test_process_per_rank_parity(world, transport):
     assert "MP_OK world=%d" % world in out
 
 
-@pytest.mark.parametrize("world,n,transport", [(4, 512, "ipc"), (8, 512, "ipc"), (2, 1024, "ipc"), (4, 512, "mock")])
+@pytest.mark.parametrize("world,n,transport", [(4, 512, "ipc"), (8, 512, "ipc"), (2, 1024, "ipc"),
+                                               pytest.param(4, 512, "mock", marks=pytest.mark.slow)])
 def test_process_per_rank_full_size(world, n, transport):
     """BASELINE config sizes over real PROCESSES and the shipped wire (these ran by hand only): 512^3
     over 4 and 8 processes, 1024^3 over 2, every pipeline flavour of the slab plan and both pencils, against the host's
@@ -177,8 +178,7 @@ def test_bench_multi_rank_prints_one_json_line(world, launcher, transport):
         assert pen["roundtrip_rel_l2"] < 1e-10 and pen["default_grid_ms_per_pair"] > 0
 
 
-@pytest.mark.parametrize("transport", TRANSPORTS)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world,transport", [(2, "ipc"), (2, "mock"), (4, "ipc"), pytest.param(4, "mock", marks=pytest.mark.slow)])
 def test_bench_starts_its_own_ranks_without_a_launcher(world, transport):
     """`python bench.py --gpus N` as the driver's 1-GPU command line would look with N > 1: no torch.distributed.run,
     no RANK / WORLD_SIZE in the environment.  bench.py starts its N ranks itself (fresh child processes) and still
@@ -274,7 +274,7 @@ def test_bench_ranks_stay_together_when_rank0_cannot_make_an_id():
     assert "first transport unavailable" in err
 
 
-@pytest.mark.parametrize("cus", [16, -1])
+@pytest.mark.parametrize("cus", [pytest.param(16, marks=pytest.mark.slow), -1])      # (CU-masked streams: with MFFT_TEST_SLOW=1)
 def test_ipc_survivor_of_a_killed_peer(cus):
     """with CU-masked (= blocking) plan streams the host-side release of a hung exchange queued behind
     the very wait kernel it must release, so a dead peer meant a permanent hang.  Two IPC processes, rank 1 SIGKILLed between
