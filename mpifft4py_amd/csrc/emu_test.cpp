@@ -1260,9 +1260,11 @@ int main() {
 #endif
 #if EMU_HAS(9)
   MFFT_PLANS_N(MFFT_PLAN)
+  MFFT_PLANS_Q(MFFT_PLAN)      // round 5: 4608 ... 7168
 #endif
 #if EMU_HAS(10)
   MFFT_PLANS_O(MFFT_PLAN)
+  MFFT_PLANS_R(MFFT_PLAN)      // round 5: 21 * 2^a, radix 42
 #endif
 #if EMU_HAS(11)
   MFFT_PLANS_P(MFFT_PLAN)

@@ -324,6 +324,10 @@ template <> struct Bfly<14> {
 template <> struct Bfly<28> {
   template <typename T> static MFFT_HD void run(cx<T> (&v)[28]) { BflyPFA<7, 4>::run(v); }
 };
+// round 5: 21 * 2^a (672, 1344, 2688 ...: plans.h group R) hold 42 values per thread: radix 42 = 6 x 7 first, radix-2 passes after
+template <> struct Bfly<42> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[42]) { BflyPFA<6, 7>::run(v); }
+};
 
 
 // ---------------------------------------------------------------------------

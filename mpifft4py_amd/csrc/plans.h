@@ -54,6 +54,12 @@
 // numpy sizes (numpy_fft.py:25-46 takes every n) and were MFFT_ERR_UNSUPPORTED as complex lengths (their real rows already
 // worked through the half-length plans); 192 / 128 / 256 / 256 threads per transform, strided tiles of 2 - 4 columns.
 #define MFFT_PLANS_Q(X) X(4608, 24, 24, 8) X(5120, 40, 8, 4, 4) X(6144, 24, 8, 8, 4) X(7168, 28, 4, 4, 4, 4)
+// Group R (round 5): 21 * 2^a -- 672, 1344, 2688 are 7-smooth meshes FFTW users pick (numpy_fft.py:25-46 takes every n) and ran
+// through the one-workgroup chirp-z kernels at ~0.17 of the roofline.  E = lcm(radices) must contain 3 and 7, and a radix-4
+// pass would make it 84: 42 values per thread (84 VGPRs of data in single precision, 168 in double: one wave per SIMD there),
+// the prime-factor butterfly 42 = 6 x 7 first (no twiddles inside), radix-2 passes for the rest.  (35 * 2^a would need 70.)
+#define MFFT_PLANS_R(X) X(42, 42) X(84, 42, 2) X(168, 42, 2, 2) X(336, 42, 2, 2, 2) X(672, 42, 2, 2, 2, 2) \
+  X(1344, 42, 2, 2, 2, 2, 2) X(2688, 42, 2, 2, 2, 2, 2, 2)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -74,6 +80,7 @@
 #define MFFT_ROWPLANS_O(X)
 #define MFFT_ROWPLANS_P(X)
 #define MFFT_ROWPLANS_Q(X)
+#define MFFT_ROWPLANS_R(X)
 #define MFFT_ROWPLANS_A(X)
 #define MFFT_ROWPLANS_B(X)
 #define MFFT_ROWPLANS_C(X)
@@ -134,4 +141,4 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
   MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X) MFFT_PLANS_N(X) \
-  MFFT_PLANS_O(X) MFFT_PLANS_P(X) MFFT_PLANS_Q(X)
+  MFFT_PLANS_O(X) MFFT_PLANS_P(X) MFFT_PLANS_Q(X) MFFT_PLANS_R(X)

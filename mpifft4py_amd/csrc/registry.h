@@ -321,7 +321,7 @@ void register_col3(const char* name) {
 // profiles/r05_radix7_c2r_bisect.txt.  Capped, 448 / 896 / 1792 spill 20 - 100 bytes of scratch per lane; the short
 // lengths (56 ... 224 with LDS twiddles) would spill 370: not capped.
 template <class S, typename T> constexpr int row_occ_wgs(int threads) {
-  return (MFFT_ROW_OCC && sizeof(T) == 8 && ((S::E % 15 == 0 && S::N >= 120) || (S::E % 7 == 0 && S::N >= 448)) && threads <= 256)
+  return (MFFT_ROW_OCC && sizeof(T) == 8 && ((S::E % 15 == 0 && S::N >= 120) || (S::E == 28 && S::N >= 448)) && threads <= 256)
              ? 512 / threads : 0;   // shorter: 500+ bytes of scratch
 }
 

@@ -52,6 +52,9 @@ run() {
     r05_alloc_shift_probe.txt) bash scripts/r05_gpu2.sh ;;
     r05_pad_align_ab.txt|r05_pad_align_bits.txt) bash scripts/r05_gpu3.sh; bash scripts/r05_gpu4.sh ;;
     r05_config5_zpitch.txt) python scripts/config5_full.py; MFFT_NO_ZPITCH=1 python scripts/config5_full.py ;;
+    r05_pad_pmc_traffic.txt) bash scripts/pad_pmc_r05.sh ;;
+    r05_radix42_sweep.txt) bash scripts/r05_gpu13.sh ;;
+    r05_col_occupancy_caps.txt|r05_row_occupancy_caps.txt) echo "(needs the library without the caps under _ab/old: see scripts/r05_gpu7.sh / r05_gpu8.sh)" ;;
     r04_rank_shapes.txt) python scripts/rank_shapes.py ;;
     r04_ypass_pitch.txt) python scripts/ypass_pitch_ab.py ;;
     r04_col3_1536.txt) bash scripts/r04_col3.sh ;;

@@ -61,7 +61,7 @@ def test_version_and_lengths(lib):
     assert all(lib.mfft_length_supported(n, 1) == 1 for n in range(2, 4097))
     # round 5: radix plans between 4096 and 8192, and EVERY other length up to 2^20 through the scratch-buffer fallback
     # (csrc/bigfft.hip) -- numpy_fft.py:25-46 takes any n
-    for n in (4608, 5120, 6144, 7168):
+    for n in (4608, 5120, 6144, 7168, 42, 84, 168, 336, 672, 1344, 2688):
         assert lib.mfft_length_route(n, 0) == 1 and lib.mfft_length_route(2 * n, 1) == 1, n
     assert all(lib.mfft_length_supported(n, 0) == 1 for n in range(1, 8193))
     assert all(lib.mfft_length_supported(n, 1) == 1 for n in range(2, 16385))

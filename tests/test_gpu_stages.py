@@ -20,8 +20,8 @@ LENGTHS = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096,
            750, 1500, 1920, 2400, 3000, 3840,
            # round 4: 7 * 2^a (plans.h group O: 28 values per thread, radix 28 = 7 x 4) and 8192
            14, 28, 56, 112, 224, 448, 896, 1792, 3584, 8192,
-           # round 5: the radix plans between 4096 and 8192 (plans.h group Q)
-           4608, 5120, 6144, 7168]
+           # round 5: the radix plans between 4096 and 8192 (plans.h group Q) and 21 * 2^a (group R: 42 values per thread)
+           4608, 5120, 6144, 7168, 42, 84, 168, 336, 672, 1344, 2688]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -164,8 +164,9 @@ def test_unsupported_length_raises():
 # odd 15-smooth ones, and the range ends of several convolution lengths
 CHIRPZ = [3, 5, 7, 9, 11, 13, 15, 17, 25, 27, 31, 33, 45, 49, 75, 84, 127, 129, 255, 257, 504,
           675, 729, 1008, 1023, 1025, 1201, 1537, 2047,
-          # round 4: convolution length 8192 -- everything up to 4096 (7-smooth meshes like 2688 = 21 * 128, primes, range ends)
-          2049, 2100, 2688, 3125, 3600, 4093, 4095]
+          # round 4: convolution length 8192 -- everything up to 4096 (7-smooth meshes like 2240 = 35 * 64, primes, range ends; 2688 has a
+          # radix plan since round 5)
+          2049, 2100, 2240, 2688, 3125, 3600, 4093, 4095]
 
 
 # round 5: lengths without a radix plan beyond the one-workgroup chirp-z range (complex n > 4096, odd real n > 4096, anything
