@@ -371,9 +371,31 @@ struct Spec {
 // One pass on the registers of thread j (0 <= j < TPT).
 //   tw  : pointer to the twiddle table (LDS or global), layout see Spec::tw_off
 // ---------------------------------------------------------------------------
+// hipcc (ROCm 7.2) miscompiles the contiguous-axis kernels of the plans with 3 and another odd prime among their radices (30 and
+// 42 values per thread) when the thread's index j inside its transform has a known power-of-two range (j = tid % 8, % 16: 240,
+// 480, 336, 672: a tenth to a third of the bins wrong on the device, exact in the emulator; tools/rowcheck.hip, round 3).  Round 5
+// found WHERE (tools/rowcheck2.hip, profiles/r05_miscompile_cure_modes.txt): in the twiddle index `(j + m * TPT) % Ns` below and
+// nowhere else -- hiding j's range only for this call (MFFT_LAUNDER_MODE 4: fft_kernels.h run_passes, the contiguous-axis kernels' driver) is as
+// exact as hiding it at its origin (mode 1, rounds 3 - 4: fft_kernels.h row_thread_index) and leaves loads, stores, LDS slots
+// and the wave shuffles of the real kernels their range information: r2c of 360 / 600 / 720 points 0.33 / 0.47 / 0.65 -> 0.20 /
+// 0.31 / 0.54 ms per 2^16 rows, of 672 in single precision 0.45 -> 0.26.  (The c2r kernels keep the cure at j's origin: they
+// compile to fewer registers that way, fft_kernels.h row_thread_index.)  Modes 0 (none), 2 (here and in pass_scatter, every
+// caller), 3 (pass_scatter only: still wrong) exist for that tool.
+#ifndef MFFT_LAUNDER_MODE
+#define MFFT_LAUNDER_MODE 4
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MFFT_HIDE_RANGE(x) asm volatile("" : "+v"(x))
+#else
+#define MFFT_HIDE_RANGE(x) ((void)0)
+#endif
+template <class S> MFFT_HDC bool launder_plan() { return S::E % 15 == 0 || S::E % 21 == 0; }
 template <class S, int P, typename T, class TwPtr>
 MFFT_HD void pass_compute(cx<T> (&v)[S::E], int j, TwPtr tw) {
   constexpr int R = S::R(P), Ns = S::Ns(P), G = S::E / R, OFF = S::tw_off(P);
+#if MFFT_LAUNDER_MODE == 2      /* tools/rowcheck2.hip only; mode 4 hides j in the caller (fft_kernels.h run_passes) */
+  if constexpr (P > 0 && launder_plan<S>()) MFFT_HIDE_RANGE(j);
+#endif
 #pragma unroll
   for (int m = 0; m < G; ++m) {
     cx<T> t[R];
@@ -397,6 +419,9 @@ MFFT_HD void pass_compute(cx<T> (&v)[S::E], int j, TwPtr tw) {
 template <class S, int P, class Put>
 MFFT_HD void pass_scatter(int j, Put put) {
   constexpr int R = S::R(P), Ns = S::Ns(P), G = S::E / R;
+#if MFFT_LAUNDER_MODE == 2 || MFFT_LAUNDER_MODE == 3      /* tools/rowcheck2.hip only */
+  if constexpr (S::E % 15 == 0 || S::E % 21 == 0) MFFT_HIDE_RANGE(j);
+#endif
 #pragma unroll
   for (int m = 0; m < G; ++m) {
     const int jb = j + m * S::TPT;

@@ -27,6 +27,8 @@
 #if defined(__HIPCC__)
 #define MFFT_D __device__ __forceinline__
 #define MFFT_BARRIER() __syncthreads()
+// (Rounds 3 - 4; since round 5 the cure sits where the fault is, fft_core.h pass_compute / MFFT_LAUNDER_MODE 4, and this one is
+// compiled only with MFFT_LAUNDER_MODE=1.)
 // hipcc (ROCm 7.2) miscompiles the contiguous-axis kernels of the 30-values-per-thread plans when the thread's index inside
 // its transform has a known power-of-two range (j = tid % 8 or tid % 16: lengths 240 and 480 -- a third of the output bins
 // wrong, the same bins for every radix order and every number of rows per workgroup, while the workgroup emulator and the
@@ -40,19 +42,25 @@
 #endif
 // (round 5: the 42-values plans of 21 * 2^a show the same fault -- 336: j = tid % 8, a tenth of the bins wrong on the device, exact in
 // the emulator -- and get the same treatment)
-template <class S> MFFT_D int row_thread_index(int tid) {
+// ORIGIN: hide j's range here, at its origin (rounds 3 - 4 for every contiguous-axis kernel; since round 5 the c2r kernels only --
+// they come out with FEWER registers that way: dense c2r of 1500 / 1800 / 750 points in double precision 216 - 230 VGPRs against
+// 258 + AGPRs, the wave-packed single-precision ones 162 against 200 - 290 -- while c2c rows and r2c keep j's range and hide it
+// only from the twiddle index, run_passes below: r2c 2 -> 3 waves per SIMD in single precision, 100 - 236 -> 12 - 56 bytes of
+// scratch under the double-precision cap).
+template <class S, bool ORIGIN = false> MFFT_D int row_thread_index(int tid) {
   int j = tid % S::TPT;
-  if constexpr (S::E % 15 == 0 || S::E % 21 == 0) {
-#if defined(MFFT_NO_LAUNDER_J)      /* tools/rowcheck.hip: show the miscompile */
-#else
+  if constexpr (::mfft::launder_plan<S>()) {
+#if MFFT_LAUNDER_MODE == 1
     MFFT_OPAQUE(j);
+#elif MFFT_LAUNDER_MODE == 4
+    if constexpr (ORIGIN) MFFT_OPAQUE(j);
 #endif
   }
   return j;
 }
 #else
 #define MFFT_OPAQUE(x) ((void)0)
-template <class S> inline int row_thread_index(int tid) { return tid % S::TPT; }
+template <class S, bool ORIGIN = false> inline int row_thread_index(int tid) { return tid % S::TPT; }
 #define MFFT_D inline
 namespace mfft { void emu_barrier(); }
 #define MFFT_BARRIER() ::mfft::emu_barrier()
@@ -269,12 +277,19 @@ struct XchSplit {
 
 // generic pass driver: runs passes P..NP-1 with LDS exchanges in between.
 // On entry v holds the inputs of pass 0 (positions j + k*TPT).
-template <class S, int P, typename T, class TwPtr, class Xch>
+template <class S, int P, typename T, class TwPtr, class Xch, bool HIDE = true>
 MFFT_D void run_passes(cx<T> (&v)[S::E], int j, TwPtr tw, Xch& xch) {
+#if MFFT_LAUNDER_MODE == 4
+  if constexpr (HIDE && P > 0 && launder_plan<S>()) {        // see fft_core.h MFFT_LAUNDER_MODE: the twiddle index must not see j's range
+    int jc = j;
+    MFFT_HIDE_RANGE(jc);
+    pass_compute<S, P, T>(v, jc, tw);
+  } else
+#endif
   pass_compute<S, P, T>(v, j, tw);
   if constexpr (P + 1 < S::NP) {
     xch.template exchange<S, P>(v, j, P > 0);
-    run_passes<S, P + 1, T>(v, j, tw, xch);
+    run_passes<S, P + 1, T, TwPtr, Xch, HIDE>(v, j, tw, xch);
   }
 }
 
@@ -779,7 +794,9 @@ struct R2CFft {
       if (dup) lr = RPW - 1;
       lane0 = lr * S::TPT;
       j = dup ? lane - RPW * S::TPT : lane - lane0;
+#if MFFT_LAUNDER_MODE == 1
       if constexpr (S::E % 15 == 0) MFFT_OPAQUE(j);
+#endif
       rl = (tid >> 6) * RPW + lr;
     } else {
       rl = tid / S::TPT;
@@ -936,11 +953,11 @@ struct C2RFft {
       if (dup) lr = RPW - 1;
       lane0 = lr * S::TPT;
       j = dup ? lane - RPW * S::TPT : lane - lane0;
-      if constexpr (S::E % 15 == 0) MFFT_OPAQUE(j);         // see row_thread_index
+      if constexpr (S::E % 15 == 0) MFFT_OPAQUE(j);         // see row_thread_index (c2r: at the origin)
       rl = (tid >> 6) * RPW + lr;
     } else {
       rl = tid / S::TPT;
-      j = row_thread_index<S>(tid);
+      j = row_thread_index<S, true>(tid);
     }
     XE* xch = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
     const i64 row = (i64)bid * ROWS + rl;
@@ -1067,8 +1084,8 @@ struct C2RFft {
       MFFT_BARRIER();
     }
     typename RowXch<SPLIT, T, PadSlot<PD>>::type xc{xch, PadSlot<PD>{}};
-    if constexpr (TWLDS) run_passes<S, 0, T>(v, j, (const cx<T>*)ltw, xc);
-    else run_passes<S, 0, T>(v, j, P.tw, xc);
+    if constexpr (TWLDS) run_passes<S, 0, T, const cx<T>*, decltype(xc), false>(v, j, (const cx<T>*)ltw, xc);
+    else run_passes<S, 0, T, const cx<T>*, decltype(xc), false>(v, j, P.tw, xc);
 
     if (active) {
       const T s = P.scale;

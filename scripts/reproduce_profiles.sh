@@ -54,6 +54,7 @@ run() {
     r05_config5_zpitch.txt) python scripts/config5_full.py; MFFT_NO_ZPITCH=1 python scripts/config5_full.py ;;
     r05_pad_pmc_traffic.txt) bash scripts/pad_pmc_r05.sh ;;
     r05_radix42_sweep.txt) bash scripts/r05_gpu13.sh ;;
+    r05_miscompile_cure_modes.txt) make -C tools rowcheck2_0 rowcheck2_1 rowcheck2_2 rowcheck2_3 rowcheck2_4; for m in 0 1 2 3 4; do tools/build/rowcheck2_$m; done ;;
     r05_col_occupancy_caps.txt|r05_row_occupancy_caps.txt) echo "(needs the library without the caps under _ab/old: see scripts/r05_gpu7.sh / r05_gpu8.sh)" ;;
     r04_rank_shapes.txt) python scripts/rank_shapes.py ;;
     r04_ypass_pitch.txt) python scripts/ypass_pitch_ab.py ;;
