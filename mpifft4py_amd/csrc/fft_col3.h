@@ -107,44 +107,31 @@ struct ColFft3 {
                                const cx<T>* ltw, char* xbuf) {
     if constexpr (TWLDS) sub_transform(w[R], j, ltw, xbuf, c);
     else sub_transform(w[R], j, P.tw, xbuf, c);
-    auto stores = [&](auto rows) {                  // fft_kernels.h rows_plain
-      constexpr bool PLAIN = decltype(rows)::value;
-      const i64 jb = PLAIN ? (i64)(3 * j) * P.out_map.lo : 0;
 #pragma unroll
-      for (int k = 0; k < EL; ++k) {
-        cx<T> val[VEC];
+    for (int k = 0; k < EL; ++k) {
+      const unsigned row = 3u * (unsigned)(j + k * SL::TPT) + (unsigned)R;
+      cx<T> val[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) val[i] = w[R][i][k];
-        store_row(op + row_off_sum<PLAIN>(P.out_map, jb, 3u * (unsigned)j, 3 * k * SL::TPT + R), nact, val, P.scale);
-      }
-    };
-    if (MFFT_PLAIN_ROWS && rows_plain(P.out_map)) stores(PlainRows{});
-    else stores(MappedRows{});
+      for (int i = 0; i < VEC; ++i) val[i] = w[R][i][k];
+      store_row(op + row_off(P.out_map, row), nact, val, P.scale);
+    }
   }
   // third R of the DIT form: its rows 3 q + R of the input, then its sub-transform
   template <int R>
   static MFFT_D void dit_third(const ColParams<T>& P, cx<T> (&w)[3][VEC][EL], int j, int c, int nact, const cx<T>* ip,
                                const cx<T>* ltw, char* xbuf, int first) {
-    auto loads = [&](auto lanes, auto rows) {
-      constexpr bool PLAIN = decltype(rows)::value;
-      const i64 jb = PLAIN ? (i64)(3 * j) * P.in_map.lo : 0;
+    auto loads = [&](auto lanes) {
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
+        const unsigned row = 3u * (unsigned)(j + k * SL::TPT) + (unsigned)R;
         cx<T> x[VEC];
-        load_row<decltype(lanes)::value>(ip + row_off_sum<PLAIN>(P.in_map, jb, 3u * (unsigned)j, 3 * k * SL::TPT + R), nact, x, first,
-                                         P.in_wrap_gap);
+        load_row<decltype(lanes)::value>(ip + row_off(P.in_map, row), nact, x, first, P.in_wrap_gap);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) w[R][i][k] = x[i];
       }
     };
-    const bool full = nact >= VEC && first == VEC;
-    if (MFFT_PLAIN_ROWS && rows_plain(P.in_map)) {
-      if (full) loads(FullLanes{}, PlainRows{});
-      else loads(RaggedLanes{}, PlainRows{});
-    } else {
-      if (full) loads(FullLanes{}, MappedRows{});
-      else loads(RaggedLanes{}, MappedRows{});
-    }
+    if (nact >= VEC && first == VEC) loads(FullLanes{});
+    else loads(RaggedLanes{});
     if constexpr (TWLDS) sub_transform(w[R], j, ltw, xbuf, c);
     else sub_transform(w[R], j, P.tw, xbuf, c);
   }
@@ -177,36 +164,28 @@ struct ColFft3 {
     if constexpr (PAD != 2) {
       // ---- DIF: rows p, p + L, p + 2L -> radix-3 butterfly -> twiddles -> three sub-transforms -> rows 3 q + r --------
       // all loads first, straight into the registers the butterflies work on (as ColFft does: no second copy of the tile)
-      auto loads = [&](auto lanes, auto rows) {
+      auto loads = [&](auto lanes) {
         constexpr bool FULL = decltype(lanes)::value;
-        constexpr bool PLAIN = decltype(rows)::value;
-        const i64 jb = PLAIN ? (i64)j * P.in_map.lo : 0;
 #pragma unroll
         for (int k = 0; k < EL; ++k) {
+          const unsigned p = (unsigned)(j + k * SL::TPT);
           cx<T> x[VEC];
-          load_row<FULL>(ip + row_off_sum<PLAIN>(P.in_map, jb, (unsigned)j, k * SL::TPT), nact, x, first, P.in_wrap_gap);
+          load_row<FULL>(ip + row_off(P.in_map, p), nact, x, first, P.in_wrap_gap);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) w[0][i][k] = x[i];
           if constexpr (PAD != 1) {                   // PAD == 1: logical rows [L, 2L) are the zero band, never loaded
-            load_row<FULL>(ip + row_off_sum<PLAIN>(P.in_map, jb, (unsigned)j, k * SL::TPT + L), nact, x, first, P.in_wrap_gap);
+            load_row<FULL>(ip + row_off(P.in_map, p + (unsigned)L), nact, x, first, P.in_wrap_gap);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) w[1][i][k] = x[i];
           }
           // (PAD == 1: logical row 2L + p is physical row L + p)
-          load_row<FULL>(ip + row_off_sum<PLAIN>(P.in_map, jb, (unsigned)j, k * SL::TPT + (PAD == 1 ? 1 : 2) * L), nact, x, first,
-                         P.in_wrap_gap);
+          load_row<FULL>(ip + row_off(P.in_map, p + (PAD == 1 ? 1u : 2u) * (unsigned)L), nact, x, first, P.in_wrap_gap);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) w[2][i][k] = x[i];
         }
       };
-      const bool full = nact >= VEC && first == VEC;
-      if (MFFT_PLAIN_ROWS && rows_plain(P.in_map)) {
-        if (full) loads(FullLanes{}, PlainRows{});
-        else loads(RaggedLanes{}, PlainRows{});
-      } else {
-        if (full) loads(FullLanes{}, MappedRows{});
-        else loads(RaggedLanes{}, MappedRows{});
-      }
+      if (nact >= VEC && first == VEC) loads(FullLanes{});
+      else loads(RaggedLanes{});
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
         const unsigned p = (unsigned)(j + k * SL::TPT);
@@ -230,28 +209,22 @@ struct ColFft3 {
       dit_third<0>(P, w, j, c, nact, ip, ltw, xbuf, first);
       dit_third<1>(P, w, j, c, nact, ip, ltw, xbuf, first);
       dit_third<2>(P, w, j, c, nact, ip, ltw, xbuf, first);
-      auto stores = [&](auto rows) {
-        constexpr bool PLAIN = decltype(rows)::value;
-        const i64 jb = PLAIN ? (i64)j * P.out_map.lo : 0;
 #pragma unroll
-        for (int k = 0; k < EL; ++k) {
-          const unsigned p = (unsigned)(j + k * SL::TPT);
-          const cx<T> t1 = tw1[p], t2 = tw2[p];
-          cx<T> lo[VEC], hi[VEC];
+      for (int k = 0; k < EL; ++k) {
+        const unsigned p = (unsigned)(j + k * SL::TPT);
+        const cx<T> t1 = tw1[p], t2 = tw2[p];
+        cx<T> lo[VEC], hi[VEC];
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            cx<T> b[3] = {w[0][i][k], w[1][i][k] * t1, w[2][i][k] * t2};
-            Bfly<3>::run(b);
-            lo[i] = b[0];
-            hi[i] = b[2];
-            if (k == 0 && j == 0 && P.fold) hi[i] = hi[i] + b[1];      // the Nyquist row L folded into row 2L (slab.py:529-533)
-          }
-          store_row(op + row_off_sum<PLAIN>(P.out_map, jb, (unsigned)j, k * SL::TPT), nact, lo, P.scale);
-          store_row(op + row_off_sum<PLAIN>(P.out_map, jb, (unsigned)j, k * SL::TPT + L), nact, hi, P.scale);
+        for (int i = 0; i < VEC; ++i) {
+          cx<T> b[3] = {w[0][i][k], w[1][i][k] * t1, w[2][i][k] * t2};
+          Bfly<3>::run(b);
+          lo[i] = b[0];
+          hi[i] = b[2];
+          if (k == 0 && j == 0 && P.fold) hi[i] = hi[i] + b[1];      // the Nyquist row L folded into row 2L (slab.py:529-533)
         }
-      };
-      if (MFFT_PLAIN_ROWS && rows_plain(P.out_map)) stores(PlainRows{});
-      else stores(MappedRows{});
+        store_row(op + row_off(P.out_map, p), nact, lo, P.scale);
+        store_row(op + row_off(P.out_map, p + (unsigned)L), nact, hi, P.scale);
+      }
     }
   }
 };
@@ -301,15 +274,14 @@ struct ColFft3S {
     const cx<T> coef = r == 0 ? mk<T>((T)1, (T)0) : mk<T>((T)-0.5, r == 1 ? h : -h);
 
     cx<T> w[VEC][EL];
-    auto loads = [&](auto lanes, auto rows) {
+    auto loads = [&](auto lanes) {
       constexpr bool FULL = decltype(lanes)::value;
-      constexpr bool PLAIN = decltype(rows)::value;
-      const i64 jb = PLAIN ? (i64)j * P.in_map.lo : 0;
       cx<T> a[EL][VEC], b[EL][VEC];
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
-        Sib::template load_row<FULL>(ip + row_off_sum<PLAIN>(P.in_map, jb, (unsigned)j, k * SL::TPT), nact, a[k]);
-        Sib::template load_row<FULL>(ip + row_off_sum<PLAIN>(P.in_map, jb, (unsigned)j, k * SL::TPT + L), nact, b[k]);      // logical row 2L + p is physical row L + p
+        const unsigned p = (unsigned)(j + k * SL::TPT);
+        Sib::template load_row<FULL>(ip + row_off(P.in_map, p), nact, a[k]);
+        Sib::template load_row<FULL>(ip + row_off(P.in_map, p + (unsigned)L), nact, b[k]);      // logical row 2L + p is physical row L + p
       }
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
@@ -319,28 +291,18 @@ struct ColFft3S {
         for (int i = 0; i < VEC; ++i) w[i][k] = (a[k][i] + coef * b[k][i]) * t;
       }
     };
-    if (MFFT_PLAIN_ROWS && rows_plain(P.in_map)) {
-      if (nact >= VEC) loads(typename Sib::FullLanes{}, PlainRows{});
-      else loads(typename Sib::RaggedLanes{}, PlainRows{});
-    } else {
-      if (nact >= VEC) loads(typename Sib::FullLanes{}, MappedRows{});
-      else loads(typename Sib::RaggedLanes{}, MappedRows{});
-    }
+    if (nact >= VEC) loads(typename Sib::FullLanes{});
+    else loads(typename Sib::RaggedLanes{});
     if constexpr (TWLDS) Sib::sub_transform(w, j, (const cx<T>*)ltw, xbuf, c);
     else Sib::sub_transform(w, j, P.tw, xbuf, c);
-    auto stores = [&](auto rows) {
-      constexpr bool PLAIN = decltype(rows)::value;
-      const i64 jb = PLAIN ? (i64)(3 * j) * P.out_map.lo : 0;
 #pragma unroll
-      for (int k = 0; k < EL; ++k) {
-        cx<T> val[VEC];
+    for (int k = 0; k < EL; ++k) {
+      const unsigned row = 3u * (unsigned)(j + k * SL::TPT) + (unsigned)r;
+      cx<T> val[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) val[i] = w[i][k];
-        Sib::store_row(op + row_off_sum<PLAIN>(P.out_map, jb, 3u * (unsigned)j, 3 * k * SL::TPT + r), nact, val, P.scale);
-      }
-    };
-    if (MFFT_PLAIN_ROWS && rows_plain(P.out_map)) stores(PlainRows{});
-    else stores(MappedRows{});
+      for (int i = 0; i < VEC; ++i) val[i] = w[i][k];
+      Sib::store_row(op + row_off(P.out_map, row), nact, val, P.scale);
+    }
   }
 };
 

@@ -22,7 +22,6 @@
 // the __global__ wrappers in kernels.hip call, and (b) by g++ for the fibre-based
 // workgroup emulator (emu_test.cpp), where MFFT_BARRIER() yields to a scheduler.
 #pragma once
-#include <type_traits>
 #include "fft_core.h"
 
 #if defined(__HIPCC__)
@@ -132,27 +131,6 @@ MFFT_HD i64 row_off(const RowMap& m, unsigned r) {
   unsigned rem = r - q * m.split;
   return (i64)q * m.hi + (i64)rem * m.lo;
 }
-
-// Rows that lie one stride apart (no split: every single-rank plan, and one side of most strided passes of a multi-rank
-// one): the strided-axis kernels then take  base + j * lo  once per thread and add  (k * TPT) * lo  per row -- the same for
-// all lanes, so scalar arithmetic -- instead of calling row_off per row: a division by multiplication and two 64-bit
-// products = six quarter-rate integer instructions per row, 60 rows per thread in the 30-values kernels, about half of the
-// VALU cycles of every strided kernel (static count, profiles/r05_plain_rows.txt).  Which form runs is one uniform branch
-// around the load loop and one around the store loop.  (Walking the general map by increments instead -- offset and
-// remainder carried from row to row -- was built first: a serial chain the compiler resolves BEFORE the loads, 5 - 30
-// registers more in every kernel, 304 of 1340 strided kernels down one occupancy step.)
-MFFT_HD bool rows_plain(const RowMap& m) { return m.split == 0x7FFFFFFFu; }
-#ifndef MFFT_PLAIN_ROWS
-#define MFFT_PLAIN_ROWS 1
-#endif
-// offset of row jrow + crow, crow the same for all lanes; jbase = jrow * lo (read by the PLAIN form only)
-template <bool PLAIN>
-MFFT_HD i64 row_off_sum(const RowMap& m, i64 jbase, unsigned jrow, int crow) {
-  if constexpr (PLAIN) return jbase + (i64)crow * m.lo;
-  else return row_off(m, jrow + (unsigned)crow);
-}
-struct PlainRows : std::true_type {};
-struct MappedRows : std::false_type {};
 
 // Complex side of a contiguous-axis kernel split into z chunks (pencil decompositions): the pack / unpack copies
 // around the z-splitting exchange -- the Alltoallw sub-array types of the reference, pencil.py:218-246, 971-999 --
@@ -499,7 +477,7 @@ MFFT_D void stage_twiddles(cx<T>* lds_tw, const cx<T>* gtw, int tid, int nthread
 //             same thread (j = 0), are summed as `fu[n/2:] += fp[-n/2:]` does.
 // SPLIT: 0 whole complex values through LDS, 1 real then imaginary parts (XchSplitV), 2 in four rounds (XchQuarterV)
 template <class S, typename T, int COLS, bool INV, bool TWLDS, int SPLIT = 0, int VEC = 1, bool NT = false,
-          int PAD = 0, bool FASTROWS = (MFFT_PLAIN_ROWS != 0)>
+          int PAD = 0>
 struct ColFft {
   static_assert(COLS % VEC == 0, "VEC must divide COLS");
   static_assert(PAD == 0 || PAD == 3 || PAD == 4 || S::E % 3 == 0, "pad/truncate fusion needs a radix-3 plan");
@@ -611,31 +589,24 @@ struct ColFft {
         for (int i = 0; i < VEC; ++i) v[i][k] = mk<T>((T)0, (T)0);
       }
     } else {
-    auto load_rows = [&](auto plain_rows) {        // see rows_plain above
-    constexpr bool PLAIN = decltype(plain_rows)::value;
-    const cx<T>* ip0 = ip;
-    if constexpr (PLAIN) ip0 = ip + (i64)j * P.in_map.lo;
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
-      int rk = k * S::TPT;                         // the row is j + rk
+      unsigned r = (unsigned)(j + k * S::TPT);
       if (PAD == 1) {
         if (k >= KLO && k < KHI) {               // the zero band of the padded spectrum: nothing to load
 #pragma unroll
           for (int i = 0; i < VEC; ++i) v[i][k] = mk<T>((T)0, (T)0);
           continue;
         }
-        if (k >= KHI) rk -= NSKIP;
+        if (k >= KHI) r -= NSKIP;
       }
-      const unsigned r = (unsigned)(j + rk);
-      const cx<T>* src;
-      if constexpr (PLAIN) src = ip0 + (i64)rk * P.in_map.lo;
-      else src = ip + row_off(P.in_map, r);
+      const cx<T>* src = ip + row_off(P.in_map, r);
       bool zero_row = false;
       if constexpr (PAD == 4) {                    // a removed row: re-read row 0 (a cache hit) and drop the value -- no branch
                                                    // (skipping the load of a register whose rows are all removed, a workgroup-
                                                    // uniform branch, was measured: 1024^3 x pass 1.84 -> 2.03 ms, fp32 1.51 -> 2.05)
         zero_row = zero_col || ((int)r >= P.b_row_lo && (int)r < P.b_row_hi);
-        if (zero_row) src = ip;                  // row_off(map, 0) == 0
+        if (zero_row) src = ip + row_off(P.in_map, 0u);
       }
       if (nact >= VEC && first == VEC) {
         const GPack g = load_pack(src);
@@ -663,9 +634,6 @@ struct ColFft {
         }
       }
     }
-    };
-    if (FASTROWS && rows_plain(P.in_map)) load_rows(std::true_type{});
-    else load_rows(std::false_type{});
     if constexpr (TWLDS && S::NP > 1) {
       stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
       MFFT_BARRIER();
@@ -685,24 +653,18 @@ struct ColFft {
     }
     }     // !tile_zero
 
-    auto store_rows = [&](auto plain_rows) {
-    constexpr bool PLAIN = decltype(plain_rows)::value;
-    cx<T>* op0 = op;
-    if constexpr (PLAIN) op0 = op + (i64)j * P.out_map.lo;
 #pragma unroll
     for (int k = 0; k < S::E; ++k) {
-      int rk = k * S::TPT;
+      unsigned r = (unsigned)(j + k * S::TPT);
       if (PAD == 2) {
         if (k >= KLO && k < KHI) continue;       // truncated band
-        if (k >= KHI) rk -= NSKIP;
+        if (k >= KHI) r -= NSKIP;
         if (k == KHI && j == 0 && P.fold) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) v[i][k] = v[i][k] + v[i][KLO];
         }
       }
-      cx<T>* dst;
-      if constexpr (PLAIN) dst = op0 + (i64)rk * P.out_map.lo;
-      else dst = op + row_off(P.out_map, (unsigned)(j + rk));
+      cx<T>* dst = op + row_off(P.out_map, r);
       if (nact >= VEC) {
         GPack g;
 #pragma unroll
@@ -721,9 +683,6 @@ struct ColFft {
         }
       }
     }
-    };
-    if (FASTROWS && rows_plain(P.out_map)) store_rows(std::true_type{});
-    else store_rows(std::false_type{});
   }
 };
 

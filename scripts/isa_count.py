@@ -1,3 +1,12 @@
+#!/usr/bin/env python3
+"""Static instruction mix of the kernels in a hipcc -S listing (VALU, quarter-rate integer multiplies, LDS, vector loads /
+stores, scalar, scratch), by demangled-name regex:
+
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I/opt/rocm/include -S --offload-device-only \
+        mpifft4py_amd/csrc/kernels_b_d.hip -o /tmp/kernels_b_d.s
+    scripts/isa_count.py /tmp/kernels_b_d.s 'ColFft<mfft::Spec<1024, 8, 8, 4, 4>, double'
+
+Used for profiles/r05_plain_rows.txt (how much of a strided kernel's VALU time is address arithmetic)."""
 import sys,re,subprocess,collections
 path=sys.argv[1]; pat=sys.argv[2]
 cur=None; stats={}

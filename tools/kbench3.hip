@@ -33,7 +33,7 @@ __global__ __launch_bounds__(K::THREADS) void kern(P p) {
 
 // the same with a register cap that lets WGS workgroups share a CU (waves per SIMD = WGS * THREADS / 256)
 template <class K, class P, int WGS>
-__global__ __launch_bounds__(K::THREADS, WGS * K::THREADS / 256) void kern_occ(P p) {
+__global__ __launch_bounds__(K::THREADS, (WGS * K::THREADS + 255) / 256) void kern_occ(P p) {      // (rounded up, as registry.h does)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
 }
@@ -88,18 +88,6 @@ Variant<T> make_tile(const char* plan) {
            K::LDS_BYTES / 1024);
   return Variant<T>{nm, false, COLS, &launch_k<K, T>, build_pass_twiddles<S, T>()};
 }
-// round 5: the same kernel with its row offsets by row_off (a division and two 64-bit products per row) or, the rows lying one
-// stride apart, by base + (k TPT) stride
-template <class S, typename T, int COLS, bool TWLDS, int SPLIT, int VEC, bool NT, bool WALK, int WGS>
-Variant<T> make_walk(const char* plan) {
-  typedef ColFft<S, T, COLS, false, TWLDS, SPLIT, VEC, NT, 0, WALK> K;   // WALK = FASTROWS of fft_kernels.h
-  char nm[160];
-  snprintf(nm, sizeof nm, "%s %s c%d v%d%s%s%s thr%d lds%dK wgs%d", WALK ? "plain " : "rowoff", plan, COLS, VEC, TWLDS ? " twlds" : "",
-           SPLIT == 2 ? " quarter" : SPLIT ? " split" : "", NT ? " nt" : "", K::THREADS, K::LDS_BYTES / 1024, WGS);
-  if constexpr (WGS > 1) return Variant<T>{nm, false, COLS, &launch_k_occ<K, T, WGS>, build_pass_twiddles<S, T>()};
-  else return Variant<T>{nm, false, COLS, &launch_k<K, T>, build_pass_twiddles<S, T>()};
-}
-
 template <class S, typename T, int COLS, int VEC>
 Variant<T> make_persist(const char* plan) {
   typedef ColFftP<S, T, COLS, false, VEC> K;
@@ -512,55 +500,25 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  if (filter[0] && strstr("walk", filter)) {       // round 5: rows one stride apart (fft_kernels.h rows_plain) against row_off per row
-    {
-      std::vector<Variant<double>> vs;
-      vs.push_back(make_walk<SD, double, 8, true, 1, 1, false, false, 0>("8x8x4x4"));
-      vs.push_back(make_walk<SD, double, 8, true, 1, 1, false, true, 0>("8x8x4x4"));
-      vs.push_back(make_walk<SD, double, 8, true, 1, 1, false, true, 2>("8x8x4x4"));
-      vs.push_back(make_walk<SD, double, 8, true, 1, 1, true, false, 0>("8x8x4x4"));
-      vs.push_back(make_walk<SD, double, 8, true, 1, 1, true, true, 0>("8x8x4x4"));
-      vs.push_back(make_walk<SD, double, 8, true, 1, 1, true, true, 2>("8x8x4x4"));
-      run_all<double>(vs, 1024, "", rounds);
-    }
+  if (filter[0] && strstr("occ1200", filter)) {    // round 5: do two workgroups per CU really run at 1200 / 1440 under the register cap?
     {
       typedef Spec<1200, 10, 10, 6, 2> S12;
       std::vector<Variant<double>> vs;
-      vs.push_back(make_walk<S12, double, 8, false, 1, 1, false, false, 0>("10x10x6x2"));
-      vs.push_back(make_walk<S12, double, 8, false, 1, 1, false, true, 0>("10x10x6x2"));
-      vs.push_back(make_walk<S12, double, 8, true, 1, 1, false, true, 0>("10x10x6x2"));
-      vs.push_back(make_walk<S12, double, 8, false, 1, 1, false, true, 2>("10x10x6x2"));
-      vs.push_back(make_walk<S12, double, 8, false, 1, 1, true, true, 0>("10x10x6x2"));
+      vs.push_back(make_tile<S12, double, 8, false, 1, 1>("10x10x6x2"));
+      vs.push_back(make_tile_occ<S12, double, 8, false, 1, 1, false, 2>("10x10x6x2"));
+      vs.push_back(make_tile_occ<S12, double, 8, false, 2, 1, false, 2>("10x10x6x2"));
+      vs.push_back(make_tile_occ<S12, double, 8, false, 2, 1, false, 3>("10x10x6x2"));
+      vs.push_back(make_tile_occ<S12, double, 4, false, 1, 1, false, 4>("10x10x6x2"));
       run_all<double>(vs, 1200, "", rounds);
     }
     {
       typedef Spec<1440, 10, 6, 6, 2, 2> S14;
       std::vector<Variant<double>> vs;
-      vs.push_back(make_walk<S14, double, 8, false, 1, 1, false, false, 0>("10x6x6x2x2"));
-      vs.push_back(make_walk<S14, double, 8, false, 1, 1, false, true, 0>("10x6x6x2x2"));
-      vs.push_back(make_walk<S14, double, 8, true, 1, 1, false, true, 0>("10x6x6x2x2"));
+      vs.push_back(make_tile<S14, double, 8, false, 1, 1>("10x6x6x2x2"));
+      vs.push_back(make_tile_occ<S14, double, 8, false, 2, 1, false, 2>("10x6x6x2x2"));
+      vs.push_back(make_tile_occ<S14, double, 8, false, 2, 1, false, 3>("10x6x6x2x2"));
+      vs.push_back(make_tile_occ<S14, double, 4, false, 1, 1, false, 3>("10x6x6x2x2"));
       run_all<double>(vs, 1440, "", rounds);
-    }
-    {
-      typedef Spec<1792, 28, 4, 4, 4> S17;
-      std::vector<Variant<double>> vs;
-      vs.push_back(make_walk<S17, double, 8, false, 1, 1, false, false, 0>("28x4x4x4"));
-      vs.push_back(make_walk<S17, double, 8, false, 1, 1, false, true, 0>("28x4x4x4"));
-      vs.push_back(make_walk<S17, double, 8, true, 1, 1, false, true, 0>("28x4x4x4"));
-      run_all<double>(vs, 1792, "", rounds);
-    }
-    {
-      std::vector<Variant<float>> vs;
-      vs.push_back(make_walk<SA, float, 16, true, 1, 1, false, false, 0>("16x8x8"));
-      vs.push_back(make_walk<SA, float, 16, true, 1, 1, false, true, 0>("16x8x8"));
-      run_all<float>(vs, 1024, "", rounds);
-    }
-    {
-      typedef Spec<512, 4, 4, 4, 4, 2> S5;
-      std::vector<Variant<double>> vs;
-      vs.push_back(make_walk<S5, double, 8, true, 1, 1, false, false, 2>("4x4x4x4x2"));
-      vs.push_back(make_walk<S5, double, 8, true, 1, 1, false, true, 2>("4x4x4x4x2"));
-      run_all<double>(vs, 512, "", rounds);
     }
     return 0;
   }
