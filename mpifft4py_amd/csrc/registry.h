@@ -74,8 +74,29 @@ template <class S, typename T> constexpr int col_vec() {
   if (col_pair<S, T>()) return 1;
   return (lanes16 > 1 && S::E * lanes16 <= 32 && S::TPT * (full / lanes16) <= 512) ? lanes16 : 1;
 }
+// Round 5, two 128-byte tiles per workgroup (256-byte row segments).  A workgroup's waves go round the four SIMDs of its CU,
+// so 5 waves (length 1200 in double precision: 40 threads per transform x 8 columns = 320 threads) put two on one SIMD and
+// the passes of the whole workgroup last as long as THAT SIMD's two waves (tools/membench stamp1200: passes 24.8 k cycles =
+// 2 x the 12.4 k cycles one wave issues).  A second workgroup cannot hide it: the dispatcher admits a workgroup only where
+// EVERY SIMD has registers for ceil(waves / 4) of its waves (tools/occ_probe: 5 waves of 168 registers -> one resident per
+// CU where the occupancy API answers two; 10 waves of 96 -> one; 4 waves of 168 -> two, three), so the second workgroup of
+// round 5's capped build never ran.  With 16 columns the one resident workgroup has 10 waves = 3 3 2 2 and twice the loads
+// in flight: 1200 fp64 strided pass 8.05 / 7.30 / 7.80 -> 6.44 / 6.42 / 6.61 ms (kbench3 occ1200: y in place, x in place, x out
+// of place; profiles/r05_wave_placement.txt).  Only where the split exchange of 16 columns fits the LDS (N <= 1280), the
+// workgroup stays within 1024 threads and the kernel is alone on its CU anyway (N > 1024): of the plans, 1200.
+#ifndef MFFT_COL_WIDE
+#define MFFT_COL_WIDE 1
+#endif
+template <class S, typename T> constexpr bool col_wide() {
+  if (!MFFT_COL_WIDE) return false;
+  constexpr int cols = 128 / (int)sizeof(cx<T>);
+  constexpr int waves = (S::TPT * cols + 63) / 64;
+  return sizeof(T) == 8 && S::NP > 1 && S::N > 1024 && waves % 4 == 1 && S::TPT * 2 * cols <= 1024 &&
+         (long long)S::N * 2 * cols * (int)sizeof(T) <= 163840;
+}
 template <class S, typename T> constexpr int col_cols() {
   constexpr int vec = col_vec<S, T>();
+  if (col_wide<S, T>()) return 2 * (128 / (int)sizeof(cx<T>));
   int cols = 128 / (int)sizeof(cx<T>);
   while (cols > vec && S::TPT * (cols / vec) > 1024) cols /= 2;
   while (cols > vec && (long long)S::N * cols * (int)sizeof(T) > 131072) cols /= 2;   // even split must fit
@@ -144,12 +165,23 @@ template <class S, typename T, bool C2R = false> constexpr bool row_twlds() { re
 // (768 and 750 looked the same but their LDS twiddle tables leave room for two workgroups only, which their registers
 // allow already; 1440 / 1536 / 1792 need the four-round exchange for a second workgroup, which costs 450 - 560 bytes of
 // scratch under the cap: round 3's result stands.)
+// Round 5, single precision 1792 (28x4x4x4; 0.45 of the roofline): one 1024-thread workgroup per CU on 128-byte tiles (112 KB
+// of split exchange) against two 512-thread workgroups on 64-byte tiles with LDS twiddles (69 KB each; 8 waves = two per
+// SIMD, so the dispatcher's rule above admits the second at <= 128 registers): kbench3 occ1200, y in place / x in place / x
+// out of place 12.52 / 13.94 / 13.56 -> 10.42 / 11.67 / 11.72 ms (without the LDS twiddles 11.54 / 13.59 / 13.27).
+#ifndef MFFT_COL_NARROW_F32
+#define MFFT_COL_NARROW_F32 1
+#endif
+template <class S, typename T> constexpr bool col_narrow_f32() {
+  return MFFT_COL_NARROW_F32 && sizeof(T) == 4 && S::N == 1792 && S::E == 28;
+}
 template <class S, typename T> constexpr int col_wgs() {
   if (sizeof(T) == 8) return ((S::N == 1152 && S::E == 12) || (S::N == 512 && S::E == 4)) ? 2 : 0;
   if (S::N == 1152 && S::E == 24) return 2;
   if (S::N == 1536 && S::E == 24) return 3;
   if (MFFT_COL_OCC_R5 && S::N == 2304 && S::E == 24) return 2;
   if (MFFT_COL_OCC_R5 && S::N == 720 && S::E == 30) return 3;
+  if (col_narrow_f32<S, T>()) return 2;
   return 0;
 }
 // ---- generic __global__ wrapper + launch thunks ------------------------------
@@ -214,8 +246,8 @@ void register_col(const char* name) {
   auto& reg = kernel_registry();
   constexpr int W = col_wgs<S, T>();
   constexpr int WM = col_wgs_mask<S, T>();
-  constexpr int C = (sizeof(T) == 4 && S::N == 1536 && W == 3) ? 8 : col_cols<S, T>();      // see col_wgs
-  constexpr bool CT = col_twlds<S, T>();
+  constexpr int C = ((sizeof(T) == 4 && S::N == 1536 && W == 3) || col_narrow_f32<S, T>()) ? 8 : col_cols<S, T>();      // see col_wgs
+  constexpr bool CT = col_twlds<S, T>() || col_narrow_f32<S, T>();
   constexpr bool CS = col_split<S, T>() || (W > 1 && (long long)S::N * C * (int)sizeof(cx<T>) * W > 163840);
   constexpr int CV = col_vec<S, T>();
   reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));

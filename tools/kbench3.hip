@@ -509,6 +509,10 @@ int main(int argc, char** argv) {
       vs.push_back(make_tile_occ<S12, double, 8, false, 2, 1, false, 2>("10x10x6x2"));
       vs.push_back(make_tile_occ<S12, double, 8, false, 2, 1, false, 3>("10x10x6x2"));
       vs.push_back(make_tile_occ<S12, double, 4, false, 1, 1, false, 4>("10x10x6x2"));
+      // 5 waves on 4 SIMDs: one SIMD carries two, and the passes last as long as ITS two waves (membench stamp1200).  Two
+      // 128-byte tiles per workgroup: 10 waves = 3 3 2 2
+      vs.push_back(make_tile<S12, double, 16, false, 1, 1>("10x10x6x2"));
+      vs.push_back(make_tile<S12, double, 16, false, 1, 1, true>("10x10x6x2"));
       run_all<double>(vs, 1200, "", rounds);
     }
     {
@@ -518,7 +522,19 @@ int main(int argc, char** argv) {
       vs.push_back(make_tile_occ<S14, double, 8, false, 2, 1, false, 2>("10x6x6x2x2"));
       vs.push_back(make_tile_occ<S14, double, 8, false, 2, 1, false, 3>("10x6x6x2x2"));
       vs.push_back(make_tile_occ<S14, double, 4, false, 1, 1, false, 3>("10x6x6x2x2"));
+      vs.push_back(make_tile<S14, double, 12, false, 1, 1>("10x6x6x2x2"));      // 9 waves = 3 2 2 2 (192-byte tiles)
+      vs.push_back(make_tile<S14, double, 16, false, 2, 1>("10x6x6x2x2"));      // 12 waves = 3 3 3 3, exchange by quarters (90 KB)
       run_all<double>(vs, 1440, "", rounds);
+    }
+    {   // single precision 1792 (0.45 of the roofline): one 1024-thread workgroup per CU as shipped, or two of 512 on 64-byte tiles
+      typedef Spec<1792, 28, 4, 4, 4> S17;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<S17, float, 16, false, 1, 1>("28x4x4x4"));
+      vs.push_back(make_tile_occ<S17, float, 8, false, 1, 1, false, 2>("28x4x4x4"));
+      vs.push_back(make_tile_occ<S17, float, 8, true, 1, 1, false, 2>("28x4x4x4"));
+      vs.push_back(make_tile_occ<S17, float, 16, false, 2, 1, false, 2>("28x4x4x4"));     // 128-byte tiles, quarter exchange (57 KB): two per CU need <= 64 registers
+      vs.push_back(make_tile<S17, float, 16, false, 1, 2>("28x4x4x4"));                   // two columns per lane: 512 threads
+      run_all<float>(vs, 1792, "", rounds);
     }
     return 0;
   }

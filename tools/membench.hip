@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 #include "fft_kernels.h"
@@ -148,8 +149,8 @@ __device__ __forceinline__ unsigned long long stamp_nowait() {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
-template <class S, int COLS, bool SPLIT>
-__global__ __launch_bounds__(S::TPT* COLS, (SPLIT ? 2 : 1) * (S::TPT * COLS / 256)) void k_stamped(ColParams<double> P, Stamp* stamps) {
+template <class S, int COLS, bool SPLIT, int WPS = (SPLIT ? 2 : 1) * (S::TPT * COLS / 256)>      // WPS: waves per SIMD the register cap admits
+__global__ __launch_bounds__(S::TPT* COLS, WPS) void k_stamped(ColParams<double> P, Stamp* stamps) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef double T;
   const int bid = P.remap ? xcd_remap((int)blockIdx.x, P.ntile_c * P.nouter) : (int)blockIdx.x;
@@ -342,11 +343,11 @@ static void run_tile_n(cx<double>* in, cx<double>* out, bool xdir, int lds_bytes
   report(nm, ms, 2.0 * N * N * 16.0 * NF);
 }
 
-template <class S, int COLS, bool SPLIT>
+template <class S, int COLS, bool SPLIT, int WPS = (SPLIT ? 2 : 1) * (S::TPT * COLS / 256)>
 static void run_stamped(const char* plan, cx<double>* buf, bool xdir) {
-  const int N = 1024, NF = 513, pitch = 513;
+  const int N = S::N, NF = S::N / 2 + 1, pitch = NF;
   char nm[160];
-  snprintf(nm, sizeof nm, "stamped %s c%d%s %s", plan, COLS, SPLIT ? " split" : "", xdir ? "x" : "y");
+  snprintf(nm, sizeof nm, "stamped %d %s c%d%s wps%d %s", N, plan, COLS, SPLIT ? " split" : "", WPS, xdir ? "x" : "y");
   if (!want(nm)) return;
   auto twh = build_pass_twiddles<S, double>();
   cx<double>* tw = nullptr;
@@ -367,12 +368,12 @@ static void run_stamped(const char* plan, cx<double>* buf, bool xdir) {
   P.ntile_c = (P.ncols + COLS - 1) / COLS;
   const int grid = P.ntile_c * P.nouter;
   const int LDS = S::N * COLS * (SPLIT ? 8 : 16);
-  CK(hipFuncSetAttribute((const void*)k_stamped<S, COLS, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  CK(hipFuncSetAttribute((const void*)k_stamped<S, COLS, SPLIT, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   int occ = 0;
-  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_stamped<S, COLS, SPLIT>, S::TPT * COLS, LDS));
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_stamped<S, COLS, SPLIT, WPS>, S::TPT * COLS, LDS));
   Stamp* ds = nullptr;
   CK(hipMalloc(&ds, sizeof(Stamp) * grid));
-  const double ms = time_ms([&] { hipLaunchKernelGGL((k_stamped<S, COLS, SPLIT>), dim3(grid), dim3(S::TPT * COLS), LDS, 0, P, ds); }, 2, 3);
+  const double ms = time_ms([&] { hipLaunchKernelGGL((k_stamped<S, COLS, SPLIT, WPS>), dim3(grid), dim3(S::TPT * COLS), LDS, 0, P, ds); }, 2, 3);
   std::vector<Stamp> hs(grid);
   CK(hipMemcpy(hs.data(), ds, sizeof(Stamp) * grid, hipMemcpyDeviceToHost));
   // shares (shader cycles of wave 0): load wait, passes, store issue, store drain
@@ -397,6 +398,38 @@ static void run_stamped(const char* plan, cx<double>* buf, bool xdir) {
          nm, ms, occ, grid, med(ph[0], .5), med(ph[0], .1), med(ph[0], .9), med(ph[1], .5), med(ph[1], .1), med(ph[1], .9),
          med(ph[2], .5), med(ph[2], .1), med(ph[2], .9), med(ph[3], .5), med(ph[3], .1), med(ph[3], .9), med(ph[4], .5),
          med(ph[4], .1), med(ph[4], .9), (double)(rt1 - rt0) / 100.0);
+  {  // round 5: per CU, how the phases of its resident workgroups lie against each other (shader-clock stamps of one CU share
+     // a counter): the share of the CU's span in which at least one workgroup has loads or stores in flight ("memory"), at
+     // least one runs its passes ("passes"), both at once ("overlapped"), and neither
+    std::map<unsigned long long, std::vector<const Stamp*>> cus;
+    for (auto& st : hs) cus[((unsigned long long)st.xcc << 32) | ((st.cu >> 8) & 0xFFu)].push_back(&st);
+    double span = 0, mem = 0, pas = 0, both = 0, none = 0;
+    for (auto& kv : cus) {
+      std::vector<std::pair<unsigned long long, int>> ev;      // (time, kind): +-1 memory, +-2 passes
+      unsigned long long lo = ~0ull, hi = 0;
+      for (const Stamp* st : kv.second) {
+        ev.push_back({st->t[0], 1}); ev.push_back({st->t[1], -1});
+        ev.push_back({st->t[1], 2}); ev.push_back({st->t[2], -2});
+        ev.push_back({st->t[2], 1}); ev.push_back({st->t[4], -1});
+        lo = std::min(lo, st->t[0]); hi = std::max(hi, st->t[4]);
+      }
+      std::sort(ev.begin(), ev.end());
+      int nm_ = 0, np_ = 0;
+      unsigned long long prev = lo;
+      for (auto& e : ev) {
+        const double dt = (double)(e.first - prev);
+        if (nm_ > 0) mem += dt;
+        if (np_ > 0) pas += dt;
+        if (nm_ > 0 && np_ > 0) both += dt;
+        if (nm_ == 0 && np_ == 0) none += dt;
+        prev = e.first;
+        if (e.second == 1) ++nm_; else if (e.second == -1) --nm_; else if (e.second == 2) ++np_; else --np_;
+      }
+      span += (double)(hi - lo);
+    }
+    printf("    %zu CUs: of a CU's span, memory phase %.1f %%, passes %.1f %%, both at once %.1f %%, neither %.1f %%\n", cus.size(), mem / span * 100,
+           pas / span * 100, both / span * 100, none / span * 100);
+  }
   // effective clock: sum of per-workgroup lifetimes / (workgroups resident at once * wall) is not known here; print the
   // mean lifetime so that lifetime * grid / (256 CUs * occ) can be compared with the wall time
   double sum = 0;
@@ -487,6 +520,48 @@ static void run_pstamped(const char* plan, cx<double>* buf, bool xdir) {
 
 int main(int argc, char** argv) {
   g_filter = argc > 1 ? argv[1] : "";
+  if (argc > 1 && !strcmp(argv[1], "stamp1200")) {  // round 5: phases of the 30-values strided kernel at one and at two workgroups per CU
+    const size_t el = (size_t)1440 * 1440 * 721 + 4096;
+    cx<double>* a = nullptr;
+    CK(hipMalloc(&a, el * sizeof(cx<double>)));
+    CK(hipMemset(a, 0, el * sizeof(cx<double>)));
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    typedef Spec<1200, 10, 10, 6, 2> S12;
+    typedef Spec<1024, 8, 8, 4, 4> S10;
+    g_filter = "";
+    for (int x = 0; x < 2; ++x) {
+      run_stamped<S10, 8, true, 8>("8x8x4x4", a, x);
+      run_stamped<S12, 8, true, 2>("10x10x6x2", a, x);
+      run_stamped<S12, 8, true, 3>("10x10x6x2", a, x);
+      run_stamped<S12, 4, true, 3>("10x10x6x2", a, x);      // 64-byte tiles: 160 threads = 3 waves, one per SIMD reserved: three resident
+      run_stamped<S12, 4, false, 3>("10x10x6x2", a, x);     // whole-complex exchange (75 KB): two resident
+    }
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "tile1200")) {   // round 5: the bare tile pattern of the 30-values kernels (320 / 384 threads, one or two per CU)
+    const size_t el = (size_t)1536 * 1536 * 769;
+    cx<double>*a = nullptr, *b = nullptr;
+    CK(hipMalloc(&a, el * sizeof(cx<double>)));
+    CK(hipMalloc(&b, el * sizeof(cx<double>)));
+    CK(hipMemset(a, 0, el * sizeof(cx<double>)));
+    CK(hipMemset(b, 0, el * sizeof(cx<double>)));
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int x = 0; x < 2; ++x) {
+      run_tile_n<1024, 8, 8, 0>(a, a, x, 80 << 10);
+      run_tile_n<1200, 8, 30, 0>(a, a, x, 90 << 10);     // one workgroup per CU, as the FFT kernel runs
+      run_tile_n<1200, 8, 30, 0>(a, a, x, 75 << 10);     // two
+      run_tile_n<1200, 8, 30, 0>(a, a, x, 0);
+      run_tile_n<1200, 8, 30, 0>(a, b, x, 90 << 10);
+      run_tile_n<1200, 8, 10, 0>(a, a, x, 75 << 10);     // 960 threads, two per CU
+      run_tile_n<1200, 8, 10, 0>(a, a, x, 0);
+      run_tile_n<1440, 8, 30, 0>(a, a, x, 90 << 10);
+      run_tile_n<1440, 8, 30, 0>(a, a, x, 0);
+      run_tile_n<1440, 8, 10, 0>(a, a, x, 0);
+    }
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "tilelong")) {   // the bare tile pattern at the lengths above 1024 (dynamic LDS only limits occupancy)
     const size_t el = (size_t)1536 * 1536 * 769;
     cx<double>*a = nullptr, *b = nullptr;
