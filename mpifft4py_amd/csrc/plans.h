@@ -102,7 +102,8 @@ template <typename T> constexpr bool mfft_has_row_override_t(int n) { return mff
 // 1024 threads and 128-byte tiles (kbench2: 2048 2.7 -> 3.8 TB/s, 4096 2.0 -> 3.1 TB/s; the E = 16 plans would need
 // two columns per lane at 1024 threads, which spills).  A length listed here gets its fp32 strided kernels from
 // this list, everything else from its MFFT_PLANS_* entry.
-#define MFFT_COLPLANS_F32_C(X) X(2048, 32, 8, 8) X(4096, 32, 32, 4)
+// (round 5: 2048 is back on its 16x16x8 plan, on 64-byte tiles with two workgroups per CU: registry.h col_narrow_f32)
+#define MFFT_COLPLANS_F32_C(X) X(4096, 32, 32, 4)
 // Strided-kernel override for DOUBLE precision: 1024 runs as 8x8x4x4 (E = 8, 1024 threads, 60 VGPRs) with LDS twiddles and
 // the split re/im exchange, i.e. 80 KB of LDS, so that TWO workgroups share a CU and one's loads and stores overlap the
 // other's passes.  Interleaved A/B at 1024^3 (kbench3, profiles/r02_kbench3_variants.txt): y in place 3.52 -> 3.44 ms,
@@ -135,7 +136,7 @@ template <typename T> constexpr bool mfft_has_row_override_t(int n) { return mff
 // stay: they are what double precision and the y passes run (core.hip launch_col has the measurements; MFFT_COL3=0 / 1).
 #define MFFT_COL3PLANS_E(X) X(1536, 512, 4, 4, 4, 4, 2)
 template <typename T> constexpr bool mfft_has_col_override(int n) {
-  return (sizeof(T) == 4 && (n == 2048 || n == 4096)) || (sizeof(T) == 8 && (n == 1024 || n == 512 || n == 384 || n == 768 || n == 1152 || n == 900));
+  return (sizeof(T) == 4 && n == 4096) || (sizeof(T) == 8 && (n == 1024 || n == 512 || n == 384 || n == 768 || n == 1152 || n == 900));
 }
 
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \

@@ -172,8 +172,15 @@ template <class S, typename T, bool C2R = false> constexpr bool row_twlds() { re
 #ifndef MFFT_COL_NARROW_F32
 #define MFFT_COL_NARROW_F32 1
 #endif
+// The same at 1440 (10x6x6x2x2: 768 threads on 128-byte tiles -> two workgroups of 384: 7.55 / 7.66 / 7.93 -> 7.17 / 7.23 / 7.32 ms) and
+// at 2048, which returns from the 32x8x8 plan of round 1 (plans.h MFFT_COLPLANS_F32_C) to 16x16x8: 16 values per thread, 1024
+// threads on 64-byte tiles, 64 registers, two workgroups per CU as the double-precision 1024 kernel has them: 17.14 / 19.37 /
+// 17.73 -> 15.39 / 16.89 / 17.30 ms (32x8x8 on 64-byte tiles: 16.86 / 17.54 / 18.15).  Not at 1200 (3.95 / 4.02 / 4.01 -> 4.08 / 3.97 /
+// 4.01), 1280 (3.94 / 3.77 / 3.60 -> 4.54 / 4.08 / 4.41), nor in double precision at 1600 (15.1 / 14.1 / 14.5 -> 18.7 / 17.5 / 17.2) and 1792
+// (22.4 / 22.0 / 22.1 -> 20.6 / 22.7 / 21.6): kbench3 narrow, profiles/r05_wave_placement.txt.
 template <class S, typename T> constexpr bool col_narrow_f32() {
-  return MFFT_COL_NARROW_F32 && sizeof(T) == 4 && S::N == 1792 && S::E == 28;
+  return MFFT_COL_NARROW_F32 && sizeof(T) == 4 &&
+         ((S::N == 1792 && S::E == 28) || (S::N == 1440 && S::E == 30) || (S::N == 2048 && S::E == 16));
 }
 template <class S, typename T> constexpr int col_wgs() {
   if (sizeof(T) == 8) return ((S::N == 1152 && S::E == 12) || (S::N == 512 && S::E == 4)) ? 2 : 0;
@@ -181,9 +188,12 @@ template <class S, typename T> constexpr int col_wgs() {
   if (S::N == 1536 && S::E == 24) return 3;
   if (MFFT_COL_OCC_R5 && S::N == 2304 && S::E == 24) return 2;
   if (MFFT_COL_OCC_R5 && S::N == 720 && S::E == 30) return 3;
-  if (col_narrow_f32<S, T>()) return 2;
+  // (16 + waves per SIMD: the cap that the dispatcher's rule asks of TWO workgroups, 2 x ceil(waves / 4) -- the plain
+  // "workgroups x threads / 256" of mfft_kern_occ gives 3 for the 6 waves of 1440, and the second workgroup would stay out)
+  if (col_narrow_f32<S, T>()) return 16 + 2 * ((S::TPT * 8 / 64 + 3) / 4);
   return 0;
 }
+constexpr int col_wgs_count(int w) { return w >= 16 ? 2 : w; }
 // ---- generic __global__ wrapper + launch thunks ------------------------------
 template <class K, class P>
 __global__ __launch_bounds__(K::THREADS) void mfft_kern(P p) {
@@ -191,8 +201,9 @@ __global__ __launch_bounds__(K::THREADS) void mfft_kern(P p) {
   K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
 }
 // the same with a register cap: WGS workgroups per CU = WGS * THREADS / 256 waves per SIMD
+// (WGS >= 16: WGS - 16 waves per SIMD, said directly)
 template <class K, class P, int WGS>
-__global__ __launch_bounds__(K::THREADS, (WGS * K::THREADS + 255) / 256) void mfft_kern_occ(P p) {
+__global__ __launch_bounds__(K::THREADS, WGS >= 16 ? WGS - 16 : (WGS * K::THREADS + 255) / 256) void mfft_kern_occ(P p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   K::body(p, (int)blockIdx.x, (int)threadIdx.x, lds);
 }
@@ -241,6 +252,12 @@ template <class S, typename T> constexpr int col_wgs_mask() {
   return r5 ? 0 : col_wgs<S, T>();
 }
 
+// non-temporal variants (for tiles whose rows are whole lines): not for the single-precision kernels with two workgroups per
+// CU (8 bytes per lane: measured worse, section header), nor for 2048 in single precision, whose 64-register cap they
+// overrun by 68 - 148 bytes of scratch
+template <class S, typename T> constexpr bool col_has_nt() {
+  return S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4) && !(col_narrow_f32<S, T>() && S::N == 2048);
+}
 template <class S, typename T>
 void register_col(const char* name) {
   auto& reg = kernel_registry();
@@ -248,8 +265,8 @@ void register_col(const char* name) {
   constexpr int WM = col_wgs_mask<S, T>();
   constexpr int C = ((sizeof(T) == 4 && S::N == 1536 && W == 3) || col_narrow_f32<S, T>()) ? 8 : col_cols<S, T>();      // see col_wgs
   constexpr bool CT = col_twlds<S, T>() || col_narrow_f32<S, T>();
-  constexpr bool CS = col_split<S, T>() || (W > 1 && (long long)S::N * C * (int)sizeof(cx<T>) * W > 163840);
-  constexpr int CV = col_vec<S, T>();
+  constexpr bool CS = col_split<S, T>() || (W > 1 && (long long)S::N * C * (int)sizeof(cx<T>) * col_wgs_count(W) > 163840);
+  constexpr int CV = col_narrow_f32<S, T>() ? 1 : col_vec<S, T>();
   reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
   reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
   if constexpr (S::E % 3 == 0 && S::N >= 6) {   // 3/2-rule lengths: pad-on-load (inverse) / truncate-on-store (forward)
@@ -261,7 +278,7 @@ void register_col(const char* name) {
   // 2/3-rule: inverse transform with the dealias mask applied on load (pad = 5)
   reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 3>, ColParams<T>, S, T, WM>(FAM_COL, S::N, 1, C, name));
   reg.back().pad = 5;
-  if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {
+  if constexpr (col_has_nt<S, T>()) {
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 3>, ColParams<T>, S, T, WM>(FAM_COL, S::N, 1, C, name));
     reg.back().pad = 5;
     reg.back().nt = 1;
@@ -270,13 +287,13 @@ void register_col(const char* name) {
   // pruned 2/3-rule passes (pad = 6)
   reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, false, 4>, ColParams<T>, S, T, WM>(FAM_COL, S::N, 1, C, name));
   reg.back().pad = 6;
-  if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {
+  if constexpr (col_has_nt<S, T>()) {
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true, 4>, ColParams<T>, S, T, WM>(FAM_COL, S::N, 1, C, name));
     reg.back().pad = 6;
     reg.back().nt = 1;
     reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;
   }
-  if constexpr (S::N >= 256 && !(col_pair<S, T>() && sizeof(T) == 4)) {     // aligned-row (non-temporal) variants
+  if constexpr (col_has_nt<S, T>()) {     // aligned-row (non-temporal) variants
     reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV, true>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
     reg.back().nt = 1;
     reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;

@@ -500,6 +500,56 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (filter[0] && strstr("narrow", filter)) {     // round 5: what 1792 fp32 gained (64-byte tiles + LDS twiddles, two workgroups per CU) at the other
+                                                   // lengths that run one big workgroup per CU
+    {
+      typedef Spec<2048, 32, 8, 8> S;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<S, float, 16, false, 1, 1>("32x8x8"));
+      vs.push_back(make_tile_occ<S, float, 8, true, 1, 1, false, 2>("32x8x8"));
+      vs.push_back(make_tile_occ<Spec<2048, 16, 16, 8>, float, 8, true, 1, 1, false, 2>("16x16x8"));
+      run_all<float>(vs, 2048, "", rounds);
+    }
+    {
+      typedef Spec<1440, 10, 6, 6, 2, 2> S;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<S, float, 16, false, 1, 1>("10x6x6x2x2"));
+      vs.push_back(make_tile_occ<S, float, 8, true, 1, 1, false, 2>("10x6x6x2x2"));
+      vs.push_back(make_tile_occ<S, float, 8, false, 1, 1, false, 2>("10x6x6x2x2"));
+      run_all<float>(vs, 1440, "", rounds);
+    }
+    {
+      typedef Spec<1200, 10, 10, 6, 2> S;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<S, float, 16, false, 1, 1>("10x10x6x2"));
+      vs.push_back(make_tile_occ<S, float, 8, true, 1, 1, false, 2>("10x10x6x2"));
+      run_all<float>(vs, 1200, "", rounds);
+    }
+    {
+      typedef Spec<1280, 8, 8, 4, 5> S;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<S, float, 16, false, 1, 1>("8x8x4x5"));
+      vs.push_back(make_tile_occ<S, float, 8, true, 1, 1, false, 2>("8x8x4x5"));
+      vs.push_back(make_tile_occ<S, float, 16, true, 1, 1, false, 2>("8x8x4x5"));
+      run_all<float>(vs, 1280, "", rounds);
+    }
+    {
+      typedef Spec<1792, 28, 4, 4, 4> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("28x4x4x4"));
+      vs.push_back(make_tile_occ<S, double, 4, false, 1, 1, false, 2>("28x4x4x4"));
+      run_all<double>(vs, 1792, "", rounds);
+    }
+    {
+      typedef Spec<1600, 20, 20, 4> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("20x20x4"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 2>("20x20x4"));
+      vs.push_back(make_tile_occ<S, double, 4, false, 1, 1, false, 2>("20x20x4"));
+      run_all<double>(vs, 1600, "", rounds);
+    }
+    return 0;
+  }
   if (filter[0] && strstr("occ1200", filter)) {    // round 5: do two workgroups per CU really run at 1200 / 1440 under the register cap?
     {
       typedef Spec<1200, 10, 10, 6, 2> S12;
