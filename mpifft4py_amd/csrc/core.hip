@@ -294,6 +294,17 @@ int launch_col(const ColArgs& a, hipStream_t s) {
   }
   if (!e && ent) e = ent;
   if (!e) e = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 0);
+  // Round 5: the y-pass builds (registry.h register_col_ytile, nt code 2: 64-byte tiles, LDS twiddles, two workgroups per
+  // CU) where the rows of a tile lie at most 64 KB apart on both sides -- the y passes of every decomposition; the x passes,
+  // rows a plane apart, lose with them (1440 / 1536 fp64: y 12.95 -> 9.62 / 13.74 -> 11.55 ms, x 12.85 -> 14.49 / 12.56 -> 14.41).  Not for the
+  // pruned 2/3-rule passes (their tile lists are built for the width of the general kernel).  MFFT_YTILE=0 never, 2 always.
+  static const int ytile_mode = getenv("MFFT_YTILE") ? atoi(getenv("MFFT_YTILE")) : 1;
+  if (ytile_mode > 0 && e && !a.band.on && e->family == FAM_COL && e->pad <= 5 && e->nt != 2) {
+    const int64_t es = (int64_t)elem_bytes(a.prec, true);
+    const bool near_rows = std::llabs(a.in_rows.lo) * es <= 65536 && std::llabs(a.out_rows.lo) * es <= 65536;
+    if (near_rows || ytile_mode > 1)
+      if (const KernelEntry* ey = find_kernel(FAM_COL, a.n, a.prec, a.inverse ? 1 : 0, 2, e->pad)) e = ey;
+  }
   void* tw = nullptr;
   if (!e) {   // no radix plan for this length: chirp-z on the next compiled length >= 2n-1
     e = find_chirpz(FAM_COLZ, a.n, a.prec, a.inverse ? 1 : 0);

@@ -264,7 +264,9 @@ void register_col(const char* name) {
   constexpr int W = col_wgs<S, T>();
   constexpr int WM = col_wgs_mask<S, T>();
   constexpr int C = ((sizeof(T) == 4 && S::N == 1536 && W == 3) || col_narrow_f32<S, T>()) ? 8 : col_cols<S, T>();      // see col_wgs
-  constexpr bool CT = col_twlds<S, T>() || col_narrow_f32<S, T>();
+  // (1536 in single precision, 64-byte tiles since round 2: with LDS twiddles 7.25 / 7.73 / 7.46 -> 6.70 / 7.34 / 7.20 ms although only two
+  // of its workgroups then fit a CU instead of three -- kbench3 tw1536)
+  constexpr bool CT = col_twlds<S, T>() || col_narrow_f32<S, T>() || (sizeof(T) == 4 && S::N == 1536 && W == 3);
   constexpr bool CS = col_split<S, T>() || (W > 1 && (long long)S::N * C * (int)sizeof(cx<T>) * col_wgs_count(W) > 163840);
   constexpr int CV = col_narrow_f32<S, T>() ? 1 : col_vec<S, T>();
   reg.push_back(make_entry<ColFft<S, T, C, false, CT, CS, CV>, ColParams<T>, S, T, W>(FAM_COL, S::N, 0, C, name));
@@ -300,6 +302,39 @@ void register_col(const char* name) {
     reg.push_back(make_entry<ColFft<S, T, C, true, CT, CS, CV, true>, ColParams<T>, S, T, W>(FAM_COL, S::N, 1, C, name));
     reg.back().nt = 1;
     reg.back().nt_inplace = (col_pair<S, T>() && S::N != 512) ? 1 : 0;
+  }
+}
+
+// Round 5, y-pass builds (KernelEntry::nt == 2; core.hip launch_col takes them when the rows of a tile lie at most 64 KB
+// apart): 64-byte tiles with LDS twiddles, two workgroups per CU by LDS alone (3 - 4 waves each, so the dispatcher's rule
+// leaves them 256 registers).  kbench3 tw64, double precision, y in place / x in place / x out of place, ms:
+//   1440  12.95 / 12.85 / 13.43 -> 9.62 / 14.49 / 14.39        1536  13.74 / 12.56 / 13.37 -> 11.55 / 14.41 / 14.04
+// -- the y pass, whose neighbouring tiles share their 128-byte lines within a few MB, gains 16 - 26 %; the x pass, whose rows
+// lie MBs apart (every row of a tile on its own page, twice the tiles), loses as much: so the build is chosen by the stride.
+// Without the LDS twiddles the same tiles gain nothing (1440: 13.7 / 13.7 / 13.3; rounds 2 and 3 tried only that).
+#ifndef MFFT_COL_YTILE
+#define MFFT_COL_YTILE 1
+#endif
+template <class S, typename T> constexpr bool col_ytile() {
+  return MFFT_COL_YTILE && sizeof(T) == 8 && ((S::N == 1440 && S::E == 30) || (S::N == 1536 && S::E == 24));
+}
+template <class S, typename T>
+void register_col_ytile(const char* name) {
+  if constexpr (col_ytile<S, T>()) {
+    auto& reg = kernel_registry();
+    constexpr int C = 64 / (int)sizeof(cx<T>);
+    auto add = [&](KernelEntry e, int pad) {
+      e.nt = 2;
+      e.pad = pad;
+      reg.push_back(e);
+    };
+    add(make_entry<ColFft<S, T, C, false, true, 1, 1>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name), 0);
+    add(make_entry<ColFft<S, T, C, true, true, 1, 1>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name), 0);
+    if constexpr (S::E % 3 == 0) {
+      add(make_entry<ColFft<S, T, C, true, true, 1, 1, false, 1>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name), 1);
+      add(make_entry<ColFft<S, T, C, false, true, 1, 1, false, 2>, ColParams<T>, S, T>(FAM_COL, S::N, 0, C, name), 2);
+    }
+    add(make_entry<ColFft<S, T, C, true, true, 1, 1, false, 3>, ColParams<T>, S, T>(FAM_COL, S::N, 1, C, name), 5);
   }
 }
 
@@ -536,6 +571,7 @@ void register_plan(const char* name) {
   constexpr bool chirp = S::N % 15 != 0 && S::N % 7 != 0;      // (nor the 28-values-per-thread plans of 7 * 2^a)
   if constexpr (!mfft_has_col_override<T>(S::N)) {
     register_col<S, T>(name);
+    register_col_ytile<S, T>(name);
     if constexpr (chirp) register_col_z<S, T>(name);
   }
   if constexpr (!mfft_has_row_override_t<T>(S::N)) {
@@ -546,6 +582,7 @@ void register_plan(const char* name) {
 template <class S, typename T>
 void register_colplan(const char* name) {
   register_col<S, T>(name);
+  register_col_ytile<S, T>(name);
   register_col_z<S, T>(name);
 }
 template <class S, typename T>

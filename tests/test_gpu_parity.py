@@ -230,7 +230,31 @@ def test_padded_generic_data(decomp, P, prec, fused, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["double", "single"])
-@pytest.mark.parametrize("N", [[768, 8, 8], [8, 768, 8], [8, 8, 768], [1024, 8, 8], [8, 1024, 8], [8, 8, 1024], [256, 8, 8],
+@pytest.mark.parametrize("P", [1, 2, 4])
+@pytest.mark.parametrize("N", [[1200, 24, 10], [24, 1200, 10], [1792, 16, 12], [16, 2048, 12], [1440, 16, 12], [16, 1440, 12]])
+def test_wide_and_narrow_tiles_over_ranks(N, P, prec):
+    """Round 5's tile shapes (registry.h col_wide: 16 columns per workgroup for 1200 in double precision; col_narrow_f32: 64-byte
+    tiles, two workgroups per CU, for 1440 / 1792 / 2048 in single) on ragged column counts (10 / 12 columns: 6 or 7 bins) and
+    on the split row maps of 2 and 4 ranks, against the oracle and numpy (the reference's own tolerance, tests/test_FFT.py:85)."""
+    rng = np.random.default_rng(sum(N) + P)
+    A = rng.random(N).astype(rdtype(prec))
+    B2 = np.fft.rfftn(A.astype(np.float64))
+    want = orc.slab_r2c_forward(orc.scatter_real(A, orc.SlabLayout(N, P)), N, prec)
+    from mpifft4py_amd import Slab_R2C
+
+    def body(comm):
+        F = Slab_R2C(np.array(N), L, comm, prec)
+        c = F.fftn(A[F.real_local_slice()].copy(), np.zeros(F.complex_shape(), dtype=cdtype(prec)))
+        b = F.ifftn(c.copy(), np.zeros(F.real_shape(), dtype=rdtype(prec)))
+        return F.complex_local_slice(), c, F.real_local_slice(), b
+    for r, (cs, c, rs, b) in enumerate(run_ranks(P, body)):
+        assert orc.rel_l2(c, want[r]) < TOL[prec]
+        assert orc.rel_l2(c, B2[cs]) < TOL[prec]
+        assert orc.rel_l2(b, A[rs]) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("N", [[800, 8, 8], [8, 800, 8], [768, 8, 8], [8, 768, 8], [8, 8, 768], [1024, 8, 8], [8, 1024, 8], [8, 8, 1024], [256, 8, 8],
                                # padded images on the round-3 plans: 1280 -> 1920, 2560 -> 3840, 1600 -> 2400, 2000 -> 3000, 1000 -> 1500
                                [1280, 8, 8], [8, 1280, 8], [8, 8, 1280], [2560, 8, 8], [8, 8, 2560], [8, 1600, 8], [8, 8, 1600],
                                [2000, 8, 8], [8, 8, 2000], [8, 1000, 8], [8, 8, 1000], [8, 500, 8]])

@@ -500,6 +500,125 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (filter[0] && strstr("y64b", filter)) {       // ... and 1344 (42 values per thread), 1500
+    {
+      typedef Spec<1344, 42, 2, 2, 2, 2, 2> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("42x2x2x2x2x2"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 2>("42x2x2x2x2x2"));
+      vs.push_back(make_tile_occ<S, double, 4, false, 1, 1, false, 2>("42x2x2x2x2x2"));
+      run_all<double>(vs, 1344, "", rounds);
+    }
+    {
+      typedef Spec<1500, 15, 10, 10> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("15x10x10"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 2>("15x10x10"));
+      run_all<double>(vs, 1500, "", rounds);
+    }
+    return 0;
+  }
+  if (filter[0] && strstr("y64", filter)) {        // round 5: 64-byte tiles with LDS twiddles won the y pass (rows a few KB apart) of 1440 / 1536 by 16 - 26 %
+                                                   // and lost the x pass (rows MBs apart): which other lengths?
+    {
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<SD, double, 8, true, 1, 1>("8x8x4x4"));
+      vs.push_back(make_tile_occ<SD, double, 4, true, 1, 1, false, 3>("8x8x4x4"));
+      vs.push_back(make_tile_occ<SD, double, 4, true, 1, 1, false, 4>("8x8x4x4"));
+      run_all<double>(vs, 1024, "", rounds);
+    }
+    {
+      typedef Spec<1152, 12, 12, 4, 2> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile_occ<S, double, 8, false, 1, 1, false, 2>("12x12x4x2"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 2>("12x12x4x2"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 3>("12x12x4x2"));
+      run_all<double>(vs, 1152, "", rounds);
+    }
+    {
+      typedef Spec<1200, 10, 10, 6, 2> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 16, false, 1, 1>("10x10x6x2"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 2>("10x10x6x2"));
+      run_all<double>(vs, 1200, "", rounds);
+    }
+    {
+      typedef Spec<1280, 8, 8, 4, 5> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("8x8x4x5"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 2>("8x8x4x5"));
+      run_all<double>(vs, 1280, "", rounds);
+    }
+    {
+      typedef Spec<1792, 28, 4, 4, 4> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("28x4x4x4"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 1>("28x4x4x4"));
+      vs.push_back(make_tile_occ<S, double, 2, true, 1, 1, false, 2>("28x4x4x4"));
+      run_all<double>(vs, 1792, "", rounds);
+    }
+    {
+      typedef Spec<2048, 16, 16, 8> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("16x16x8"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 1>("16x16x8"));
+      run_all<double>(vs, 2048, "", rounds);
+    }
+    return 0;
+  }
+  if (filter[0] && strstr("tw64", filter)) {       // round 5: 64-byte tiles WITH LDS twiddles in double precision (the trials of rounds 2 / 3 had none)
+    {
+      typedef Spec<1536, 8, 8, 8, 3> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("8x8x8x3"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 2>("8x8x8x3"));
+      vs.push_back(make_tile_occ<S, double, 4, false, 1, 1, false, 3>("8x8x8x3"));
+      run_all<double>(vs, 1536, "", rounds);
+    }
+    {
+      typedef Spec<1440, 10, 6, 6, 2, 2> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("10x6x6x2x2"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 2>("10x6x6x2x2"));
+      run_all<double>(vs, 1440, "", rounds);
+    }
+    {
+      typedef Spec<2304, 24, 24, 4> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 1, 1>("24x24x4"));
+      vs.push_back(make_tile_occ<S, double, 4, true, 1, 1, false, 2>("24x24x4"));
+      run_all<double>(vs, 2304, "", rounds);
+    }
+    return 0;
+  }
+  if (filter[0] && strstr("tw1536", filter)) {     // round 5: LDS twiddles were what made the 64-byte tiles of 1792 fp32 pay; 1536 / 1152 fp32 run without
+    {
+      typedef Spec<1536, 8, 8, 8, 3> S;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile_occ<S, float, 8, false, 1, 1, false, 3>("8x8x8x3"));      // shipped (three per CU by the API; 8 waves: 6 per SIMD, 80 registers)
+      vs.push_back(make_tile_occ<S, float, 8, true, 1, 1, false, 2>("8x8x8x3"));
+      vs.push_back(make_tile_occ<S, float, 8, true, 1, 1, false, 3>("8x8x8x3"));
+      vs.push_back(make_tile_occ<Spec<1536, 16, 8, 4, 3>, float, 8, true, 1, 1, false, 2>("16x8x4x3"));
+      run_all<float>(vs, 1536, "", rounds);
+    }
+    {
+      typedef Spec<1152, 24, 24, 2> S;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile_occ<S, float, 16, false, 1, 1, false, 2>("24x24x2"));     // shipped
+      vs.push_back(make_tile_occ<S, float, 8, true, 1, 1, false, 2>("24x24x2"));
+      vs.push_back(make_tile_occ<Spec<1152, 12, 12, 4, 2>, float, 16, true, 1, 1, false, 2>("12x12x4x2"));
+      run_all<float>(vs, 1152, "", rounds);
+    }
+    {
+      typedef Spec<896, 28, 4, 4, 2> S;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<S, float, 16, true, 1, 1>("28x4x4x2"));                   // shipped (col_pair: split + LDS twiddles)
+      vs.push_back(make_tile_occ<S, float, 16, true, 1, 1, false, 2>("28x4x4x2"));
+      vs.push_back(make_tile_occ<S, float, 8, true, 1, 1, false, 4>("28x4x4x2"));
+      run_all<float>(vs, 896, "", rounds);
+    }
+    return 0;
+  }
   if (filter[0] && strstr("narrow", filter)) {     // round 5: what 1792 fp32 gained (64-byte tiles + LDS twiddles, two workgroups per CU) at the other
                                                    // lengths that run one big workgroup per CU
     {

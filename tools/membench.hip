@@ -539,6 +539,28 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 1 && !strcmp(argv[1], "tile1024w")) {  // round 5: does the bare tile pattern of 1024 get faster with wider tiles (256 / 512-byte row segments)?
+    const size_t el = (size_t)1024 * 1024 * 584;
+    cx<double>*a = nullptr, *b = nullptr;
+    CK(hipMalloc(&a, el * sizeof(cx<double>)));
+    CK(hipMalloc(&b, el * sizeof(cx<double>)));
+    CK(hipMemset(a, 0, el * sizeof(cx<double>)));
+    CK(hipMemset(b, 0, el * sizeof(cx<double>)));
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep)
+      for (int x = 0; x < 2; ++x) {
+        run_tile_n<1024, 8, 8, 0>(a, a, x, 80 << 10);      // as the FFT kernel runs: 1024 threads, two per CU
+        run_tile_n<1024, 8, 8, 0>(a, a, x, 0);
+        run_tile_n<1024, 16, 16, 0>(a, a, x, 80 << 10);    // 256-byte segments, 1024 threads, two per CU
+        run_tile_n<1024, 16, 16, 0>(a, a, x, 0);
+        run_tile_n<1024, 16, 32, 0>(a, a, x, 0);           // 512 threads
+        run_tile_n<1024, 32, 32, 0>(a, a, x, 0);           // 512-byte segments, 1024 threads
+        run_tile_n<1024, 8, 8, 0>(a, b, x, 80 << 10);
+        run_tile_n<1024, 16, 16, 0>(a, b, x, 80 << 10);
+      }
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "tile1200")) {   // round 5: the bare tile pattern of the 30-values kernels (320 / 384 threads, one or two per CU)
     const size_t el = (size_t)1536 * 1536 * 769;
     cx<double>*a = nullptr, *b = nullptr;
