@@ -94,8 +94,24 @@ template <class S, typename T> constexpr bool col_wide() {
   return sizeof(T) == 8 && S::NP > 1 && S::N > 1024 && waves % 4 == 1 && S::TPT * 2 * cols <= 1024 &&
          (long long)S::N * 2 * cols * (int)sizeof(T) <= 163840;
 }
+// The same idea at the other end: plans with 8 or 16 threads per transform make 64- or 128-thread workgroups on 128-byte
+// tiles -- one or two waves that each reserve a wave's registers on ALL four SIMDs (the rule above), at 150 - 260 registers
+// two or three such workgroups = 128 - 384 threads per CU.  With 256 threads (one wave per SIMD; 256- or 512-byte row
+// segments, split exchange) the same registers hold twice the threads.  kbench3 wide16 / wideb, double precision, y in place /
+// x in place / x out of place, ms:   448 (28x4x4) 0.332 / 0.317 / 0.330 -> 0.287 / 0.302 / 0.287;   480 (10x6x2x2x2) 0.447 / 0.414 / 0.410 ->
+// 0.369 / 0.377 / 0.372;   672 (42x2x2x2x2) 1.387 / 1.276 / 1.339 -> 1.221 / 1.169 / 1.219;   336 0.180 / 0.162 / 0.174 -> 0.164 / 0.152 / 0.159;
+// 320 (40x8) 0.117 / 0.105 / 0.128 -> 0.107 / 0.100 / 0.121;   240 0.062 / 0.059 / 0.057 -> 0.046 / 0.045 / 0.044;   single precision 448
+// 0.160 / 0.145 / 0.158 -> 0.149 / 0.138 / 0.150.   Not: 640 (+-2 %), 600, 720 (their three-wave workgroups stay ahead), 480 fp32.
+template <class S, typename T> constexpr int col_wide_small() {        // columns per workgroup, 0: the default
+  if (!MFFT_COL_WIDE || S::NP < 2) return 0;
+  if (sizeof(T) == 8 && S::TPT == 16 && (S::N == 448 || S::N == 480 || S::N == 672)) return 16;
+  if (sizeof(T) == 8 && S::TPT == 8 && (S::N == 240 || S::N == 320 || S::N == 336)) return 32;
+  if (sizeof(T) == 4 && S::TPT == 16 && S::N == 448) return 32;
+  return 0;
+}
 template <class S, typename T> constexpr int col_cols() {
   constexpr int vec = col_vec<S, T>();
+  if (col_wide_small<S, T>() > 0) return col_wide_small<S, T>();
   if (col_wide<S, T>()) return 2 * (128 / (int)sizeof(cx<T>));
   int cols = 128 / (int)sizeof(cx<T>);
   while (cols > vec && S::TPT * (cols / vec) > 1024) cols /= 2;
@@ -104,9 +120,11 @@ template <class S, typename T> constexpr int col_cols() {
   return cols;
 }
 template <class S, typename T> constexpr bool col_split() {
+  if (col_wide_small<S, T>() > 0) return true;
   return S::NP > 1 && (col_pair<S, T>() || (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) > 131072);
 }
 template <class S, typename T> constexpr bool col_twlds() {
+  if (col_wide_small<S, T>() > 0) return S::N != 672;      // (672: 1.22 / 1.17 / 1.22 without against 1.27 / 1.20 / 1.26 with the table in LDS)
   return S::NP > 1 && (col_pair<S, T>() || (!col_split<S, T>() &&
          (long long)S::N * col_cols<S, T>() * (int)sizeof(cx<T>) + S::TW * (int)sizeof(cx<T>) <= 65536));
 }
@@ -531,7 +549,8 @@ void register_rows(const char* name) {
 // exchanges is faster (1000^3 fp64: 10.3 -> 8.2 ms per pass).  With 512 threads or fewer the 128-byte tile with
 // split exchanges stays ahead (720^3, M = 1536: 3.5 vs 4.5 ms).
 template <class S, typename T> constexpr int colz_cols() {
-  constexpr int c = col_cols<S, T>(), v = col_vec<S, T>();
+  // (the wide tiles of round 5's col_wide_small are a measurement of the radix kernels: the chirp-z kernels keep theirs)
+  constexpr int c = col_wide_small<S, T>() > 0 ? 128 / (int)sizeof(cx<T>) : col_cols<S, T>(), v = col_vec<S, T>();
   return (col_split<S, T>() && S::TPT * (c / v) > 512 && c / 2 >= v && c / 2 >= 64 / (int)sizeof(cx<T>) &&
           (long long)S::N * (c / 2) * (int)sizeof(cx<T>) <= 131072 && S::TPT * (c / 2 / v) >= 64) ? c / 2 : c;
 }

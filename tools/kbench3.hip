@@ -500,6 +500,98 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (filter[0] && strstr("wideb", filter)) {      // ... and the 42-values plans (8 - 16 threads per transform: 64 - 128 threads on 8 columns), 320, 240, 224
+    {
+      typedef Spec<672, 42, 2, 2, 2, 2> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, true, 1, 1>("42x2x2x2x2"));
+      vs.push_back(make_tile<S, double, 16, false, 1, 1>("42x2x2x2x2"));
+      vs.push_back(make_tile<S, double, 16, true, 1, 1>("42x2x2x2x2"));
+      run_all<double>(vs, 672, "", rounds);
+    }
+    {
+      typedef Spec<336, 42, 2, 2, 2> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, true, 0, 1>("42x2x2x2"));
+      vs.push_back(make_tile<S, double, 16, true, 0, 1>("42x2x2x2"));
+      vs.push_back(make_tile<S, double, 32, true, 1, 1>("42x2x2x2"));
+      run_all<double>(vs, 336, "", rounds);
+    }
+    {
+      typedef Spec<320, 40, 8> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, true, 0, 1>("40x8"));
+      vs.push_back(make_tile<S, double, 16, true, 0, 1>("40x8"));
+      vs.push_back(make_tile<S, double, 32, true, 1, 1>("40x8"));
+      run_all<double>(vs, 320, "", rounds);
+    }
+    {
+      typedef Spec<240, 10, 6, 2, 2> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, true, 0, 1>("10x6x2x2"));
+      vs.push_back(make_tile<S, double, 16, true, 0, 1>("10x6x2x2"));
+      vs.push_back(make_tile<S, double, 32, true, 1, 1>("10x6x2x2"));
+      run_all<double>(vs, 240, "", rounds);
+    }
+    {
+      typedef Spec<448, 28, 4, 4> S;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<S, float, 16, true, 0, 1>("28x4x4"));
+      vs.push_back(make_tile<S, float, 32, false, 1, 1>("28x4x4"));
+      vs.push_back(make_tile<S, float, 32, true, 1, 1>("28x4x4"));
+      run_all<float>(vs, 448, "", rounds);
+    }
+    {
+      typedef Spec<480, 10, 6, 2, 2, 2> S;
+      std::vector<Variant<float>> vs;
+      vs.push_back(make_tile<S, float, 16, true, 0, 1>("10x6x2x2x2"));
+      vs.push_back(make_tile<S, float, 32, true, 1, 1>("10x6x2x2x2"));
+      run_all<float>(vs, 480, "", rounds);
+    }
+    return 0;
+  }
+  if (filter[0] && strstr("wide16", filter)) {     // round 5: 16 columns for the plans whose 8-column workgroups are 2 - 3 waves (16 - 24 threads per transform)
+    {
+      typedef Spec<448, 28, 4, 4> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, true, 0, 1>("28x4x4"));
+      vs.push_back(make_tile<S, double, 16, false, 1, 1>("28x4x4"));
+      vs.push_back(make_tile<S, double, 16, true, 1, 1>("28x4x4"));
+      run_all<double>(vs, 448, "", rounds);
+    }
+    {
+      typedef Spec<480, 10, 6, 2, 2, 2> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 0, 1>("10x6x2x2x2"));
+      vs.push_back(make_tile<S, double, 16, false, 1, 1>("10x6x2x2x2"));
+      vs.push_back(make_tile<S, double, 16, true, 1, 1>("10x6x2x2x2"));
+      run_all<double>(vs, 480, "", rounds);
+    }
+    {
+      typedef Spec<640, 8, 4, 4, 5> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 0, 1>("8x4x4x5"));
+      vs.push_back(make_tile<S, double, 16, false, 1, 1>("8x4x4x5"));
+      vs.push_back(make_tile<S, double, 16, true, 1, 1>("8x4x4x5"));
+      run_all<double>(vs, 640, "", rounds);
+    }
+    {
+      typedef Spec<720, 10, 6, 6, 2> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, true, 1, 1>("10x6x6x2"));
+      vs.push_back(make_tile<S, double, 16, false, 1, 1>("10x6x6x2"));
+      vs.push_back(make_tile<S, double, 16, true, 1, 1>("10x6x6x2"));
+      run_all<double>(vs, 720, "", rounds);
+    }
+    {
+      typedef Spec<600, 10, 10, 6> S;
+      std::vector<Variant<double>> vs;
+      vs.push_back(make_tile<S, double, 8, false, 0, 1>("10x10x6"));
+      vs.push_back(make_tile<S, double, 16, true, 1, 1>("10x10x6"));
+      run_all<double>(vs, 600, "", rounds);
+    }
+    return 0;
+  }
   if (filter[0] && strstr("y64b", filter)) {       // ... and 1344 (42 values per thread), 1500
     {
       typedef Spec<1344, 42, 2, 2, 2, 2, 2> S;
