@@ -142,6 +142,19 @@ template <class S, typename T> constexpr bool col_twlds() {
 // fp64 960^3 6.30 / 4.11 -> 4.90 / 4.08, 720^3 2.88 / 2.15 -> 2.72 / 1.93, 480^3 0.80 / 0.54 -> 0.64 / 0.43;
 // fp32 960^3 2.25 / 3.41 -> 2.71 / 2.56, 720^3 0.94 / 1.47 -> 1.11 / 1.05, 1200^3 4.45 / 6.48 -> 5.14 / 4.91).
 // (their double-precision kernels then get a register cap as well: row_occ_wgs below)
+// Round 5, the 42-values plans (21 * 2^a) in double precision: their contiguous-axis kernels hold 280 - 430 registers (AGPRs
+// included), so a CU admits ONE workgroup whatever its size (the dispatcher reserves a wave's registers on every SIMD per
+// started group of four waves: section "Round 5" of DESIGN.md 4) -- and the 40 KB LDS budget below made that workgroup 64
+// threads: one wave per CU (1344^3: c2r 21.4 ms, r2c 16.6, where a strided pass takes 12 - 13).  They take 256 threads (one
+// wave per SIMD) with the split exchange in up to 128 KB instead.
+#ifndef MFFT_ROW_WIDE42
+#define MFFT_ROW_WIDE42 1
+#endif
+// Measured (1344^3 / 672^3 / 336^3 pairs, stage ms): c2r 21.36 -> 19.24 / 2.58 -> 2.23 / 0.33 -> 0.22, r2c 16.57 -> 17.57 / 1.72 -> 1.91 / 0.20 -> 0.21:
+// the c2r kernels take it, the others keep their rows.
+template <class S, typename T, bool C2R = false> constexpr bool row_wide42() {
+  return MFFT_ROW_WIDE42 && C2R && sizeof(T) == 8 && S::E % 21 == 0 && S::N >= 168 && S::NP > 1;
+}
 template <class S, typename T, bool C2R = false> constexpr bool row_lean15() {
   return S::E % 15 == 0 && S::N >= 120 && (sizeof(T) == 8 || C2R);
 }
@@ -150,18 +163,21 @@ template <class S, typename T, bool C2R = false> constexpr bool row_lean() {
 }
 template <class S, typename T, bool C2R = false> constexpr bool row_split() {
   // the c2r kernels of the E = 20 plans lose with it (1280: 7.2 -> 8.3 ms)
+  if (row_wide42<S, T, C2R>()) return true;
   return S::NP > 1 && row_lean<S, T, C2R>() && !(C2R && S::E >= 20 && !row_lean15<S, T, C2R>());
 }
 template <class S, typename T, bool SPLIT, bool C2R = false> constexpr int row_rows_n() {
   int rows = 256 / S::TPT;
   if (rows < 1) rows = 1;
   const long long per_row = (long long)(S::N + S::N / S::R(0) + 1) * (int)(SPLIT ? sizeof(T) : sizeof(cx<T>));
-  const long long budget = row_lean15<S, T, C2R>() ? 20480 : 40960;
+  const long long budget = row_wide42<S, T, C2R>() && SPLIT ? 131072 : row_lean15<S, T, C2R>() ? 20480 : 40960;
   while (rows > 1 && per_row * rows > budget && S::TPT * (rows / 2) >= 64) rows /= 2;   // never below one wave
   return rows;
 }
 template <class S, typename T, bool C2R = false> constexpr int row_rows() { return row_rows_n<S, T, row_split<S, T, C2R>(), C2R>(); }
-template <class S, typename T, bool C2R = false> constexpr bool row_twlds() { return S::NP > 1 && !row_lean<S, T, C2R>(); }
+template <class S, typename T, bool C2R = false> constexpr bool row_twlds() {
+  return S::NP > 1 && !row_lean<S, T, C2R>() && !row_wide42<S, T, C2R>();
+}
 
 #ifndef MFFT_COL_OCC_R5
 #define MFFT_COL_OCC_R5 1
