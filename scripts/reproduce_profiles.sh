@@ -54,7 +54,7 @@ run() {
     r05_config5_zpitch.txt) python scripts/config5_full.py; MFFT_NO_ZPITCH=1 python scripts/config5_full.py ;;
     r05_pad_pmc_traffic.txt) bash scripts/pad_pmc_r05.sh ;;
     r05_radix42_sweep.txt) bash scripts/r05_gpu13.sh ;;
-    r05_ytile_builds.txt) make -C tools kbench3 membench; for f in tw64 y64 y64b tw1536; do tools/build/kbench3 $f 3; done; tools/build/membench tile1024w; bash scripts/r05_gpu25.sh ;;
+    r05_ytile_builds.txt) make -C tools kbench3 membench; for f in tw64 y64 y64b tw1536; do tools/build/kbench3 $f 3; done; tools/build/membench tile1024w; bash scripts/r05_gpu25.sh; bash scripts/r05_gpu28.sh ;;
     r05_plain_rows.txt) echo "git checkout <the commit 'plain rows: measured'>; make -C mpifft4py_amd/csrc -j8 && make -C tools kbench3; bash scripts/r05_gpu16.sh" ;;
     r05_wave_placement.txt) make -C tools occ_probe membench kbench3; tools/build/occ_probe; tools/build/membench stamp1200; tools/build/membench tile1200; tools/build/kbench3 occ1200 5; tools/build/kbench3 narrow 3; tools/build/kbench3 wide16 5; tools/build/kbench3 wideb 5; bash scripts/r05_gpu19.sh; bash scripts/r05_gpu26.sh ;;
     r05_miscompile_cure_modes.txt) make -C tools rowcheck2_0 rowcheck2_1 rowcheck2_2 rowcheck2_3 rowcheck2_4; for m in 0 1 2 3 4; do tools/build/rowcheck2_$m; done ;;
