@@ -803,6 +803,31 @@ def main():
         except Exception as e:      # noqa: BLE001  - the headline (slab) line must survive
             extras["dealias"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- secondary measurement (one GPU): the APPLICATION the transforms are for -- the reference demo's Taylor-Green RK4 loop
+    # (demo/spectral_dns_solver.py:83-98) with the state in HBM, 3/2-rule, double precision.  `fused`: the nonlinear term as one
+    # plan operation (mfft_nonlinear_cross, csrc/fft_nlz.h) + one sweep per Runge-Kutta stage; `composed`: rounds 3 - 5 (36
+    # transforms + element-wise kernels per step).  ms per RK4 step and the split by plan stage (HIP events).
+    if world == 1 and args.decomp == "slab" and args.pencil_extra != "off" and os.environ.get("MFFT_BENCH_DNS", "1") != "0":
+        try:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples"))
+            import spectral_dns_device as dns
+            tg = {}
+            for m_, modes in ((8, ("fused",)), (9, ("fused", "composed"))):
+                for mode in modes:
+                    rep = {}
+                    k_ = dns.solve(comm, M=m_, dealias="3/2-rule", steps=3, report=rep, fused=mode == "fused", timing=True)
+                    tg["%d^3_%s" % (2 ** m_, mode)] = {
+                        "rk4_step_ms": round(rep["ms_per_step"], 3), "k_after_3_steps": k_,
+                        "fused_nonlinear_z_stage": bool(rep.get("fused_nonlinear")), "plan_work_GB": round(rep["work_bytes"] / 1e9, 2),
+                        "stage_ms_per_step": {a_: round(b_[0], 3) for a_, b_ in sorted(rep.get("stages", {}).items()) if b_[1]}}
+            f_, c_ = tg["512^3_fused"], tg["512^3_composed"]
+            f_["element_wise_ms_per_step"] = round(f_["rk4_step_ms"] - sum(f_["stage_ms_per_step"].values()), 3)
+            c_["element_wise_ms_per_step"] = round(c_["rk4_step_ms"] - sum(c_["stage_ms_per_step"].values()), 3)
+            tg["fused_over_composed_512^3"] = round(f_["rk4_step_ms"] / c_["rk4_step_ms"], 3)
+            extras["taylor_green_rk4"] = tg
+        except Exception as e:      # noqa: BLE001  - the headline (slab) line must survive
+            extras["taylor_green_rk4"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # correctness gate: a wrong transform must not print a headline number with rc 0
     tol = 1e-10 if args.precision == "double" else 1e-4
     rt_all = [mres["rt_err"]] + [v["roundtrip_rel_l2"] for v in extras.values() if "roundtrip_rel_l2" in v]

@@ -22,7 +22,11 @@ from mpifft4py_amd.slab import R2C as Slab_R2C  # noqa: E402
 
 
 def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double", nu=0.000625, dt=0.01, steps=10,
-          report=None):
+          report=None, fused=True, timing=False):
+    """fused=True (round 6): the nonlinear term is ONE plan operation (spectral.cross_transform: no real-space work
+    arrays, the z stages one kernel) and a Runge-Kutta stage's projection, viscous term, both updates and the next
+    curl are ONE sweep (spectral.ns_rk_stage).  fused=False: the composition of rounds 3 - 5 (nine transforms, cross,
+    curl, rhs and axpbz kernels per stage), kept for A/B timing and as the parity partner of the fused path."""
     N = np.array([2 ** M] * 3, dtype=int)
     L = np.array([2 * np.pi] * 3, dtype=float)
     if decomposition == 'slab':
@@ -44,12 +48,42 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
     U_hat0 = DeviceArray.empty((3,) + cs, cx)
     U_hat1 = DeviceArray.empty((3,) + cs, cx)
     dU = DeviceArray.empty((3,) + cs, cx)
+    a = [1. / 6., 1. / 3., 1. / 3., 1. / 6.]
+    b = [0.5, 0.5, 1.]
+    if timing:
+        FFT.enable_timing(True)
+
+    if fused:
+        for i in range(3):
+            FFT.fftn(U.component(i), U_hat.component(i))
+        spectral.axpbz(FFT, U_hat0, U_hat, U_hat, 1.0, 0.0)
+        spectral.axpbz(FFT, U_hat1, U_hat, U_hat, 1.0, 0.0)
+        spectral.curl_hat(FFT, K, U_hat, dU)               # dU doubles as the curl's spectrum between the stages
+        FFT.sync()
+        if timing:
+            FFT.reset_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for rk in range(4):
+                spectral.cross_transform(FFT, U_hat, dU, dU, dealias)          # dU = fftn(U x curl U)
+                spectral.ns_rk_stage(FFT, K, dU, U_hat, U_hat0, U_hat1, nu, a[rk] * dt, b[rk] * dt if rk < 3 else 0.0, rk == 3)
+        FFT.sync()
+        wall = time.perf_counter() - t0
+        if report is not None:
+            report["ms_per_step"] = 1e3 * wall / steps
+            report["fused_nonlinear"] = FFT.plan_info({"3/2-rule": "nonlinear_fused_3_2", "2/3-rule": "nonlinear_fused_2_3"}.get(
+                dealias, "nonlinear_fused_none"))
+            report["work_bytes"] = FFT.plan_info("nonlinear_bytes") + FFT.workspace_bytes()
+            if timing:
+                report["stages"] = {k: (v[0] / steps, v[1] // steps) for k, v in FFT.stage_times().items()}
+        for i in range(3):
+            FFT.ifftn(U_hat.component(i), U.component(i))
+        return FFT.comm.reduce(spectral.sumsq(FFT, U) / float(N[0]) / float(N[1]) / float(N[2]) / 2)
+
     W_hat = DeviceArray.empty((3,) + cs, cx)
     Ud = DeviceArray.empty((3,) + ws, fl)
     Cd = DeviceArray.empty((3,) + ws, fl)
     Rd = DeviceArray.empty((3,) + ws, fl)
-    a = [1. / 6., 1. / 3., 1. / 3., 1. / 6.]
-    b = [0.5, 0.5, 1.]
 
     def compute_rhs():
         for i in range(3):
@@ -65,6 +99,8 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
     for i in range(3):
         FFT.fftn(U.component(i), U_hat.component(i))
     FFT.sync()
+    if timing:
+        FFT.reset_timing()
     t0 = time.perf_counter()
     for _ in range(steps):
         spectral.axpbz(FFT, U_hat0, U_hat, U_hat, 1.0, 0.0)
@@ -82,6 +118,10 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
     k = FFT.comm.reduce(spectral.sumsq(FFT, U) / float(N[0]) / float(N[1]) / float(N[2]) / 2)
     if report is not None:
         report["ms_per_step"] = 1e3 * wall / steps
+        report["fused_nonlinear"] = 0
+        report["work_bytes"] = FFT.workspace_bytes() + 3 * Ud.nbytes
+        if timing:
+            report["stages"] = {k: (v[0] / steps, v[1] // steps) for k, v in FFT.stage_times().items()}
     return k
 
 
@@ -92,17 +132,26 @@ def main():
     ap.add_argument("--ranks", type=int, default=1)
     ap.add_argument("--dealias", default="3/2-rule", choices=["3/2-rule", "2/3-rule", "None"])
     ap.add_argument("--precision", default="double")
+    ap.add_argument("--composed", action="store_true", help="the nine-transform composition of rounds 3 - 5 instead of the fused operations")
+    ap.add_argument("--stages", action="store_true", help="print the per-stage HIP-event times")
     args = ap.parse_args()
     dealias = None if args.dealias == "None" else args.dealias
     from mpifft4py_amd import LocalGroup, SelfComm
     rep = {}
     if args.ranks > 1:
         ks = LocalGroup(args.ranks).run(lambda c: solve(c, args.M, dealias, steps=args.steps, precision=args.precision,
-                                                        report=rep if c.Get_rank() == 0 else None))
+                                                        report=rep if c.Get_rank() == 0 else None, fused=not args.composed,
+                                                        timing=args.stages))
     else:
-        ks = [solve(SelfComm(), args.M, dealias, steps=args.steps, precision=args.precision, report=rep)]
-    print("N = %d^3, %d RK4 steps, %.3f ms per step (36 transforms + fused element-wise kernels, device-resident)"
-          % (2 ** args.M, args.steps, rep.get("ms_per_step", float("nan"))))
+        ks = [solve(SelfComm(), args.M, dealias, steps=args.steps, precision=args.precision, report=rep,
+                    fused=not args.composed, timing=args.stages)]
+    print("N = %d^3, %d RK4 steps, %.3f ms per step (%s, device-resident; plan work buffers %.2f GB)"
+          % (2 ** args.M, args.steps, rep.get("ms_per_step", float("nan")),
+             "composed: 36 transforms + element-wise kernels" if args.composed else
+             ("fused nonlinear z stage" if rep.get("fused_nonlinear") else "one plan operation per nonlinear term, composed inside"),
+             rep.get("work_bytes", 0) / 1e9))
+    for name, (ms, calls) in sorted(rep.get("stages", {}).items()):
+        print("  %-10s %8.3f ms per step  (%d launches)" % (name, ms, calls))
     print("k =", repr(ks[0]))
     if args.M == 5 and args.steps == 10 and args.precision == "double":
         assert round(ks[0] - 0.124953117517, 7) == 0

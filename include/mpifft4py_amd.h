@@ -214,6 +214,13 @@ MFFT_API int mfft_c2c_strided(const void* in, void* out, int64_t n, int64_t nout
                               int64_t in_pitch, int64_t out_outer, int64_t out_pitch, int inverse, int precision);
 MFFT_API int mfft_r2c_last(const void* in, void* out, const int64_t real_shape[3], int precision);    /* rfft axis=2 */
 MFFT_API int mfft_c2r_last(const void* in, void* out, const int64_t real_shape[3], int precision);    /* irfft axis=2, scaled 1/n */
+/* The fused nonlinear z stage on its own (csrc/fft_nlz.h; the z stages of mfft_nonlinear_cross): a, b, out are
+ * (3, nrows, pitch) complex arrays of half-spectra rows of real length n of which the first `valid` bins exist
+ * (n/2 + 1, or fewer: 3/2-rule); out_f[row] = rfft((irfft(a[:, row]) x irfft(b[:, row]))_f)[:valid], irfft as numpy's.
+ * out may be a or b.  sync = 0: enqueued on the default stream and left running (timing loops).  Replaces the z stages
+ * of six FFT.ifftn + three FFT.fftn around the demo's cross product (demo/spectral_dns_solver.py:53-71). */
+MFFT_API int mfft_nlz_rows(const void* a, const void* b, void* out, int64_t nrows, int64_t n, int64_t pitch, int64_t valid,
+                           int precision, int sync);
 /* slab pack / unpack (slab.py:403; cython/maths.pyx:21-31 transpose_Uc) */
 MFFT_API int mfft_slab_pack(const void* uc_hatT, void* u_mpi, int P, int64_t np0, int64_t np1, int64_t nf, int precision);
 MFFT_API int mfft_slab_unpack(const void* u_mpi, void* uc_hatT, int P, int64_t np0, int64_t np1, int64_t nf, int precision);
@@ -247,7 +254,27 @@ MFFT_API int mfft_ew_ns_rhs(mfft_plan_t plan, void* dU, const void* U_hat, const
                             const int64_t shape[3], double nu, int precision);                          /* demo:73-77 */
 MFFT_API int mfft_ew_axpbz(mfft_plan_t plan, void* y, const void* x, const void* z, double alpha, double beta, size_t n_real,
                            int precision);                                                              /* demo:94-97 */
+/* One Runge-Kutta stage of the demo's loop in one sweep (demo:73-77 compute_rhs' projection and viscous term, :94-97 the two
+ * updates, :60-64 the curl the NEXT stage transforms): on entry N_hat holds the nonlinear term (mfft_nonlinear_cross);
+ *   dU = N_hat - K (K . N_hat)/|K|^2 - nu |K|^2 U_hat;   U_hat1 += a_dt dU;
+ *   last == 0: U_hat = U_hat0 + b_dt dU        last != 0: U_hat = U_hat0 = U_hat1   (the next step's `U_hat1[:] = U_hat0[:] = U_hat`)
+ *   N_hat = i K x U_hat (new).
+ * All four fields (3,) + shape, component-major; a_dt = a[rk] dt, b_dt = b[rk] dt. */
+MFFT_API int mfft_ew_ns_rk_stage(mfft_plan_t plan, void* N_hat, void* U_hat, void* U_hat0, void* U_hat1, const void* kx,
+                                 const void* ky, const void* kz, const int64_t shape[3], double nu, double a_dt, double b_dt,
+                                 int last, int precision);
 MFFT_API int mfft_ew_sumsq(mfft_plan_t plan, const void* x, size_t n_real, int precision, double* result_host);           /* demo:103 */
+
+/* The nonlinear term of a pseudo-spectral step as ONE operation:
+ *     out_hat = fftn(ifftn(a_hat) x ifftn(b_hat))        (cross product in real space, component by component)
+ * with the plan's own transforms under `dealias` -- what demo/spectral_dns_solver.py:53-71 composes from six
+ * FFT.ifftn(.., dealias), numpy products and three FFT.fftn(.., dealias).  a_hat, b_hat, out_hat: (3,) + local complex
+ * shape, component-major, device-resident; out_hat may be a_hat or b_hat.  On one rank with radix kernels on every axis
+ * (slab R2C plans; mfft_plan_get_info "nonlinear_fused_3_2" / "_none" / "_2_3") the z stages are ONE kernel per batch of x
+ * planes (csrc/fft_nlz.h): six half-spectra rows in, the cross product formed in registers, three rows out -- the nine
+ * real-space work arrays of the composition (9 x 1536^3 x 8 B at 1024^3 with the 3/2-rule) never exist.  Every other plan
+ * runs the composition on work arrays of its own.  Enqueued on the plan's stream like mfft_forward. */
+MFFT_API int mfft_nonlinear_cross(mfft_plan_t plan, const void* a_hat, const void* b_hat, void* out_hat, int dealias);
 
 /* Direct evaluation of up to 16 DFT bins of a distributed field, for checking transforms of meshes that no host
  * transform can hold (BASELINE config 5, 2048^3): result[2b], result[2b+1] = Re, Im of

@@ -79,14 +79,15 @@ class DistFFTBase(object):
     #     then only for the whole-array hashes.
     #   * The upload is COLLECTIVE for plans over more than one rank (mfft_plan_set_dealias_mask: the ranks agree on the
     #     pruned route), and an edit may touch one rank's block only, so the ranks VOTE on "somebody's filter changed" with
-    #     one small host all-reduce.  Where that stays on the host (the IPC and in-process transports: two shared-memory
-    #     barriers, ~5 us, no device stream involved) they vote on every '2/3-rule' call; over RCCL the all-reduce is a
-    #     copy + ncclAllReduce + stream synchronisation that ends the host's asynchronous run-ahead, so there the vote is
-    #     taken every 16th call only (`dealias_vote_every`; a locally found edit waits for it) and ASSIGNMENT must happen
-    #     on every rank at the same point of the program (as SPMD codes do).
+    #     one small host all-reduce on every '2/3-rule' call (default, as the reference's per-call read: an assignment or
+    #     an edit on ONE rank counts at that rank's next call, and no rank ever enters the collective upload alone).  Where
+    #     the all-reduce stays on the host (the IPC and in-process transports: two shared-memory barriers) it costs ~5 us;
+    #     over RCCL it is a copy + ncclAllReduce + stream synchronisation that ends the host's asynchronous run-ahead --
+    #     codes that mind may set `dealias_vote_every = 16`: a change found or made locally then waits for the next vote
+    #     (results use the previous filter until then), still without a rank uploading by itself.
     dealias_check = True
     dealias_full_every = 64
-    dealias_vote_every = None             # None: 1 where host collectives stay on the host, 16 over RCCL
+    dealias_vote_every = None             # None / 1: every '2/3-rule' call; n: every n-th call (opt-in)
     _FULL_HASH_BYTES = 256 << 10
     _SAMPLES = 1 << 13
     _sample_index = {}                    # element count -> sorted flat positions; shape -> the same as an index tuple
@@ -249,12 +250,19 @@ class DistFFTBase(object):
                     self._whole_hash_start()
         stale = not self._mask_set
         if mode and self.num_processes > 1:
-            every = self.dealias_vote_every or (1 if self.comm.get_option("host_collectives") == 1 else 16)
-            self._mask_pending = self._mask_pending or changed
-            if every <= 1:
-                stale = self.comm.allreduce(1.0 if (stale or self._mask_pending) else 0.0, MAX) > 0
-            elif self._mask_calls % every == 0:         # assignment (stale) is SPMD here: no vote needed for it
-                stale = self.comm.allreduce(1.0 if self._mask_pending else 0.0, MAX) > 0 or stale
+            # The upload is collective, so no rank may decide on it alone.  The FIRST upload is every rank's first
+            # '2/3-rule' call (SPMD by construction); after it, an assignment on this rank (`stale`) and an in-place edit
+            # found here (`changed`) both only raise this rank's hand, and all ranks upload together at the next vote --
+            # the reference lets one rank assign `F.dealias` by itself (it reads the attribute per rank, slab.py:237-245).
+            every = int(self.dealias_vote_every or 1)
+            first = self._mask_serial == 0
+            self._mask_pending = self._mask_pending or changed or (stale and not first)
+            if first:
+                pass
+            elif every <= 1 or self._mask_calls % every == 0:
+                stale = self.comm.allreduce(1.0 if self._mask_pending else 0.0, MAX) > 0
+            else:
+                stale = False
         else:
             stale = stale or changed
         if not stale:

@@ -85,16 +85,20 @@ _SIGNATURES = {
     "mfft_c2c_strided": ([c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int], c_int),
     "mfft_r2c_last": ([c_void_p, c_void_p, POINTER(c_int64), c_int], c_int),
     "mfft_c2r_last": ([c_void_p, c_void_p, POINTER(c_int64), c_int], c_int),
+    "mfft_nlz_rows": ([c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int], c_int),
     "mfft_slab_pack": ([c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int], c_int),
     "mfft_slab_unpack": ([c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int], c_int),
     "mfft_dealias_filter": ([c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_length_supported": ([c_int64, c_int], c_int),
     "mfft_length_route": ([c_int64, c_int], c_int),
     "mfft_kernel_name": ([c_int, c_int64, c_int, c_int, c_int, c_void_p, c_size_t], c_int),
+    "mfft_nonlinear_cross": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int], c_int),
     "mfft_ew_cross": ([c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_ew_curl_hat": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int], c_int),
     "mfft_ew_ns_rhs": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_double, c_int], c_int),
     "mfft_ew_axpbz": ([c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_size_t, c_int], c_int),
+    "mfft_ew_ns_rk_stage": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64),
+                             c_double, c_double, c_double, c_int, c_int], c_int),
     "mfft_ew_sumsq": ([c_void_p, c_void_p, c_size_t, c_int, POINTER(c_double)], c_int),
     "mfft_ew_dft_bins": ([c_void_p, c_void_p, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int, c_int,
                           POINTER(c_int64), c_int, POINTER(c_double)], c_int),

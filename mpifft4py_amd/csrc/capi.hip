@@ -227,6 +227,24 @@ int mfft_c2r_last(const void* in, void* out, const int64_t rshape[3], int precis
   return 0;
 }
 
+// fused nonlinear z stage on rows (csrc/fft_nlz.h): a, b, out are (3, nrows, pitch) complex, `valid` bins per row exist
+int mfft_nlz_rows(const void* a, const void* b, void* out, int64_t nrows, int64_t n, int64_t pitch, int64_t valid, int precision,
+                  int sync) {
+  if (!a || !b || !out || nrows < 1 || n < 2 || pitch < valid || valid < 1) return set_error(MFFT_ERR_INVALID, "bad argument");
+  const size_t es = elem_bytes(precision, true);
+  NlzArgs z;
+  for (int f = 0; f < 3; ++f) {
+    z.a[f] = static_cast<const char*>(a) + (size_t)(f * nrows * pitch) * es;
+    z.b[f] = static_cast<const char*>(b) + (size_t)(f * nrows * pitch) * es;
+    z.out[f] = static_cast<char*>(out) + (size_t)(f * nrows * pitch) * es;
+  }
+  z.n = (int)n; z.prec = precision; z.in_stride = pitch; z.out_stride = pitch; z.nrows = nrows; z.valid = (int)valid;
+  z.scale = 1.0 / ((double)n * (double)n);
+  MFFT_TRY(launch_nlz(z, nullptr));
+  if (sync) MFFT_HIP(hipStreamSynchronize(nullptr));
+  return 0;
+}
+
 // U_mpi[p, i, j, k] = Uc_hatT[i, p*Np1 + j, k]   (slab.py:403)
 int mfft_slab_pack(const void* uc_hatT, void* u_mpi, int P, int64_t np0, int64_t np1, int64_t nf, int precision) {
   if (!uc_hatT || !u_mpi || P < 1) return set_error(MFFT_ERR_INVALID, "bad argument");

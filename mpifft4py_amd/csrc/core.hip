@@ -10,6 +10,7 @@
 #include <unordered_map>
 #include <tuple>
 #include "mfft_internal.h"
+#include "fft_nlz.h"
 
 namespace mfft {
 
@@ -98,6 +99,7 @@ struct DevCache {
   std::map<std::pair<int, int>, void*> rtw;
   std::map<const void*, bool> attr_done;
   std::map<std::tuple<int, int, int>, std::pair<void*, void*>> ztab;   // (n, M, prec) -> (chirp, bhat)
+  std::map<std::pair<int, int>, void*> rt3;                            // (L, prec) -> twiddles of the pruned nonlinear z stage
 };
 static std::mutex g_cache_mu;
 static std::map<int, DevCache> g_cache;
@@ -145,6 +147,30 @@ static int real_twiddles(int n, int prec, void** out) {
       MFFT_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
     }
     it = c.rtw.emplace(key, d).first;
+  }
+  *out = it->second;
+  return 0;
+}
+
+static int nlz3_twiddles(int L, int prec, void** out) {
+  int dev = 0;
+  MFFT_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  DevCache& c = g_cache[dev];
+  auto key = std::make_pair(L, prec);
+  auto it = c.rt3.find(key);
+  if (it == c.rt3.end()) {
+    void* d = nullptr;
+    if (prec == MFFT_DOUBLE) {
+      auto v = build_nlz3_twiddles<double>(L);
+      MFFT_HIP(hipMalloc(&d, v.size() * sizeof(v[0])));
+      MFFT_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+    } else {
+      auto v = build_nlz3_twiddles<float>(L);
+      MFFT_HIP(hipMalloc(&d, v.size() * sizeof(v[0])));
+      MFFT_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+    }
+    it = c.rt3.emplace(key, d).first;
   }
   *out = it->second;
   return 0;
@@ -464,6 +490,54 @@ static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
 
 int launch_r2c(const RealArgs& a, hipStream_t s) { return launch_real(FAM_R2C, a, s); }
 int launch_c2r(const RealArgs& a, hipStream_t s) { return launch_real(FAM_C2R, a, s); }
+
+// fused nonlinear z stage (fft_nlz.h): out_f = rfft((irfft(a) x irfft(b))_f) along the contiguous axis, row by row
+bool nlz_supported(int64_t n, int prec) {
+  return n >= 2 && n < 65536 && (find_kernel(FAM_NLZ, (int)n, prec, 0) != nullptr || find_kernel(FAM_NLZ, (int)n, prec, 0, 0, 3) != nullptr);
+}
+template <typename T>
+static int launch_nlz_t(const KernelEntry* e, const NlzArgs& a, void* tw, void* rt3, hipStream_t s) {
+  NlzParams<T> P;
+  P.rt3 = static_cast<const cx<T>*>(rt3);
+  for (int f = 0; f < 3; ++f) {
+    P.a[f] = static_cast<const cx<T>*>(a.a[f]);
+    P.b[f] = static_cast<const cx<T>*>(a.b[f]);
+    P.out[f] = static_cast<cx<T>*>(a.out[f]);
+  }
+  P.tw = static_cast<const cx<T>*>(tw);
+  P.in_stride = a.in_stride;
+  P.out_stride = a.out_stride;
+  P.nrows = a.nrows;
+  P.valid = a.valid > 0 && a.valid < a.n / 2 + 1 ? a.valid : a.n / 2 + 1;
+  P.scale = (T)a.scale;
+  const int64_t grid = (a.nrows + 2 * e->tile - 1) / (2 * e->tile);      // a thread group works through a PAIR of rows
+  if (grid <= 0) return 0;
+  if (grid > 0x7FFFFFFF) return set_error(MFFT_ERR_UNSUPPORTED, "grid too large");
+  e->launch(&P, (int)grid, s);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+int launch_nlz(const NlzArgs& a, hipStream_t s) {
+  const KernelEntry* e = a.n < 65536 ? find_kernel(FAM_NLZ, a.n, a.prec, 0) : nullptr;
+  // 3/2-rule rows (n = 3 L with the L + 1 bins of the un-padded mesh) also have the pruned kernel (fft_nlz.h Nlz3Fft: three
+  // sub-transforms of length L in three thread groups, a third of the registers).  Measured EVEN with NlzFft at 768 (1.36 ms per
+  // 73,728 rows both) and behind at 1536 (1.80 - 1.91 against 1.59 ms per 36,864 rows): profiles/r06_nlz_variants.txt -- its
+  // staging and combination cost what the skipped radix-3 pass saves.  MFFT_NLZ3=1 takes it; where NlzFft has no plan it runs anyway.
+  static const bool nlz3_on = getenv("MFFT_NLZ3") && atoi(getenv("MFFT_NLZ3")) != 0;
+  const bool rows3 = a.n % 3 == 0 && a.valid == a.n / 3 + 1 && a.n < 65536;
+  if ((nlz3_on || !e) && rows3)
+    if (const KernelEntry* e3 = find_kernel(FAM_NLZ, a.n, a.prec, 0, 0, 3)) e = e3;
+  static const int variant = getenv("MFFT_NLZ_VARIANT") ? atoi(getenv("MFFT_NLZ_VARIANT")) : 0;      // experiment builds only
+  if (variant > 0 && a.n < 65536 && (variant < 10 || rows3))
+    if (const KernelEntry* ev = find_kernel(FAM_NLZ, a.n, a.prec, 0, 0, variant)) e = ev;
+  if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no fused nonlinear z-stage kernel of length %d", a.n);
+  for (int f = 0; f < 3; ++f)
+    if (!a.a[f] || !a.b[f] || !a.out[f]) return set_error(MFFT_ERR_INVALID, "null argument");
+  void *tw = nullptr, *rt3 = nullptr;
+  MFFT_TRY(prepare_kernel(e, &tw));
+  if (e->pad >= 3) MFFT_TRY(nlz3_twiddles(a.n / 3, a.prec, &rt3));
+  return a.prec == MFFT_DOUBLE ? launch_nlz_t<double>(e, a, tw, rt3, s) : launch_nlz_t<float>(e, a, tw, rt3, s);
+}
 
 // ---------------------------------------------------------------------------
 // data-movement kernels

@@ -19,6 +19,7 @@
 #include "fft_kernels.h"
 #include "fft_chirpz.h"
 #include "fft_col3.h"
+#include "fft_nlz.h"
 #include "twiddle.h"
 #include "plans.h"
 
@@ -1147,6 +1148,138 @@ static void test_col3() {
   }
 }
 
+// ---------------------------------------------------------------------------
+// fused nonlinear z stage (fft_nlz.h): out_f = rfft((irfft(a) x irfft(b))_f), rows of `valid` bins, against long-double DFTs
+template <class S, typename T, int ROWS, bool TWLDS, bool SPLIT>
+static void test_nlz(int valid, bool inplace) {
+  typedef NlzFft<S, T, ROWS, TWLDS, SPLIT> K;
+  const int M = S::N;
+  const int nrows = 2 * ROWS + 3;                 // an odd count: the last pair has one row
+  const int pin = valid + 2, pout = inplace ? pin : valid + 1;
+  std::mt19937_64 rng(4242 + M + valid);
+  std::uniform_real_distribution<double> U(-1, 1);
+  std::vector<cx<T>> in[6], out[3];
+  for (auto& f : in) {
+    f.resize((size_t)nrows * pin);
+    for (auto& z : f) z = mk<T>((T)U(rng), (T)U(rng));
+  }
+  std::vector<cx<T>> keep[6];
+  for (int f = 0; f < 6; ++f) keep[f] = in[f];
+  for (auto& f : out) f.assign((size_t)nrows * pout, mk<T>((T)7, (T)7));
+  auto tw = build_pass_twiddles<S, T>();
+  NlzParams<T> P;
+  for (int f = 0; f < 3; ++f) { P.a[f] = in[f].data(); P.b[f] = in[3 + f].data(); P.out[f] = inplace ? in[f].data() : out[f].data(); }
+  P.tw = tw.data(); P.in_stride = pin; P.out_stride = pout; P.nrows = nrows; P.valid = valid;
+  P.scale = (T)(1.0 / ((double)M * (double)M));
+  emu_launch((nrows + 2 * ROWS - 1) / (2 * ROWS), K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  long double num = 0, den = 0;
+  for (int r = 0; r < nrows; ++r) {
+    std::vector<std::vector<long double>> re(6, std::vector<long double>(M));
+    for (int f = 0; f < 6; ++f) {
+      lvec X(M);
+      for (int p = 0; p < M; ++p) { X[p].x = 0; X[p].y = 0; }
+      for (int q = 0; q < valid; ++q) {
+        cx<T> z = keep[f][(size_t)r * pin + q];
+        long double zr = z.x, zi = z.y;
+        if (q == 0 || (M % 2 == 0 && q == M / 2)) zi = 0;
+        X[q].x = zr; X[q].y = zi;
+        if (q != 0 && q != M - q) { X[M - q].x = zr; X[M - q].y = -zi; }
+      }
+      lvec x = naive_dft(X, +1);
+      for (int p = 0; p < M; ++p) re[f][p] = x[p].x / M;
+    }
+    for (int c = 0; c < 3; ++c) {
+      const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+      lvec x(M);
+      for (int p = 0; p < M; ++p) { x[p].x = re[c1][p] * re[3 + c2][p] - re[c2][p] * re[3 + c1][p]; x[p].y = 0; }
+      lvec X = naive_dft(x, -1);
+      const cx<T>* g = (inplace ? in[c].data() : out[c].data()) + (size_t)r * pout;
+      for (int q = 0; q < valid; ++q) {
+        num += (g[q].x - X[q].x) * (g[q].x - X[q].x) + (g[q].y - X[q].y) * (g[q].y - X[q].y);
+        den += X[q].x * X[q].x + X[q].y * X[q].y;
+      }
+      if (!inplace)
+        for (int q = valid; q < pout; ++q)
+          if (g[q].x != (T)7 || g[q].y != (T)7) { num += 1; }      // nothing is stored beyond the valid bins
+    }
+  }
+  char name[64];
+  snprintf(name, sizeof name, "nlz r%d v%d%s%s%s", ROWS, valid, TWLDS ? " twlds" : "", SPLIT ? " split" : "", inplace ? " inpl" : "");
+  report(name, M, pname<T>(), (double)sqrtl(num / den), sizeof(T) == 8 ? 4e-14 : 2e-5);
+}
+// the pruned 3/2-rule flavour (Nlz3Fft): M = 3 L, L + 1 bins per row, three sub-transforms per row
+template <class SL, typename T, int ROWS, bool TWLDS>
+static void test_nlz3(bool inplace) {
+  typedef Nlz3Fft<SL, T, ROWS, TWLDS> K;
+  const int L = SL::N, M = 3 * L, valid = L + 1;
+  const int nrows = 2 * ROWS + 3;
+  const int pin = valid + 2, pout = inplace ? pin : valid + 1;
+  std::mt19937_64 rng(777 + M);
+  std::uniform_real_distribution<double> U(-1, 1);
+  std::vector<cx<T>> in[6], out[3], keep[6];
+  for (auto& f : in) {
+    f.resize((size_t)nrows * pin);
+    for (auto& z : f) z = mk<T>((T)U(rng), (T)U(rng));
+  }
+  for (int f = 0; f < 6; ++f) keep[f] = in[f];
+  for (auto& f : out) f.assign((size_t)nrows * pout, mk<T>((T)7, (T)7));
+  auto tw = build_pass_twiddles<SL, T>();
+  auto rt = build_nlz3_twiddles<T>(L);
+  NlzParams<T> P;
+  for (int f = 0; f < 3; ++f) { P.a[f] = in[f].data(); P.b[f] = in[3 + f].data(); P.out[f] = inplace ? in[f].data() : out[f].data(); }
+  P.tw = tw.data(); P.rt3 = rt.data(); P.in_stride = pin; P.out_stride = pout; P.nrows = nrows; P.valid = valid;
+  P.scale = (T)(1.0 / ((double)M * (double)M));
+  emu_launch((nrows + 2 * ROWS - 1) / (2 * ROWS), K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
+  long double num = 0, den = 0;
+  for (int r = 0; r < nrows; ++r) {
+    std::vector<std::vector<long double>> re(6, std::vector<long double>(M));
+    for (int f = 0; f < 6; ++f) {
+      lvec X(M);
+      for (int p = 0; p < M; ++p) { X[p].x = 0; X[p].y = 0; }
+      for (int q = 0; q < valid; ++q) {
+        cx<T> z = keep[f][(size_t)r * pin + q];
+        long double zr = z.x, zi = z.y;
+        if (q == 0) zi = 0;
+        X[q].x = zr; X[q].y = zi;
+        if (q != 0) { X[M - q].x = zr; X[M - q].y = -zi; }
+      }
+      lvec x = naive_dft(X, +1);
+      for (int p = 0; p < M; ++p) re[f][p] = x[p].x / M;
+    }
+    for (int c = 0; c < 3; ++c) {
+      const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+      lvec x(M);
+      for (int p = 0; p < M; ++p) { x[p].x = re[c1][p] * re[3 + c2][p] - re[c2][p] * re[3 + c1][p]; x[p].y = 0; }
+      lvec X = naive_dft(x, -1);
+      const cx<T>* g = (inplace ? in[c].data() : out[c].data()) + (size_t)r * pout;
+      for (int q = 0; q < valid; ++q) {
+        num += (g[q].x - X[q].x) * (g[q].x - X[q].x) + (g[q].y - X[q].y) * (g[q].y - X[q].y);
+        den += X[q].x * X[q].x + X[q].y * X[q].y;
+      }
+      if (!inplace)
+        for (int q = valid; q < pout; ++q)
+          if (g[q].x != (T)7 || g[q].y != (T)7) { num += 1; }
+    }
+  }
+  char name[64];
+  snprintf(name, sizeof name, "nlz3 r%d%s%s", ROWS, TWLDS ? " twlds" : "", inplace ? " inpl" : "");
+  report(name, M, pname<T>(), (double)sqrtl(num / den), sizeof(T) == 8 ? 4e-14 : 2e-5);
+}
+template <class SL> static void test_nlz3_all() {
+  test_nlz3<SL, double, 2, true>(false);
+  test_nlz3<SL, double, 1, false>(true);
+  test_nlz3<SL, float, 3, false>(false);
+  test_nlz3<SL, float, 2, true>(true);
+}
+template <class S> static void test_nlz_all() {
+  const int M = S::N;
+  const int full = M / 2 + 1, lim = M / 3 + 1;     // every bin / the bins of the un-padded mesh under the 3/2-rule
+  test_nlz<S, double, 2, true, false>(full, false);
+  test_nlz<S, double, 1, false, true>(lim, true);
+  test_nlz<S, float, 3, false, false>(lim, false);
+  test_nlz<S, float, 2, true, true>(full, true);
+}
+
 template <class S> static void test_chirpz_all() {
   const int nmax = (S::N + 1) / 2;
   for (int n : {nmax, nmax - 1, (S::N / 4) + 1, 7}) {
@@ -1272,6 +1405,15 @@ int main() {
 #endif
 #if EMU_HAS(5)
   MFFT_FOR_EACH_ROWPLAN(MFFT_PLAN) MFFT_ROWPLANS_F64_K(MFFT_PLAN)
+#endif
+#if EMU_HAS(12)
+#define MFFT_NLZ(N, ...) test_nlz_all<Spec<N, __VA_ARGS__>>();
+  MFFT_NLZPLANS_P2(MFFT_NLZ) MFFT_NLZPLANS_3(MFFT_NLZ)      // round 6: the fused nonlinear z stage
+#undef MFFT_NLZ
+#define MFFT_NLZ3(N, ...) test_nlz3_all<Spec<N, __VA_ARGS__>>();
+  MFFT_NLZ3PLANS(MFFT_NLZ3)
+  test_nlz3_all<Spec<256, 4, 4, 4, 4>>();
+#undef MFFT_NLZ3
 #endif
 #undef MFFT_PLAN
   printf("%s (%d failures)\n", g_fail ? "EMU TESTS FAILED" : "EMU TESTS PASSED", g_fail);

@@ -106,6 +106,21 @@ struct RealArgs {
 int launch_r2c(const RealArgs& a, hipStream_t s);
 int launch_c2r(const RealArgs& a, hipStream_t s);
 
+// fused nonlinear z stage (fft_nlz.h): rows of half-spectra of two vector fields in, rows of the half-spectra of their
+// cross product out (may alias the inputs row for row)
+struct NlzArgs {
+  const void* a[3] = {nullptr, nullptr, nullptr};
+  const void* b[3] = {nullptr, nullptr, nullptr};
+  void* out[3] = {nullptr, nullptr, nullptr};
+  int n = 0;             // REAL length of a z row
+  int prec = MFFT_DOUBLE;
+  int64_t in_stride = 0, out_stride = 0, nrows = 0;   // complex elements
+  int valid = 0;         // bins per row present in memory (0 = all n/2+1)
+  double scale = 1.0;    // applied to the product (1 / n^2: both inverse transforms normalised)
+};
+bool nlz_supported(int64_t n, int prec);
+int launch_nlz(const NlzArgs& a, hipStream_t s);
+
 // strided 3-D box copy: dst[i][j][k] = src[i][j][k] over extents e0,e1,e2 with
 // element strides (k contiguous); elem = bytes per element (8 or 16)
 struct BoxArgs {

@@ -124,6 +124,8 @@ struct mfft_plan_s {
     if (mask) (void)hipFree(mask);
     if (band_tiles) (void)hipFree(band_tiles);
     if (work3) (void)wfree(work3);
+    for (void* b : {nlx, nly, nlr})
+      if (b) (void)dev_free(b);
     for (auto& t : timers) {
       for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
       for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -712,6 +714,28 @@ struct mfft_plan_s {
   int pencil_forward_padded(const void* u, void* fu);
   int pencil_backward_padded(const void* fu, void* u);
   int apply_mask_copy(const void* fu, void** masked_out);
+  // ---- round 6: the nonlinear term a x b of a pseudo-spectral step as one operation (fft_nlz.h) ----
+  void* nlx = nullptr;          // fused route: the six spectra after their inverse x pass, (L0, N1, Za) each
+  size_t nlx_bytes = 0;
+  void* nly = nullptr;          // ... and a batch of their x planes after the inverse y pass, (mb, L1, Za) each
+  size_t nly_bytes = 0;
+  void* nlr = nullptr;          // composed route: nine real-space work arrays
+  size_t nlr_bytes = 0;
+  int ensure_buf(void** b, size_t* have, size_t bytes) {
+    if (*b && *have >= bytes) return 0;
+    drop_graphs();
+    if (*b) MFFT_TRY(dev_free(*b));
+    *b = nullptr;
+    *have = 0;
+    MFFT_TRY(dev_alloc(b, bytes));
+    *have = bytes;
+    return 0;
+  }
+  bool nonlinear_fusable(int dealias) const;
+  int64_t local_real_count(bool padded) const;
+  int nonlinear_cross(const void* a, const void* b, void* out, int dealias);
+  int nonlinear_cross_fused(const void* a, const void* b, void* out, int dealias);
+  int nonlinear_cross_composed(const void* a, const void* b, void* out, int dealias);
   int64_t local_complex_count() const {
     if (d.decomp == MFFT_SLAB) return N0 * Np1 * Nf;
     if (d.decomp == MFFT_PENCIL_X) return N0 * N1_1 * q;
@@ -1351,6 +1375,160 @@ int mfft_plan_s::slab_forward_padded(const void* u, void* fu) {
   // R2C folds the x Nyquist plane (slab.py:480-482); C2C copies the two halves (slab.py:796-797)
   MFFT_TRY(stage("trunc_x", 0, [&] { return trunc_axis(xin, fu, 1, N0, M0, Np1 * Nf, Np1 * Nf, isc3, r2c); }));
   return 0;
+}
+
+// ===========================================================================
+// Round 6: the nonlinear term of a pseudo-spectral step, out = fftn(ifftn(a) x ifftn(b)), as ONE plan-level operation
+// (what demo/spectral_dns_solver.py:53-71 composes from six ifftn, a cross product in real space and three fftn).
+// ===========================================================================
+extern "C" int mfft_ew_cross(mfft_plan_t plan, const void* a, const void* b, void* out, size_t n, int precision);
+
+int64_t mfft_plan_s::local_real_count(bool padded) const {
+  if (d.line2d) return 0;
+  if (d.decomp == MFFT_SLAB) return padded ? (int64_t)(d.padsize * Np0) * M1 * M2 : Np0 * N1 * N2;
+  return padded ? (int64_t)(d.padsize * N1_0) * (int64_t)(d.padsize * N2_1) * M2 : N1_0 * N2_1 * N2;
+}
+
+// Composed route (every decomposition and length): the transforms the caller would run, on nine work arrays of the plan.
+int mfft_plan_s::nonlinear_cross_composed(const void* a, const void* b, void* out, int dealias) {
+  const bool pad = dealias == MFFT_DEALIAS_3_2, masked = dealias == MFFT_DEALIAS_2_3;
+  const int64_t nr = local_real_count(pad), nc = local_complex_count();
+  if (nr <= 0 || !r2c) return set_error(MFFT_ERR_UNSUPPORTED, "nonlinear_cross needs a 3-D real-to-complex plan");
+  MFFT_TRY(ensure_buf(&nlr, &nlr_bytes, (size_t)(9 * nr) * rs));
+  char* R = static_cast<char*>(nlr);
+  auto back = [&](const void* in, void* o) {
+    if (d.decomp == MFFT_SLAB) return pad ? slab_backward_padded(in, o) : slab_backward(in, o, masked);
+    return pad ? pencil_backward_padded(in, o) : pencil_backward(in, o, masked);
+  };
+  auto fwd = [&](const void* in, void* o) {
+    if (d.decomp == MFFT_SLAB) return pad ? slab_forward_padded(in, o) : slab_forward(in, o);
+    return pad ? pencil_forward_padded(in, o) : pencil_forward(in, o);
+  };
+  for (int f = 0; f < 3; ++f) {
+    MFFT_TRY(back(static_cast<const char*>(a) + (size_t)(f * nc) * es, R + (size_t)(f * nr) * rs));
+    MFFT_TRY(back(static_cast<const char*>(b) + (size_t)(f * nc) * es, R + (size_t)((3 + f) * nr) * rs));
+  }
+  MFFT_TRY(stage("nl_cross", 9.0 * (double)nr * rs, [&] {
+    return mfft_ew_cross(this, R, R + (size_t)(3 * nr) * rs, R + (size_t)(6 * nr) * rs, (size_t)nr, prec);
+  }));
+  for (int f = 0; f < 3; ++f) MFFT_TRY(fwd(R + (size_t)((6 + f) * nr) * rs, static_cast<char*>(out) + (size_t)(f * nc) * es));
+  return 0;
+}
+
+// Fused route: one rank, slab, real data, radix kernels on every axis.
+bool mfft_plan_s::nonlinear_fusable(int dealias) const {
+  static const bool off = getenv("MFFT_NO_NLZ") && atoi(getenv("MFFT_NO_NLZ")) != 0;
+  if (off || d.decomp != MFFT_SLAB || P != 1 || !r2c || d.line2d || d.drop_nyquist || N0 < 2 || N1 < 2 || N2 < 2) return false;
+  if (dealias == MFFT_DEALIAS_3_2) return can_fuse_pad() && nlz_supported(M2, prec);
+  auto plain_ok = [&](int64_t n) {
+    return n < 65536 && find_kernel(FAM_COL, (int)n, prec, 0) && find_kernel(FAM_COL, (int)n, prec, 1);
+  };
+  if (!plain_ok(N0) || !plain_ok(N1) || !nlz_supported(N2, prec)) return false;
+  if (dealias == MFFT_DEALIAS_2_3) return mask && mask_count == (size_t)local_complex_count() && mask_fusable(N0, prec);
+  return dealias == MFFT_DEALIAS_NONE;
+}
+
+// The six spectra go through their inverse x passes into (L0, N1, Za) buffers of the plan (L = the padded mesh under the
+// 3/2-rule; Za = the row pitch, whole cache lines where rows are long).  Everything after that is local to an x plane, so
+// batches of x planes then run: inverse y pass of the six fields -> NlzFft (six z rows in, the three rows of the cross
+// product out, in place on the first three) -> forward y pass of the three results back into the x-pass buffers, whose
+// planes of that batch are free by then.  Three forward x passes finish.  The real-space arrays never exist; the batch
+// buffers are a quarter of the x-pass buffers (1024^3 with the 3/2-rule: 6 x 13.1 GB of x-pass buffers + 29.4 GB of batch
+// buffers, where the composed route needs 9 x 29 GB of real work arrays).
+int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, int dealias) {
+  const bool pad = dealias == MFFT_DEALIAS_3_2, masked = dealias == MFFT_DEALIAS_2_3;
+  const int64_t L0 = pad ? M0 : N0, L1 = pad ? M1 : N1, L2 = pad ? M2 : N2;
+  const int64_t line = (int64_t)(128 / es);
+  static const int align_mode = getenv("MFFT_NLZ_ALIGN") ? atoi(getenv("MFFT_NLZ_ALIGN")) : -1;      // 0 compact rows, 1 aligned, unset: rows of 2 KiB and more
+  const bool aligned = align_mode > 0 || (align_mode < 0 && Nf * (int64_t)es >= 2048);
+  const int64_t Za = aligned ? (Nf + line - 1) / line * line : Nf;
+  const int64_t C = N0 * N1 * Nf;                  // elements of one component of the caller's arrays
+  const size_t xelems = (size_t)(L0 * N1 * Za);    // ... of one x-pass buffer
+  // Batch of x planes.  Large batches win (512^3 with the 3/2-rule, ms per Runge-Kutta step against the MiB of a batch's six
+  // y-pass outputs: 80: 181, 160: 157, 320: 143, 640: 130, 1536: 117, 6000: 111 -- batches that would fit the 256 MB Infinity Cache
+  // gain nothing from it and pay for their short launches: profiles/r06_dns_batch.txt), so: FOUR batches, the batch buffers
+  // a quarter of the x-pass buffers; small meshes (all six outputs under 256 MiB) one.  MFFT_NLZ_BATCH_MB overrides.
+  static const long batch_mb = getenv("MFFT_NLZ_BATCH_MB") ? atol(getenv("MFFT_NLZ_BATCH_MB")) : 0;
+  const size_t plane6 = (size_t)(6 * L1 * Za) * es;
+  int64_t mb = batch_mb > 0 ? (int64_t)(((size_t)batch_mb << 20) / plane6)
+                            : (plane6 * (size_t)L0 <= ((size_t)256 << 20) ? L0 : (L0 + 3) / 4);
+  if (mb < 1) mb = 1;
+  if (mb > L0) mb = L0;
+  MFFT_TRY(ensure_buf(&nlx, &nlx_bytes, 6 * xelems * es));
+  MFFT_TRY(ensure_buf(&nly, &nly_bytes, (size_t)mb * plane6));
+  char* X = static_cast<char*>(nlx);
+  char* Y = static_cast<char*>(nly);
+  const size_t yelems = (size_t)(mb * L1 * Za);
+  const double sc3 = pad ? padscale() : 1.0;
+  const double Cb = (double)C * es, Xb = (double)(L0 * N1 * Nf) * es, Yb = (double)(L0 * L1 * Nf) * es;
+  struct MaskScope {            // the mask belongs to this call only
+    mfft_plan_s* p;
+    ~MaskScope() { p->mask_src = nullptr; p->lband_use = false; }
+  } mask_scope{this};
+  lband_use = false;
+  MFFT_TRY(stage("nl_x_inv", 6 * (Cb + Xb), [&] {
+    for (int f = 0; f < 6; ++f) {
+      const void* src = static_cast<const char*>(f < 3 ? a : b) + (size_t)((f % 3) * C) * es;
+      void* dst = X + (size_t)f * xelems * es;
+      if (masked) {                                // `fu * dealias` (slab.py:237-245) applied while the spectrum is loaded
+        mask_src = src;
+        MFFT_TRY(col(src, dst, N0, true, N1, Nf, Nf, plain(N1 * Nf), Za, plain(N1 * Za)));
+        mask_src = nullptr;
+      } else if (Za != Nf) {                       // one outer batch per y row: compact rows in, pitched rows out
+        MFFT_TRY(col_pad(src, dst, L0, true, pad ? 1 : 0, false, N1, Nf, Nf, plain(N1 * Nf), Za, plain(N1 * Za), sc3 / (double)L0,
+                         0, 0, 1));
+      } else {
+        MFFT_TRY(col_pad(src, dst, L0, true, pad ? 1 : 0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf), sc3 / (double)L0));
+      }
+    }
+    return 0;
+  }));
+  for (int64_t i0 = 0; i0 < L0; i0 += mb) {
+    const int64_t m = std::min(mb, L0 - i0);
+    const double frac = (double)m / (double)L0;
+    MFFT_TRY(stage("nl_y_inv", 6 * (Xb + Yb) * frac, [&] {
+      for (int f = 0; f < 6; ++f)
+        MFFT_TRY(col_pad(X + ((size_t)f * xelems + (size_t)(i0 * N1 * Za)) * es, Y + (size_t)f * yelems * es, L1, true, pad ? 1 : 0,
+                         false, m, Nf, N1 * Za, plain(Za), L1 * Za, plain(Za), 1.0 / (double)L1));
+      return 0;
+    }));
+    MFFT_TRY(stage("nl_z", 9 * Yb * frac, [&] {
+      NlzArgs z;
+      for (int f = 0; f < 3; ++f) {
+        z.a[f] = Y + (size_t)f * yelems * es;
+        z.b[f] = Y + (size_t)(3 + f) * yelems * es;
+        z.out[f] = Y + (size_t)f * yelems * es;
+      }
+      z.n = (int)L2; z.prec = prec; z.in_stride = Za; z.out_stride = Za; z.nrows = m * L1; z.valid = (int)Nf;
+      z.scale = 1.0 / ((double)L2 * (double)L2);
+      return launch_nlz(z, stream);
+    }));
+    MFFT_TRY(stage("nl_y_fwd", 3 * (Xb + Yb) * frac, [&] {
+      for (int f = 0; f < 3; ++f)
+        MFFT_TRY(col_pad(Y + (size_t)f * yelems * es, X + ((size_t)f * xelems + (size_t)(i0 * N1 * Za)) * es, L1, false, pad ? 2 : 0,
+                         pad, m, Nf, L1 * Za, plain(Za), N1 * Za, plain(Za), 1.0));
+      return 0;
+    }));
+  }
+  MFFT_TRY(stage("nl_x_fwd", 3 * (Cb + Xb), [&] {
+    for (int f = 0; f < 3; ++f) {
+      const void* src = X + (size_t)f * xelems * es;
+      void* dst = static_cast<char*>(out) + (size_t)(f * C) * es;
+      if (Za != Nf)                                // tiles of the compact result; input column (y, z) sits at y * Za + z
+        MFFT_TRY(col_pad(src, dst, L0, false, pad ? 2 : 0, pad, 1, N1 * Nf, 0, plain(N1 * Za), 0, plain(N1 * Nf), 1.0 / sc3, Nf, Za - Nf));
+      else
+        MFFT_TRY(col_pad(src, dst, L0, false, pad ? 2 : 0, pad, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf), 1.0 / sc3));
+    }
+    return 0;
+  }));
+  return 0;
+}
+
+int mfft_plan_s::nonlinear_cross(const void* a, const void* b, void* out, int dealias) {
+  if (dealias == MFFT_DEALIAS_2_3 && (!mask || mask_count != (size_t)local_complex_count()))
+    return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask was set");
+  if (nonlinear_fusable(dealias)) return nonlinear_cross_fused(a, b, out, dealias);
+  return nonlinear_cross_composed(a, b, out, dealias);
 }
 
 // ===========================================================================
@@ -2479,6 +2657,16 @@ int mfft_backward(mfft_plan_t p, const void* fu, void* u, int dealias) {
   return run_direct(p, false, fu, u, dealias);
 }
 
+// out = fftn(ifftn(a) x ifftn(b)) with the plan's transforms under the given dealias mode: a, b, out are vector fields of
+// shape (3,) + the local complex shape, component-major; out may be a or b.  See include/mpifft4py_amd.h.
+int mfft_nonlinear_cross(mfft_plan_t p, const void* a_hat, const void* b_hat, void* out_hat, int dealias) {
+  MFFT_TRY(check_ready(p, a_hat, b_hat));
+  if (!out_hat) return set_error(MFFT_ERR_INVALID, "null argument");
+  if (dealias != MFFT_DEALIAS_NONE && dealias != MFFT_DEALIAS_2_3 && dealias != MFFT_DEALIAS_3_2)
+    return set_error(MFFT_ERR_INVALID, "unknown dealias mode %d", dealias);
+  return p->nonlinear_cross(a_hat, b_hat, out_hat, dealias);
+}
+
 int mfft_plan_sync(mfft_plan_t p) {
   if (!p) return set_error(MFFT_ERR_INVALID, "null plan");
   if (p->cstream) MFFT_HIP(hipStreamSynchronize(p->cstream));
@@ -2510,6 +2698,10 @@ int mfft_plan_get_info(mfft_plan_t p, const char* key, int64_t* value) {
   else if (k == "row_batches") *value = p->nbatch;
   else if (k == "zfuse") *value = p->zfuse ? 1 : 0;
   else if (k == "ranks") *value = p->P;
+  else if (k == "nonlinear_fused_none") *value = p->nonlinear_fusable(MFFT_DEALIAS_NONE) ? 1 : 0;
+  else if (k == "nonlinear_fused_2_3") *value = p->nonlinear_fusable(MFFT_DEALIAS_2_3) ? 1 : 0;
+  else if (k == "nonlinear_fused_3_2") *value = p->nonlinear_fusable(MFFT_DEALIAS_3_2) ? 1 : 0;
+  else if (k == "nonlinear_bytes") *value = (int64_t)(p->nlx_bytes + p->nly_bytes + p->nlr_bytes);
   else if (k == "plane_pad") *value = (p->P == 1 && p->d.decomp == MFFT_SLAB) ? p->p1_plane_pad() : 0;   // elements added to the intermediate's plane pitch
   else return set_error(MFFT_ERR_INVALID, "mfft_plan_get_info: unknown key '%s'", key);
   return 0;

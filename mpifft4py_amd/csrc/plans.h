@@ -139,6 +139,19 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
   return (sizeof(T) == 4 && n == 4096) || (sizeof(T) == 8 && (n == 1024 || n == 512 || n == 384 || n == 768 || n == 1152 || n == 900));
 }
 
+// Round 6: complex plans of the fused nonlinear z stage (fft_nlz.h NlzFft: X(M, radices) with M the REAL length of a z row --
+// two real rows ride on one complex transform of length M).  Powers of two (dealias None / 2/3-rule) with 8 values per
+// thread and the 3 * 2^a images of the 3/2-rule with 12: the kernel parks 2 E complex + E real values per thread next to
+// the working set of a transform, so few values per thread (many threads per row) is what keeps it at two waves per SIMD.
+#define MFFT_NLZPLANS_P2(X) X(16, 8, 2) X(32, 8, 4) X(64, 8, 8) X(128, 8, 4, 4) X(256, 8, 8, 4) X(512, 8, 8, 8) \
+  X(1024, 8, 8, 4, 4) X(2048, 8, 8, 8, 4) X(4096, 8, 8, 8, 8)
+#define MFFT_NLZPLANS_3(X) X(12, 12) X(24, 12, 2) X(48, 12, 4) X(96, 12, 4, 2) X(192, 12, 4, 4) X(384, 12, 4, 4, 2) \
+  X(768, 12, 4, 4, 4) X(1536, 12, 4, 4, 4, 2) X(3072, 12, 4, 4, 4, 4)
+
+// ... and the sub-plans of its pruned 3/2-rule flavour (Nlz3Fft: X(L, radices) with L = N/2 = M/3, three sub-transforms of
+// length L per row in three thread groups)
+#define MFFT_NLZ3PLANS(X) X(4, 4) X(8, 8) X(16, 4, 4) X(32, 8, 4) X(64, 8, 8) X(128, 8, 4, 4) X(256, 8, 8, 4) X(512, 8, 8, 8) \
+  X(1024, 8, 8, 4, 4)
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
   MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X) MFFT_PLANS_N(X) \

@@ -15,7 +15,8 @@ enum Family {
   FAM_COL = 0, FAM_ROW = 1, FAM_R2C = 2, FAM_C2R = 3,
   // chirp-z (Bluestein) variants: entry.n is the convolution length M, the logical length is a launch parameter
   FAM_COLZ = 4, FAM_ROWZ = 5, FAM_R2CZ = 6, FAM_C2RZ = 7,
-  FAM_R2CZH = 8, FAM_C2RZH = 9     // even real length: chirp-z of n/2 complex values + split pass
+  FAM_R2CZH = 8, FAM_C2RZH = 9,    // even real length: chirp-z of n/2 complex values + split pass
+  FAM_NLZ = 10                     // fused nonlinear z stage (fft_nlz.h): entry.n is the REAL length of a z row, tile = row PAIRS per workgroup
 };
 
 struct KernelEntry {

@@ -1,0 +1,59 @@
+// registry_nlz.h -- registration of the fused nonlinear z-stage kernels (fft_nlz.h); included by kernels_nlz_*.hip only, so
+// that an edit of those kernels does not rebuild every translation unit.
+#pragma once
+#include "registry.h"
+#include "fft_nlz.h"
+
+namespace mfft {
+
+// Round 6: the fused nonlinear z stage (fft_nlz.h NlzFft), one kernel per (length, precision).  256 threads per workgroup
+// where a row has fewer; whole complex values through LDS while two workgroups (with their twiddle tables) fit a CU,
+// real and imaginary parts one after the other beyond; the twiddles in LDS while the table stays under 48 KB.  The register
+// cap asks for two waves per SIMD: the kernel parks 5 E real values per thread next to a transform's working set.
+template <class S, typename T> constexpr int nlz_rows() { return 256 / S::TPT > 0 ? 256 / S::TPT : 1; }
+template <class S, typename T> constexpr bool nlz_twlds() { return S::NP > 1 && (long long)S::TW * (int)sizeof(cx<T>) <= 49152; }
+template <class S, typename T> constexpr bool nlz_split() {
+  constexpr long long tw = nlz_twlds<S, T>() ? (long long)S::TW * (int)sizeof(cx<T>) : 0;
+  return tw + (long long)padded_len<S::N, S::R(0)>() * nlz_rows<S, T>() * (int)sizeof(cx<T>) > 81920;
+}
+#ifndef MFFT_NLZ_OCC
+#define MFFT_NLZ_OCC 2
+#endif
+// experiment variants (MFFT_NLZ_VARIANT = pad code): rows per workgroup / LDS twiddles / register cap
+template <class S, typename T, int ROWS, bool TWL, int OCC, int VAR>
+void register_nlz_var(const char* name) {
+  auto& reg = kernel_registry();
+  constexpr int R = ROWS > 0 ? ROWS : 1;
+  constexpr bool TW = TWL && S::NP > 1;
+  constexpr long long tw = TW ? (long long)S::TW * (int)sizeof(cx<T>) : 0;
+  constexpr bool SP = tw + (long long)padded_len<S::N, S::R(0)>() * R * (int)sizeof(cx<T>) > 81920;
+  constexpr int W = OCC > 1 ? 16 + OCC : 0;
+  reg.push_back(make_entry<NlzFft<S, T, R, TW, SP>, NlzParams<T>, S, T, W>(FAM_NLZ, S::N, 0, R, name));
+  reg.back().pad = VAR;
+}
+template <class S, typename T>
+void register_nlz(const char* name) {
+  auto& reg = kernel_registry();
+  constexpr int R = nlz_rows<S, T>();
+  constexpr int W = MFFT_NLZ_OCC > 1 ? 16 + MFFT_NLZ_OCC : 0;        // waves per SIMD, said directly (registry.h mfft_kern_occ)
+  reg.push_back(make_entry<NlzFft<S, T, R, nlz_twlds<S, T>(), nlz_split<S, T>()>, NlzParams<T>, S, T, W>(FAM_NLZ, S::N, 0, R, name));
+}
+
+// ... and its pruned 3/2-rule flavour (Nlz3Fft: pad code 3, entry.n = M = 3 L): three thread groups of SL::TPT threads per row
+template <class SL, typename T> constexpr int nlz3_rows() { return 256 / (3 * SL::TPT) > 0 ? 256 / (3 * SL::TPT) : 1; }
+template <class SL, typename T>
+void register_nlz3(const char* name) {
+  auto& reg = kernel_registry();
+  constexpr int R = nlz3_rows<SL, T>();
+  reg.push_back(make_entry<Nlz3Fft<SL, T, R, true>, NlzParams<T>, SL, T>(FAM_NLZ, 3 * SL::N, 0, R, name));
+  reg.back().pad = 3;
+}
+template <class SL, typename T, int ROWS, int OCC, int VAR>
+void register_nlz3_var(const char* name) {
+  auto& reg = kernel_registry();
+  constexpr int W = OCC > 0 ? 16 + OCC : 0;
+  reg.push_back(make_entry<Nlz3Fft<SL, T, ROWS, true>, NlzParams<T>, SL, T, W>(FAM_NLZ, 3 * SL::N, 0, ROWS, name));
+  reg.back().pad = VAR;
+}
+
+}  // namespace mfft

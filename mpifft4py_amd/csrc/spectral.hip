@@ -71,6 +71,51 @@ __global__ __launch_bounds__(EW_BLOCK) void rhs_kernel(cx<T>* __restrict__ dU, c
   }
 }
 
+// One Runge-Kutta stage of the demo's time loop (demo/spectral_dns_solver.py:73-77, 91-98) in ONE sweep: N holds the
+// nonlinear term (mfft_nonlinear_cross); per element
+//     dU = N - K (K . N) / |K|^2 - nu |K|^2 U          pressure projection + viscous term
+//     U1 += a_dt dU
+//     U   = U0 + b_dt dU                  (stages 0 - 2)     |    U = U0 = U1   (last stage: the next step's starting values)
+//     N   = i K x U                       the curl the next stage transforms
+// instead of the rhs kernel, two or three axpbz sweeps and the curl kernel over the same arrays (15 field passes -> 7).
+template <typename T, bool LAST>
+__global__ __launch_bounds__(EW_BLOCK) void rk_stage_kernel(cx<T>* __restrict__ N, cx<T>* __restrict__ U, cx<T>* __restrict__ U0,
+                                                           cx<T>* __restrict__ U1, const T* __restrict__ kx,
+                                                           const T* __restrict__ ky, const T* __restrict__ kz, int64_t s1,
+                                                           int64_t s2, size_t n, T nu, T a_dt, T b_dt) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int64_t k = (int64_t)(i % s2), j = (int64_t)((i / s2) % s1), l = (int64_t)(i / (s2 * s1));
+    const T K[3] = {kx[l], ky[j], kz[k]};
+    const T k2 = K[0] * K[0] + K[1] * K[1] + K[2] * K[2];
+    const T inv = k2 == (T)0 ? (T)1 : (T)1 / k2;
+    cx<T> d[3], u[3], w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { d[c] = N[c * n + i]; u[c] = U[c * n + i]; w[c] = U1[c * n + i]; }
+    const cx<T> P = mk<T>((d[0].x * K[0] + d[1].x * K[1] + d[2].x * K[2]) * inv, (d[0].y * K[0] + d[1].y * K[1] + d[2].y * K[2]) * inv);
+    const T v = nu * k2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      d[c] = mk<T>(d[c].x - P.x * K[c] - v * u[c].x, d[c].y - P.y * K[c] - v * u[c].y);
+      w[c] = mk<T>(w[c].x + a_dt * d[c].x, w[c].y + a_dt * d[c].y);
+      if constexpr (LAST) {
+        u[c] = w[c];
+        U0[c * n + i] = w[c];
+      } else {
+        const cx<T> u0 = U0[c * n + i];
+        u[c] = mk<T>(u0.x + b_dt * d[c].x, u0.y + b_dt * d[c].y);
+      }
+      U1[c * n + i] = w[c];
+      U[c * n + i] = u[c];
+    }
+    const cx<T> c0 = mk<T>(K[1] * u[2].x - K[2] * u[1].x, K[1] * u[2].y - K[2] * u[1].y);
+    const cx<T> c1 = mk<T>(K[2] * u[0].x - K[0] * u[2].x, K[2] * u[0].y - K[0] * u[2].y);
+    const cx<T> c2 = mk<T>(K[0] * u[1].x - K[1] * u[0].x, K[0] * u[1].y - K[1] * u[0].y);
+    N[i] = mk<T>(-c0.y, c0.x);
+    N[n + i] = mk<T>(-c1.y, c1.x);
+    N[2 * n + i] = mk<T>(-c2.y, c2.x);
+  }
+}
+
 // y = alpha * x + beta * z   (any of the pointers may alias); counts in reals
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void axpbz_kernel(T* y, const T* x, const T* z, T alpha, T beta, size_t n) {
@@ -227,6 +272,25 @@ int mfft_ew_ns_rhs(mfft_plan_t plan, void* dU, const void* U_hat, const void* kx
   else
     hipLaunchKernelGGL(rhs_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, (cx<float>*)dU,
                        (const cx<float>*)U_hat, (const float*)kx, (const float*)ky, (const float*)kz, shape[1], shape[2], n, (float)nu);
+  MFFT_HIP(hipGetLastError());
+  return 0;
+}
+
+int mfft_ew_ns_rk_stage(mfft_plan_t plan, void* N_hat, void* U_hat, void* U_hat0, void* U_hat1, const void* kx, const void* ky,
+                        const void* kz, const int64_t shape[3], double nu, double a_dt, double b_dt, int last, int precision) {
+  hipStream_t st = plan_stream(plan);
+  if (!N_hat || !U_hat || !U_hat0 || !U_hat1 || !kx || !ky || !kz || !shape) return set_error(MFFT_ERR_INVALID, "null argument");
+  const size_t n = (size_t)(shape[0] * shape[1] * shape[2]);
+  const dim3 grid(ew_grid(n)), block(EW_BLOCK);
+  if (precision == MFFT_DOUBLE) {
+    typedef cx<double> C;
+    if (last) hipLaunchKernelGGL((rk_stage_kernel<double, true>), grid, block, 0, st, (C*)N_hat, (C*)U_hat, (C*)U_hat0, (C*)U_hat1, (const double*)kx, (const double*)ky, (const double*)kz, shape[1], shape[2], n, nu, a_dt, b_dt);
+    else hipLaunchKernelGGL((rk_stage_kernel<double, false>), grid, block, 0, st, (C*)N_hat, (C*)U_hat, (C*)U_hat0, (C*)U_hat1, (const double*)kx, (const double*)ky, (const double*)kz, shape[1], shape[2], n, nu, a_dt, b_dt);
+  } else {
+    typedef cx<float> C;
+    if (last) hipLaunchKernelGGL((rk_stage_kernel<float, true>), grid, block, 0, st, (C*)N_hat, (C*)U_hat, (C*)U_hat0, (C*)U_hat1, (const float*)kx, (const float*)ky, (const float*)kz, shape[1], shape[2], n, (float)nu, (float)a_dt, (float)b_dt);
+    else hipLaunchKernelGGL((rk_stage_kernel<float, false>), grid, block, 0, st, (C*)N_hat, (C*)U_hat, (C*)U_hat0, (C*)U_hat1, (const float*)kx, (const float*)ky, (const float*)kz, shape[1], shape[2], n, (float)nu, (float)a_dt, (float)b_dt);
+  }
   MFFT_HIP(hipGetLastError());
   return 0;
 }

@@ -39,6 +39,19 @@ std::vector<cx<T>> build_real_twiddles(int N) {
   return tw;
 }
 
+// pruned 3/2-rule z stage (fft_nlz.h Nlz3Fft), M = 3 L: exp(+2 pi i k / M), k = 0..L, then exp(+2 pi i 2k / M), k = 0..L
+template <typename T>
+std::vector<cx<T>> build_nlz3_twiddles(int L) {
+  std::vector<cx<T>> tw(2 * (L + 1));
+  const long double two_pi = 6.283185307179586476925286766559L;
+  for (int q = 1; q <= 2; ++q)
+    for (int k = 0; k <= L; ++k) {
+      const long double a = two_pi * (long double)((long long)q * k % (3LL * L)) / (long double)(3LL * L);
+      tw[(q - 1) * (L + 1) + k] = mk<T>((T)cosl(a), (T)sinl(a));
+    }
+  return tw;
+}
+
 // ---- chirp-z (Bluestein) tables, fft_chirpz.h ------------------------------------
 // chirp w[r] = exp(-i pi r^2 / n), r = 0..n-1; the angle is reduced exactly: r^2 mod 2n
 template <typename T>

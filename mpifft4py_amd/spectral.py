@@ -48,6 +48,33 @@ def ns_rhs(FFT, K, dU, U_hat, nu):
     return dU
 
 
+def cross_transform(FFT, a_hat, b_hat, out_hat, dealias=None):
+    """out_hat = fftn(ifftn(a_hat) x ifftn(b_hat)), the nonlinear term of a pseudo-spectral step as ONE operation of the
+    plan (mfft_nonlinear_cross): what the reference demo composes from six `FFT.ifftn(.., dealias)`, a cross product of
+    numpy arrays and three `FFT.fftn(.., dealias)` (demo/spectral_dns_solver.py:53-71).  All three are DeviceArrays of
+    shape (3,) + FFT.complex_shape(); out_hat may be a_hat or b_hat.  On one rank (slab) the z stages are one fused kernel
+    and no real-space work array exists (`FFT.plan_info("nonlinear_fused_3_2")`); elsewhere the plan composes it."""
+    from ._base import _DEALIAS
+    assert dealias in ('3/2-rule', '2/3-rule', 'None', None)
+    shape = (3,) + tuple(int(s) for s in FFT.complex_shape())
+    for x in (a_hat, b_hat, out_hat):
+        assert x.shape == shape and x.dtype == np.dtype(FFT.complex), (x.shape, x.dtype, shape)
+    code = _DEALIAS[dealias]
+    FFT.comm.use_device()
+    if code == _lib.DEALIAS_2_3:
+        FFT._ensure_mask()
+    _lib.call("mfft_nonlinear_cross", FFT._plan, a_hat.ptr, b_hat.ptr, out_hat.ptr, code)
+    return out_hat
+
+
+def ns_rk_stage(FFT, K, N_hat, U_hat, U_hat0, U_hat1, nu, a_dt, b_dt, last):
+    """One Runge-Kutta stage in one sweep (mfft_ew_ns_rk_stage): N_hat holds the nonlinear term on entry and the curl of
+    the updated U_hat on return; U_hat1 += a_dt dU; U_hat = U_hat0 + b_dt dU, or (last) U_hat = U_hat0 = U_hat1."""
+    _lib.call("mfft_ew_ns_rk_stage", FFT._plan, N_hat.ptr, U_hat.ptr, U_hat0.ptr, U_hat1.ptr, K.dev[0].ptr, K.dev[1].ptr,
+              K.dev[2].ptr, K.cshape, float(nu), float(a_dt), float(b_dt), 1 if last else 0, _prec(FFT))
+    return U_hat
+
+
 def axpbz(FFT, y, x, z, alpha, beta):
     """y = alpha * x + beta * z (element-wise over the raw real storage; aliasing allowed)."""
     n_real = y.size * (2 if y.dtype.kind == "c" else 1)

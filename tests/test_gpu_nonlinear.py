@@ -1,0 +1,224 @@
+"""GPU: the nonlinear term of a pseudo-spectral step as one plan operation (mfft_nonlinear_cross, csrc/fft_nlz.h) and
+the one-sweep Runge-Kutta stage (mfft_ew_ns_rk_stage) against the ORACLE's transforms -- what the reference demo
+composes from six FFT.ifftn, numpy products and three FFT.fftn (demo/spectral_dns_solver.py:53-98) -- on the same
+seeded spectra, through the C ABI."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gpu_util import L, TOL, cdtype, have_gpu, orc, rdtype, run_ranks
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+INFO = {"3/2-rule": "nonlinear_fused_3_2", "2/3-rule": "nonlinear_fused_2_3", None: "nonlinear_fused_none"}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not have_gpu():
+        pytest.fail("no GPU visible")
+
+
+def _spectra(F, N, prec, seed, hermitian):
+    """Two vector fields in spectral space: transforms of random real fields (what a solver holds), or arbitrary complex
+    numbers (the transforms' conventions for the bins a real field would not have: c2r ignores Im of kz = 0, N/2)."""
+    rng = np.random.default_rng(seed)
+    cs = tuple(F.complex_shape())
+    if hermitian:
+        a = np.stack([np.fft.rfftn(rng.random(tuple(N)) - 0.5) for _ in range(3)])
+        b = np.stack([np.fft.rfftn(rng.random(tuple(N)) - 0.5) for _ in range(3)])
+    else:
+        a = rng.random((3,) + cs) - 0.5 + 1j * (rng.random((3,) + cs) - 0.5)
+        b = rng.random((3,) + cs) - 0.5 + 1j * (rng.random((3,) + cs) - 0.5)
+    return a.astype(cdtype(prec)), b.astype(cdtype(prec))
+
+
+def _oracle_cross(a, b, N, prec, dealias, mask=None):
+    """fftn(ifftn(a) x ifftn(b)) with the oracle's one-rank transforms in the mode `dealias`."""
+    if dealias == "3/2-rule":
+        back = lambda x: orc.slab_r2c_backward_padded([x], N, prec)[0]
+        fwd = lambda x: orc.slab_r2c_forward_padded([x], N, prec)[0]
+    else:
+        back = lambda x: orc.slab_r2c_backward([x if mask is None else orc.apply_mask(x, mask)], N, prec)[0]
+        fwd = lambda x: orc.slab_r2c_forward([x], N, prec)[0]
+    ua = [np.asarray(back(a[i]), dtype=np.float64) for i in range(3)]
+    ub = [np.asarray(back(b[i]), dtype=np.float64) for i in range(3)]
+    r = np.cross(np.stack(ua), np.stack(ub), axis=0).astype(rdtype(prec))
+    return np.stack([fwd(r[i]) for i in range(3)])
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("dealias", ["3/2-rule", "2/3-rule", None])
+@pytest.mark.parametrize("N,fused", [([32, 64, 128], True), ([64, 32, 32], True), ([8, 16, 32], True), ([16, 32, 24], None),
+                                     ([128, 128, 128], True), ([20, 24, 40], None)])
+@pytest.mark.parametrize("hermitian", [True, False])
+def test_nonlinear_cross_one_rank(N, fused, dealias, prec, hermitian):
+    """One rank, slab: the fused route (x passes -> batches of y pass / fused z stage / y pass -> x passes) where every
+    axis has its kernels, the plan's own composition otherwise -- both against the oracle."""
+    from mpifft4py_amd import DeviceArray, SelfComm, Slab_R2C, spectral
+    N = np.array(N)
+    F = Slab_R2C(N, L, SelfComm(0), prec)
+    a, b = _spectra(F, N, prec, 11 + int(N[2]), hermitian)
+    mask = None
+    if dealias == "2/3-rule":
+        mask = F.get_dealias_filter()
+    want = _oracle_cross(a, b, N, prec, dealias, mask)
+    da, db = DeviceArray.from_numpy(a), DeviceArray.from_numpy(b)
+    out = DeviceArray.empty(a.shape, a.dtype)
+    spectral.cross_transform(F, da, db, out, dealias)
+    F.sync()
+    if fused:
+        assert F.plan_info(INFO[dealias]) == 1
+    assert orc.rel_l2(out.get(), want) < 4 * TOL[prec]
+    assert np.array_equal(da.get(), a) and np.array_equal(db.get(), b)          # inputs preserved
+    spectral.cross_transform(F, da, db, db, dealias)                             # in place on the second field
+    F.sync()
+    assert orc.rel_l2(db.get(), want) < 4 * TOL[prec]
+
+
+@pytest.mark.parametrize("batch_mb,align", [("1", "1"), ("1", "0"), ("4", "-1")])
+def test_nonlinear_cross_batches(batch_mb, align):
+    """Several batches of x planes (the last one ragged) and both row pitches of the intermediates: a fresh process,
+    the switches are read once."""
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from gpu_util import L, orc
+from mpifft4py_amd import DeviceArray, SelfComm, Slab_R2C, spectral
+import test_gpu_nonlinear as t
+for N, dealias in (([40, 32, 64], '3/2-rule'), ([24, 64, 128], None)):
+    N = np.array(N)
+    F = Slab_R2C(N, L, SelfComm(0), 'double')
+    a, b = t._spectra(F, N, 'double', 3, True)
+    want = t._oracle_cross(a, b, N, 'double', dealias)
+    out = DeviceArray.empty(a.shape, a.dtype)
+    spectral.cross_transform(F, DeviceArray.from_numpy(a), DeviceArray.from_numpy(b), out, dealias)
+    F.sync()
+    assert F.plan_info(t.INFO[dealias]) == 1
+    e = orc.rel_l2(out.get(), want)
+    assert e < 4e-10, e
+print('ok')
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, MFFT_NLZ_BATCH_MB=batch_mb, MFFT_NLZ_ALIGN=align)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("dealias", ["3/2-rule", "2/3-rule", None])
+@pytest.mark.parametrize("decomp,P", [("slab", 2), ("slab", 4), ("pencilX", 4), ("pencilY", 4)])
+def test_nonlinear_cross_ranks(decomp, P, dealias):
+    """Several ranks / pencils: the plan composes the operation from its own transforms; same call, same result as six
+    ifftn + cross + three fftn issued by the caller."""
+    from mpifft4py_amd import DeviceArray, spectral
+    from mpifft4py_amd.pencil import R2C as Pencil_R2C
+    from mpifft4py_amd.slab import R2C as Slab_R2C
+    N = np.array([16, 32, 32])
+
+    def work(comm):
+        if decomp == "slab":
+            F = Slab_R2C(N, L, comm, "double")
+        else:
+            F = Pencil_R2C(N, L, comm, "double", communication="Alltoallw", alignment=decomp[-1])
+        rng = np.random.default_rng(77 + comm.Get_rank())
+        cs, ws = tuple(F.complex_shape()), tuple(F.work_shape(dealias))
+        a = DeviceArray.empty((3,) + cs, F.complex)
+        b = DeviceArray.empty((3,) + cs, F.complex)
+        for x in (a, b):                                           # spectra of real fields
+            for i in range(3):
+                F.fftn(DeviceArray.from_numpy(rng.random(F.real_shape()) - 0.5), x.component(i))
+        ua, ub, r = (DeviceArray.empty((3,) + ws, F.float) for _ in range(3))
+        for i in range(3):
+            F.ifftn(a.component(i), ua.component(i), dealias)
+            F.ifftn(b.component(i), ub.component(i), dealias)
+        spectral.cross(F, ua, ub, r)
+        want = DeviceArray.empty((3,) + cs, F.complex)
+        for i in range(3):
+            F.fftn(r.component(i), want.component(i), dealias)
+        got = DeviceArray.empty((3,) + cs, F.complex)
+        spectral.cross_transform(F, a, b, got, dealias)
+        F.sync()
+        return orc.rel_l2(got.get(), want.get())
+
+    errs = run_ranks(P, work)
+    assert max(errs) < 1e-13, errs
+
+
+@pytest.mark.parametrize("prec", ["double", "single"])
+@pytest.mark.parametrize("last", [False, True])
+def test_rk_stage_matches_numpy(prec, last):
+    """mfft_ew_ns_rk_stage == the demo's compute_rhs tail + its two updates + the next curl (demo:60-64, 73-77, 94-97)."""
+    from mpifft4py_amd import DeviceArray, SelfComm, Slab_R2C, spectral
+    N = np.array([16, 32, 24])
+    F = Slab_R2C(N, np.array([2 * np.pi, 4 * np.pi, 2 * np.pi]), SelfComm(0), prec)
+    rng = np.random.default_rng(8)
+    K = np.array(F.get_local_wavenumbermesh(scaled=True, broadcast=True))
+    Kd = spectral.Wavenumbers(F)
+    shape = (3,) + tuple(F.complex_shape())
+    rnd = lambda: (rng.random(shape) + 1j * rng.random(shape)).astype(cdtype(prec))
+    Nh, U, U0, U1 = rnd(), rnd(), rnd(), rnd()
+    nu, a_dt, b_dt = 0.01, 0.02, 0.005
+    K2 = np.sum(K * K, 0)
+    P_hat = np.sum(Nh * K / np.where(K2 == 0, 1, K2), 0)
+    dU = Nh - P_hat * K - nu * K2 * U
+    U1n = U1 + a_dt * dU
+    Un = U1n if last else U0 + b_dt * dU
+    U0n = U1n if last else U0
+    curl = 1j * np.cross(K, Un, axis=0)
+    d = [DeviceArray.from_numpy(x) for x in (Nh, U, U0, U1)]
+    spectral.ns_rk_stage(F, Kd, d[0], d[1], d[2], d[3], nu, a_dt, b_dt, last)
+    F.sync()
+    tol = 1e-13 if prec == "double" else 2e-5
+    for got, want in zip(d, (curl, Un, U0n, U1n)):
+        assert np.allclose(got.get(), want, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dealias", ["3/2-rule", "2/3-rule", None])
+def test_taylor_green_fused_equals_composed(dealias, golden_dir):
+    """The fused time loop and the nine-transform composition of rounds 3 - 5 agree to rounding, and both give the
+    reference's known answer (tests/golden/taylor_green.json, written from the reference's own run)."""
+    import spectral_dns_device as demo
+    from mpifft4py_amd import SelfComm
+    gold = json.load(open(os.path.join(golden_dir, "taylor_green.json")))
+    rep = {}
+    kf = demo.solve(SelfComm(0), dealias=dealias, fused=True, report=rep)
+    kc = demo.solve(SelfComm(0), dealias=dealias, fused=False)
+    assert rep["fused_nonlinear"] == 1
+    assert round(kf - gold["k_expected_demo"], 7) == 0
+    assert abs(kf - gold["k_P1_%s" % dealias]) < 1e-11
+    assert abs(kf - kc) < 1e-13
+
+
+def test_nonlinear_cross_512_padded_against_composition():
+    """512^3 with the 3/2-rule (the mesh the solver's bench line runs): the fused operation against six ifftn + cross +
+    three fftn of the same plan (each parity-tested against the oracle at the sizes it finishes), and the work-buffer
+    bill: the composition holds 9 x 768^3 x 8 B = 32.6 GB of real arrays, the fused route under a third of it."""
+    from mpifft4py_amd import DeviceArray, SelfComm, Slab_R2C, spectral
+    N = np.array([512, 512, 512])
+    F = Slab_R2C(N, L, SelfComm(0), "double")
+    cs, ws = tuple(F.complex_shape()), tuple(F.work_shape("3/2-rule"))
+    a = DeviceArray.empty((3,) + cs, F.complex)
+    b = DeviceArray.empty((3,) + cs, F.complex)
+    for s, x in enumerate((a, b)):
+        for i in range(3):
+            F.fftn(DeviceArray.random(F.real_shape(), F.float, seed=100 + 3 * s + i), x.component(i))
+    got = DeviceArray.empty((3,) + cs, F.complex)
+    spectral.cross_transform(F, a, b, got, "3/2-rule")
+    F.sync()
+    assert F.plan_info("nonlinear_fused_3_2") == 1
+    assert F.plan_info("nonlinear_bytes") < 14e9
+    ua, ub, r = (DeviceArray.empty((3,) + ws, F.float) for _ in range(3))
+    for i in range(3):
+        F.ifftn(a.component(i), ua.component(i), "3/2-rule")
+        F.ifftn(b.component(i), ub.component(i), "3/2-rule")
+    spectral.cross(F, ua, ub, r)
+    want = DeviceArray.empty((3,) + cs, F.complex)
+    for i in range(3):
+        F.fftn(r.component(i), want.component(i), "3/2-rule")
+    F.sync()
+    g, w = got.get(), want.get()
+    assert orc.rel_l2(g, w) < 1e-12
