@@ -9,6 +9,7 @@ inputs and outputs resident in HBM.  N ranks share ONE cube (strong scaling,
 slab decomposition, RCCL all-to-all over xGMI).  Rank 0 prints one JSON line.
 """
 import argparse
+import ctypes
 import json
 import os
 import subprocess
@@ -529,10 +530,34 @@ def main():
         b0 = u2.leading(0, k).get()
         rt_err = float(np.linalg.norm((a0 - b0).ravel()) / np.linalg.norm(a0.ravel()))
         return {"dt": dt, "stages": stages, "rt_err": rt_err, "pipeline": pipeline, "comm_cus": comm_cus,
-                "transport": cand_name(comm, pull)}
+                "transport": cand_name(comm, pull), "ranks": ranks_report(comm)}
 
     def comm_name(c):
         return getattr(c, "transport_name", "rccl" if world > 1 else "none")
+
+    def ranks_report(c):
+        """Who ran: the physical GPU behind every rank (PCI bus id) and, when the communicator is RCCL's, what the library
+        ITSELF reports for it (csrc/comm.hip RcclComm::get_option: ncclCommCount / ncclGetVersion / ncclCommUserRank /
+        ncclCommCuDevice) -- so that a multi-GPU line proves which library built a communicator over how many ranks
+        (the reference asks MPI: slab.py:77-81).  Collective."""
+        buf = ctypes.create_string_buffer(64)
+        _lib.call("mfft_device_pci_bus_id", int(c.device), buf, 64)
+        dom, bus, devfn = buf.value.decode().split(":")
+        dev_, fn_ = devfn.split(".")
+        code = (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev_, 16) << 3) | int(fn_, 16)
+        v = np.zeros(3 * world)
+        v[3 * rank] = code
+        if comm_name(c) == "rccl":
+            v[3 * rank + 1] = c.get_option("rccl_rank") + 1          # 0 = the library has no such entry point
+            v[3 * rank + 2] = c.get_option("rccl_device") + 1
+        v = c.allreduce(v) if world > 1 else v
+        rep = {"devices": ["%04x:%02x:%02x.%x" % (int(x) >> 16, (int(x) >> 8) & 255, (int(x) >> 3) & 31, int(x) & 7) for x in v[0::3]]}
+        if comm_name(c) == "rccl":
+            ver = c.get_option("rccl_version")
+            rep.update(rccl_nranks=c.get_option("rccl_nranks"),
+                       rccl_version=("%d.%d.%d" % (ver // 10000, ver // 100 % 100, ver % 100)) if ver > 0 else None,
+                       rccl_user_ranks=[int(x) - 1 for x in v[1::3]], rccl_devices=[int(x) - 1 for x in v[2::3]])
+        return rep
 
     def cand_name(c, pull):
         return comm_name(c) + (PULL_NAMES.get(pull, "") if pull is not None else "")
@@ -595,6 +620,8 @@ def main():
                        "exchange_pipeline_depth": mres["pipeline"] if world > 1 else None,
                        "exchange_comm_cus": mres.get("comm_cus") if world > 1 else None,
                        "exchange_transport": mres["transport"] if world > 1 else None,
+                       # the GPUs behind the ranks and, over RCCL, what the library itself says about the communicator
+                       **mres["ranks"],
                        "exchange_pipeline_tuning_ms_per_pair": tuning,
                        "alg_bytes_per_pair": alg_pair,
                        "whole_path_hbm_GBs_per_gpu": alg_pair / world / (ms * 1e-3) / 1e9,

@@ -21,6 +21,12 @@ from mpifft4py_amd.pencil import R2C as Pencil_R2C  # noqa: E402
 from mpifft4py_amd.slab import R2C as Slab_R2C  # noqa: E402
 
 
+def _zero(a):
+    from mpifft4py_amd import _lib
+    _lib.call("mfft_memset", a.ptr, 0, a.nbytes)
+    return a
+
+
 def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double", nu=0.000625, dt=0.01, steps=10,
           report=None, fused=True, timing=False):
     """fused=True (round 6): the nonlinear term is ONE plan operation (spectral.cross_transform: no real-space work
@@ -37,13 +43,19 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
     fl, cx = FFT.float, FFT.complex
     K = spectral.Wavenumbers(FFT)
 
-    # initial condition on the host (once), everything else on the device
-    X = FFT.get_local_mesh()
-    U0 = np.empty((3,) + rs, dtype=fl)
-    U0[0] = np.sin(X[0]) * np.cos(X[1]) * np.cos(X[2])
-    U0[1] = -np.cos(X[0]) * np.sin(X[1]) * np.cos(X[2])
-    U0[2] = 0
-    U = DeviceArray.from_numpy(U0)
+    # Taylor-Green initial condition (demo:81-84), built on the host in chunks of x planes (a 1024^3 field is 26 GB: the
+    # chunks keep the host side at a few hundred MB) from the 1-D coordinates of this rank's block; everything else on the device
+    sl = FFT.real_local_slice()
+    x, y, z = (np.arange(s_.start, s_.stop, dtype=float) * (L[i] / N[i]) for i, s_ in enumerate(sl))
+    U = DeviceArray.empty((3,) + rs, fl)
+    cyz = np.cos(y)[:, None] * np.cos(z)[None, :]
+    syz = np.sin(y)[:, None] * np.cos(z)[None, :]
+    step = max(1, (64 << 20) // (8 * rs[1] * rs[2]))
+    for i0 in range(0, rs[0], step):
+        i1 = min(rs[0], i0 + step)
+        U.component(0).leading(i0, i1).set((np.sin(x[i0:i1])[:, None, None] * cyz[None]).astype(fl))
+        U.component(1).leading(i0, i1).set((-np.cos(x[i0:i1])[:, None, None] * syz[None]).astype(fl))
+    _zero(U.component(2))
     U_hat = DeviceArray.empty((3,) + cs, cx)
     U_hat0 = DeviceArray.empty((3,) + cs, cx)
     U_hat1 = DeviceArray.empty((3,) + cs, cx)

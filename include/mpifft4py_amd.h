@@ -55,6 +55,7 @@ MFFT_API int mfft_set_device(int device);
 MFFT_API int mfft_get_device(int* device);
 MFFT_API int mfft_device_name(char* buf, size_t buflen);
 MFFT_API int mfft_device_sync(void);
+MFFT_API int mfft_device_pci_bus_id(int device, char* buf, size_t buflen);   /* "0000:05:00.0": which physical GPU a rank ran on */
 
 /* ---- device memory (replaces mpibase.py:38-51 empty/zeros and the
  *      work_arrays cache, mpibase.py:53-131, for device-resident buffers) ---

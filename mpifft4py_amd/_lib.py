@@ -37,6 +37,7 @@ _SIGNATURES = {
     "mfft_get_device": ([POINTER(c_int)], c_int),
     "mfft_device_name": ([c_char_p, c_size_t], c_int),
     "mfft_device_sync": ([], c_int),
+    "mfft_device_pci_bus_id": ([c_int, c_char_p, c_size_t], c_int),
     "mfft_malloc": ([POINTER(c_void_p), c_size_t], c_int),
     "mfft_free": ([c_void_p], c_int),
     "mfft_memset": ([c_void_p, c_int, c_size_t], c_int),

@@ -122,6 +122,13 @@ int mfft_comm_set_option(mfft_comm_t c, const char* key, int64_t value) {
   if (!c || !key) return set_error(MFFT_ERR_INVALID, "null argument");
   return c->set_option(key, (long long)value);
 }
+// PCI bus id of a device ("0000:05:00.0"): names the physical GPU behind a rank in a bench line
+int mfft_device_pci_bus_id(int device, char* buf, size_t buflen) {
+  if (!buf || buflen < 16) return set_error(MFFT_ERR_INVALID, "buffer of at least 16 bytes needed");
+  MFFT_HIP(hipDeviceGetPCIBusId(buf, (int)buflen, device));
+  return 0;
+}
+
 int mfft_comm_get_option(mfft_comm_t c, const char* key, int64_t* value) {
   if (!c || !key || !value) return set_error(MFFT_ERR_INVALID, "null argument");
   *value = (int64_t)c->get_option(key);

@@ -109,6 +109,11 @@ struct RcclApi {
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  // what the library itself says about a communicator (optional: a library without them answers -1)
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
+  decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 
 static RcclApi* rccl_api() {
@@ -136,6 +141,10 @@ static RcclApi* rccl_api() {
     MFFT_SYM(Broadcast);
     MFFT_SYM(AllReduce);
     MFFT_SYM(GetErrorString);
+    MFFT_SYM(CommCount);
+    MFFT_SYM(CommUserRank);
+    MFFT_SYM(CommCuDevice);
+    MFFT_SYM(GetVersion);
 #undef MFFT_SYM
     ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.Send && api.Recv && api.GroupStart &&
          api.GroupEnd && api.Broadcast && api.AllReduce && api.GetErrorString;
@@ -181,7 +190,19 @@ struct RcclComm : mfft_comm_s {
     }
     return 0;
   }
-  long long get_option(const char* key) override { return key && !strcmp(key, "host_collectives") ? 0 : mfft_comm_s::get_option(key); }
+  // "rccl_nranks" / "rccl_rank" / "rccl_device" / "rccl_version": what RCCL ITSELF reports for this communicator
+  // (ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion) -- so that a bench line can prove which library
+  // built a communicator over how many ranks (slab.py:77-81 asks MPI the same: comm.Get_size(), comm.Get_rank())
+  long long get_option(const char* key) override {
+    if (!key) return -1;
+    if (!strcmp(key, "host_collectives")) return 0;
+    int v = -1;
+    if (!strcmp(key, "rccl_nranks")) return (api->CommCount && api->CommCount(comm, &v) == ncclSuccess) ? v : -1;
+    if (!strcmp(key, "rccl_rank")) return (api->CommUserRank && api->CommUserRank(comm, &v) == ncclSuccess) ? v : -1;
+    if (!strcmp(key, "rccl_device")) return (api->CommCuDevice && api->CommCuDevice(comm, &v) == ncclSuccess) ? v : -1;
+    if (!strcmp(key, "rccl_version")) return (api->GetVersion && api->GetVersion(&v) == ncclSuccess) ? v : -1;
+    return mfft_comm_s::get_option(key);
+  }
   int barrier() override {
     double v = 0;
     return allreduce_host(&v, 1, 0);

@@ -111,6 +111,27 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
   return ncclSuccess;
 }
 
+// what a communicator says about itself (csrc/comm.hip RcclComm::get_option "rccl_*"); version 9.99.0 marks the stand-in
+ncclResult_t ncclCommCount(const ncclComm_t c, int* count) {
+  if (!c || !count) return ncclInvalidArgument;
+  *count = c->nranks;
+  return ncclSuccess;
+}
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int* rank) {
+  if (!c || !rank) return ncclInvalidArgument;
+  *rank = c->rank;
+  return ncclSuccess;
+}
+ncclResult_t ncclCommCuDevice(const ncclComm_t c, int* device) {
+  if (!c || !device) return ncclInvalidArgument;
+  return hipGetDevice(device) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+}
+ncclResult_t ncclGetVersion(int* version) {
+  if (!version) return ncclInvalidArgument;
+  *version = 99900;
+  return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
   if (c) {
     munmap(c->base, c->total);

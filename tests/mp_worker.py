@@ -39,6 +39,17 @@ def main():
     assert comm.allreduce(float(rank)) == sum(range(P))
     assert comm.bcast({"hello": P} if rank == 0 else None)["hello"] == P
     comm.selftest(1 << 18, 30000)           # verified all-to-all of a byte pattern through the transport under test
+    if comm.get_option("ipc_pull") < 0:
+        # RCCL's entry points: what the LIBRARY says about the communicator (ncclCommCount / ncclCommUserRank / ncclGetVersion
+        # behind get_option "rccl_*"; bench.py prints them) must be what the launcher asked for; 9.99.0 is the stand-in
+        assert comm.get_option("rccl_nranks") == P and comm.get_option("rccl_rank") == rank, \
+            (comm.get_option("rccl_nranks"), comm.get_option("rccl_rank"))
+        assert comm.get_option("rccl_version") > 0 and comm.get_option("rccl_device") >= 0
+        if os.environ.get("MFFT_RCCL_LIB", "").endswith("libmockrccl.so"):
+            assert comm.get_option("rccl_version") == 99900
+        buf = __import__("ctypes").create_string_buffer(64)
+        _lib.call("mfft_device_pci_bus_id", comm.device, buf, 64)
+        assert buf.value.count(b":") == 2, buf.value
 
     # IPC transport: every way of pulling the chunks (one kernel over all peers, per-peer copy streams, copies one after the
     # other) x CU-masked streams or not must give the SAME bits; the other transports have one mode
