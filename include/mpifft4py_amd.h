@@ -67,6 +67,10 @@ MFFT_API int mfft_memset(void* dptr, int value, size_t bytes);
 MFFT_API int mfft_memcpy_h2d(void* dst, const void* src_host, size_t bytes);
 MFFT_API int mfft_memcpy_d2h(void* dst_host, const void* src, size_t bytes);
 MFFT_API int mfft_memcpy_d2d(void* dst, const void* src, size_t bytes);
+/* rows of width_bytes, device rows dev_pitch_bytes apart <-> packed host rows: how numpy arrays of the reference's shapes
+ * (slab.py:102-104) go into / come out of a pitched spectrum (mfft_plan_desc::complex_pitch) */
+MFFT_API int mfft_memcpy_rows_h2d(void* dst, size_t dev_pitch_bytes, const void* src_host, size_t width_bytes, size_t rows);
+MFFT_API int mfft_memcpy_rows_d2h(void* dst_host, const void* src, size_t dev_pitch_bytes, size_t width_bytes, size_t rows);
 MFFT_API int mfft_fill_uniform(void* dptr, size_t count, int precision, uint64_t seed); /* U[0,1) synthetic input */
 
 /* ---- communicators (replace the mpi4py Comm injected at slab.py:77-81,
@@ -128,7 +132,13 @@ typedef struct {
                          CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags): work
                          on the legacy null stream of the device then orders against the plan's streams, which the
                          plain (non-blocking) plan streams do not.  The library itself never relies on either. */
-  int reserved[4];
+  int complex_pitch;  /* PITCHED SPECTRUM (round 6; SURVEY 7 "padded device pitch internally, exact Nf at the API boundary"): 0 =
+                         the caller's complex array is compact, rows of the local z extent (Nf = N2/2 + 1 bins: 8208 bytes
+                         at 1024^3, never a whole cache line); -1 = rows a whole number of 128-byte lines apart (513 -> 520
+                         bins); n > 0 = rows n elements apart.  The logical shape stays the reference's (slab.py:102-104);
+                         mfft_layout_complex_pitch says what to allocate.  One-rank slab R2C plans run every pass on the
+                         pitched rows; all other plans convert at the boundary (one more pass, same results). */
+  int reserved[3];
 } mfft_plan_desc;
 
 MFFT_API int mfft_plan_create(mfft_comm_t comm, const mfft_plan_desc* desc, mfft_plan_t* plan);
@@ -144,6 +154,7 @@ MFFT_API int mfft_plan_layout(mfft_plan_t plan, int64_t real_shape[3], int64_t c
 MFFT_API int mfft_layout_query(const mfft_plan_desc* desc, int nranks, int rank, int64_t real_shape[3],
                                int64_t complex_shape[3], int64_t real_start[3], int64_t complex_start[3],
                                int64_t real_shape_padded[3], int64_t grid[2], int64_t subranks[2]);
+MFFT_API int mfft_layout_complex_pitch(const mfft_plan_desc* desc, int nranks, int rank, int64_t* pitch_elems, int64_t* alloc_elems);
 MFFT_API int mfft_plan_workspace_bytes(mfft_plan_t plan, size_t* bytes);
 /* The all-to-all-v a rank performs, computed on the host WITHOUT a device: the peer
  * list (world ranks, in group order) and byte counts / displacements of every chunk.

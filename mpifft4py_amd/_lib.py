@@ -22,7 +22,7 @@ UNIQUE_ID_BYTES = 128
 class PlanDesc(ctypes.Structure):
     _fields_ = [("n", c_int64 * 3), ("precision", c_int), ("kind", c_int), ("decomp", c_int),
                 ("p1", c_int), ("padsize", c_double), ("pipeline", c_int), ("drop_nyquist", c_int),
-                ("line2d", c_int), ("comm_cus", c_int), ("reserved", c_int * 4)]
+                ("line2d", c_int), ("comm_cus", c_int), ("complex_pitch", c_int), ("reserved", c_int * 3)]
 
 
 class MfftError(RuntimeError):
@@ -43,6 +43,8 @@ _SIGNATURES = {
     "mfft_memset": ([c_void_p, c_int, c_size_t], c_int),
     "mfft_memcpy_h2d": ([c_void_p, c_void_p, c_size_t], c_int),
     "mfft_memcpy_d2h": ([c_void_p, c_void_p, c_size_t], c_int),
+    "mfft_memcpy_rows_h2d": ([c_void_p, c_size_t, c_void_p, c_size_t, c_size_t], c_int),
+    "mfft_memcpy_rows_d2h": ([c_void_p, c_void_p, c_size_t, c_size_t, c_size_t], c_int),
     "mfft_memcpy_d2d": ([c_void_p, c_void_p, c_size_t], c_int),
     "mfft_fill_uniform": ([c_void_p, c_size_t, c_int, c_uint64], c_int),
     "mfft_comm_create_self": ([POINTER(c_void_p)], c_int),
@@ -64,6 +66,7 @@ _SIGNATURES = {
     "mfft_plan_destroy": ([c_void_p], c_int),
     "mfft_plan_layout": ([c_void_p] + [POINTER(c_int64)] * 7, c_int),
     "mfft_layout_query": ([POINTER(PlanDesc), c_int, c_int] + [POINTER(c_int64)] * 7, c_int),
+    "mfft_layout_complex_pitch": ([POINTER(PlanDesc), c_int, c_int, POINTER(c_int64), POINTER(c_int64)], c_int),
     "mfft_plan_workspace_bytes": ([c_void_p, POINTER(c_size_t)], c_int),
     "mfft_plan_exchange_schedule": ([POINTER(PlanDesc), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),
                                      POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t),

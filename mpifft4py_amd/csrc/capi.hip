@@ -68,6 +68,19 @@ int mfft_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   MFFT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return 0;
 }
+// rows of `width_bytes` bytes, `rows` of them: device rows dev_pitch_bytes apart <-> packed host rows (pitched spectra)
+int mfft_memcpy_rows_h2d(void* dst, size_t dev_pitch_bytes, const void* src_host, size_t width_bytes, size_t rows) {
+  if (width_bytes > dev_pitch_bytes) return set_error(MFFT_ERR_INVALID, "row wider than its pitch");
+  MFFT_HIP(hipDeviceSynchronize());
+  MFFT_HIP(hipMemcpy2D(dst, dev_pitch_bytes, src_host, width_bytes, width_bytes, rows, hipMemcpyHostToDevice));
+  return 0;
+}
+int mfft_memcpy_rows_d2h(void* dst_host, const void* src, size_t dev_pitch_bytes, size_t width_bytes, size_t rows) {
+  if (width_bytes > dev_pitch_bytes) return set_error(MFFT_ERR_INVALID, "row wider than its pitch");
+  MFFT_HIP(hipDeviceSynchronize());
+  MFFT_HIP(hipMemcpy2D(dst_host, width_bytes, src, dev_pitch_bytes, width_bytes, rows, hipMemcpyDeviceToHost));
+  return 0;
+}
 int mfft_memcpy_d2d(void* dst, const void* src, size_t bytes) {
   MFFT_HIP(hipDeviceSynchronize());
   MFFT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));

@@ -124,7 +124,7 @@ struct mfft_plan_s {
     if (mask) (void)hipFree(mask);
     if (band_tiles) (void)hipFree(band_tiles);
     if (work3) (void)wfree(work3);
-    for (void* b : {nlx, nly, nlr})
+    for (void* b : {nlx, nly, nlr, pcomp})
       if (b) (void)dev_free(b);
     for (auto& t : timers) {
       for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -317,7 +317,7 @@ struct mfft_plan_s {
     a.in_outer = in_outer; a.out_outer = out_outer; a.in_rows = in_rows; a.out_rows = out_rows;
     a.scale = scale != 0.0 ? scale : (inv ? 1.0 / (double)n : 1.0);
     // 2/3-rule (fuse_mask below): a pass that reads the caller's spectrum applies the dealias mask while it loads
-    if (mask_src && in >= mask_src && static_cast<const char*>(in) < static_cast<const char*>(mask_src) + mask_count * es) {
+    if (mask_src && in >= mask_src && static_cast<const char*>(in) < static_cast<const char*>(mask_src) + (size_t)local_complex_alloc_native() * es) {
       const int64_t off = (static_cast<const char*>(in) - static_cast<const char*>(mask_src)) / (int64_t)es;
       if (lband_use) {           // pencils, the reference's own filter: its three 1-D conditions instead of the bytes
         a.band = local_band(d.decomp == MFFT_PENCIL_Y ? off / (N1 * q) : 0);
@@ -557,6 +557,7 @@ struct mfft_plan_s {
   // gives back what the x pass wins.  MFFT_P1_XPAD = lines switches it on (read when a plan is created).
   int p1_xpad_lines = MFFT_P1_XPAD_DEFAULT;     // read when the plan is created
   int64_t p1_plane_pad() const {
+    if (nat_pitch()) return slow_pitch_pad(N1 * Zp);      // pitched rows: 1024 x 520 x 16 B is a multiple of 64 KiB
     if (const int64_t c = r2c ? 0 : plane_pad(N1 * Nf)) return c;
     if (p1_xpad_lines <= 0 || d.line2d) return 0;
     return slow_pitch_pad(N1 * Nf) ? (int64_t)p1_xpad_lines * (int64_t)(128 / es) : 0;
@@ -714,6 +715,33 @@ struct mfft_plan_s {
   int pencil_forward_padded(const void* u, void* fu);
   int pencil_backward_padded(const void* fu, void* u);
   int apply_mask_copy(const void* fu, void** masked_out);
+  // ---- round 6: pitched spectrum (mfft_plan_desc::complex_pitch) ----
+  // The caller's complex array keeps its logical shape but its z rows lie Zp >= Nf elements apart (whole cache lines:
+  // 513 -> 520 bins in double precision), so that every strided pass and both real transforms meet line-aligned rows.
+  // One-rank slab R2C plans run on such arrays natively (nat_pitch); every other plan converts at the boundary through a
+  // compact copy of its own (correct everywhere, fast where it was asked for).
+  int64_t Zp = 0;               // row pitch of the caller's spectrum in complex elements; 0: compact rows of Nf
+  void* pcomp = nullptr;        // compact copy for the plans that do not run on pitched rows natively
+  size_t pcomp_bytes = 0;
+  bool pitched() const { return Zp > 0; }
+  bool nat_pitch() const { return Zp > 0 && d.decomp == MFFT_SLAB && P == 1 && r2c && !d.line2d && !d.drop_nyquist; }
+  int64_t Zc() const { return nat_pitch() ? Zp : Nf; }          // row pitch the one-rank slab routes run with
+  void cdims(int64_t* d0, int64_t* d1, int64_t* d2) const {     // local complex extents
+    if (d.decomp == MFFT_SLAB) { *d0 = N0; *d1 = Np1; *d2 = Nf; }
+    else if (d.decomp == MFFT_PENCIL_X) { *d0 = N0; *d1 = N1_1; *d2 = q; }
+    else { *d0 = N2_0; *d1 = N1; *d2 = q; }
+  }
+  int64_t local_complex_alloc_native() const { return nat_pitch() ? N0 * Np1 * Zp : local_complex_count(); }   // what the routes see
+  int64_t local_complex_alloc() const {                          // elements of the caller's (possibly pitched) spectrum
+    int64_t a, b, c;
+    cdims(&a, &b, &c);
+    return a * b * (pitched() ? Zp : c);
+  }
+  int repitch(const void* src, void* dst, bool to_pitched) {     // compact <-> pitched copy of one local spectrum
+    int64_t a, b, c;
+    cdims(&a, &b, &c);
+    return to_pitched ? box(src, dst, a, b, c, b * c, c, b * Zp, Zp) : box(src, dst, a, b, c, b * Zp, Zp, b * c, c);
+  }
   // ---- round 6: the nonlinear term a x b of a pseudo-spectral step as one operation (fft_nlz.h) ----
   void* nlx = nullptr;          // fused route: the six spectra after their inverse x pass, (L0, N1, Za) each
   size_t nlx_bytes = 0;
@@ -734,6 +762,7 @@ struct mfft_plan_s {
   bool nonlinear_fusable(int dealias) const;
   int64_t local_real_count(bool padded) const;
   int nonlinear_cross(const void* a, const void* b, void* out, int dealias);
+  int exec(bool forward, const void* in, void* out, int dealias);       // one transform, pitched callers' arrays converted where needed
   int nonlinear_cross_fused(const void* a, const void* b, void* out, int dealias);
   int nonlinear_cross_composed(const void* a, const void* b, void* out, int dealias);
   int64_t local_complex_count() const {
@@ -837,28 +866,29 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
   const double Cb = (double)(N0 * Np1 * Nf) * es;            // local complex bytes
   const double Rb = (double)(Np0 * N1 * N2) * rs;            // local real-space bytes
   if (P == 1) {
+    const int64_t Z = Zc();          // row pitch of the spectrum and of the intermediates: Nf, or the caller's pitch
     if (const int64_t xpad = p1_plane_pad()) {
-      MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Nf); }));
+      MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Z); }));
       // power-of-two plane stride: the y transform writes planes one cache line apart from that, the x transform reads them
-      const int64_t pl = N1 * Nf + xpad;
+      const int64_t pl = N1 * Z + xpad;
       MFFT_TRY(ensure_work(0, (size_t)(N0 * pl) * es));
       void* A = work[0];
-      MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(fu, A, N1, false, N0, Nf, N1 * Nf, plain(Nf), pl, plain(Nf)); }));
-      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Nf, 0, plain(pl), 0, plain(N1 * Nf)); }));
+      MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(fu, A, N1, false, N0, Nf, N1 * Z, plain(Z), pl, plain(Z)); }));
+      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Z, 0, plain(pl), 0, plain(N1 * Z)); }));
       return 0;
     }
-    MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Nf); }));
+    MFFT_TRY(stage("fwd_z", Rb + Cb, [&] { return z_forward(u, fu, N0 * N1, N2, Z); }));
     if (fwd_out_of_place((size_t)Cb)) {
       // y transform into the work buffer (the one the inverse uses anyway), x transform out of it into the result: both
       // passes out of place (MFFT_FWD_OOP, see fwd_out_of_place)
-      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nf) * es));
+      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Z) * es));
       void* A = work[0];
-      MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(fu, A, N1, false, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
-      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
+      MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(fu, A, N1, false, N0, Nf, N1 * Z, plain(Z), N1 * Z, plain(Z)); }));
+      MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(A, fu, N0, false, 1, N1 * Z, 0, plain(N1 * Z), 0, plain(N1 * Z)); }));
       return 0;
     }
-    MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(fu, fu, N1, false, N0, Nf, N1 * Nf, plain(Nf), N1 * Nf, plain(Nf)); }));
-    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf)); }));
+    MFFT_TRY(stage("fwd_y", 2 * Cb, [&] { return col(fu, fu, N1, false, N0, Nf, N1 * Z, plain(Z), N1 * Z, plain(Z)); }));
+    MFFT_TRY(stage("fwd_x", 2 * Cb, [&] { return col(fu, fu, N0, false, 1, N1 * Z, 0, plain(N1 * Z), 0, plain(N1 * Z)); }));
     return 0;
   }
   if (nbatch > 1) return slab_forward_rows(u, fu);
@@ -889,9 +919,10 @@ int mfft_plan_s::slab_forward(const void* u, void* fu) {
 int mfft_plan_s::apply_mask_copy(const void* fu, void** masked_out) {
   const size_t cnt = (size_t)local_complex_count();
   if (!mask || mask_count != cnt) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask of %zu entries was set", cnt);
-  MFFT_TRY(ensure_work(2, cnt * es));
-  MFFT_HIP(hipMemcpyAsync(work[2], fu, cnt * es, hipMemcpyDeviceToDevice, stream));
-  MFFT_TRY(launch_mask(work[2], mask, cnt, prec, stream));
+  const size_t cna = (size_t)local_complex_alloc_native();      // pitched rows: the device mask has the same pitch
+  MFFT_TRY(ensure_work(2, cna * es));
+  MFFT_HIP(hipMemcpyAsync(work[2], fu, cna * es, hipMemcpyDeviceToDevice, stream));
+  MFFT_TRY(launch_mask(work[2], mask, cna, prec, stream));
   *masked_out = work[2];
   return 0;
 }
@@ -904,7 +935,7 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     mfft_plan_s* p;
     ~MaskScope() { p->mask_src = nullptr; }
   } mask_scope{this};
-  if (masked && P == 1 && band_ok && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
+  if (masked && P == 1 && band_ok && !nat_pitch() && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
     if (!mask || mask_count != (size_t)local_complex_count()) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask was set");
     MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nf) * es));
     void* Aw = work[0];
@@ -961,11 +992,12 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
       src = m;
     }
   }
-  const size_t cb = (size_t)(Np0 * N1 * Nf) * es;
+  const int64_t Z = P == 1 ? Zc() : Nf;
+  const size_t cb = (size_t)(Np0 * N1 * Z) * es;
   if (const int64_t xpad = P == 1 ? p1_plane_pad() : 0) {
     // slow plane stride (p1_plane_pad): y first (into padded planes), x out of them -- complex data: into the result, z in
     // place there; real data: into a second work buffer that c2r reads
-    const int64_t pl = N1 * Nf + xpad;
+    const int64_t pl = N1 * Z + xpad;
     MFFT_TRY(ensure_work(0, (size_t)(N0 * pl) * es));
     void* Ap = work[0];
     void* X = u;
@@ -973,13 +1005,19 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
       MFFT_TRY(ensure_work(1, cb));
       X = work[1];
     }
-    MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(src, Ap, N1, true, N0, Nf, N1 * Nf, plain(Nf), pl, plain(Nf)); }));
-    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(Ap, X, N0, true, 1, N1 * Nf, 0, plain(pl), 0, plain(N1 * Nf)); }));
-    MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(X, u, N0 * N1, N2, Nf); }));
+    MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(src, Ap, N1, true, N0, Nf, N1 * Z, plain(Z), pl, plain(Z)); }));
+    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(Ap, X, N0, true, 1, N1 * Z, 0, plain(pl), 0, plain(N1 * Z)); }));
+    MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(X, u, N0 * N1, N2, Z); }));
     return 0;
   }
   MFFT_TRY(ensure_work(0, cb));
   void* A = work[0];
+  if (P == 1 && Z != Nf) {       // pitched rows everywhere (the caller's array and the intermediate alike)
+    MFFT_TRY(stage("bwd_x", 2 * Cb, [&] { return col(src, A, N0, true, 1, N1 * Z, 0, plain(N1 * Z), 0, plain(N1 * Z)); }));
+    MFFT_TRY(stage("bwd_y", 2 * Cb, [&] { return col(A, A, N1, true, N0, Nf, N1 * Z, plain(Z), N1 * Z, plain(Z)); }));
+    MFFT_TRY(stage("bwd_z", Rb + Cb, [&] { return z_backward(A, u, N0 * N1, N2, Z); }));
+    return 0;
+  }
   if (P == 1) {
     // (Round 4 measured two more one-rank routes and removed them again -- a line-aligned intermediate (rows of N2/2 + 1 bins
     // rounded up to whole cache lines: one per cent at 1024^3 for the inverse, a loss forward and at 512^3) and a forward
@@ -1210,11 +1248,18 @@ bool mfft_plan_s::can_fuse_pad() const {
 int mfft_plan_s::slab_backward_padded_fused(const void* fu, void* u) {
   const double sc3 = padscale();
   const int64_t Mp0 = M0 / P;
-  if (const int64_t Za = pad_pitch(); Za != Nf) {          // one rank, line-aligned z rows in both intermediates
+  if (const int64_t Za = nat_pitch() ? Zp : pad_pitch(); Za != Nf) {          // one rank, line-aligned z rows in both intermediates
     MFFT_TRY(ensure_work(0, (size_t)(M0 * N1 * Za) * es));
     MFFT_TRY(ensure_work(2, (size_t)(M0 * M1 * Za) * es));
     void *W0 = work[0], *W2 = work[2];
-    if (pad_align_inv == 3) {            // the y pass converts: x compact -> compact, y compact -> pitched
+    if (nat_pitch()) {                   // the caller's rows have the pitch already: whole planes of N1 * Za columns
+      MFFT_TRY(stage("bwd_x", 0, [&] {
+        return col_pad(fu, W0, M0, true, 1, false, 1, N1 * Za, 0, plain(N1 * Za), 0, plain(N1 * Za), sc3 / (double)M0);
+      }));
+      MFFT_TRY(stage("bwd_y", 0, [&] {
+        return col_pad(W0, W2, M1, true, 1, false, M0, Nf, N1 * Za, plain(Za), M1 * Za, plain(Za), 1.0 / (double)M1);
+      }));
+    } else if (pad_align_inv == 3) {     // the y pass converts: x compact -> compact, y compact -> pitched
       MFFT_TRY(stage("bwd_x", 0, [&] {
         return col_pad(fu, W0, M0, true, 1, false, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf), sc3 / (double)M0);
       }));
@@ -1258,7 +1303,7 @@ int mfft_plan_s::slab_backward_padded_fused(const void* fu, void* u) {
 int mfft_plan_s::slab_forward_padded_fused(const void* u, void* fu) {
   const double isc3 = 1.0 / padscale();
   const int64_t Mp0 = M0 / P;
-  if (const int64_t Za = pad_pitch(); Za != Nf) {          // one rank, line-aligned z rows in both intermediates
+  if (const int64_t Za = nat_pitch() ? Zp : pad_pitch(); Za != Nf) {          // one rank, line-aligned z rows in both intermediates
     MFFT_TRY(ensure_work(0, (size_t)(M0 * N1 * Za) * es));
     MFFT_TRY(ensure_work(2, (size_t)(M0 * M1 * Za) * es));
     void *W0 = work[0], *W2 = work[2];
@@ -1266,6 +1311,12 @@ int mfft_plan_s::slab_forward_padded_fused(const void* u, void* fu) {
     MFFT_TRY(stage("fwd_y", 0, [&] {
       return col_pad(W2, W0, M1, false, 2, true, M0, Nf, M1 * Za, plain(Za), N1 * Za, plain(Za), 1.0);
     }));
+    if (nat_pitch()) {                   // pitched result: whole planes of N1 * Za columns, no conversion
+      MFFT_TRY(stage("fwd_x", 0, [&] {
+        return col_pad(W0, fu, M0, false, 2, true, 1, N1 * Za, 0, plain(N1 * Za), 0, plain(N1 * Za), isc3);
+      }));
+      return 0;
+    }
     MFFT_TRY(stage("fwd_x", 0, [&] {     // tiles of the compact result; input column c = (y, z) sits at y * Za + z
       return col_pad(W0, fu, M0, false, 2, true, 1, N1 * Nf, 0, plain(N1 * Za), 0, plain(N1 * Nf), isc3, Nf, Za - Nf);
     }));
@@ -1392,18 +1443,12 @@ int64_t mfft_plan_s::local_real_count(bool padded) const {
 // Composed route (every decomposition and length): the transforms the caller would run, on nine work arrays of the plan.
 int mfft_plan_s::nonlinear_cross_composed(const void* a, const void* b, void* out, int dealias) {
   const bool pad = dealias == MFFT_DEALIAS_3_2, masked = dealias == MFFT_DEALIAS_2_3;
-  const int64_t nr = local_real_count(pad), nc = local_complex_count();
+  const int64_t nr = local_real_count(pad), nc = local_complex_alloc();       // (pitched arrays: a component is that much larger)
   if (nr <= 0 || !r2c) return set_error(MFFT_ERR_UNSUPPORTED, "nonlinear_cross needs a 3-D real-to-complex plan");
   MFFT_TRY(ensure_buf(&nlr, &nlr_bytes, (size_t)(9 * nr) * rs));
   char* R = static_cast<char*>(nlr);
-  auto back = [&](const void* in, void* o) {
-    if (d.decomp == MFFT_SLAB) return pad ? slab_backward_padded(in, o) : slab_backward(in, o, masked);
-    return pad ? pencil_backward_padded(in, o) : pencil_backward(in, o, masked);
-  };
-  auto fwd = [&](const void* in, void* o) {
-    if (d.decomp == MFFT_SLAB) return pad ? slab_forward_padded(in, o) : slab_forward(in, o);
-    return pad ? pencil_forward_padded(in, o) : pencil_forward(in, o);
-  };
+  auto back = [&](const void* in, void* o) { return exec(false, in, o, dealias); };
+  auto fwd = [&](const void* in, void* o) { return exec(true, in, o, masked ? (int)MFFT_DEALIAS_NONE : dealias); };
   for (int f = 0; f < 3; ++f) {
     MFFT_TRY(back(static_cast<const char*>(a) + (size_t)(f * nc) * es, R + (size_t)(f * nr) * rs));
     MFFT_TRY(back(static_cast<const char*>(b) + (size_t)(f * nc) * es, R + (size_t)((3 + f) * nr) * rs));
@@ -1441,8 +1486,9 @@ int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, 
   const int64_t line = (int64_t)(128 / es);
   static const int align_mode = getenv("MFFT_NLZ_ALIGN") ? atoi(getenv("MFFT_NLZ_ALIGN")) : -1;      // 0 compact rows, 1 aligned, unset: rows of 2 KiB and more
   const bool aligned = align_mode > 0 || (align_mode < 0 && Nf * (int64_t)es >= 2048);
-  const int64_t Za = aligned ? (Nf + line - 1) / line * line : Nf;
-  const int64_t C = N0 * N1 * Nf;                  // elements of one component of the caller's arrays
+  const int64_t Zi = Zc();                         // row pitch of the caller's arrays
+  const int64_t Za = nat_pitch() ? Zp : aligned ? (Nf + line - 1) / line * line : Nf;
+  const int64_t C = N0 * N1 * Zi;                  // elements of one component of the caller's arrays
   const size_t xelems = (size_t)(L0 * N1 * Za);    // ... of one x-pass buffer
   // Batch of x planes.  Large batches win (512^3 with the 3/2-rule, ms per Runge-Kutta step against the MiB of a batch's six
   // y-pass outputs: 80: 181, 160: 157, 320: 143, 640: 130, 1536: 117, 6000: 111 -- batches that would fit the 256 MB Infinity Cache
@@ -1472,8 +1518,10 @@ int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, 
       void* dst = X + (size_t)f * xelems * es;
       if (masked) {                                // `fu * dealias` (slab.py:237-245) applied while the spectrum is loaded
         mask_src = src;
-        MFFT_TRY(col(src, dst, N0, true, N1, Nf, Nf, plain(N1 * Nf), Za, plain(N1 * Za)));
+        MFFT_TRY(col(src, dst, N0, true, N1, Nf, Zi, plain(N1 * Zi), Za, plain(N1 * Za)));
         mask_src = nullptr;
+      } else if (Zi == Za && Za != Nf) {           // pitched caller rows: whole planes of N1 * Za columns
+        MFFT_TRY(col_pad(src, dst, L0, true, pad ? 1 : 0, false, 1, N1 * Za, 0, plain(N1 * Za), 0, plain(N1 * Za), sc3 / (double)L0));
       } else if (Za != Nf) {                       // one outer batch per y row: compact rows in, pitched rows out
         MFFT_TRY(col_pad(src, dst, L0, true, pad ? 1 : 0, false, N1, Nf, Nf, plain(N1 * Nf), Za, plain(N1 * Za), sc3 / (double)L0,
                          0, 0, 1));
@@ -1514,7 +1562,9 @@ int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, 
     for (int f = 0; f < 3; ++f) {
       const void* src = X + (size_t)f * xelems * es;
       void* dst = static_cast<char*>(out) + (size_t)(f * C) * es;
-      if (Za != Nf)                                // tiles of the compact result; input column (y, z) sits at y * Za + z
+      if (Zi == Za && Za != Nf)                    // pitched result
+        MFFT_TRY(col_pad(src, dst, L0, false, pad ? 2 : 0, pad, 1, N1 * Za, 0, plain(N1 * Za), 0, plain(N1 * Za), 1.0 / sc3));
+      else if (Za != Nf)                           // tiles of the compact result; input column (y, z) sits at y * Za + z
         MFFT_TRY(col_pad(src, dst, L0, false, pad ? 2 : 0, pad, 1, N1 * Nf, 0, plain(N1 * Za), 0, plain(N1 * Nf), 1.0 / sc3, Nf, Za - Nf));
       else
         MFFT_TRY(col_pad(src, dst, L0, false, pad ? 2 : 0, pad, 1, N1 * Nf, 0, plain(N1 * Nf), 0, plain(N1 * Nf), 1.0 / sc3));
@@ -2277,6 +2327,7 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
   if (getenv("MFFT_PAD_ALIGN_INV")) p->pad_align_inv = atoi(getenv("MFFT_PAD_ALIGN_INV"));
   const int P = p->P;
   if (p->r2c && p->N2 % 2) return set_error(MFFT_ERR_UNSUPPORTED, "odd N[2]=%lld is not supported for R2C", (long long)p->N2);
+  p->Zp = 0;                     // complex_pitch: resolved below, once the local z extent is known
   if (desc->decomp == MFFT_SLAB) {
     if (p->N0 % P || p->N1 % P) return set_error(MFFT_ERR_INVALID, "N[0]=%lld and N[1]=%lld must be divisible by the number of ranks %d", (long long)p->N0, (long long)p->N1, P);
     p->Np0 = p->N0 / P;
@@ -2344,6 +2395,15 @@ static int decomp_init(mfft_plan_s* p, const mfft_plan_desc* desc, int nranks, i
       p->nbatch = (int)std::min<int64_t>(want, std::min(p->N1_0, p->N2_0));
   } else {
     return set_error(MFFT_ERR_INVALID, "bad decomposition %d", desc->decomp);
+  }
+  // pitched spectrum (complex_pitch): -1 = whole cache lines, > 0 = that many elements (at least the local z extent)
+  if (desc->complex_pitch != 0) {
+    int64_t a_, b_, zloc = 0;
+    p->cdims(&a_, &b_, &zloc);
+    const int64_t line = (int64_t)(128 / p->es);
+    const int64_t want = desc->complex_pitch < 0 ? (zloc + line - 1) / line * line : (int64_t)desc->complex_pitch;
+    if (want < zloc) return set_error(MFFT_ERR_INVALID, "complex_pitch %lld is shorter than the local z extent %lld", (long long)want, (long long)zloc);
+    p->Zp = want;
   }
   // every transform length must have a kernel
   auto need = [&](int64_t n, bool real) -> int {
@@ -2575,9 +2635,22 @@ int mfft_layout_query(const mfft_plan_desc* desc, int nranks, int rank, int64_t 
   return layout_of(&p, rshape, cshape, rstart, cstart, rshape_pad, grid, sub);
 }
 
+// Row pitch (complex elements) and allocation size (elements) of this rank's spectrum under desc->complex_pitch: what a
+// caller must allocate -- shape (d0, d1, pitch) physically, (d0, d1, d2) logically.  Device-free.
+int mfft_layout_complex_pitch(const mfft_plan_desc* desc, int nranks, int rank, int64_t* pitch, int64_t* alloc_elems) {
+  if (!desc || !pitch || !alloc_elems) return set_error(MFFT_ERR_INVALID, "null argument");
+  mfft_plan_s p;
+  MFFT_TRY(decomp_init(&p, desc, nranks, rank));
+  int64_t a, b, c;
+  p.cdims(&a, &b, &c);
+  *pitch = p.pitched() ? p.Zp : c;
+  *alloc_elems = p.local_complex_alloc();
+  return 0;
+}
+
 int mfft_plan_workspace_bytes(mfft_plan_t p, size_t* bytes) {
   if (!p || !bytes) return set_error(MFFT_ERR_INVALID, "null argument");
-  *bytes = p->work_bytes[0] + p->work_bytes[1] + p->work_bytes[2] + p->work3_bytes;
+  *bytes = p->work_bytes[0] + p->work_bytes[1] + p->work_bytes[2] + p->work3_bytes + p->pcomp_bytes;
   return 0;
 }
 
@@ -2589,7 +2662,7 @@ static int check_ready(mfft_plan_t p, const void* a, const void* b) {
   return 0;
 }
 
-static int run_direct(mfft_plan_t p, bool forward, const void* in, void* out, int dealias) {
+static int run_route(mfft_plan_t p, bool forward, const void* in, void* out, int dealias) {
   const bool pad = dealias == MFFT_DEALIAS_3_2, masked = dealias == MFFT_DEALIAS_2_3;
   if (forward) {
     if (p->d.decomp == MFFT_SLAB) return pad ? p->slab_forward_padded(in, out) : p->slab_forward(in, out);
@@ -2598,6 +2671,21 @@ static int run_direct(mfft_plan_t p, bool forward, const void* in, void* out, in
   if (p->d.decomp == MFFT_SLAB) return pad ? p->slab_backward_padded(in, out) : p->slab_backward(in, out, masked);
   return pad ? p->pencil_backward_padded(in, out) : p->pencil_backward(in, out, masked);
 }
+
+// A pitched spectrum on a plan whose routes want compact rows (several ranks, pencils, complex data): converted at the
+// boundary through the plan's compact copy -- one more pass over the spectrum, every decomposition served.
+int mfft_plan_s::exec(bool forward, const void* in, void* out, int dealias) {
+  if (!pitched() || nat_pitch()) return run_route(this, forward, in, out, dealias);
+  MFFT_TRY(ensure_buf(&pcomp, &pcomp_bytes, (size_t)local_complex_count() * es));
+  if (forward) {
+    MFFT_TRY(run_route(this, true, in, pcomp, dealias));
+    return stage("fwd_pitch", 0, [&] { return repitch(pcomp, out, true); });
+  }
+  MFFT_TRY(stage("bwd_pitch", 0, [&] { return repitch(in, pcomp, false); }));
+  return run_route(this, false, pcomp, out, dealias);
+}
+
+static int run_direct(mfft_plan_t p, bool forward, const void* in, void* out, int dealias) { return p->exec(forward, in, out, dealias); }
 
 // Small single-rank transforms are launch-bound (six ~10 us kernels per pair): the kernel sequence of
 // a (direction, in, out, dealias) combination is captured into a hipGraph the second time it is seen
@@ -2680,8 +2768,15 @@ int mfft_plan_set_dealias_mask(mfft_plan_t p, const uint8_t* mask_host, size_t c
   p->drop_graphs();              // captured sequences hold the old mask pointer
   if (p->mask) MFFT_HIP(hipFree(p->mask));
   p->mask = nullptr;
-  MFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p->mask), count));
-  MFFT_HIP(hipMemcpy(p->mask, mask_host, count, hipMemcpyHostToDevice));
+  if (p->nat_pitch()) {          // the masked-load kernels index the mask like the spectrum: same row pitch, zeros between
+    const size_t rows = (size_t)(p->N0 * p->Np1);
+    MFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p->mask), rows * (size_t)p->Zp));
+    MFFT_HIP(hipMemset(p->mask, 0, rows * (size_t)p->Zp));
+    MFFT_HIP(hipMemcpy2D(p->mask, (size_t)p->Zp, mask_host, (size_t)p->Nf, (size_t)p->Nf, rows, hipMemcpyHostToDevice));
+  } else {
+    MFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p->mask), count));
+    MFFT_HIP(hipMemcpy(p->mask, mask_host, count, hipMemcpyHostToDevice));
+  }
   p->mask_count = count;
   p->detect_band(mask_host);
   p->detect_band_local(mask_host);
@@ -2698,6 +2793,8 @@ int mfft_plan_get_info(mfft_plan_t p, const char* key, int64_t* value) {
   else if (k == "row_batches") *value = p->nbatch;
   else if (k == "zfuse") *value = p->zfuse ? 1 : 0;
   else if (k == "ranks") *value = p->P;
+  else if (k == "complex_pitch") *value = p->pitched() ? p->Zp : 0;        // row pitch of the caller's spectrum (elements), 0 = compact
+  else if (k == "complex_pitch_native") *value = p->nat_pitch() ? 1 : 0;  // 1: the routes run on the pitched rows themselves
   else if (k == "nonlinear_fused_none") *value = p->nonlinear_fusable(MFFT_DEALIAS_NONE) ? 1 : 0;
   else if (k == "nonlinear_fused_2_3") *value = p->nonlinear_fusable(MFFT_DEALIAS_2_3) ? 1 : 0;
   else if (k == "nonlinear_fused_3_2") *value = p->nonlinear_fusable(MFFT_DEALIAS_3_2) ? 1 : 0;
