@@ -827,6 +827,37 @@ def main():
                 del upd, fud2
             extras["dealias"] = d_extra
             del Fd, fud
+            # the same two pairs on a PITCHED device spectrum (complex_pitch="auto": rows of 520 instead of 513 bins at 1024^3
+            # fp64; the logical shapes stay the reference's, slab.py:102-104).  Opt-in: the headline above is the compact layout.
+            Fp = Slab_R2C(N, L, comm, args.precision, complex_pitch="auto")
+            up_ = DeviceArray.random(Fp.real_shape(), Fp.float, seed=6)
+            fup = Fp.empty_complex()
+            up2 = DeviceArray.empty(Fp.real_shape(), Fp.float)
+            Fd = Fp                                   # timed() synchronises through Fd
+
+            def plain_pair():
+                Fp.fftn(up_, fup)
+                Fp.ifftn(fup, up2)
+            timed(plain_pair, 3)
+            Fp.enable_timing(True)
+            Fp.reset_timing()
+            p_extra = {"bins_per_row": Fp.complex_pitch, "pair_ms": timed(plain_pair, 10)}
+            p_extra["stage_ms"] = {a_: round(b_[0] / max(b_[1], 1), 3) for a_, b_ in sorted(Fp.stage_times().items()) if b_[1]}
+            Fp.enable_timing(False)
+            rt = float(np.linalg.norm((up_.leading(0, 1).get() - up2.leading(0, 1).get()).ravel()) / np.linalg.norm(up_.leading(0, 1).get().ravel()))
+            p_extra["roundtrip_rel_l2"] = rt
+            del up2
+            if 3 * n % 2 == 0 and 27 * n ** 3 * (8 if args.precision == "double" else 4) < 0.3 * 288e9 * 8:
+                upd = DeviceArray.empty(Fp.real_shape_padded(), Fp.float)
+                fup2 = Fp.empty_complex()
+
+                def padded_pair_p():
+                    Fp.ifftn(fup, upd, "3/2-rule")
+                    Fp.fftn(upd, fup2, "3/2-rule")
+                p_extra["three_halves_rule_ifftn_fftn_pair_ms"] = timed(padded_pair_p, 3)
+                del upd, fup2
+            extras["pitched_spectrum"] = p_extra
+            del Fp, Fd, up_, fup
         except Exception as e:      # noqa: BLE001  - the headline (slab) line must survive
             extras["dealias"] = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -28,7 +28,7 @@ def _zero(a):
 
 
 def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double", nu=0.000625, dt=0.01, steps=10,
-          report=None, fused=True, timing=False):
+          report=None, fused=True, timing=False, complex_pitch=None):
     """fused=True (round 6): the nonlinear term is ONE plan operation (spectral.cross_transform: no real-space work
     arrays, the z stages one kernel) and a Runge-Kutta stage's projection, viscous term, both updates and the next
     curl are ONE sweep (spectral.ns_rk_stage).  fused=False: the composition of rounds 3 - 5 (nine transforms, cross,
@@ -36,9 +36,9 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
     N = np.array([2 ** M] * 3, dtype=int)
     L = np.array([2 * np.pi] * 3, dtype=float)
     if decomposition == 'slab':
-        FFT = Slab_R2C(N, L, comm, precision)
+        FFT = Slab_R2C(N, L, comm, precision, complex_pitch=complex_pitch)
     else:
-        FFT = Pencil_R2C(N, L, comm, precision, communication="Alltoallw", alignment="X")
+        FFT = Pencil_R2C(N, L, comm, precision, communication="Alltoallw", alignment="X", complex_pitch=complex_pitch)
     rs, cs, ws = FFT.real_shape(), FFT.complex_shape(), FFT.work_shape(dealias)
     fl, cx = FFT.float, FFT.complex
     K = spectral.Wavenumbers(FFT)
@@ -56,10 +56,7 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
         U.component(0).leading(i0, i1).set((np.sin(x[i0:i1])[:, None, None] * cyz[None]).astype(fl))
         U.component(1).leading(i0, i1).set((-np.cos(x[i0:i1])[:, None, None] * syz[None]).astype(fl))
     _zero(U.component(2))
-    U_hat = DeviceArray.empty((3,) + cs, cx)
-    U_hat0 = DeviceArray.empty((3,) + cs, cx)
-    U_hat1 = DeviceArray.empty((3,) + cs, cx)
-    dU = DeviceArray.empty((3,) + cs, cx)
+    U_hat, U_hat0, U_hat1, dU = (FFT.empty_complex(3) for _ in range(4))      # (3,) + cs, rows `complex_pitch` apart if asked for
     a = [1. / 6., 1. / 3., 1. / 3., 1. / 6.]
     b = [0.5, 0.5, 1.]
     if timing:
@@ -92,7 +89,7 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
             FFT.ifftn(U_hat.component(i), U.component(i))
         return FFT.comm.reduce(spectral.sumsq(FFT, U) / float(N[0]) / float(N[1]) / float(N[2]) / 2)
 
-    W_hat = DeviceArray.empty((3,) + cs, cx)
+    W_hat = FFT.empty_complex(3)
     Ud = DeviceArray.empty((3,) + ws, fl)
     Cd = DeviceArray.empty((3,) + ws, fl)
     Rd = DeviceArray.empty((3,) + ws, fl)
@@ -146,6 +143,7 @@ def main():
     ap.add_argument("--precision", default="double")
     ap.add_argument("--composed", action="store_true", help="the nine-transform composition of rounds 3 - 5 instead of the fused operations")
     ap.add_argument("--stages", action="store_true", help="print the per-stage HIP-event times")
+    ap.add_argument("--pitched", action="store_true", help="spectra with rows a whole number of cache lines apart (complex_pitch='auto')")
     args = ap.parse_args()
     dealias = None if args.dealias == "None" else args.dealias
     from mpifft4py_amd import LocalGroup, SelfComm
@@ -153,10 +151,10 @@ def main():
     if args.ranks > 1:
         ks = LocalGroup(args.ranks).run(lambda c: solve(c, args.M, dealias, steps=args.steps, precision=args.precision,
                                                         report=rep if c.Get_rank() == 0 else None, fused=not args.composed,
-                                                        timing=args.stages))
+                                                        timing=args.stages, complex_pitch="auto" if args.pitched else None))
     else:
         ks = [solve(SelfComm(), args.M, dealias, steps=args.steps, precision=args.precision, report=rep,
-                    fused=not args.composed, timing=args.stages)]
+                    fused=not args.composed, timing=args.stages, complex_pitch="auto" if args.pitched else None)]
     print("N = %d^3, %d RK4 steps, %.3f ms per step (%s, device-resident; plan work buffers %.2f GB)"
           % (2 ** args.M, args.steps, rep.get("ms_per_step", float("nan")),
              "composed: 36 transforms + element-wise kernels" if args.composed else

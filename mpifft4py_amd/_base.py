@@ -85,6 +85,7 @@ class DistFFTBase(object):
     #     over RCCL it is a copy + ncclAllReduce + stream synchronisation that ends the host's asynchronous run-ahead --
     #     codes that mind may set `dealias_vote_every = 16`: a change found or made locally then waits for the next vote
     #     (results use the previous filter until then), still without a rank uploading by itself.
+    default_complex_pitch = None          # what `complex_pitch=None` means (tests set "auto" here to run whole suites pitched)
     dealias_check = True
     dealias_full_every = 64
     dealias_vote_every = None             # None / 1: every '2/3-rule' call; n: every n-th call (opt-in)
@@ -171,6 +172,8 @@ class DistFFTBase(object):
         d.drop_nyquist = 1 if drop_nyquist else 0
         d.line2d = 1 if line2d else 0
         d.comm_cus = int(getattr(self, "_comm_cus", 0) or 0)
+        req = getattr(self, "_complex_pitch_req", None) or self.default_complex_pitch
+        d.complex_pitch = 0 if not req else (-1 if req in ("auto", "line", True) else int(req))
         self._desc = d
         arrs = [(ctypes.c_int64 * 3)() for _ in range(5)]
         grid = (ctypes.c_int64 * 2)()
@@ -184,6 +187,10 @@ class DistFFTBase(object):
         self._c_real_shape_padded = tuple(arrs[4])
         self._c_grid = tuple(grid)
         self._c_sub = tuple(sub)
+        # pitched spectrum (mfft_plan_desc::complex_pitch): elements between the z rows of this rank's complex array
+        pitch, alloc = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.call("mfft_layout_complex_pitch", ctypes.byref(d), self.num_processes, self.rank, ctypes.byref(pitch), ctypes.byref(alloc))
+        self.complex_pitch = int(pitch.value) if d.complex_pitch else None        # None: compact rows
 
     def _block(self, half_axis=2, drop_axes=0):
         """This rank's block for the mesh helpers (`drop_axes`: leading axes of the plan's mesh the class does not
@@ -206,31 +213,48 @@ class DistFFTBase(object):
         self._plan = h.value
 
     # -- marshalling ----------------------------------------------------------
-    def _staging(self, tag, shape, dtype):
-        key = (tag, tuple(shape), np.dtype(dtype).str)
+    def _staging(self, tag, shape, dtype, pitch=None):
+        key = (tag, tuple(shape), np.dtype(dtype).str, pitch)
         buf = self._stage.get(key)
         if buf is None:
-            buf = DeviceArray(shape, dtype)
+            buf = DeviceArray(shape, dtype, pitch=pitch)
             self._stage[key] = buf
         return buf
 
-    def _dev_in(self, tag, arr, shape, dtype):
+    def _check_pitch(self, arr, pitch):
+        want = None if (pitch is None or pitch == arr.shape[-1]) else pitch
+        if arr.pitch != want:
+            raise ValueError("this object's complex arrays have rows %s elements apart (complex_pitch), the array passed has %s: "
+                             "allocate it with FFT.empty_complex()" % (want or arr.shape[-1], arr.pitch or arr.shape[-1]))
+
+    def _dev_in(self, tag, arr, shape, dtype, pitch=None):
         if is_device_array(arr):
             assert arr.shape == tuple(shape), (arr.shape, tuple(shape))
             assert arr.dtype == np.dtype(dtype), (arr.dtype, dtype)
+            self._check_pitch(arr, pitch)
             return arr
         a = np.asarray(arr)
         assert a.shape == tuple(shape), (a.shape, tuple(shape))
-        return self._staging(tag, shape, dtype).set(a.astype(dtype, copy=False))
+        return self._staging(tag, shape, dtype, pitch).set(a.astype(dtype, copy=False))
 
-    def _dev_out(self, tag, arr, shape, dtype):
+    def _dev_out(self, tag, arr, shape, dtype, pitch=None):
         if is_device_array(arr):
             assert arr.shape == tuple(shape), (arr.shape, tuple(shape))
             assert arr.dtype == np.dtype(dtype), (arr.dtype, dtype)
+            self._check_pitch(arr, pitch)
             return arr, None
         a = arr
         assert a.shape == tuple(shape), (a.shape, tuple(shape))
-        return self._staging(tag, shape, dtype), a
+        return self._staging(tag, shape, dtype, pitch), a
+
+    def empty_complex(self, components=None):
+        """A DeviceArray for this rank's spectrum -- shape complex_shape(), or (components,) + complex_shape() for a vector
+        field -- with the row pitch this object was built with (`complex_pitch`): what fftn writes and ifftn reads.  numpy
+        arrays keep the reference's compact shapes (slab.py:102-104) and are converted on the way in and out."""
+        shape = tuple(int(x) for x in self.complex_shape())
+        if components:
+            shape = (int(components),) + shape
+        return DeviceArray.empty(shape, self.complex, pitch=self.complex_pitch)
 
     def _ensure_mask(self):
         if np.shape(self.dealias) == (0,):
@@ -288,8 +312,9 @@ class DistFFTBase(object):
         self.comm.use_device()
         if code == _lib.DEALIAS_2_3 and not forward:
             self._ensure_mask()
-        d_in = self._dev_in("in%d" % forward, src, src_shape, src_dtype)
-        d_out, host_out = self._dev_out("out%d" % forward, dst, dst_shape, dst_dtype)
+        # the spectrum (output of fftn, input of ifftn) carries the object's row pitch, the other side is compact
+        d_in = self._dev_in("in%d" % forward, src, src_shape, src_dtype, None if forward else self.complex_pitch)
+        d_out, host_out = self._dev_out("out%d" % forward, dst, dst_shape, dst_dtype, self.complex_pitch if forward else None)
         fn = "mfft_forward" if forward else "mfft_backward"
         # forward with the 2/3-rule is the regular transform (slab.py:355-362)
         _lib.call(fn, self._plan, d_in.ptr, d_out.ptr, code if (code != _lib.DEALIAS_2_3 or not forward) else _lib.DEALIAS_NONE)
@@ -301,7 +326,7 @@ class DistFFTBase(object):
 
     def plan_info(self, key):
         """What the plan decided (mfft_plan_get_info): "pruned_route", "comm_cus", "kz_slices", "row_batches", "zfuse",
-        "plane_pad"."""
+        "plane_pad", "complex_pitch", "complex_pitch_native", "nonlinear_fused_3_2" / "_none" / "_2_3", "nonlinear_bytes"."""
         v = ctypes.c_int64(0)
         _lib.call("mfft_plan_get_info", self._plan, key.encode(), ctypes.byref(v))
         return int(v.value)

@@ -723,8 +723,9 @@ struct mfft_plan_s {
   int64_t Zp = 0;               // row pitch of the caller's spectrum in complex elements; 0: compact rows of Nf
   void* pcomp = nullptr;        // compact copy for the plans that do not run on pitched rows natively
   size_t pcomp_bytes = 0;
+  bool conv_now = false;        // exec(): this call runs on the compact copy (a route without a pitched flavour)
   bool pitched() const { return Zp > 0; }
-  bool nat_pitch() const { return Zp > 0 && d.decomp == MFFT_SLAB && P == 1 && r2c && !d.line2d && !d.drop_nyquist; }
+  bool nat_pitch() const { return Zp > 0 && !conv_now && d.decomp == MFFT_SLAB && P == 1 && r2c && !d.line2d && !d.drop_nyquist; }
   int64_t Zc() const { return nat_pitch() ? Zp : Nf; }          // row pitch the one-rank slab routes run with
   void cdims(int64_t* d0, int64_t* d1, int64_t* d2) const {     // local complex extents
     if (d.decomp == MFFT_SLAB) { *d0 = N0; *d1 = Np1; *d2 = Nf; }
@@ -2675,13 +2676,22 @@ static int run_route(mfft_plan_t p, bool forward, const void* in, void* out, int
 // A pitched spectrum on a plan whose routes want compact rows (several ranks, pencils, complex data): converted at the
 // boundary through the plan's compact copy -- one more pass over the spectrum, every decomposition served.
 int mfft_plan_s::exec(bool forward, const void* in, void* out, int dealias) {
-  if (!pitched() || nat_pitch()) return run_route(this, forward, in, out, dealias);
+  // (a one-rank plan whose 3/2-rule route is the copy-based one -- lengths without pad / truncate kernels -- converts too)
+  const bool native = nat_pitch() && (dealias != MFFT_DEALIAS_3_2 || can_fuse_pad());
+  if (!pitched() || native) return run_route(this, forward, in, out, dealias);
   MFFT_TRY(ensure_buf(&pcomp, &pcomp_bytes, (size_t)local_complex_count() * es));
+  struct Scope {
+    mfft_plan_s* p;
+    ~Scope() { p->conv_now = false; }
+  } scope{this};
   if (forward) {
+    conv_now = true;
     MFFT_TRY(run_route(this, true, in, pcomp, dealias));
+    conv_now = false;
     return stage("fwd_pitch", 0, [&] { return repitch(pcomp, out, true); });
   }
   MFFT_TRY(stage("bwd_pitch", 0, [&] { return repitch(in, pcomp, false); }));
+  conv_now = true;
   return run_route(this, false, pcomp, out, dealias);
 }
 

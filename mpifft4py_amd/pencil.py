@@ -35,8 +35,9 @@ class R2CY(DistFFTBase):
     _kind = _lib.R2C
 
     def __init__(self, N, L, comm, precision, P1=None, communication='Alltoallw', padsize=1.5, threads=1,
-                 planner_effort=None, allow_single=False, pipeline=0, allow_odd_grid=False, comm_cus=0):
+                 planner_effort=None, allow_single=False, pipeline=0, allow_odd_grid=False, comm_cus=0, complex_pitch=None):
         self._comm_cus = comm_cus
+        self._complex_pitch_req = complex_pitch       # see slab.R2C; pencil plans convert at the boundary
         self._init_common(N, L, comm, precision, communication, padsize, threads,
                           planner_effort if planner_effort is not None else default_planner_effort())
         N = self.N
@@ -198,10 +199,10 @@ class R2CX(R2CY):
     _decomp = _lib.PENCIL_X
 
     def __init__(self, N, L, comm, precision, P1=None, communication='Alltoall', padsize=1.5, threads=1,
-                 planner_effort=None, allow_single=False, pipeline=0, allow_odd_grid=False, comm_cus=0):
+                 planner_effort=None, allow_single=False, pipeline=0, allow_odd_grid=False, comm_cus=0, complex_pitch=None):
         R2CY.__init__(self, N, L, comm, precision, P1=P1, communication=communication, padsize=padsize,
                       threads=threads, planner_effort=planner_effort, allow_single=allow_single,
-                      pipeline=pipeline, allow_odd_grid=allow_odd_grid, comm_cus=comm_cus)
+                      pipeline=pipeline, allow_odd_grid=allow_odd_grid, comm_cus=comm_cus, complex_pitch=complex_pitch)
 
     def complex_shape(self):
         return (int(self.N[0]), int(self.N1[1]), self.N2f)

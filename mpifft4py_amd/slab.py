@@ -27,12 +27,17 @@ class R2C(DistFFTBase):
         0 = default (4 kz slices), 1 = one blocking exchange.
         comm_cus -- pipelined plans: compute units set aside for the communication stream (0 = library default,
         < 0 = none), see include/mpifft4py_amd.h.
+        complex_pitch -- None: the device spectrum is compact, rows of Nf bins (the reference's layout, slab.py:102-104);
+        "auto": its rows lie a whole number of 128-byte cache lines apart (513 -> 520 bins), an integer: that many
+        elements.  complex_shape() stays (N0, N1/P, Nf); allocate with FFT.empty_complex().  On one rank every pass
+        then meets line-aligned rows; on several ranks the plan converts at the boundary.
     """
     _kind = _lib.R2C
 
     def __init__(self, N, L, comm, precision, communication="Alltoallw", padsize=1.5, threads=1,
-                 planner_effort=None, pipeline=0, comm_cus=0):
+                 planner_effort=None, pipeline=0, comm_cus=0, complex_pitch=None):
         self._comm_cus = comm_cus
+        self._complex_pitch_req = complex_pitch
         self._init_common(N, L, comm, precision, communication, padsize, threads,
                           planner_effort if planner_effort is not None else default_planner_effort())
         N = self.N
@@ -167,9 +172,10 @@ class C2C(R2C):
     _kind = _lib.C2C
 
     def __init__(self, N, L, comm, precision, communication="Alltoall", padsize=1.5, threads=1,
-                 planner_effort=None, pipeline=0, comm_cus=0):
+                 planner_effort=None, pipeline=0, comm_cus=0, complex_pitch=None):
         R2C.__init__(self, N, L, comm, precision, communication=communication, padsize=padsize,
-                     threads=threads, planner_effort=planner_effort, pipeline=pipeline, comm_cus=comm_cus)
+                     threads=threads, planner_effort=planner_effort, pipeline=pipeline, comm_cus=comm_cus,
+                     complex_pitch=complex_pitch)
 
     copy_to_padded = staticmethod(_padding.c2c_copy_to_padded)        # slab.py:803-825
     copy_from_padded = staticmethod(_padding.c2c_copy_from_padded)

@@ -19,8 +19,13 @@ class Wavenumbers(object):
         self.shape = tuple(int(s) for s in FFT.complex_shape())
         vecs = [np.ascontiguousarray(np.asarray(K[i], dtype=FFT.float).reshape(-1)) for i in range(3)]
         assert tuple(len(v) for v in vecs) == self.shape
+        # pitched spectra (FFT.complex_pitch): the element-wise kernels sweep the rows as they lie in memory, the elements
+        # between the rows included (wavenumber 0 there; nothing reads what they compute)
+        pitch = getattr(FFT, "complex_pitch", None)
+        if pitch:
+            vecs[2] = np.concatenate([vecs[2], np.zeros(pitch - len(vecs[2]), dtype=vecs[2].dtype)])
         self.dev = [DeviceArray.from_numpy(v) for v in vecs]
-        self.cshape = (ctypes.c_int64 * 3)(*self.shape)
+        self.cshape = (ctypes.c_int64 * 3)(self.shape[0], self.shape[1], len(vecs[2]))
 
 
 def _prec(FFT):
@@ -29,6 +34,7 @@ def _prec(FFT):
 
 def cross(FFT, a, b, out):
     """out = a x b for real vector fields of shape (3,) + real shape."""
+    assert a.pitch is None and b.pitch is None and out.pitch is None
     n = a.size // 3
     _lib.call("mfft_ew_cross", FFT._plan, a.ptr, b.ptr, out.ptr, n, _prec(FFT))
     return out
@@ -59,6 +65,7 @@ def cross_transform(FFT, a_hat, b_hat, out_hat, dealias=None):
     shape = (3,) + tuple(int(s) for s in FFT.complex_shape())
     for x in (a_hat, b_hat, out_hat):
         assert x.shape == shape and x.dtype == np.dtype(FFT.complex), (x.shape, x.dtype, shape)
+        FFT._check_pitch(x, FFT.complex_pitch)
     code = _DEALIAS[dealias]
     FFT.comm.use_device()
     if code == _lib.DEALIAS_2_3:
@@ -77,12 +84,15 @@ def ns_rk_stage(FFT, K, N_hat, U_hat, U_hat0, U_hat1, nu, a_dt, b_dt, last):
 
 def axpbz(FFT, y, x, z, alpha, beta):
     """y = alpha * x + beta * z (element-wise over the raw real storage; aliasing allowed)."""
-    n_real = y.size * (2 if y.dtype.kind == "c" else 1)
+    assert x.nbytes == y.nbytes == z.nbytes and x.pitch == y.pitch == z.pitch
+    n_real = y.nbytes // np.dtype(FFT.float).itemsize          # the rows as they lie in memory (pitched arrays: all of it)
     _lib.call("mfft_ew_axpbz", FFT._plan, y.ptr, x.ptr, z.ptr, float(alpha), float(beta), n_real, _prec(FFT))
     return y
 
 
 def sumsq(FFT, x):
+    if x.pitch is not None:
+        raise ValueError("sumsq of a pitched array would count the elements between its rows")
     n_real = x.size * (2 if x.dtype.kind == "c" else 1)
     r = ctypes.c_double(0.0)
     _lib.call("mfft_ew_sumsq", FFT._plan, x.ptr, n_real, _prec(FFT), ctypes.byref(r))
