@@ -527,15 +527,12 @@ int launch_nlz(const NlzArgs& a, hipStream_t s) {
   const bool rows3 = a.n % 3 == 0 && a.valid == a.n / 3 + 1 && a.n < 65536;
   if ((nlz3_on || !e) && rows3)
     if (const KernelEntry* e3 = find_kernel(FAM_NLZ, a.n, a.prec, 0, 0, 3)) e = e3;
-  static const int variant = getenv("MFFT_NLZ_VARIANT") ? atoi(getenv("MFFT_NLZ_VARIANT")) : 0;      // experiment builds only
-  if (variant > 0 && a.n < 65536 && (variant < 10 || rows3))
-    if (const KernelEntry* ev = find_kernel(FAM_NLZ, a.n, a.prec, 0, 0, variant)) e = ev;
   if (!e) return set_error(MFFT_ERR_UNSUPPORTED, "no fused nonlinear z-stage kernel of length %d", a.n);
   for (int f = 0; f < 3; ++f)
     if (!a.a[f] || !a.b[f] || !a.out[f]) return set_error(MFFT_ERR_INVALID, "null argument");
   void *tw = nullptr, *rt3 = nullptr;
   MFFT_TRY(prepare_kernel(e, &tw));
-  if (e->pad >= 3) MFFT_TRY(nlz3_twiddles(a.n / 3, a.prec, &rt3));
+  if (e->pad == 3) MFFT_TRY(nlz3_twiddles(a.n / 3, a.prec, &rt3));
   return a.prec == MFFT_DOUBLE ? launch_nlz_t<double>(e, a, tw, rt3, s) : launch_nlz_t<float>(e, a, tw, rt3, s);
 }
 

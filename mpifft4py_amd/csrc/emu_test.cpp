@@ -1150,9 +1150,9 @@ static void test_col3() {
 
 // ---------------------------------------------------------------------------
 // fused nonlinear z stage (fft_nlz.h): out_f = rfft((irfft(a) x irfft(b))_f), rows of `valid` bins, against long-double DFTs
-template <class S, typename T, int ROWS, bool TWLDS, bool SPLIT>
+template <class S, typename T, int ROWS, bool TWLDS, bool SPLIT, bool WAVE = false>
 static void test_nlz(int valid, bool inplace) {
-  typedef NlzFft<S, T, ROWS, TWLDS, SPLIT> K;
+  typedef NlzFft<S, T, ROWS, TWLDS, SPLIT, WAVE> K;
   const int M = S::N;
   const int nrows = 2 * ROWS + 3;                 // an odd count: the last pair has one row
   const int pin = valid + 2, pout = inplace ? pin : valid + 1;
@@ -1204,7 +1204,7 @@ static void test_nlz(int valid, bool inplace) {
     }
   }
   char name[64];
-  snprintf(name, sizeof name, "nlz r%d v%d%s%s%s", ROWS, valid, TWLDS ? " twlds" : "", SPLIT ? " split" : "", inplace ? " inpl" : "");
+  snprintf(name, sizeof name, "nlz r%d v%d%s%s%s%s", ROWS, valid, TWLDS ? " twlds" : "", SPLIT ? " split" : "", inplace ? " inpl" : "", WAVE ? " wave" : "");
   report(name, M, pname<T>(), (double)sqrtl(num / den), sizeof(T) == 8 ? 4e-14 : 2e-5);
 }
 // the pruned 3/2-rule flavour (Nlz3Fft): M = 3 L, L + 1 bins per row, three sub-transforms per row
@@ -1274,6 +1274,10 @@ template <class SL> static void test_nlz3_all() {
 template <class S> static void test_nlz_all() {
   const int M = S::N;
   const int full = M / 2 + 1, lim = M / 3 + 1;     // every bin / the bins of the un-padded mesh under the 3/2-rule
+  if constexpr (S::TPT <= 64 && 64 % S::TPT == 0) {      // the wave-synchronous build (in the emulator its wave barriers are workgroup barriers)
+    test_nlz<S, double, 2, true, false, true>(lim, true);
+    test_nlz<S, float, 3, false, false, true>(full, false);
+  }
   test_nlz<S, double, 2, true, false>(full, false);
   test_nlz<S, double, 1, false, true>(lim, true);
   test_nlz<S, float, 3, false, false>(lim, false);

@@ -25,6 +25,7 @@
 // number of bins a row holds in memory (M/2 + 1, or N/2 + 1 of the un-padded mesh for the 3/2-rule: the rest reads as zero
 // and is not stored -- what C2RFft / R2CFft LIMIT do).
 #pragma once
+#include <type_traits>
 #include "fft_kernels.h"
 
 namespace mfft {
@@ -42,18 +43,46 @@ struct NlzParams {
   const cx<T>* rt3;            // Nlz3Fft: exp(+2 pi i k / M), k = 0..L, then exp(+2 pi i 2k / M), k = 0..L   (M = 3 L)
 };
 
-template <class S, typename T, int ROWS, bool TWLDS, bool SPLIT>
+// WAVE: a row's threads sit inside ONE wave (TPT divides 64), so the exchanges of its transforms need no workgroup barrier at
+// all: LDS operations of a wave execute in issue order, what a lane wrote is there for every lane's later read, and the only
+// thing to stop is the compiler moving a read above a write (a wave barrier: no instruction).  The waves of a workgroup then
+// drift apart -- one loads while another computes -- instead of meeting 60 times per pair of rows (SQ_WAIT_ANY was 55 % of
+// the wave cycles with workgroup barriers, profiles/r06_nlz_pmc_counters.txt).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MFFT_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define MFFT_WAVE_SYNC() MFFT_BARRIER()
+#endif
+template <bool WAVE> MFFT_D void nlz_sync() {
+  if constexpr (WAVE) MFFT_WAVE_SYNC();
+  else MFFT_BARRIER();
+}
+template <typename T, class Slot, bool WAVE>
+struct XchFullW {
+  cx<T>* buf;
+  Slot slot;
+  template <class S, int P>
+  MFFT_D void exchange(cx<T> (&v)[S::E], int j, bool pre_barrier) {
+    if (pre_barrier) nlz_sync<WAVE>();
+    pass_scatter<S, P>(j, [&](int pos, int reg) { buf[slot(pos)] = v[reg]; });
+    nlz_sync<WAVE>();
+    pass_gather<S>(j, [&](int pos, int reg) { v[reg] = buf[slot(pos)]; });
+  }
+};
+
+template <class S, typename T, int ROWS, bool TWLDS, bool SPLIT, bool WAVE = false>
 struct NlzFft {
+  static_assert(!WAVE || (!SPLIT && S::TPT <= 64 && 64 % S::TPT == 0), "wave-synchronous rows: whole rows inside a wave, whole-complex exchange");
   typedef typename RowXch<SPLIT, T, PadSlot<S::R(0)>>::elem XE;
   static constexpr int M = S::N;
   static constexpr int E = S::E;
   static constexpr int THREADS = S::TPT * ROWS;
-  static constexpr int PD = S::R(0);
+  static constexpr int PD = S::R(0);       // (pad periods of 16 / 24 / 32 elements: no gain, 16 loses 50 % at 512: profiles/r06_nlz_variants.txt)
   static constexpr int PLEN = padded_len<M, PD>();
   static constexpr int TW_BYTES = (TWLDS && S::NP > 1) ? (int)(S::TW * sizeof(cx<T>)) : 0;
   static constexpr int XCH_BYTES = (int)(PLEN * ROWS * sizeof(XE));      // also the mirror exchange of the forward split
   static constexpr int LDS_BYTES = TW_BYTES + XCH_BYTES;
-  typedef typename RowXch<SPLIT, T, PadSlot<PD>>::type Xch;
+  typedef typename std::conditional<WAVE, XchFullW<T, PadSlot<PD>, true>, typename RowXch<SPLIT, T, PadSlot<PD>>::type>::type Xch;
 
   // Z = A + iB at the positions of thread j, ready for the inverse passes (swap identity)
   static MFFT_D void load_pair(cx<T> (&v)[E], const cx<T>* ra, const cx<T>* rb, int j, int valid) {
@@ -80,7 +109,7 @@ struct NlzFft {
     // 216 -> 160 VGPRs for the 8-values plans -- and 5 % SLOWER, 512: 0.555 -> 0.583 ms, 1024: 0.879 -> 0.923; the 12-values plans
     // spill more, not less, 768: 1.36 -> 1.66 ms: profiles/r06_nlz_variants.txt.  Not done.)
     load_pair(v, ra, rb, j, valid);
-    MFFT_BARRIER();
+    nlz_sync<WAVE>();
     run_passes<S, 0, T>(v, j, tw, xc);
   }
 
@@ -88,7 +117,7 @@ struct NlzFft {
   template <class TwPtr>
   static MFFT_D void forward_pair(cx<T> (&v)[E], int j, TwPtr tw, Xch& xc, XE* xb, cx<T>* oa, cx<T>* ob, bool sa, bool sb,
                                   int valid) {
-    MFFT_BARRIER();                                // the buffer is free: everybody has left the previous exchange
+    nlz_sync<WAVE>();                                // the buffer is free: everybody has left the previous exchange
     run_passes<S, 0, T>(v, j, tw, xc);
     constexpr int KMAX = (M / 2) / S::TPT;         // registers beyond it hold positions > M/2 only: nothing to store
     const T half = (T)0.5;
@@ -101,29 +130,29 @@ struct NlzFft {
     };
     if constexpr (SPLIT) {
       T mx[KMAX + 1];
-      if constexpr (S::NP > 1) MFFT_BARRIER();
+      if constexpr (S::NP > 1) nlz_sync<WAVE>();
 #pragma unroll
       for (int k = 0; k < E; ++k) xb[padpos<PD>(j + k * S::TPT)] = v[k].x;
-      MFFT_BARRIER();
+      nlz_sync<WAVE>();
 #pragma unroll
       for (int k = 0; k <= KMAX; ++k) {
         const int p = j + k * S::TPT;
         mx[k] = xb[padpos<PD>(p == 0 ? 0 : M - p)];
       }
-      MFFT_BARRIER();
+      nlz_sync<WAVE>();
 #pragma unroll
       for (int k = 0; k < E; ++k) xb[padpos<PD>(j + k * S::TPT)] = v[k].y;
-      MFFT_BARRIER();
+      nlz_sync<WAVE>();
 #pragma unroll
       for (int k = 0; k <= KMAX; ++k) {
         const int p = j + k * S::TPT;
         emit(p, v[k], mk<T>(mx[k], xb[padpos<PD>(p == 0 ? 0 : M - p)]));
       }
     } else {
-      if constexpr (S::NP > 1) MFFT_BARRIER();
+      if constexpr (S::NP > 1) nlz_sync<WAVE>();
 #pragma unroll
       for (int k = 0; k < E; ++k) xb[padpos<PD>(j + k * S::TPT)] = v[k];
-      MFFT_BARRIER();
+      nlz_sync<WAVE>();
 #pragma unroll
       for (int k = 0; k <= KMAX; ++k) {
         const int p = j + k * S::TPT;
@@ -137,7 +166,10 @@ struct NlzFft {
     const int rl = tid / S::TPT;
     const int j = row_thread_index<S>(tid);
     XE* xb = reinterpret_cast<XE*>(lds + TW_BYTES) + rl * PLEN;
-    if constexpr (TWLDS && S::NP > 1) stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);      // (the first barrier below covers it)
+    if constexpr (TWLDS && S::NP > 1) {
+      stage_twiddles<S, T>(ltw, P.tw, tid, THREADS);
+      if constexpr (WAVE) MFFT_BARRIER();          // the table is shared by the workgroup's waves: the one real barrier
+    }                                              // (otherwise the first barrier below covers it)
     const cx<T>* tw = (TWLDS && S::NP > 1) ? (const cx<T>*)ltw : P.tw;
     Xch xc{xb, PadSlot<PD>{}};
     const i64 unit = (i64)bid * ROWS + rl;         // a pair of rows

@@ -19,24 +19,19 @@ template <class S, typename T> constexpr bool nlz_split() {
 #ifndef MFFT_NLZ_OCC
 #define MFFT_NLZ_OCC 2
 #endif
-// experiment variants (MFFT_NLZ_VARIANT = pad code): rows per workgroup / LDS twiddles / register cap
-template <class S, typename T, int ROWS, bool TWL, int OCC, int VAR>
-void register_nlz_var(const char* name) {
-  auto& reg = kernel_registry();
-  constexpr int R = ROWS > 0 ? ROWS : 1;
-  constexpr bool TW = TWL && S::NP > 1;
-  constexpr long long tw = TW ? (long long)S::TW * (int)sizeof(cx<T>) : 0;
-  constexpr bool SP = tw + (long long)padded_len<S::N, S::R(0)>() * R * (int)sizeof(cx<T>) > 81920;
-  constexpr int W = OCC > 1 ? 16 + OCC : 0;
-  reg.push_back(make_entry<NlzFft<S, T, R, TW, SP>, NlzParams<T>, S, T, W>(FAM_NLZ, S::N, 0, R, name));
-  reg.back().pad = VAR;
+// wave-synchronous build (fft_nlz.h NlzFft WAVE): rows inside one wave, no workgroup barriers in the transforms
+#ifndef MFFT_NLZ_WAVE
+#define MFFT_NLZ_WAVE 1
+#endif
+template <class S, typename T> constexpr bool nlz_wave() {
+  return MFFT_NLZ_WAVE && S::TPT <= 64 && 64 % S::TPT == 0 && !nlz_split<S, T>();
 }
 template <class S, typename T>
 void register_nlz(const char* name) {
   auto& reg = kernel_registry();
   constexpr int R = nlz_rows<S, T>();
   constexpr int W = MFFT_NLZ_OCC > 1 ? 16 + MFFT_NLZ_OCC : 0;        // waves per SIMD, said directly (registry.h mfft_kern_occ)
-  reg.push_back(make_entry<NlzFft<S, T, R, nlz_twlds<S, T>(), nlz_split<S, T>()>, NlzParams<T>, S, T, W>(FAM_NLZ, S::N, 0, R, name));
+  reg.push_back(make_entry<NlzFft<S, T, R, nlz_twlds<S, T>(), nlz_split<S, T>(), nlz_wave<S, T>()>, NlzParams<T>, S, T, W>(FAM_NLZ, S::N, 0, R, name));
 }
 
 // ... and its pruned 3/2-rule flavour (Nlz3Fft: pad code 3, entry.n = M = 3 L): three thread groups of SL::TPT threads per row
@@ -47,13 +42,6 @@ void register_nlz3(const char* name) {
   constexpr int R = nlz3_rows<SL, T>();
   reg.push_back(make_entry<Nlz3Fft<SL, T, R, true>, NlzParams<T>, SL, T>(FAM_NLZ, 3 * SL::N, 0, R, name));
   reg.back().pad = 3;
-}
-template <class SL, typename T, int ROWS, int OCC, int VAR>
-void register_nlz3_var(const char* name) {
-  auto& reg = kernel_registry();
-  constexpr int W = OCC > 0 ? 16 + OCC : 0;
-  reg.push_back(make_entry<Nlz3Fft<SL, T, ROWS, true>, NlzParams<T>, SL, T, W>(FAM_NLZ, 3 * SL::N, 0, ROWS, name));
-  reg.back().pad = VAR;
 }
 
 }  // namespace mfft

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the fused nonlinear z stage (mfft_nlz_rows, csrc/fft_nlz.h) on its own: rows of real length n with `valid` bins,
 in place on the first field as the plan runs it.  Prints ms per launch and TB/s of algorithmic traffic (9 rows of
-valid bins per (x, y) row).  MFFT_NLZ_VARIANT selects an experiment build's variant.
+valid bins per (x, y) row).  (the experiment builds behind profiles/r06_nlz_variants.txt selected their variants with MFFT_NLZ_VARIANT)
 
     python scripts/nlz_bench.py [n valid nrows precision] ..."""
 import ctypes
