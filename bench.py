@@ -873,6 +873,7 @@ def main():
             for m_, modes in ((8, ("fused",)), (9, ("fused", "composed"))):
                 for mode in modes:
                     rep = {}
+                    # (fused: pitched spectra, the demo's default; composed: compact, as rounds 3 - 5 measured it)
                     k_ = dns.solve(comm, M=m_, dealias="3/2-rule", steps=3, report=rep, fused=mode == "fused", timing=True)
                     tg["%d^3_%s" % (2 ** m_, mode)] = {
                         "rk4_step_ms": round(rep["ms_per_step"], 3), "k_after_3_steps": k_,

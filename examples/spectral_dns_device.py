@@ -28,11 +28,13 @@ def _zero(a):
 
 
 def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double", nu=0.000625, dt=0.01, steps=10,
-          report=None, fused=True, timing=False, complex_pitch=None):
+          report=None, fused=True, timing=False, complex_pitch="default"):
     """fused=True (round 6): the nonlinear term is ONE plan operation (spectral.cross_transform: no real-space work
     arrays, the z stages one kernel) and a Runge-Kutta stage's projection, viscous term, both updates and the next
     curl are ONE sweep (spectral.ns_rk_stage).  fused=False: the composition of rounds 3 - 5 (nine transforms, cross,
     curl, rhs and axpbz kernels per stage), kept for A/B timing and as the parity partner of the fused path."""
+    if complex_pitch == "default":       # the fused loop keeps its spectra pitched (rows a whole number of cache lines apart);
+        complex_pitch = "auto" if fused else None      # the composition of rounds 3 - 5 stays as it was measured then
     N = np.array([2 ** M] * 3, dtype=int)
     L = np.array([2 * np.pi] * 3, dtype=float)
     if decomposition == 'slab':
@@ -143,7 +145,7 @@ def main():
     ap.add_argument("--precision", default="double")
     ap.add_argument("--composed", action="store_true", help="the nine-transform composition of rounds 3 - 5 instead of the fused operations")
     ap.add_argument("--stages", action="store_true", help="print the per-stage HIP-event times")
-    ap.add_argument("--pitched", action="store_true", help="spectra with rows a whole number of cache lines apart (complex_pitch='auto')")
+    ap.add_argument("--compact", action="store_true", help="compact spectra (rows of Nf bins) instead of the fused loop's default, rows a whole number of cache lines apart")
     args = ap.parse_args()
     dealias = None if args.dealias == "None" else args.dealias
     from mpifft4py_amd import LocalGroup, SelfComm
@@ -151,10 +153,10 @@ def main():
     if args.ranks > 1:
         ks = LocalGroup(args.ranks).run(lambda c: solve(c, args.M, dealias, steps=args.steps, precision=args.precision,
                                                         report=rep if c.Get_rank() == 0 else None, fused=not args.composed,
-                                                        timing=args.stages, complex_pitch="auto" if args.pitched else None))
+                                                        timing=args.stages, complex_pitch=None if args.compact else "default"))
     else:
         ks = [solve(SelfComm(), args.M, dealias, steps=args.steps, precision=args.precision, report=rep,
-                    fused=not args.composed, timing=args.stages, complex_pitch="auto" if args.pitched else None)]
+                    fused=not args.composed, timing=args.stages, complex_pitch=None if args.compact else "default")]
     print("N = %d^3, %d RK4 steps, %.3f ms per step (%s, device-resident; plan work buffers %.2f GB)"
           % (2 ** args.M, args.steps, rep.get("ms_per_step", float("nan")),
              "composed: 36 transforms + element-wise kernels" if args.composed else

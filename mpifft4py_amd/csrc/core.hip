@@ -523,7 +523,7 @@ int launch_nlz(const NlzArgs& a, hipStream_t s) {
   // sub-transforms of length L in three thread groups, a third of the registers).  Measured EVEN with NlzFft at 768 (1.36 ms per
   // 73,728 rows both) and behind at 1536 (1.80 - 1.91 against 1.59 ms per 36,864 rows): profiles/r06_nlz_variants.txt -- its
   // staging and combination cost what the skipped radix-3 pass saves.  MFFT_NLZ3=1 takes it; where NlzFft has no plan it runs anyway.
-  static const bool nlz3_on = getenv("MFFT_NLZ3") && atoi(getenv("MFFT_NLZ3")) != 0;
+  static const int nlz3_on = getenv("MFFT_NLZ3") ? atoi(getenv("MFFT_NLZ3")) : 0;
   const bool rows3 = a.n % 3 == 0 && a.valid == a.n / 3 + 1 && a.n < 65536;
   if ((nlz3_on || !e) && rows3)
     if (const KernelEntry* e3 = find_kernel(FAM_NLZ, a.n, a.prec, 0, 0, 3)) e = e3;

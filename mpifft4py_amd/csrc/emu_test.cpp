@@ -1416,7 +1416,7 @@ int main() {
 #undef MFFT_NLZ
 #define MFFT_NLZ3(N, ...) test_nlz3_all<Spec<N, __VA_ARGS__>>();
   MFFT_NLZ3PLANS(MFFT_NLZ3)
-  test_nlz3_all<Spec<256, 4, 4, 4, 4>>();
+  test_nlz3_all<Spec<256, 8, 8, 4>>();
 #undef MFFT_NLZ3
 #endif
 #undef MFFT_PLAN

@@ -232,6 +232,9 @@ struct NlzFft {
 // 8-values plans of the powers of two: profiles/r06_nlz_variants.txt).  The rows of the six fields are staged through LDS
 // (every bin is read from memory once; a thread needs the bins kappa and L - kappa of both fields of a pair), the forward
 // combination reads the three F_s back out of LDS.  Same arithmetic contract as NlzFft with valid = L + 1.
+// (A prefetching build -- the rows of the NEXT pair of fields loaded into three more registers per thread while the passes of the
+// current pair run; hipcc's workgroup barrier waits for LDS only, so the loads do stay in flight -- was exact and SLOWER: 768
+// 1.39 -> 1.64 ms, 1536 1.92 -> 2.10, profiles/r06_nlz_variants.txt section 4.  Removed.)
 template <class SL, typename T, int ROWS, bool TWLDS>
 struct Nlz3Fft {
   static constexpr int L = SL::N, M = 3 * SL::N, E = SL::E, TPT = SL::TPT, G = 3 * SL::TPT;
@@ -245,6 +248,27 @@ struct Nlz3Fft {
   static constexpr int NOUT = (L + 1 + G - 1) / G;                      // output bins per thread
   typedef XchFull<T, PadSlot<PD>> Xch;
 
+  // Y_s of this thread's positions out of the staged rows (see the header), ready for the inverse passes
+  static MFFT_D void combine(cx<T> (&v)[E], int s, int j, const cx<T>* B, const cx<T>* rt) {
+    const T h3 = (T)0.866025403784438646764L;
+    const T wr = s == 0 ? (T)1 : (T)-0.5, wi = s == 0 ? (T)0 : (s == 1 ? -h3 : h3);      // w^{-s}: 1, conj(w), w
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const int kap = j + k * TPT;
+      cx<T> a = B[kap], b = B[L + 1 + kap];
+      const cx<T> am = B[L - kap], bm = B[2 * L + 1 - kap];
+      if (kap == 0) { a.y = (T)0; b.y = (T)0; }    // Im of the k = 0 bins is ignored (as c2r does)
+      const cx<T> u = mk<T>(a.x - b.y, a.y + b.x);                      // Z[kappa]     = a + i b
+      const cx<T> vm = mk<T>(am.x + bm.y, bm.x - am.y);                 // Z[kappa - L] = conj(am) + i conj(bm)
+      cx<T> y = mk<T>(u.x + wr * vm.x - wi * vm.y, u.y + wr * vm.y + wi * vm.x);
+      if (kap == 0) {                              // ... and Z[L] w^s = (am + i bm) conj(w^{-s})
+        const cx<T> zl = mk<T>(am.x - bm.y, am.y + bm.x);
+        y = mk<T>(y.x + wr * zl.x + wi * zl.y, y.y + wr * zl.y - wi * zl.x);
+      }
+      if (s != 0) y = y * rt[(s - 1) * (L + 1) + kap];                  // W^{kappa s}
+      v[k] = swapri(y);
+    }
+  }
   template <class TwPtr>
   static MFFT_D void inverse_pair(cx<T> (&v)[E], const cx<T>* ra, const cx<T>* rb, int t, int s, int j, cx<T>* B,
                                   const cx<T>* rt, TwPtr tw, Xch& xc) {
@@ -263,25 +287,7 @@ struct Nlz3Fft {
       if (i < 2 * (L + 1)) B[i] = x;
     }
     MFFT_BARRIER();
-    // w^{-s}: 1, conj(w), w
-    const T h3 = (T)0.866025403784438646764L;
-    const T wr = s == 0 ? (T)1 : (T)-0.5, wi = s == 0 ? (T)0 : (s == 1 ? -h3 : h3);
-#pragma unroll
-    for (int k = 0; k < E; ++k) {
-      const int kap = j + k * TPT;
-      cx<T> a = B[kap], b = B[L + 1 + kap];
-      const cx<T> am = B[L - kap], bm = B[2 * L + 1 - kap];
-      if (kap == 0) { a.y = (T)0; b.y = (T)0; }    // Im of the k = 0 bins is ignored (as c2r does)
-      const cx<T> u = mk<T>(a.x - b.y, a.y + b.x);                      // Z[kappa]     = a + i b
-      const cx<T> vm = mk<T>(am.x + bm.y, bm.x - am.y);                 // Z[kappa - L] = conj(am) + i conj(bm)
-      cx<T> y = mk<T>(u.x + wr * vm.x - wi * vm.y, u.y + wr * vm.y + wi * vm.x);
-      if (kap == 0) {                              // ... and Z[L] w^s = (am + i bm) conj(w^{-s})
-        const cx<T> zl = mk<T>(am.x - bm.y, am.y + bm.x);
-        y = mk<T>(y.x + wr * zl.x + wi * zl.y, y.y + wr * zl.y - wi * zl.x);
-      }
-      if (s != 0) y = y * rt[(s - 1) * (L + 1) + kap];                  // W^{kappa s}
-      v[k] = swapri(y);
-    }
+    combine(v, s, j, B, rt);
     MFFT_BARRIER();                                // the staged rows are consumed: B becomes the exchange buffer
     run_passes<SL, 0, T>(v, j, tw, xc);
   }

@@ -150,7 +150,7 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 
 // ... and the sub-plans of its pruned 3/2-rule flavour (Nlz3Fft: X(L, radices) with L = N/2 = M/3, three sub-transforms of
 // length L per row in three thread groups)
-#define MFFT_NLZ3PLANS(X) X(4, 4) X(8, 8) X(16, 4, 4) X(32, 8, 4) X(64, 8, 8) X(128, 8, 4, 4) X(256, 8, 8, 4) X(512, 8, 8, 8) \
+#define MFFT_NLZ3PLANS(X) X(4, 4) X(8, 8) X(16, 4, 4) X(32, 8, 4) X(64, 8, 8) X(128, 8, 4, 4) X(256, 4, 4, 4, 4) X(512, 4, 4, 4, 4, 2) \
   X(1024, 8, 8, 4, 4)
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
