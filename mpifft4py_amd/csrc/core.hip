@@ -446,11 +446,19 @@ static int launch_real_t(const KernelEntry* e, const RealArgs& a, void* tw, void
   return 0;
 }
 
+// c2r kernels with the mirrors through LDS (registry.h c2r_mlds_candidate: built where they were measured ahead): taken where
+// they exist; MFFT_C2R_MLDS=0: never
+static int c2r_mlds_mode() {
+  static const int m = getenv("MFFT_C2R_MLDS") ? atoi(getenv("MFFT_C2R_MLDS")) : 1;
+  return m;
+}
 static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
   if (a.zs.nchunk) {
     // column-limited as well (3/2-rule: only the first `valid` of the n/2+1 bins exist, and those are what is chunked)
     const bool lim = a.valid > 0 && a.valid < a.n / 2 + 1;
     const KernelEntry* ec = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, lim ? 7 : 4);
+    if (fam == FAM_C2R && c2r_mlds_mode() > 0)
+      if (const KernelEntry* em = find_kernel(fam, a.n, a.prec, 1, 1, lim ? 7 : 4)) ec = em;
     const int64_t real_stride_c = fam == FAM_R2C ? a.in_stride : a.out_stride;
     if (!ec || real_stride_c % 2 != 0) return set_error(MFFT_ERR_UNSUPPORTED, "no z-chunked real kernel of length %d", a.n);
     void *twc = nullptr, *rtwc = nullptr;
@@ -460,6 +468,8 @@ static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
   }
   const bool limited = a.valid > 0 && a.valid < a.n / 2 + 1;
   const KernelEntry* e = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, limited ? 3 : 0);
+  if (fam == FAM_C2R && c2r_mlds_mode() > 0)
+    if (const KernelEntry* em = find_kernel(fam, a.n, a.prec, 1, 1, limited ? 3 : 0)) e = em;
   if (!e && limited) return set_error(MFFT_ERR_UNSUPPORTED, "no column-limited real kernel of length %d", a.n);
   // the radix kernels read a real row as (n/2) complex values: rows must stay 2-element aligned
   const int64_t real_stride = fam == FAM_R2C ? a.in_stride : a.out_stride;

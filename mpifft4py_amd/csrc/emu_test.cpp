@@ -544,7 +544,7 @@ static void test_row() {
   }
 }
 
-template <class S, typename T, int ROWS, bool TWLDS, bool SPLIT = false>
+template <class S, typename T, int ROWS, bool TWLDS, bool SPLIT = false, bool MLDS = false>
 static void test_real() {
   const int M = S::N, N = 2 * M;
   const int nrows = ROWS + 2;
@@ -583,7 +583,7 @@ static void test_real() {
     out[(size_t)r * pout + M].y = (T)-2.25;
   }
   {
-    typedef C2RFft<S, T, ROWS, TWLDS, false, false, SPLIT> K;
+    typedef C2RFft<S, T, ROWS, TWLDS, false, false, SPLIT, false, MLDS> K;
     RealParams<T> P{out.data(), back.data(), tw.data(), rtw.data(), pout, pin, nrows, M + 1, (T)(1.0 / N)};
     emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
@@ -595,7 +595,7 @@ static void test_real() {
       num += d * d;
       den += (long double)in[(size_t)r * pin + i] * in[(size_t)r * pin + i];
     }
-  snprintf(name, sizeof name, "c2r(r2c) r%d%s%s", ROWS, TWLDS ? " twlds" : "", SPLIT ? " split" : "");
+  snprintf(name, sizeof name, "c2r(r2c) r%d%s%s%s", ROWS, TWLDS ? " twlds" : "", SPLIT ? " split" : "", MLDS ? " mlds" : "");
   report(name, N, pname<T>(), (double)sqrtl(num / den), 4 * tol_of<T>());
   // 3/2-rule column handling: r2c keeps only the first `valid` bins, c2r treats the missing ones as zero
   if (M >= 4) {
@@ -619,7 +619,7 @@ static void test_real() {
     report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
     std::vector<T> b2((size_t)nrows * pin, (T)0);
     {
-      typedef C2RFft<S, T, ROWS, TWLDS, true, false, SPLIT> K;
+      typedef C2RFft<S, T, ROWS, TWLDS, true, false, SPLIT, false, MLDS> K;
       RealParams<T> P{part.data(), b2.data(), tw.data(), rtw.data(), valid, pin, nrows, valid, (T)(1.0 / N)};
       emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES,
                  [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
@@ -670,7 +670,7 @@ static void test_real() {
       report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
       std::vector<T> b3((size_t)nrows * pin, (T)0);
       {
-        typedef C2RFft<S, T, ROWS, TWLDS, false, true, SPLIT> K;
+        typedef C2RFft<S, T, ROWS, TWLDS, false, true, SPLIT, false, MLDS> K;
         RealParams<T> P{blocks.data(), b3.data(), tw.data(), rtw.data(), 0, pin, nrows, M + 1, (T)(1.0 / N), zs, row0};
         emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
       }
@@ -719,7 +719,7 @@ static void test_real() {
     report(name, N, pname<T>(), (double)sqrtl(nn / dd), 4 * tol_of<T>());
     std::vector<T> b4((size_t)nrows * pin, (T)0);
     {
-      typedef C2RFft<S, T, ROWS, TWLDS, true, true, SPLIT> K;
+      typedef C2RFft<S, T, ROWS, TWLDS, true, true, SPLIT, false, MLDS> K;
       RealParams<T> P{blocks.data(), b4.data(), tw.data(), rtw.data(), 0, pin, nrows, valid, (T)(1.0 / N), zs, row0};
       emu_launch((nrows + ROWS - 1) / ROWS, K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
     }
@@ -1329,6 +1329,11 @@ template <class S> static void test_spec_all() {
     test_row<S, double, 2, false, false, true>();
     test_row<S, double, 2, true, false, true>();
     test_real<S, double, 2, false, true>();
+  }
+  if constexpr (S::NP > 1 && !(S::TPT <= 64 && 64 % S::TPT == 0)) {      // mirrors through LDS (C2RFft MLDS): the plans no shuffle serves
+    test_real<S, double, 2, false, false, true>();
+    test_real<S, float, 3, true, false, true>();
+    if constexpr (S::E >= 12) test_real<S, double, 2, false, true, true>();
   }
   PadTests<S>::run();
   test_c2r_wave_packed<S, double, 1, false>();

@@ -929,7 +929,12 @@ struct R2CFft {
 // they store nothing).  No row straddles a wave any more, so the mirrored bin X[M - pos] comes through a wave shuffle
 // as it does for the power-of-two thread counts, and every bin is read from memory ONCE (the unpacked layout loaded
 // both bins of a pair: 1.23 x the algorithmic HBM traffic at 720^3, profiles/r03_720_pmc_traffic.json).
-template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false, bool SPLIT = false, bool WP = false>
+// MLDS (round 6): where no wave shuffle reaches the mirrored bin (threads per transform that neither divide a wave nor run
+// wave-packed: 15, 24, 30, 48 ... threads), every bin is still read from memory ONCE and the mirrors come through the
+// exchange buffer, which is idle before the first pass -- instead of a second global load per bin (1.31 x the algorithmic
+// fetch at 1440^3, profiles/r05_ytile_builds.txt).
+template <class S, typename T, int ROWS, bool TWLDS, bool LIMIT = false, bool CHUNK = false, bool SPLIT = false, bool WP = false,
+          bool MLDS = false>
 struct C2RFft {
   typedef typename RowXch<SPLIT, T, PadSlot<S::R(0)>>::elem XE;
   static constexpr int M = S::N;
@@ -1052,6 +1057,60 @@ struct C2RFft {
           if (k % 3 == 2) MFFT_SCHED_FENCE();
         }
       }
+    } else if constexpr (MLDS && S::NP > 1) {
+      // every bin once into v, position M (thread 0's partner of position 0) beside it; the mirrors through LDS
+#pragma unroll
+      for (int k = 0; k < S::E; ++k) {
+        const int pos = j + k * S::TPT;
+        if constexpr (LIMIT) {
+          const bool ok = pos < P.valid;
+          v[k] = keep_bits(bin(ok ? pos : 0), ok);
+        } else {
+          v[k] = bin(pos);
+        }
+      }
+      cx<T> xM = mk<T>((T)0, (T)0);
+      if (j == 0 && (!LIMIT || M < P.valid)) xM = bin(M);
+      auto prepass = [&](cx<T> xk, cx<T> pm, int pos) {
+        cx<T> xm = conj(pm);
+        if (pos == 0) {              // imaginary parts of the k=0 and k=N/2 bins are ignored
+          xk.y = (T)0;
+          xm.y = (T)0;
+        }
+        const cx<T> e = xk + xm;
+        const cx<T> dd = xk - xm;
+        return swapri(e + mul_pi(dd * conj(P.rtw[pos])));
+      };
+      if constexpr (SPLIT) {         // real parts, then imaginary parts, through the half-size buffer (slot padpos(M) exists: PLEN > M + M/PD)
+        T pmx[S::E];
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) xch[padpos<PD>(j + k * S::TPT)] = v[k].x;
+        if (j == 0) xch[padpos<PD>(M)] = xM.x;
+        MFFT_BARRIER();
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) pmx[k] = xch[padpos<PD>(M - (j + k * S::TPT))];
+        MFFT_BARRIER();
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) xch[padpos<PD>(j + k * S::TPT)] = v[k].y;
+        if (j == 0) xch[padpos<PD>(M)] = xM.y;
+        MFFT_BARRIER();
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) {
+          const int pos = j + k * S::TPT;
+          v[k] = prepass(v[k], mk<T>(pmx[k], xch[padpos<PD>(M - pos)]), pos);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) xch[padpos<PD>(j + k * S::TPT)] = v[k];
+        if (j == 0) xch[padpos<PD>(M)] = xM;
+        MFFT_BARRIER();
+#pragma unroll
+        for (int k = 0; k < S::E; ++k) {
+          const int pos = j + k * S::TPT;
+          v[k] = prepass(v[k], xch[padpos<PD>(M - pos)], pos);
+        }
+      }
+      MFFT_BARRIER();                // the buffer goes back to the passes' exchanges
     } else {
 #pragma unroll
       for (int k = 0; k < S::E; ++k) {

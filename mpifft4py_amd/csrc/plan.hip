@@ -1479,8 +1479,8 @@ bool mfft_plan_s::nonlinear_fusable(int dealias) const {
 // batches of x planes then run: inverse y pass of the six fields -> NlzFft (six z rows in, the three rows of the cross
 // product out, in place on the first three) -> forward y pass of the three results back into the x-pass buffers, whose
 // planes of that batch are free by then.  Three forward x passes finish.  The real-space arrays never exist; the batch
-// buffers are a quarter of the x-pass buffers (1024^3 with the 3/2-rule: 6 x 13.1 GB of x-pass buffers + 29.4 GB of batch
-// buffers, where the composed route needs 9 x 29 GB of real work arrays).
+// buffers are at most 16 GiB (1024^3 with the 3/2-rule: 6 x 13.1 GB of x-pass buffers + 14.7 GB of batch buffers, where the
+// composed route needs 9 x 29 GB of real work arrays).
 int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, int dealias) {
   const bool pad = dealias == MFFT_DEALIAS_3_2, masked = dealias == MFFT_DEALIAS_2_3;
   const int64_t L0 = pad ? M0 : N0, L1 = pad ? M1 : N1, L2 = pad ? M2 : N2;
@@ -1493,12 +1493,13 @@ int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, 
   const size_t xelems = (size_t)(L0 * N1 * Za);    // ... of one x-pass buffer
   // Batch of x planes.  Large batches win (512^3 with the 3/2-rule, ms per Runge-Kutta step against the MiB of a batch's six
   // y-pass outputs: 80: 181, 160: 157, 320: 143, 640: 130, 1536: 117, 6000: 111 -- batches that would fit the 256 MB Infinity Cache
-  // gain nothing from it and pay for their short launches: profiles/r06_dns_batch.txt), so: FOUR batches, the batch buffers
-  // a quarter of the x-pass buffers; small meshes (all six outputs under 256 MiB) one.  MFFT_NLZ_BATCH_MB overrides.
-  static const long batch_mb = getenv("MFFT_NLZ_BATCH_MB") ? atol(getenv("MFFT_NLZ_BATCH_MB")) : 0;
+  // gain nothing from it and pay for their short launches: profiles/r06_dns_batch.txt), so: batches of 16 GiB -- ONE batch up to
+  // 512^3 with the 3/2-rule (14.9 GB), four at 768^3, eight at 1024^3 (14.7 GB of batch buffers beside 78.5 GB of x-pass
+  // buffers).  MFFT_NLZ_BATCH_MB overrides.
+  static const long batch_mb = getenv("MFFT_NLZ_BATCH_MB") ? atol(getenv("MFFT_NLZ_BATCH_MB")) : 16384;
   const size_t plane6 = (size_t)(6 * L1 * Za) * es;
-  int64_t mb = batch_mb > 0 ? (int64_t)(((size_t)batch_mb << 20) / plane6)
-                            : (plane6 * (size_t)L0 <= ((size_t)256 << 20) ? L0 : (L0 + 3) / 4);
+  const int64_t nbat = (int64_t)((plane6 * (size_t)L0 + ((size_t)batch_mb << 20) - 1) / ((size_t)batch_mb << 20));
+  int64_t mb = (L0 + std::max<int64_t>(nbat, 1) - 1) / std::max<int64_t>(nbat, 1);
   if (mb < 1) mb = 1;
   if (mb > L0) mb = L0;
   MFFT_TRY(ensure_buf(&nlx, &nlx_bytes, 6 * xelems * es));

@@ -505,6 +505,20 @@ template <class S, typename T, int FAM> constexpr int row_occ_r5(int threads) {
   return 0;
 }
 
+#ifndef MFFT_C2R_MLDS
+#define MFFT_C2R_MLDS 1
+#endif
+// Measured on every plan it applies to (profiles/r06_c2r_mlds.txt, z stage of (256, 256, n) meshes, second load -> LDS mirrors):
+// the 12-values plans of 1152 / 2304 complex points gain 4 - 11 % (real 2304: 0.549 -> 0.528 ms fp64, 0.357 -> 0.321 fp32; real 4608: 1.10
+// -> 0.98 / 0.75 -> 0.68), in single precision also 576 (real 1152: 0.150 -> 0.139) and the 20-values plan of 1000 (real 2000: 0.390 ->
+// 0.368); the 30-values plans in double precision -- whose 1.31 x fetch at 1440^3 was the reason to try -- LOSE 2.2 x (the split
+// exchange parks E more reals: 226 -> 289 VGPRs + 33 AGPRs, one wave per SIMD; 1440^3 bwd_z 10.1 -> 23.9 ms) and keep the second load,
+// as do 500 / 576 / 1000 in double precision (+-4 %, +10 %).  Built for the winners only.
+template <class S, typename T> constexpr bool c2r_mlds_candidate() {
+  if (!MFFT_C2R_MLDS || S::NP < 2 || c2r_wave_packed<S, T>() || (S::TPT <= 64 && 64 % S::TPT == 0)) return false;
+  if (S::E == 12 && (S::N == 1152 || S::N == 2304)) return true;
+  return sizeof(T) == 4 && ((S::E == 12 && S::N == 576) || (S::E == 20 && S::N == 1000));
+}
 template <class S, typename T>
 void register_rows(const char* name) {
   auto& reg = kernel_registry();
@@ -557,6 +571,23 @@ void register_rows(const char* name) {
   if constexpr (S::N >= 4) {                    // column-limited c2r: 3/2-rule lengths and the pruned 2/3-rule (any length)
     reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, false, SC, WPC>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
     reg.back().pad = 3;
+  }
+  // Round 6: c2r kernels that no wave shuffle serves, with the mirrors through LDS instead of a second load (C2RFft MLDS;
+  // KernelEntry::nt = 1; core.hip launch_real takes them where they exist, MFFT_C2R_MLDS=0: never)
+  if constexpr (c2r_mlds_candidate<S, T>()) {
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, false, SC, false, true>, RealParams<T>, S, T, WOC>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.back().nt = 1;
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, false, true, SC, false, true>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.back().nt = 1;
+    reg.back().pad = 4;
+    reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, false, SC, false, true>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
+    reg.back().nt = 1;
+    reg.back().pad = 3;
+    if constexpr (S::N % 3 == 0 && S::N >= 6) {
+      reg.push_back(make_entry<C2RFft<S, T, RC, RTC, true, true, SC, false, true>, RealParams<T>, S, T, WOV>(FAM_C2R, 2 * S::N, 1, RC, name));
+      reg.back().nt = 1;
+      reg.back().pad = 7;
+    }
   }
 }
 

@@ -196,7 +196,8 @@ def test_taylor_green_fused_equals_composed(dealias, golden_dir):
 def test_nonlinear_cross_512_padded_against_composition():
     """512^3 with the 3/2-rule (the mesh the solver's bench line runs): the fused operation against six ifftn + cross +
     three fftn of the same plan (each parity-tested against the oracle at the sizes it finishes), and the work-buffer
-    bill: the composition holds 9 x 768^3 x 8 B = 32.6 GB of real arrays, the fused route under a third of it."""
+    bill: the composition holds 9 x 768^3 x 8 B = 32.6 GB of real arrays, the fused route 10 GB of x-pass buffers and one 15 GB
+    batch (batches are capped at 16 GiB: larger meshes take several)."""
     from mpifft4py_amd import DeviceArray, SelfComm, Slab_R2C, spectral
     N = np.array([512, 512, 512])
     F = Slab_R2C(N, L, SelfComm(0), "double")
@@ -210,7 +211,7 @@ def test_nonlinear_cross_512_padded_against_composition():
     spectral.cross_transform(F, a, b, got, "3/2-rule")
     F.sync()
     assert F.plan_info("nonlinear_fused_3_2") == 1
-    assert F.plan_info("nonlinear_bytes") < 14e9
+    assert F.plan_info("nonlinear_bytes") < 26e9
     ua, ub, r = (DeviceArray.empty((3,) + ws, F.float) for _ in range(3))
     for i in range(3):
         F.ifftn(a.component(i), ua.component(i), "3/2-rule")

@@ -519,6 +519,50 @@ def test_two_thirds_rule_filter_edited_in_place(decomp, P):
     assert not np.array_equal(res[0][0][0][0], res[0][0][1][0]) or P == 1      # the other ranks' results changed too
 
 
+@pytest.mark.parametrize("decomp,P", [("slab", 2), ("slab", 4), ("pencilX", 4)])
+@pytest.mark.parametrize("vote_every", [None, 3])
+def test_two_thirds_rule_filter_assigned_on_one_rank(decomp, P, vote_every):
+    """The reference reads `self.dealias` per rank on every call (slab.py:237-245), so ONE rank may assign a new filter by
+    itself.  The device upload is collective: the assigning rank must not enter it alone (that was a hang with the
+    sampled vote) -- it raises its hand and all ranks upload at the next vote (every call by default; with
+    `dealias_vote_every = n` at the latest n calls later, the old filter until then)."""
+    from mpifft4py_amd import Pencil_R2C, Slab_R2C
+    N = [16, 32, 32]
+    C = np.fft.rfftn(np.random.default_rng(43).random(N))
+
+    def body(comm):
+        F = (Slab_R2C(np.array(N), L, comm, "double") if decomp == "slab" else
+             Pencil_R2C(np.array(N), L, comm, "double", communication="Alltoallw", alignment="X"))
+        F.dealias_vote_every = vote_every
+        sl = F.complex_local_slice()
+        c = np.ascontiguousarray(C[sl])
+        u0 = F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule").copy()      # first upload: every rank's first call
+        m0 = np.broadcast_to(F.dealias, F.complex_shape()).copy()
+        m1 = m0
+        if comm.Get_rank() == 1:
+            m1 = np.ones(F.complex_shape(), dtype=np.uint8)
+            m1[..., -2:] = 0
+            F.dealias = m1                                                       # assignment on ONE rank
+        us = [F.ifftn(c, np.zeros(F.real_shape()), dealias="2/3-rule").copy() for _ in range(4)]
+        return u0, m0, us, m1, sl, F.real_local_slice()
+    res = run_ranks(P, body)
+    M0 = np.zeros(C.shape, dtype=np.uint8)
+    M1 = np.zeros(C.shape, dtype=np.uint8)
+    for _, m0, _, m1, sl, _ in res:
+        M0[sl] = m0
+        M1[sl] = m1
+    w0 = np.fft.irfftn(C * M0, s=N, axes=(0, 1, 2))
+    w1 = np.fft.irfftn(C * M1, s=N, axes=(0, 1, 2))
+    tol = 1e-13 * max(np.abs(w0).max(), 1.0)
+    for u0, _, us, _, _, rsl in res:
+        assert np.abs(u0 - w0[rsl]).max() <= tol
+        assert np.abs(us[-1] - w1[rsl]).max() <= tol                              # everybody ends up with the new filter
+        if vote_every is None:
+            assert np.abs(us[0] - w1[rsl]).max() <= tol                           # ... at the very next call by default
+        for u in us:                                                              # and never with a mixture of the two
+            assert min(np.abs(u - w0[rsl]).max(), np.abs(u - w1[rsl]).max()) <= tol
+
+
 def test_two_thirds_rule_large_filter_sampled_fingerprint():
     """A filter above 256 KiB is fingerprinted by 8192 samples: band and plane edits are seen."""
     from mpifft4py_amd import Slab_R2C
