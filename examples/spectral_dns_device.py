@@ -33,8 +33,9 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
     arrays, the z stages one kernel) and a Runge-Kutta stage's projection, viscous term, both updates and the next
     curl are ONE sweep (spectral.ns_rk_stage).  fused=False: the composition of rounds 3 - 5 (nine transforms, cross,
     curl, rhs and axpbz kernels per stage), kept for A/B timing and as the parity partner of the fused path."""
-    if complex_pitch == "default":       # the fused loop keeps its spectra pitched (rows a whole number of cache lines apart);
-        complex_pitch = "auto" if fused else None      # the composition of rounds 3 - 5 stays as it was measured then
+    if complex_pitch == "default":       # the fused loop on ONE rank keeps its spectra pitched (rows a whole number of cache lines
+        # apart: every pass runs on them); several ranks and the composition of rounds 3 - 5 keep compact rows
+        complex_pitch = "auto" if (fused and comm.Get_size() == 1) else None
     N = np.array([2 ** M] * 3, dtype=int)
     L = np.array([2 * np.pi] * 3, dtype=float)
     if decomposition == 'slab':

@@ -126,6 +126,8 @@ struct mfft_plan_s {
     if (work3) (void)wfree(work3);
     for (void* b : {nlx, nly, nlr, pcomp})
       if (b) (void)dev_free(b);
+    for (void* b : nlw)
+      if (b) (void)wfree(b);
     for (auto& t : timers) {
       for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
       for (auto& e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -761,6 +763,19 @@ struct mfft_plan_s {
     return 0;
   }
   bool nonlinear_fusable(int dealias) const;
+  int nonlinear_cross_fused_ranks(const void* a, const void* b, void* out, int dealias);
+  void* nlw[2] = {nullptr, nullptr};     // several ranks: the six x-pass outputs / exchange buffers (from the communicator: exchanged)
+  size_t nlw_bytes[2] = {0, 0};
+  int ensure_xbuf(int i, size_t bytes) {
+    if (nlw[i] && nlw_bytes[i] >= bytes) return 0;
+    drop_graphs();
+    if (nlw[i]) MFFT_TRY(wfree(nlw[i]));
+    nlw[i] = nullptr;
+    nlw_bytes[i] = 0;
+    MFFT_TRY(walloc(&nlw[i], bytes));
+    nlw_bytes[i] = bytes;
+    return 0;
+  }
   int64_t local_real_count(bool padded) const;
   int nonlinear_cross(const void* a, const void* b, void* out, int dealias);
   int exec(bool forward, const void* in, void* out, int dealias);       // one transform, pitched callers' arrays converted where needed
@@ -1464,7 +1479,9 @@ int mfft_plan_s::nonlinear_cross_composed(const void* a, const void* b, void* ou
 // Fused route: one rank, slab, real data, radix kernels on every axis.
 bool mfft_plan_s::nonlinear_fusable(int dealias) const {
   static const bool off = getenv("MFFT_NO_NLZ") && atoi(getenv("MFFT_NO_NLZ")) != 0;
-  if (off || d.decomp != MFFT_SLAB || P != 1 || !r2c || d.line2d || d.drop_nyquist || N0 < 2 || N1 < 2 || N2 < 2) return false;
+  static const bool ranks_off = getenv("MFFT_NO_NLZ_RANKS") && atoi(getenv("MFFT_NO_NLZ_RANKS")) != 0;
+  if (off || d.decomp != MFFT_SLAB || !r2c || d.line2d || d.drop_nyquist || N0 < 2 || N1 < 2 || N2 < 2) return false;
+  if (P > 1 && (ranks_off || pitched() || (dealias == MFFT_DEALIAS_3_2 && P > N0 / 2))) return false;
   if (dealias == MFFT_DEALIAS_3_2) return can_fuse_pad() && nlz_supported(M2, prec);
   auto plain_ok = [&](int64_t n) {
     return n < 65536 && find_kernel(FAM_COL, (int)n, prec, 0) && find_kernel(FAM_COL, (int)n, prec, 1);
@@ -1576,10 +1593,94 @@ int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, 
   return 0;
 }
 
+// The same over several ranks of a slab plan (blocking exchanges, whatever pipeline the plan's transforms use): six inverse x
+// passes, six all-to-alls, then batches of the rank's x planes -- inverse y passes reading the receive layout through the
+// two-level row map (transpose_Uc fused, maths.pyx:21-31), the fused z kernel, forward y passes writing the packed send
+// layout (slab.py:403) -- three all-to-alls, three forward x passes.  Nine exchanges as in the composition, no real arrays.
+int mfft_plan_s::nonlinear_cross_fused_ranks(const void* a, const void* b, void* out, int dealias) {
+  const bool pad = dealias == MFFT_DEALIAS_3_2, masked = dealias == MFFT_DEALIAS_2_3;
+  const int64_t L0 = pad ? M0 : N0, L1 = pad ? M1 : N1, L2 = pad ? M2 : N2, Lp0 = L0 / P;
+  const int64_t line = (int64_t)(128 / es);
+  const int64_t Za = Nf * (int64_t)es >= 2048 ? (Nf + line - 1) / line * line : Nf;        // batch buffers: line-aligned rows
+  const int64_t S = Np1 * Nf + (pad ? 0 : xplane_pad(true));      // x-row pitch of the forward exchange's layout (sched())
+  const int64_t C = N0 * Np1 * Nf;                                 // one component of the caller's arrays
+  const size_t xelems = (size_t)(L0 * S);                          // one field in any of the exchanged layouts
+  static const long batch_mb = getenv("MFFT_NLZ_BATCH_MB") ? atol(getenv("MFFT_NLZ_BATCH_MB")) : 16384;
+  const size_t plane6 = (size_t)(6 * L1 * Za) * es;
+  const int64_t nbat = (int64_t)((plane6 * (size_t)Lp0 + ((size_t)batch_mb << 20) - 1) / ((size_t)batch_mb << 20));
+  const int64_t mb = (Lp0 + std::max<int64_t>(nbat, 1) - 1) / std::max<int64_t>(nbat, 1);
+  MFFT_TRY(ensure_xbuf(0, 6 * xelems * es));
+  MFFT_TRY(ensure_xbuf(1, 6 * xelems * es));
+  MFFT_TRY(ensure_buf(&nly, &nly_bytes, (size_t)mb * plane6));
+  char *X = static_cast<char*>(nlw[0]), *R = static_cast<char*>(nlw[1]), *Y = static_cast<char*>(nly);
+  const size_t yelems = (size_t)(mb * L1 * Za);
+  const double sc3 = pad ? padscale() : 1.0;
+  struct MaskScope {
+    mfft_plan_s* p;
+    ~MaskScope() { p->mask_src = nullptr; p->lband_use = false; }
+  } mask_scope{this};
+  lband_use = false;
+  MFFT_TRY(stage("nl_x_inv", 0, [&] {
+    for (int f = 0; f < 6; ++f) {
+      const void* src = static_cast<const char*>(f < 3 ? a : b) + (size_t)((f % 3) * C) * es;
+      void* dst = X + (size_t)f * xelems * es;
+      if (masked) {
+        mask_src = src;
+        MFFT_TRY(col(src, dst, N0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)));
+        mask_src = nullptr;
+      } else {
+        MFFT_TRY(col_pad(src, dst, L0, true, pad ? 1 : 0, false, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf), sc3 / (double)L0));
+      }
+    }
+    return 0;
+  }));
+  MFFT_TRY(stage("nl_a2a_inv", 0, [&] {
+    for (int f = 0; f < 6; ++f) MFFT_TRY(xchg(0, false, pad, X + (size_t)f * xelems * es, R + (size_t)f * xelems * es));
+    return 0;
+  }));
+  for (int64_t i0 = 0; i0 < Lp0; i0 += mb) {
+    const int64_t m = std::min(mb, Lp0 - i0);
+    MFFT_TRY(stage("nl_y_inv", 0, [&] {
+      for (int f = 0; f < 6; ++f)
+        MFFT_TRY(col_pad(R + ((size_t)f * xelems + (size_t)(i0 * Np1 * Nf)) * es, Y + (size_t)f * yelems * es, L1, true, pad ? 1 : 0,
+                         false, m, Nf, Np1 * Nf, two_level(Np1, Lp0 * Np1 * Nf, Nf), L1 * Za, plain(Za), 1.0 / (double)L1));
+      return 0;
+    }));
+    MFFT_TRY(stage("nl_z", 0, [&] {
+      NlzArgs z;
+      for (int f = 0; f < 3; ++f) {
+        z.a[f] = Y + (size_t)f * yelems * es;
+        z.b[f] = Y + (size_t)(3 + f) * yelems * es;
+        z.out[f] = Y + (size_t)f * yelems * es;
+      }
+      z.n = (int)L2; z.prec = prec; z.in_stride = Za; z.out_stride = Za; z.nrows = m * L1; z.valid = (int)Nf;
+      z.scale = 1.0 / ((double)L2 * (double)L2);
+      return launch_nlz(z, stream);
+    }));
+    MFFT_TRY(stage("nl_y_fwd", 0, [&] {      // truncate + fold in y, straight into the packed (P, Lp0, S) send layout
+      for (int f = 0; f < 3; ++f)
+        MFFT_TRY(col_pad(Y + (size_t)f * yelems * es, X + ((size_t)f * xelems + (size_t)(i0 * S)) * es, L1, false, pad ? 2 : 0, pad, m,
+                         Nf, L1 * Za, plain(Za), S, two_level(Np1, Lp0 * S, Nf), 1.0));
+      return 0;
+    }));
+  }
+  MFFT_TRY(stage("nl_a2a_fwd", 0, [&] {
+    for (int f = 0; f < 3; ++f) MFFT_TRY(xchg(0, true, pad, X + (size_t)f * xelems * es, R + (size_t)f * xelems * es));
+    return 0;
+  }));
+  MFFT_TRY(stage("nl_x_fwd", 0, [&] {
+    for (int f = 0; f < 3; ++f)
+      MFFT_TRY(col_pad(R + (size_t)f * xelems * es, static_cast<char*>(out) + (size_t)(f * C) * es, L0, false, pad ? 2 : 0, pad, 1,
+                       Np1 * Nf, 0, plain(S), 0, plain(Np1 * Nf), 1.0 / sc3));
+    return 0;
+  }));
+  return 0;
+}
+
 int mfft_plan_s::nonlinear_cross(const void* a, const void* b, void* out, int dealias) {
   if (dealias == MFFT_DEALIAS_2_3 && (!mask || mask_count != (size_t)local_complex_count()))
     return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask was set");
-  if (nonlinear_fusable(dealias)) return nonlinear_cross_fused(a, b, out, dealias);
+  if (nonlinear_fusable(dealias)) return P == 1 ? nonlinear_cross_fused(a, b, out, dealias) : nonlinear_cross_fused_ranks(a, b, out, dealias);
   return nonlinear_cross_composed(a, b, out, dealias);
 }
 
@@ -2809,7 +2910,7 @@ int mfft_plan_get_info(mfft_plan_t p, const char* key, int64_t* value) {
   else if (k == "nonlinear_fused_none") *value = p->nonlinear_fusable(MFFT_DEALIAS_NONE) ? 1 : 0;
   else if (k == "nonlinear_fused_2_3") *value = p->nonlinear_fusable(MFFT_DEALIAS_2_3) ? 1 : 0;
   else if (k == "nonlinear_fused_3_2") *value = p->nonlinear_fusable(MFFT_DEALIAS_3_2) ? 1 : 0;
-  else if (k == "nonlinear_bytes") *value = (int64_t)(p->nlx_bytes + p->nly_bytes + p->nlr_bytes);
+  else if (k == "nonlinear_bytes") *value = (int64_t)(p->nlx_bytes + p->nly_bytes + p->nlr_bytes + p->nlw_bytes[0] + p->nlw_bytes[1]);
   else if (k == "plane_pad") *value = (p->P == 1 && p->d.decomp == MFFT_SLAB) ? p->p1_plane_pad() : 0;   // elements added to the intermediate's plane pitch
   else return set_error(MFFT_ERR_INVALID, "mfft_plan_get_info: unknown key '%s'", key);
   return 0;
