@@ -92,7 +92,9 @@ MFFT_API int mfft_comm_barrier(mfft_comm_t comm);
 MFFT_API int mfft_comm_selftest(mfft_comm_t comm, size_t bytes_per_peer, int timeout_ms);
 /* Transport knobs, per communicator.  The IPC transport (the stand-in for the MPI library's intra-node all-to-all,
  * slab.py:406/281, pencil.py:741-750) knows "ipc_pull" = how a rank fetches its chunks from the peers' buffers: 1 one
- * pull kernel over all peers at once (default), 2 one copy-engine transfer per peer on per-peer streams, 0 copy-engine
+ * pull kernel over all peers at once (default), 2 one copy-engine transfer per peer on per-peer streams (EXPERIMENTAL: the one
+ * mode that ever stalled -- twice, with ranks sharing a device, round 4 -- and that the default test run therefore does not sweep:
+ * MP_WORKER_STREAMS=1 / MFFT_BENCH_PULL_STREAMS=1 add it; do not rely on it before it has run on a node with a GPU per rank), 0 copy-engine
  * transfers one after the other; and "ipc_pull_wgs" = workgroups per peer of that kernel.  A rank-local choice (the
  * flag protocol is the same).  "ipc_relay" = 1 / 0: sub-group exchanges of pencil plans use the links to the ranks
  * outside the group as well (mfft_plan_relay_schedule) -- every rank must set the same value.  Other transports reject

@@ -261,6 +261,22 @@ int scratch_for(hipStream_t s, size_t bytes, void** p) {
   return 0;
 }
 
+}  // namespace (the release hook below is called from plan.hip)
+// A plan's stream is going away: its scratch buffer (up to 256 MiB) goes with it instead of staying for the life of the process.
+void big_release_stream(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+  std::lock_guard<std::mutex> lk(g_big_mu);
+  auto it = g_scratch.find(std::make_pair(dev, s));
+  if (it == g_scratch.end()) return;
+  if (it->second.first) {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(it->second.first);
+  }
+  g_scratch.erase(it);
+}
+namespace {
+
 template <typename T, int MODE>
 int run_big_t(const void* in, void* out, const VecMap& imap, const VecMap& omap, i64 nvec, int n, int nout, int valid, bool inverse,
               double scale, bool vfast, int prec, hipStream_t s) {

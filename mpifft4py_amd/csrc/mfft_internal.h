@@ -147,6 +147,7 @@ int length_route(int64_t n, bool real_transform);   // 1 radix plan, 2 one-workg
 // a scratch buffer (the fallback behind the radix plans and the one-workgroup chirp-z kernels); plain transforms only
 #define MFFT_BIG_MAX_LENGTH (1 << 20)
 bool big_length_ok(int64_t n);
+void big_release_stream(hipStream_t s);   // frees the scratch buffer bigfft.hip keeps for a stream (plan destruction)
 bool radix_plan_exists(int contiguous, int64_t n, int prec);   // a plain strided (0) / contiguous-axis c2c (1) radix kernel of length n
 int big_col(const ColArgs& a, hipStream_t s);
 int big_row(const RowArgs& a, hipStream_t s);

@@ -137,8 +137,8 @@ struct mfft_plan_s {
     for (hipEvent_t e : ev_comm) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev2_compute) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev2_comm) (void)hipEventDestroy(e);
-    if (cstream) (void)hipStreamDestroy(cstream);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (cstream) { big_release_stream(cstream); (void)hipStreamDestroy(cstream); }
+    if (stream) { big_release_stream(stream); (void)hipStreamDestroy(stream); }
   }
 
   int walloc(void** p, size_t bytes) { return comm ? comm->work_alloc(p, bytes) : dev_alloc(p, bytes); }
