@@ -249,3 +249,26 @@ def test_bench_cpu_baseline_cache_is_private_dated_and_versioned(tmp_path, monke
     assert "cached" not in bench.cpu_baseline_cached(64, 8)
     os.chmod(cache_dir, 0o700)
     assert bench.cpu_baseline_cached(64, 8)["cached"] is True
+
+
+@pytest.mark.parametrize("prec,line", [("double", 8), ("single", 16)])
+def test_complex_pitch_layout_is_device_free(prec, line):
+    """The pitched device spectrum (mfft_plan_desc::complex_pitch): what a caller must allocate is host arithmetic
+    (mfft_layout_complex_pitch) -- the logical shapes stay the reference's (slab.py:102-104, pencil.py:248-287), the rows of
+    the local z extent are rounded up to whole 128-byte lines ("auto") or set to the number asked for; a pitch shorter than
+    a row is refused.  On a LayoutComm: no device, no plan."""
+    from mpifft4py_amd import LayoutComm, _lib
+    from mpifft4py_amd.pencil import R2C as Pencil_R2C
+    Nm = np.array([16, 32, 1024])
+    L = np.array([2 * np.pi] * 3)
+    F = R2C(Nm, L, LayoutComm(2, 1), prec, complex_pitch="auto")
+    assert tuple(F.complex_shape()) == (16, 16, 513)                       # logical shape: untouched
+    assert F.complex_pitch == (513 + line - 1) // line * line              # 520 bins in double, 528 in single precision
+    assert R2C(Nm, L, LayoutComm(2, 1), prec).complex_pitch is None        # compact is the default
+    assert R2C(Nm, L, LayoutComm(1, 0), prec, complex_pitch=600).complex_pitch == 600
+    with pytest.raises(_lib.MfftError):
+        R2C(Nm, L, LayoutComm(1, 0), prec, complex_pitch=512)              # shorter than the 513 bins of a row
+    # pencils: the local z extent is a chunk of the Nf bins (the rank with the Nyquist column has one more)
+    for rank, q in ((0, 256), (3, 257)):
+        G = Pencil_R2C(Nm, L, LayoutComm(4, rank), prec, communication="Alltoallw", alignment="X", complex_pitch="auto")
+        assert G.complex_shape()[2] == q and G.complex_pitch == (q + line - 1) // line * line
