@@ -71,6 +71,9 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
         spectral.axpbz(FFT, U_hat0, U_hat, U_hat, 1.0, 0.0)
         spectral.axpbz(FFT, U_hat1, U_hat, U_hat, 1.0, 0.0)
         spectral.curl_hat(FFT, K, U_hat, dU)               # dU doubles as the curl's spectrum between the stages
+        # warm-up outside the timed loop: the plan allocates its buffers (25 GB at 512^3) at the first call; the state is restored
+        spectral.cross_transform(FFT, U_hat, dU, dU, dealias)
+        spectral.curl_hat(FFT, K, U_hat, dU)
         FFT.sync()
         if timing:
             FFT.reset_timing()
@@ -110,6 +113,7 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
 
     for i in range(3):
         FFT.fftn(U.component(i), U_hat.component(i))
+    compute_rhs()                      # warm-up outside the timed loop (work buffers of the padded transforms); writes dU only
     FFT.sync()
     if timing:
         FFT.reset_timing()
