@@ -115,6 +115,30 @@ def main():
         want = np.fft.irfftn(B2 * gm, s=N, axes=(0, 1, 2))
         assert orc.rel_l2(ud, want[Fd.real_local_slice()]) < 4e-10, ("2/3-rule vs oracle", pipeline)
         assert Fd.plan_info("pruned_route") == (2 if not mask.any() else 1), (Fd.plan_info("pruned_route"), int(mask.sum()))
+    # the nonlinear term as one plan operation (mfft_nonlinear_cross: over several ranks the fused z kernel between blocking
+    # exchanges, on buffers the plan takes from the communicator) against six ifftn + cross + three fftn of the same object
+    stage("nonlinear cross")
+    from mpifft4py_amd import spectral
+    for dealias in ("3/2-rule", None):
+        Fn = Slab_R2C(np.array(N), L, comm, "double")
+        rng_n = np.random.default_rng(900 + rank)
+        a, b, got, want_n = (Fn.empty_complex(3) for _ in range(4))
+        for x in (a, b):
+            for i in range(3):
+                Fn.fftn(DeviceArray.from_numpy(rng_n.random(Fn.real_shape()) - 0.5), x.component(i))
+        ws = Fn.work_shape(dealias)
+        ua, ub, rr = (DeviceArray.empty((3,) + tuple(ws), Fn.float) for _ in range(3))
+        for i in range(3):
+            Fn.ifftn(a.component(i), ua.component(i), dealias)
+            Fn.ifftn(b.component(i), ub.component(i), dealias)
+        spectral.cross(Fn, ua, ub, rr)
+        for i in range(3):
+            Fn.fftn(rr.component(i), want_n.component(i), dealias)
+        spectral.cross_transform(Fn, a, b, got, dealias)
+        Fn.sync()
+        assert Fn.plan_info("nonlinear_fused_3_2" if dealias else "nonlinear_fused_none") == 1
+        assert orc.rel_l2(got.get(), want_n.get()) < 1e-13, ("nonlinear", dealias)
+        del Fn, a, b, got, want_n, ua, ub, rr
     # C2C
     Ac = A + 1j * np.random.default_rng(7).random(N)
     Fc = Slab_C2C(np.array(N), L, comm, "single")
