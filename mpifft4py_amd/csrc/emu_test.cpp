@@ -1408,6 +1408,9 @@ int main() {
   MFFT_PLANS_O(MFFT_PLAN)
   MFFT_PLANS_R(MFFT_PLAN)      // round 5: 21 * 2^a, radix 42
 #endif
+#if EMU_HAS(13)
+  MFFT_PLANS_S(MFFT_PLAN)      // round 6: 35 * 2^a, radix 70 (shipped in single precision)
+#endif
 #if EMU_HAS(11)
   MFFT_PLANS_P(MFFT_PLAN)
   test_chirpz_all<Spec<8192, 32, 16, 16>>();

@@ -328,6 +328,10 @@ template <> struct Bfly<28> {
 template <> struct Bfly<42> {
   template <typename T> static MFFT_HD void run(cx<T> (&v)[42]) { BflyPFA<6, 7>::run(v); }
 };
+// round 6: 35 * 2^a in SINGLE precision (560, 1120, 2240: plans.h group S) hold 70 values per thread (140 VGPRs of data): radix 70 = 7 x 10
+template <> struct Bfly<70> {
+  template <typename T> static MFFT_HD void run(cx<T> (&v)[70]) { BflyPFA<7, 10>::run(v); }
+};
 
 
 // ---------------------------------------------------------------------------
@@ -389,7 +393,8 @@ struct Spec {
 #else
 #define MFFT_HIDE_RANGE(x) ((void)0)
 #endif
-template <class S> MFFT_HDC bool launder_plan() { return S::E % 15 == 0 || S::E % 21 == 0; }
+// (round 6: the 70-values plans of 35 * 2^a show it too -- 560: j = tid % 8, wrong bins along the contiguous axis in single precision)
+template <class S> MFFT_HDC bool launder_plan() { return S::E % 15 == 0 || S::E % 21 == 0 || S::E % 35 == 0; }
 template <class S, int P, typename T, class TwPtr>
 MFFT_HD void pass_compute(cx<T> (&v)[S::E], int j, TwPtr tw) {
   constexpr int R = S::R(P), Ns = S::Ns(P), G = S::E / R, OFF = S::tw_off(P);
@@ -420,7 +425,7 @@ template <class S, int P, class Put>
 MFFT_HD void pass_scatter(int j, Put put) {
   constexpr int R = S::R(P), Ns = S::Ns(P), G = S::E / R;
 #if MFFT_LAUNDER_MODE == 2 || MFFT_LAUNDER_MODE == 3      /* tools/rowcheck2.hip only */
-  if constexpr (S::E % 15 == 0 || S::E % 21 == 0) MFFT_HIDE_RANGE(j);
+  if constexpr (launder_plan<S>()) MFFT_HIDE_RANGE(j);
 #endif
 #pragma unroll
   for (int m = 0; m < G; ++m) {

@@ -61,6 +61,14 @@
 #define MFFT_PLANS_R(X) X(42, 42) X(84, 42, 2) X(168, 42, 2, 2) X(336, 42, 2, 2, 2) X(672, 42, 2, 2, 2, 2) \
   X(1344, 42, 2, 2, 2, 2, 2) X(2688, 42, 2, 2, 2, 2, 2, 2)
 
+// Group S (round 6): 35 * 2^a in SINGLE precision only -- 560, 1120, 2240 are 7-smooth meshes that ran through the one-workgroup
+// chirp-z kernels at 0.11 - 0.19 of the roofline (profiles/r06_any_n_sweep.txt).  E = lcm(radices) must contain 5 and 7 and a
+// radix-4 pass would make it 140: 70 values per thread (140 VGPRs of data in single precision; double precision would need
+// 280 and keeps chirp-z), the prime-factor butterfly 70 = 7 x 10 first (no twiddles inside), radix-2 passes for the rest.
+#define MFFT_PLANS_S(X) X(70, 70) X(140, 70, 2) X(280, 70, 2, 2) X(560, 70, 2, 2, 2) X(1120, 70, 2, 2, 2, 2) \
+  X(2240, 70, 2, 2, 2, 2, 2)
+#define MFFT_ROWPLANS_S(X)
+
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
 // the CU of waves.  For the 3- and 5-smooth lengths >= 96 the row kernels therefore use radix

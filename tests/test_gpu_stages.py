@@ -21,7 +21,9 @@ LENGTHS = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096,
            # round 4: 7 * 2^a (plans.h group O: 28 values per thread, radix 28 = 7 x 4) and 8192
            14, 28, 56, 112, 224, 448, 896, 1792, 3584, 8192,
            # round 5: the radix plans between 4096 and 8192 (plans.h group Q) and 21 * 2^a (group R: 42 values per thread)
-           4608, 5120, 6144, 7168, 42, 84, 168, 336, 672, 1344, 2688]
+           4608, 5120, 6144, 7168, 42, 84, 168, 336, 672, 1344, 2688,
+           # round 6: 35 * 2^a (plans.h group S: 70 values per thread, radix 70 = 7 x 10, single precision; double: chirp-z)
+           70, 140, 280, 560, 1120, 2240]
 
 
 @pytest.fixture(scope="module", autouse=True)

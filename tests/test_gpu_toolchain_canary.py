@@ -1,6 +1,7 @@
 """GPU: a CANARY for the two hipcc miscompile workarounds that live in the hot kernels (csrc/fft_core.h MFFT_LAUNDER_MODE,
 csrc/fft_kernels.h row_thread_index).  ROCm 7.2 miscompiles the contiguous-axis kernels of the 30- and 42-values-per-thread
-plans when a thread's index inside its transform has a known power-of-two range (480, 336, 672: a tenth to a third of the
+plans (round 6: and of the 70-values plans of 35 * 2^a) when a thread's index inside its transform has a known power-of-two
+range (480, 336, 672, 560: a tenth to a third of the
 bins wrong on the device, exact in the CPU emulator); the cure -- hiding the range from the twiddle index -- costs the z
 stages of those plans time.  Nothing else would tell when a toolchain update FIXES the bug (the cure could go) or MOVES it
 (the cure might stop working), so this test builds the reproducer tools/rowcheck2.hip twice on the GPU box:
@@ -24,7 +25,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (plan, precision) pairs whose UNCURED kernels are wrong under ROCm 7.2 (profiles/r05_miscompile_cure_modes.txt)
-KNOWN_WRONG = {("480", "fp64"), ("336", "fp64"), ("672", "fp64"), ("480", "fp32"), ("672", "fp32")}
+KNOWN_WRONG = {("480", "fp64"), ("336", "fp64"), ("672", "fp64"), ("480", "fp32"), ("672", "fp32"), ("560", "fp32")}
 
 
 @pytest.fixture(scope="module")
@@ -53,7 +54,7 @@ def rowcheck():
                 m = re.match(r"mode (\d)\s+(\d+) \S+\s+(fp\d\d) .* c2c rel-L2 (\S+) (ok|WRONG)", line)
                 if m:
                     rows[(m.group(2), m.group(3))] = (float(m.group(4)), m.group(5))
-            assert len(rows) == 9, r.stdout
+            assert len(rows) == 10, r.stdout
             out[mode] = rows
         yield out
     finally:

@@ -88,5 +88,6 @@ int main() {
   check<Spec<480, 10, 6, 2, 2, 2>, float, 8>("480 10x6x2x2x2");
   check<Spec<720, 10, 6, 6, 2>, float, 4>("720 10x6x6x2");
   check<Spec<672, 42, 2, 2, 2, 2>, float, 4>("672 42x2x2x2x2");
+  check<Spec<560, 70, 2, 2, 2>, float, 8>("560 70x2x2x2");        // round 6: the 70-values plans of 35 * 2^a (single precision only)
   return 0;
 }
