@@ -250,12 +250,18 @@ int scratch_for(hipStream_t s, size_t bytes, void** p) {
   auto& e = g_scratch[std::make_pair(dev, s)];
   if (e.second < bytes) {
     if (e.first) {
+      // growth frees the old buffer: never under a capture (MFFT_GRAPH=1) -- a graph captured earlier on this stream would
+      // keep the old pointer.  The first allocation is the full budget, so growth only happens for a single vector beyond it.
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+      if (cs != hipStreamCaptureStatusNone) return set_error(MFFT_ERR_INVALID, "four-step scratch would grow inside a stream capture");
       MFFT_HIP(hipStreamSynchronize(s));
       MFFT_HIP(hipFree(e.first));
       e = {nullptr, 0};
     }
-    MFFT_HIP(hipMalloc(&e.first, bytes));
-    e.second = bytes;
+    const size_t want = std::max(bytes, BIG_SCRATCH_BYTES);
+    MFFT_HIP(hipMalloc(&e.first, want));
+    e.second = want;
   }
   *p = e.first;
   return 0;
