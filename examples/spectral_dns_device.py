@@ -28,7 +28,7 @@ def _zero(a):
 
 
 def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double", nu=0.000625, dt=0.01, steps=10,
-          report=None, fused=True, timing=False, complex_pitch="default"):
+          report=None, fused=True, timing=False, complex_pitch="default", edge=None):
     """fused=True (round 6): the nonlinear term is ONE plan operation (spectral.cross_transform: no real-space work
     arrays, the z stages one kernel) and a Runge-Kutta stage's projection, viscous term, both updates and the next
     curl are ONE sweep (spectral.ns_rk_stage).  fused=False: the composition of rounds 3 - 5 (nine transforms, cross,
@@ -36,7 +36,7 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
     if complex_pitch == "default":       # the fused loop on ONE rank keeps its spectra pitched (rows a whole number of cache lines
         # apart: every pass runs on them); several ranks and the composition of rounds 3 - 5 keep compact rows
         complex_pitch = "auto" if (fused and comm.Get_size() == 1) else None
-    N = np.array([2 ** M] * 3, dtype=int)
+    N = np.array([edge or 2 ** M] * 3, dtype=int)        # edge: a mesh that is not a power of two (576, 1152 ...)
     L = np.array([2 * np.pi] * 3, dtype=float)
     if decomposition == 'slab':
         FFT = Slab_R2C(N, L, comm, precision, complex_pitch=complex_pitch)
@@ -144,6 +144,7 @@ def solve(comm, M=5, dealias='3/2-rule', decomposition='slab', precision="double
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--M", type=int, default=5)
+    ap.add_argument("--N", type=int, default=0, help="mesh edge instead of 2**M (576, 1152 ...: any length with radix plans)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--ranks", type=int, default=1)
     ap.add_argument("--dealias", default="3/2-rule", choices=["3/2-rule", "2/3-rule", "None"])
@@ -158,19 +159,21 @@ def main():
     if args.ranks > 1:
         ks = LocalGroup(args.ranks).run(lambda c: solve(c, args.M, dealias, steps=args.steps, precision=args.precision,
                                                         report=rep if c.Get_rank() == 0 else None, fused=not args.composed,
-                                                        timing=args.stages, complex_pitch=None if args.compact else "default"))
+                                                        timing=args.stages, complex_pitch=None if args.compact else "default",
+                                                        edge=args.N or None))
     else:
         ks = [solve(SelfComm(), args.M, dealias, steps=args.steps, precision=args.precision, report=rep,
-                    fused=not args.composed, timing=args.stages, complex_pitch=None if args.compact else "default")]
+                    fused=not args.composed, timing=args.stages, complex_pitch=None if args.compact else "default",
+                    edge=args.N or None)]
     print("N = %d^3, %d RK4 steps, %.3f ms per step (%s, device-resident; plan work buffers %.2f GB)"
-          % (2 ** args.M, args.steps, rep.get("ms_per_step", float("nan")),
+          % (args.N or 2 ** args.M, args.steps, rep.get("ms_per_step", float("nan")),
              "composed: 36 transforms + element-wise kernels" if args.composed else
              ("fused nonlinear z stage" if rep.get("fused_nonlinear") else "one plan operation per nonlinear term, composed inside"),
              rep.get("work_bytes", 0) / 1e9))
     for name, (ms, calls) in sorted(rep.get("stages", {}).items()):
         print("  %-10s %8.3f ms per step  (%d launches)" % (name, ms, calls))
     print("k =", repr(ks[0]))
-    if args.M == 5 and args.steps == 10 and args.precision == "double":
+    if args.M == 5 and not args.N and args.steps == 10 and args.precision == "double":
         assert round(ks[0] - 0.124953117517, 7) == 0
         print("matches the reference demo's known answer 0.124953117517")
 

@@ -452,12 +452,27 @@ static int c2r_mlds_mode() {
   static const int m = getenv("MFFT_C2R_MLDS") ? atoi(getenv("MFFT_C2R_MLDS")) : 1;
   return m;
 }
+// MFFT_C2R_MLDS: 0 never, 1 (default) where measured ahead, 2 wherever a build exists, 3 the column-limited kernels of the 3/2-rule
+// only.  profiles/r06_c2r_mlds.txt: the 12-values plans of 288 ... 3456 complex points that no shuffle serves gain 1 - 15 % on plain
+// rows and 15 - 47 % on column-limited ones (3/2-rule pair of 576^3 fp64: bwd_z 3.08 -> 1.65 ms, of 768^3: 6.60 -> 3.91); rows of more
+// than a wave's threads: real 6144 / 8192 +4 ... +15 %, real 4096 in double precision only (+10 %; single -5 %), real 3072 only
+// column-limited in single precision (+5 %; plain -2 ... -9 %).
+static bool c2r_mlds_take(int n, int prec, bool limited) {
+  const int m = c2r_mlds_mode();
+  if (m <= 0) return false;
+  if (m == 2) return true;
+  if (m == 3) return limited;
+  const int c = n / 2;
+  if (c == 1536) return limited && prec == MFFT_SINGLE;
+  if (c == 2048) return !limited && prec == MFFT_DOUBLE;
+  return true;
+}
 static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
   if (a.zs.nchunk) {
     // column-limited as well (3/2-rule: only the first `valid` of the n/2+1 bins exist, and those are what is chunked)
     const bool lim = a.valid > 0 && a.valid < a.n / 2 + 1;
     const KernelEntry* ec = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, lim ? 7 : 4);
-    if (fam == FAM_C2R && c2r_mlds_mode() > 0)
+    if (fam == FAM_C2R && c2r_mlds_take(a.n, a.prec, lim))
       if (const KernelEntry* em = find_kernel(fam, a.n, a.prec, 1, 1, lim ? 7 : 4)) ec = em;
     const int64_t real_stride_c = fam == FAM_R2C ? a.in_stride : a.out_stride;
     if (!ec || real_stride_c % 2 != 0) return set_error(MFFT_ERR_UNSUPPORTED, "no z-chunked real kernel of length %d", a.n);
@@ -468,7 +483,7 @@ static int launch_real(int fam, const RealArgs& a, hipStream_t s) {
   }
   const bool limited = a.valid > 0 && a.valid < a.n / 2 + 1;
   const KernelEntry* e = find_kernel(fam, a.n, a.prec, fam == FAM_C2R ? 1 : 0, 0, limited ? 3 : 0);
-  if (fam == FAM_C2R && c2r_mlds_mode() > 0)
+  if (fam == FAM_C2R && c2r_mlds_take(a.n, a.prec, limited))
     if (const KernelEntry* em = find_kernel(fam, a.n, a.prec, 1, 1, limited ? 3 : 0)) e = em;
   if (!e && limited) return set_error(MFFT_ERR_UNSUPPORTED, "no column-limited real kernel of length %d", a.n);
   // the radix kernels read a real row as (n/2) complex values: rows must stay 2-element aligned

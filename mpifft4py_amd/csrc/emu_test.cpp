@@ -1411,6 +1411,9 @@ int main() {
 #if EMU_HAS(13)
   MFFT_PLANS_S(MFFT_PLAN)      // round 6: 35 * 2^a, radix 70 (shipped in single precision)
 #endif
+#if EMU_HAS(14)
+  MFFT_PLANS_T(MFFT_PLAN)      // round 6: 27 * 2^a, the 3/2-rule images of the 9 * 2^a meshes
+#endif
 #if EMU_HAS(11)
   MFFT_PLANS_P(MFFT_PLAN)
   test_chirpz_all<Spec<8192, 32, 16, 16>>();
@@ -1420,7 +1423,7 @@ int main() {
 #endif
 #if EMU_HAS(12)
 #define MFFT_NLZ(N, ...) test_nlz_all<Spec<N, __VA_ARGS__>>();
-  MFFT_NLZPLANS_P2(MFFT_NLZ) MFFT_NLZPLANS_3(MFFT_NLZ)      // round 6: the fused nonlinear z stage
+  MFFT_NLZPLANS_P2(MFFT_NLZ) MFFT_NLZPLANS_3(MFFT_NLZ) MFFT_NLZPLANS_9(MFFT_NLZ)     // round 6: the fused nonlinear z stage
 #undef MFFT_NLZ
 #define MFFT_NLZ3(N, ...) test_nlz3_all<Spec<N, __VA_ARGS__>>();
   MFFT_NLZ3PLANS(MFFT_NLZ3)

@@ -1,0 +1,8 @@
+// gfx950 instantiations: fused nonlinear z stage (fft_nlz.h), double precision
+#include "registry_nlz.h"
+#include "plans.h"
+namespace {
+#define MFFT_REG_NLZ(N, ...) mfft::register_nlz<mfft::Spec<N, __VA_ARGS__>, double>("nlz n" #N "(" #__VA_ARGS__ ")double");
+#define MFFT_REG_NLZ3(N, ...) mfft::register_nlz3<mfft::Spec<N, __VA_ARGS__>, double>("nlz3 l" #N "(" #__VA_ARGS__ ")double");
+mfft::PlanRegistrar registrar([] { MFFT_NLZPLANS_9(MFFT_REG_NLZ) });
+}

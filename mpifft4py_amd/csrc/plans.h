@@ -69,6 +69,14 @@
   X(2240, 70, 2, 2, 2, 2, 2)
 #define MFFT_ROWPLANS_S(X)
 
+// Group T (round 6): 27 * 2^a -- the 3/2-rule images of the 9 * 2^a meshes (288 -> 432, 576 -> 864, 1152 -> 1728, 2304 -> 3456:
+// slab.py:75-76, 487-489), which had no radix plan, so a 3/2-rule transform of 576^3 or 1152^3 had no fused pad / truncate passes
+// (MFFT_ERR_UNSUPPORTED) and the plain transforms of these lengths ran through chirp-z.  24 values per thread like 576 ... 2304
+// for the strided kernels, 12 for the contiguous-axis kernels (MFFT_ROWPLANS_T) and the fused nonlinear z stage.
+#define MFFT_PLANS_T(X) X(54, 6, 3, 3) X(108, 12, 3, 3) X(216, 24, 3, 3) X(432, 24, 6, 3) X(864, 24, 12, 3) X(1728, 24, 24, 3) \
+  X(3456, 24, 24, 6)
+#define MFFT_ROWPLANS_T(X) X(216, 12, 6, 3) X(432, 12, 12, 3) X(864, 12, 12, 6) X(1728, 12, 12, 12) X(3456, 12, 12, 12, 2)
+
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
 // the CU of waves.  For the 3- and 5-smooth lengths >= 96 the row kernels therefore use radix
@@ -93,7 +101,8 @@
 #define MFFT_ROWPLANS_B(X)
 #define MFFT_ROWPLANS_C(X)
 #define MFFT_FOR_EACH_ROWPLAN(X) \
-  MFFT_ROWPLANS_D(X) MFFT_ROWPLANS_E(X) MFFT_ROWPLANS_F(X) MFFT_ROWPLANS_G(X) MFFT_ROWPLANS_H(X) MFFT_ROWPLANS_I(X)
+  MFFT_ROWPLANS_D(X) MFFT_ROWPLANS_E(X) MFFT_ROWPLANS_F(X) MFFT_ROWPLANS_G(X) MFFT_ROWPLANS_H(X) MFFT_ROWPLANS_I(X) \
+  MFFT_ROWPLANS_T(X)
 
 // Double precision only: the contiguous-axis kernels of 500 keep 5x5x5x4 -- with 20x5x5 the c2r kernel of real length 1000
 // doubled its time (1000^3 bwd_z 3.3 -> 6.6 ms) while single precision gains from it (2.03 -> 1.88 ms).
@@ -101,7 +110,8 @@
 // true if complex length n takes its row kernels from MFFT_ROWPLANS_*
 constexpr bool mfft_has_row_override(int n) {
   return n == 96 || n == 192 || n == 384 || n == 768 || n == 1536 || n == 3072 || n == 160 || n == 320 || n == 640 ||
-         n == 1280 || n == 2560 || n == 144 || n == 288 || n == 576 || n == 1152 || n == 2304;
+         n == 1280 || n == 2560 || n == 144 || n == 288 || n == 576 || n == 1152 || n == 2304 || n == 216 || n == 432 ||
+         n == 864 || n == 1728 || n == 3456;
 }
 
 template <typename T> constexpr bool mfft_has_row_override_t(int n) { return mfft_has_row_override(n) || (sizeof(T) == 8 && n == 500); }
@@ -155,6 +165,9 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
   X(1024, 8, 8, 4, 4) X(2048, 8, 8, 8, 4) X(4096, 8, 8, 8, 8)
 #define MFFT_NLZPLANS_3(X) X(12, 12) X(24, 12, 2) X(48, 12, 4) X(96, 12, 4, 2) X(192, 12, 4, 4) X(384, 12, 4, 4, 2) \
   X(768, 12, 4, 4, 4) X(1536, 12, 4, 4, 4, 2) X(3072, 12, 4, 4, 4, 4)
+// the 9 * 2^a meshes (dealias None / 2/3-rule) and their 3/2-rule images 27 * 2^a
+#define MFFT_NLZPLANS_9(X) X(144, 12, 12) X(288, 12, 12, 2) X(576, 12, 12, 4) X(1152, 12, 12, 4, 2) X(2304, 12, 12, 4, 4) \
+  X(216, 12, 6, 3) X(432, 12, 12, 3) X(864, 12, 12, 6) X(1728, 12, 12, 12) X(3456, 12, 12, 12, 2)
 
 // ... and the sub-plans of its pruned 3/2-rule flavour (Nlz3Fft: X(L, radices) with L = N/2 = M/3, three sub-transforms of
 // length L per row in three thread groups)
@@ -163,4 +176,4 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
   MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X) MFFT_PLANS_N(X) \
-  MFFT_PLANS_O(X) MFFT_PLANS_P(X) MFFT_PLANS_Q(X) MFFT_PLANS_R(X)
+  MFFT_PLANS_O(X) MFFT_PLANS_P(X) MFFT_PLANS_Q(X) MFFT_PLANS_R(X) MFFT_PLANS_T(X)

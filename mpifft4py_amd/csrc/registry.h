@@ -222,6 +222,8 @@ template <class S, typename T> constexpr int col_wgs() {
   if (S::N == 1152 && S::E == 24) return 2;
   if (S::N == 1536 && S::E == 24) return 3;
   if (MFFT_COL_OCC_R5 && S::N == 2304 && S::E == 24) return 2;
+  // (1728 in single precision -- 24x24x3, 576 threads = 9 waves on 64-byte tiles, 0.40 of the roofline -- capped at 80 registers for two
+  // workgroups with the split exchange, 2 x 55 KB instead of one with 110 KB: 1728^3 pair 70.5 - 71.1 -> 70.3 ms, nothing; not kept)
   if (MFFT_COL_OCC_R5 && S::N == 720 && S::E == 30) return 3;
   // (16 + waves per SIMD: the cap that the dispatcher's rule asks of TWO workgroups, 2 x ceil(waves / 4) -- the plain
   // "workgroups x threads / 256" of mfft_kern_occ gives 3 for the 6 waves of 1440, and the second workgroup would stay out)
@@ -517,7 +519,12 @@ template <class S, typename T, int FAM> constexpr int row_occ_r5(int threads) {
 template <class S, typename T> constexpr bool c2r_mlds_candidate() {
   if (!MFFT_C2R_MLDS || S::NP < 2 || c2r_wave_packed<S, T>() || (S::TPT <= 64 && 64 % S::TPT == 0)) return false;
   if (S::E == 12 && (S::N == 1152 || S::N == 2304)) return true;
-  return sizeof(T) == 4 && ((S::E == 12 && S::N == 576) || (S::E == 20 && S::N == 1000));
+  // the 27 * 2^a row plans (plans.h group T) and, for the column-limited kernels of the 3/2-rule, their 9 * 2^a neighbours:
+  // which of the builds is TAKEN is core.hip c2r_mlds_take's rule
+  if (S::E == 12 && (S::N == 432 || S::N == 864 || S::N == 1728 || S::N == 3456 || S::N == 288 || S::N == 576)) return true;
+  // rows of more than a wave's threads (real 3072 / 6144 with 12 values per thread, real 4096 / 8192 with 16)
+  if ((S::E == 12 && (S::N == 1536 || S::N == 3072)) || (S::E == 16 && (S::N == 2048 || S::N == 4096))) return true;
+  return sizeof(T) == 4 && (S::E == 20 && S::N == 1000);
 }
 template <class S, typename T>
 void register_rows(const char* name) {

@@ -257,7 +257,10 @@ def test_wide_and_narrow_tiles_over_ranks(N, P, prec):
 @pytest.mark.parametrize("N", [[800, 8, 8], [8, 800, 8], [768, 8, 8], [8, 768, 8], [8, 8, 768], [1024, 8, 8], [8, 1024, 8], [8, 8, 1024], [256, 8, 8],
                                # padded images on the round-3 plans: 1280 -> 1920, 2560 -> 3840, 1600 -> 2400, 2000 -> 3000, 1000 -> 1500
                                [1280, 8, 8], [8, 1280, 8], [8, 8, 1280], [2560, 8, 8], [8, 8, 2560], [8, 1600, 8], [8, 8, 1600],
-                               [2000, 8, 8], [8, 8, 2000], [8, 1000, 8], [8, 8, 1000], [8, 500, 8]])
+                               [2000, 8, 8], [8, 8, 2000], [8, 1000, 8], [8, 8, 1000], [8, 500, 8],
+                               # round 6: 9 * 2^a meshes on the 27 * 2^a plans: 576 -> 864, 1152 -> 1728, 2304 -> 3456, 288 -> 432
+                               [576, 8, 8], [8, 576, 8], [8, 8, 576], [1152, 8, 8], [8, 1152, 8], [8, 8, 1152], [8, 2304, 8], [8, 8, 2304],
+                               [8, 288, 8]])
 def test_padded_long_axes(N, prec):
     """3/2-rule with one LONG axis: the pad-on-load / truncate-on-store builds of the 1152- and 1536-point strided
     kernels (12 values per thread, register caps, 64-byte tiles in single precision: registry.h col_wgs) and the

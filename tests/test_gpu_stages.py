@@ -23,7 +23,9 @@ LENGTHS = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096,
            # round 5: the radix plans between 4096 and 8192 (plans.h group Q) and 21 * 2^a (group R: 42 values per thread)
            4608, 5120, 6144, 7168, 42, 84, 168, 336, 672, 1344, 2688,
            # round 6: 35 * 2^a (plans.h group S: 70 values per thread, radix 70 = 7 x 10, single precision; double: chirp-z)
-           70, 140, 280, 560, 1120, 2240]
+           70, 140, 280, 560, 1120, 2240,
+           # round 6: 27 * 2^a (plans.h group T: the 3/2-rule images of the 9 * 2^a meshes)
+           54, 108, 216, 432, 864, 1728, 3456]
 
 
 @pytest.fixture(scope="module", autouse=True)
