@@ -6,7 +6,7 @@
 // Lengths covered: 2^a (2..4096), 3*2^a (6..3072), 5*2^a (10..2560): these are
 // what the reference's power-of-two meshes and their 3/2-rule padded
 // counterparts (slab.py:75-76, 487-489) produce; 9*2^a (18..2304) are the 3/2-rule
-// images of the 3*2^a meshes, 25*2^a (50..1600) and 125*2^a (250..2000: 1000^3 is a mesh people run) round off the
+// images of the 3*2^a meshes, 27*2^a (54..3456, group T) theirs in turn, 25*2^a (50..1600) and 125*2^a (250..2000: 1000^3 is a mesh people run) round off the
 // 5-smooth sizes; groups L and M (below) the lengths with both 3 and 5 among their factors.  Every
 // other length goes through the chirp-z kernels (fft_chirpz.h).  The groups only exist
 // so the instantiations can be compiled in parallel translation units.
