@@ -534,6 +534,7 @@ static int launch_nlz_t(const KernelEntry* e, const NlzArgs& a, void* tw, void* 
   P.out_stride = a.out_stride;
   P.nrows = a.nrows;
   P.valid = a.valid > 0 && a.valid < a.n / 2 + 1 ? a.valid : a.n / 2 + 1;
+  P.valid_in = a.valid_in > 0 && a.valid_in < P.valid ? a.valid_in : P.valid;
   P.scale = (T)a.scale;
   const int64_t grid = (a.nrows + 2 * e->tile - 1) / (2 * e->tile);      // a thread group works through a PAIR of rows
   if (grid <= 0) return 0;

@@ -1151,8 +1151,9 @@ static void test_col3() {
 // ---------------------------------------------------------------------------
 // fused nonlinear z stage (fft_nlz.h): out_f = rfft((irfft(a) x irfft(b))_f), rows of `valid` bins, against long-double DFTs
 template <class S, typename T, int ROWS, bool TWLDS, bool SPLIT, bool WAVE = false>
-static void test_nlz(int valid, bool inplace) {
+static void test_nlz(int valid, bool inplace, int valid_in = 0) {      // valid_in: fewer input bins than stored ones (pruned 2/3-rule)
   typedef NlzFft<S, T, ROWS, TWLDS, SPLIT, WAVE> K;
+  const int vin = valid_in > 0 ? valid_in : valid;
   const int M = S::N;
   const int nrows = 2 * ROWS + 3;                 // an odd count: the last pair has one row
   const int pin = valid + 2, pout = inplace ? pin : valid + 1;
@@ -1169,7 +1170,7 @@ static void test_nlz(int valid, bool inplace) {
   auto tw = build_pass_twiddles<S, T>();
   NlzParams<T> P;
   for (int f = 0; f < 3; ++f) { P.a[f] = in[f].data(); P.b[f] = in[3 + f].data(); P.out[f] = inplace ? in[f].data() : out[f].data(); }
-  P.tw = tw.data(); P.in_stride = pin; P.out_stride = pout; P.nrows = nrows; P.valid = valid;
+  P.tw = tw.data(); P.in_stride = pin; P.out_stride = pout; P.nrows = nrows; P.valid = valid; P.valid_in = vin;
   P.scale = (T)(1.0 / ((double)M * (double)M));
   emu_launch((nrows + 2 * ROWS - 1) / (2 * ROWS), K::THREADS, K::LDS_BYTES, [&](int b, int t, char* lds) { K::body(P, b, t, lds); });
   long double num = 0, den = 0;
@@ -1178,7 +1179,7 @@ static void test_nlz(int valid, bool inplace) {
     for (int f = 0; f < 6; ++f) {
       lvec X(M);
       for (int p = 0; p < M; ++p) { X[p].x = 0; X[p].y = 0; }
-      for (int q = 0; q < valid; ++q) {
+      for (int q = 0; q < vin; ++q) {
         cx<T> z = keep[f][(size_t)r * pin + q];
         long double zr = z.x, zi = z.y;
         if (q == 0 || (M % 2 == 0 && q == M / 2)) zi = 0;
@@ -1204,7 +1205,7 @@ static void test_nlz(int valid, bool inplace) {
     }
   }
   char name[64];
-  snprintf(name, sizeof name, "nlz r%d v%d%s%s%s%s", ROWS, valid, TWLDS ? " twlds" : "", SPLIT ? " split" : "", inplace ? " inpl" : "", WAVE ? " wave" : "");
+  snprintf(name, sizeof name, "nlz r%d v%d/%d%s%s%s%s", ROWS, vin, valid, TWLDS ? " twlds" : "", SPLIT ? " split" : "", inplace ? " inpl" : "", WAVE ? " wave" : "");
   report(name, M, pname<T>(), (double)sqrtl(num / den), sizeof(T) == 8 ? 4e-14 : 2e-5);
 }
 // the pruned 3/2-rule flavour (Nlz3Fft): M = 3 L, L + 1 bins per row, three sub-transforms per row
@@ -1282,6 +1283,10 @@ template <class S> static void test_nlz_all() {
   test_nlz<S, double, 1, false, true>(lim, true);
   test_nlz<S, float, 3, false, false>(lim, false);
   test_nlz<S, float, 2, true, true>(full, true);
+  if (lim < full) {                                 // pruned 2/3-rule: the kept kz bins in, every bin out
+    test_nlz<S, double, 2, true, false>(full, true, lim);
+    test_nlz<S, float, 3, false, false>(full, false, (2 * full) / 3);
+  }
 }
 
 template <class S> static void test_chirpz_all() {

@@ -38,7 +38,8 @@ struct NlzParams {
   const cx<T>* tw;             // inter-pass twiddles of S
   i64 in_stride, out_stride;   // complex elements between consecutive rows
   i64 nrows;
-  int valid;                   // bins per row that exist in memory
+  int valid;                   // bins per OUTPUT row that are stored (and exist in memory)
+  int valid_in;                // bins per INPUT row that exist (<= valid: the pruned 2/3-rule reads the kept kz only)
   T scale;                     // applied to a x b (both inverse transforms are un-normalised: 1 / M^2 gives numpy's irfft)
   const cx<T>* rt3;            // Nlz3Fft: exp(+2 pi i k / M), k = 0..L, then exp(+2 pi i 2k / M), k = 0..L   (M = 3 L)
 };
@@ -186,13 +187,13 @@ struct NlzFft {
       const i64 io = lrow * P.in_stride;
       cx<T> pk[2][E];
       cx<T> v[E];
-      inverse_pair(v, P.a[0] + io, P.b[0] + io, j, P.valid, tw, xc);
+      inverse_pair(v, P.a[0] + io, P.b[0] + io, j, P.valid_in, tw, xc);
 #pragma unroll
       for (int k = 0; k < E; ++k) pk[0][k] = v[k];
-      inverse_pair(v, P.a[1] + io, P.b[1] + io, j, P.valid, tw, xc);
+      inverse_pair(v, P.a[1] + io, P.b[1] + io, j, P.valid_in, tw, xc);
 #pragma unroll
       for (int k = 0; k < E; ++k) pk[1][k] = v[k];
-      inverse_pair(v, P.a[2] + io, P.b[2] + io, j, P.valid, tw, xc);
+      inverse_pair(v, P.a[2] + io, P.b[2] + io, j, P.valid_in, tw, xc);
       // the results are swapped (inverse through the swap identity): .y = a_f, .x = b_f at position j + k TPT
       T r2[E];
 #pragma unroll

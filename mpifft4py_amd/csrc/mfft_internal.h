@@ -116,6 +116,7 @@ struct NlzArgs {
   int prec = MFFT_DOUBLE;
   int64_t in_stride = 0, out_stride = 0, nrows = 0;   // complex elements
   int valid = 0;         // bins per row present in memory (0 = all n/2+1)
+  int valid_in = 0;      // bins per INPUT row, where fewer than `valid` exist (pruned 2/3-rule); 0 = valid
   double scale = 1.0;    // applied to the product (1 / n^2: both inverse transforms normalised)
 };
 bool nlz_supported(int64_t n, int prec);

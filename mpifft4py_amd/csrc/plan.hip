@@ -1531,11 +1531,23 @@ int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, 
     ~MaskScope() { p->mask_src = nullptr; p->lband_use = false; }
   } mask_scope{this};
   lband_use = false;
-  MFFT_TRY(stage("nl_x_inv", 6 * (Cb + Xb), [&] {
+  // 2/3-rule with the reference's own filter (detect_band): the six inverse transforms are PRUNED as in slab_backward -- the x
+  // pass neither loads the removed kx rows nor touches the removed ky and kz columns, the y pass works on the kept kz columns
+  // and does not load the removed ky rows, the fused z kernel reads ba2 bins per row (NlzParams::valid_in) and stores all Nf.
+  // 512^3, per Taylor-Green step: nl_x_inv 12.9 -> 5.9 ms, nl_y_inv 9.3 -> 5.2, nl_z 8.2 -> 7.1; step 60.3 -> 45.5 ms
+  // (profiles/r06_dns_23rule.txt).  MFFT_NO_PRUNE=1: the masked loads below.
+  const bool pruned = masked && band_ok && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0);
+  const double keep0 = pruned ? 1.0 - (double)(bb0 - ba0) / (double)N0 : 1.0, keep1 = pruned ? 1.0 - (double)(bb1 - ba1) / (double)N1 : 1.0,
+               keep2 = pruned ? (double)ba2 / (double)Nf : 1.0;
+  MFFT_TRY(stage("nl_x_inv", 6 * (Cb * keep0 + Xb) * keep1 * keep2, [&] {
     for (int f = 0; f < 6; ++f) {
       const void* src = static_cast<const char*>(f < 3 ? a : b) + (size_t)((f % 3) * C) * es;
       void* dst = X + (size_t)f * xelems * es;
-      if (masked) {                                // `fu * dealias` (slab.py:237-245) applied while the spectrum is loaded
+      if (pruned) {                                // one outer batch per ky, the kept kz columns of it
+        ColArgs::Band bx;
+        bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1;
+        MFFT_TRY(col_band(src, dst, N0, N1, ba2, Zi, plain(N1 * Zi), Za, plain(N1 * Za), bx));
+      } else if (masked) {                                // `fu * dealias` (slab.py:237-245) applied while the spectrum is loaded
         mask_src = src;
         MFFT_TRY(col(src, dst, N0, true, N1, Nf, Zi, plain(N1 * Zi), Za, plain(N1 * Za)));
         mask_src = nullptr;
@@ -1553,13 +1565,21 @@ int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, 
   for (int64_t i0 = 0; i0 < L0; i0 += mb) {
     const int64_t m = std::min(mb, L0 - i0);
     const double frac = (double)m / (double)L0;
-    MFFT_TRY(stage("nl_y_inv", 6 * (Xb + Yb) * frac, [&] {
-      for (int f = 0; f < 6; ++f)
-        MFFT_TRY(col_pad(X + ((size_t)f * xelems + (size_t)(i0 * N1 * Za)) * es, Y + (size_t)f * yelems * es, L1, true, pad ? 1 : 0,
-                         false, m, Nf, N1 * Za, plain(Za), L1 * Za, plain(Za), 1.0 / (double)L1));
+    MFFT_TRY(stage("nl_y_inv", 6 * (Xb * keep1 + Yb) * keep2 * frac, [&] {
+      for (int f = 0; f < 6; ++f) {
+        const void* src = X + ((size_t)f * xelems + (size_t)(i0 * N1 * Za)) * es;
+        void* dst = Y + (size_t)f * yelems * es;
+        if (pruned) {
+          ColArgs::Band by;
+          by.row_lo = ba1; by.row_hi = bb1; by.c_lim = ba2;
+          MFFT_TRY(col_band(src, dst, N1, m, ba2, N1 * Za, plain(Za), L1 * Za, plain(Za), by));
+        } else {
+          MFFT_TRY(col_pad(src, dst, L1, true, pad ? 1 : 0, false, m, Nf, N1 * Za, plain(Za), L1 * Za, plain(Za), 1.0 / (double)L1));
+        }
+      }
       return 0;
     }));
-    MFFT_TRY(stage("nl_z", 9 * Yb * frac, [&] {
+    MFFT_TRY(stage("nl_z", (6 * keep2 + 3) * Yb * frac, [&] {
       NlzArgs z;
       for (int f = 0; f < 3; ++f) {
         z.a[f] = Y + (size_t)f * yelems * es;
@@ -1567,6 +1587,7 @@ int mfft_plan_s::nonlinear_cross_fused(const void* a, const void* b, void* out, 
         z.out[f] = Y + (size_t)f * yelems * es;
       }
       z.n = (int)L2; z.prec = prec; z.in_stride = Za; z.out_stride = Za; z.nrows = m * L1; z.valid = (int)Nf;
+      z.valid_in = pruned ? ba2 : 0;
       z.scale = 1.0 / ((double)L2 * (double)L2);
       return launch_nlz(z, stream);
     }));
