@@ -951,12 +951,29 @@ int mfft_plan_s::slab_backward(const void* fu, void* u, bool masked) {
     mfft_plan_s* p;
     ~MaskScope() { p->mask_src = nullptr; }
   } mask_scope{this};
-  if (masked && P == 1 && band_ok && !nat_pitch() && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
+  if (masked && P == 1 && band_ok && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0)) {
     if (!mask || mask_count != (size_t)local_complex_count()) return set_error(MFFT_ERR_INVALID, "2/3-rule requested but no dealias mask was set");
-    MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nf) * es));
-    void* Aw = work[0];
     const double keep0 = 1.0 - (double)(bb0 - ba0) / (double)N0, keep1 = 1.0 - (double)(bb1 - ba1) / (double)N1, keep2 = (double)ba2 / (double)Nf;
     ColArgs::Band bx, by;
+    if (nat_pitch()) {
+      // pitched rows (round 6): the tile list below was made for rows of Nf bins, so the x pass takes one outer batch per ky
+      // (removed ky: nothing launched does anything) with the kept kz of it as its columns -- the form the pruned exchange uses
+      const int64_t Z = Zp;
+      MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Z) * es));
+      void* Aw = work[0];
+      bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1;
+      by.row_lo = ba1; by.row_hi = bb1; by.c_lim = ba2;
+      MFFT_TRY(stage("bwd_x", Cb * keep1 * keep2 * (keep0 + 1.0), [&] {
+        return col_band(fu, Aw, N0, N1, ba2, Z, plain(N1 * Z), Z, plain(N1 * Z), bx);
+      }));
+      MFFT_TRY(stage("bwd_y", Cb * keep2 * (keep1 + 1.0), [&] {
+        return col_band(Aw, Aw, N1, N0, ba2, N1 * Z, plain(Z), N1 * Z, plain(Z), by);
+      }));
+      MFFT_TRY(stage("bwd_z", Rb + Cb * keep2, [&] { return c2r_rows(Aw, u, N0 * N1, N2, Z, N2, 1.0 / (double)N2, ba2); }));
+      return 0;
+    }
+    MFFT_TRY(ensure_work(0, (size_t)(N0 * N1 * Nf) * es));
+    void* Aw = work[0];
     bx.row_lo = ba0; bx.row_hi = bb0; bx.c_off = 0; bx.c_per = (int)Nf; bx.c_lim = ba2; bx.g_off = 0; bx.g_step = 0; bx.g_lo = ba1; bx.g_hi = bb1;
     bx.tile_list = band_tiles; bx.ntiles_listed = band_ntiles;
     by.row_lo = ba1; by.row_hi = bb1; by.c_lim = ba2;        // columns = kz of one x plane: only the first a2 are launched
@@ -1641,11 +1658,24 @@ int mfft_plan_s::nonlinear_cross_fused_ranks(const void* a, const void* b, void*
     ~MaskScope() { p->mask_src = nullptr; p->lband_use = false; }
   } mask_scope{this};
   lband_use = false;
+  // 2/3-rule with the reference's own filter: the six inverse transforms pruned as in slab_backward's blocking route -- the x
+  // pass reads the kept kx rows and writes (N0, Np1, ap) with the kept kz only (zeros for the ky this rank's mask removes), the
+  // six inverse exchanges carry ap / Nf of the bytes, the y pass and the fused z kernel work on a2 bins per row
+  const int64_t a2 = ba2, ap = (a2 + line - 1) / line * line;      // rows of the pruned layout start on cache lines
+  const bool pruned = masked && band_ok && ap <= Nf && !(getenv("MFFT_NO_PRUNE") && atoi(getenv("MFFT_NO_PRUNE")) != 0);
   MFFT_TRY(stage("nl_x_inv", 0, [&] {
     for (int f = 0; f < 6; ++f) {
       const void* src = static_cast<const char*>(f < 3 ? a : b) + (size_t)((f % 3) * C) * es;
       void* dst = X + (size_t)f * xelems * es;
-      if (masked) {
+      if (pruned) {
+        if (band_allzero) {                        // nothing of this rank's spectrum survives the mask
+          MFFT_TRY(zero(dst, (size_t)(N0 * Np1 * ap) * es));
+        } else {
+          ColArgs::Band bx;
+          bx.row_lo = ba0; bx.row_hi = bb0; bx.g_off = 0; bx.g_step = 1; bx.g_lo = ba1; bx.g_hi = bb1; bx.g_zero = 1;
+          MFFT_TRY(col_band(src, dst, N0, Np1, a2, Nf, plain(Np1 * Nf), ap, plain(Np1 * ap), bx));
+        }
+      } else if (masked) {
         mask_src = src;
         MFFT_TRY(col(src, dst, N0, true, 1, Np1 * Nf, 0, plain(Np1 * Nf), 0, plain(Np1 * Nf)));
         mask_src = nullptr;
@@ -1656,15 +1686,23 @@ int mfft_plan_s::nonlinear_cross_fused_ranks(const void* a, const void* b, void*
     return 0;
   }));
   MFFT_TRY(stage("nl_a2a_inv", 0, [&] {
-    for (int f = 0; f < 6; ++f) MFFT_TRY(xchg(0, false, pad, X + (size_t)f * xelems * es, R + (size_t)f * xelems * es));
+    for (int f = 0; f < 6; ++f) {
+      if (pruned) MFFT_TRY(exchange_equal(world, X + (size_t)f * xelems * es, R + (size_t)f * xelems * es, (size_t)(Np0 * Np1 * ap) * es));
+      else MFFT_TRY(xchg(0, false, pad, X + (size_t)f * xelems * es, R + (size_t)f * xelems * es));
+    }
     return 0;
   }));
   for (int64_t i0 = 0; i0 < Lp0; i0 += mb) {
     const int64_t m = std::min(mb, Lp0 - i0);
     MFFT_TRY(stage("nl_y_inv", 0, [&] {
-      for (int f = 0; f < 6; ++f)
-        MFFT_TRY(col_pad(R + ((size_t)f * xelems + (size_t)(i0 * Np1 * Nf)) * es, Y + (size_t)f * yelems * es, L1, true, pad ? 1 : 0,
-                         false, m, Nf, Np1 * Nf, two_level(Np1, Lp0 * Np1 * Nf, Nf), L1 * Za, plain(Za), 1.0 / (double)L1));
+      for (int f = 0; f < 6; ++f) {
+        if (pruned)
+          MFFT_TRY(col(R + ((size_t)f * xelems + (size_t)(i0 * Np1 * ap)) * es, Y + (size_t)f * yelems * es, N1, true, m, a2, Np1 * ap,
+                       two_level(Np1, Np0 * Np1 * ap, ap), L1 * Za, plain(Za)));
+        else
+          MFFT_TRY(col_pad(R + ((size_t)f * xelems + (size_t)(i0 * Np1 * Nf)) * es, Y + (size_t)f * yelems * es, L1, true, pad ? 1 : 0,
+                           false, m, Nf, Np1 * Nf, two_level(Np1, Lp0 * Np1 * Nf, Nf), L1 * Za, plain(Za), 1.0 / (double)L1));
+      }
       return 0;
     }));
     MFFT_TRY(stage("nl_z", 0, [&] {
@@ -1675,6 +1713,7 @@ int mfft_plan_s::nonlinear_cross_fused_ranks(const void* a, const void* b, void*
         z.out[f] = Y + (size_t)f * yelems * es;
       }
       z.n = (int)L2; z.prec = prec; z.in_stride = Za; z.out_stride = Za; z.nrows = m * L1; z.valid = (int)Nf;
+      z.valid_in = pruned ? (int)a2 : 0;
       z.scale = 1.0 / ((double)L2 * (double)L2);
       return launch_nlz(z, stream);
     }));

@@ -1,4 +1,4 @@
-"""Cost of the 2/3-rule on the inverse transform (developer tool): python scripts/maskprof.py n [precision] [slab|X|Y]
+"""Cost of the 2/3-rule on the inverse transform (developer tool): python scripts/maskprof.py n [precision] [slab|pitched|X|Y]
 Times ifftn(fu, u) and ifftn(fu, u, dealias="2/3-rule") on one GPU and prints the stage times of the latter
 (X / Y: the pencil class on a 1 x 1 grid; MFFT_NO_PRUNE=1 gives the mask-byte path for comparison)."""
 import os, sys, time
@@ -9,11 +9,13 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 prec = sys.argv[2] if len(sys.argv) > 2 else "double"
 N = np.array([n] * 3); L = np.array([2 * np.pi] * 3)
 kind = sys.argv[3] if len(sys.argv) > 3 else "slab"
-if kind == "slab":
+if kind == "pitched":          # slab, spectrum rows a whole number of cache lines apart (complex_pitch="auto")
+    F = Slab_R2C(N, L, SelfComm(0), prec, complex_pitch="auto")
+elif kind == "slab":
     F = Slab_R2C(N, L, SelfComm(0), prec)
 else:
     F = Pencil_R2C(N, L, SelfComm(0), prec, communication="Alltoallw", alignment=kind, allow_single=True)
-fu = DeviceArray.random(F.complex_shape(), F.complex, seed=1)
+fu = F.empty_complex() if kind == "pitched" else DeviceArray.random(F.complex_shape(), F.complex, seed=1)
 u = DeviceArray.empty(F.real_shape(), F.float)
 def run(dealias, reps=8):
     for _ in range(2):
