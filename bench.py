@@ -883,6 +883,15 @@ def main():
             f_["element_wise_ms_per_step"] = round(f_["rk4_step_ms"] - sum(f_["stage_ms_per_step"].values()), 3)
             c_["element_wise_ms_per_step"] = round(c_["rk4_step_ms"] - sum(c_["stage_ms_per_step"].values()), 3)
             tg["fused_over_composed_512^3"] = round(f_["rk4_step_ms"] / c_["rk4_step_ms"], 3)
+            # ... and under the 2/3-rule (the reference's cheaper dealiasing, slab.py:237-245): pruned inverse passes inside the operation
+            for mode in ("fused", "composed"):
+                rep = {}
+                k_ = dns.solve(comm, M=9, dealias="2/3-rule", steps=3, report=rep, fused=mode == "fused", timing=True)
+                tg["512^3_two_thirds_rule_%s" % mode] = {
+                    "rk4_step_ms": round(rep["ms_per_step"], 3), "k_after_3_steps": k_,
+                    "stage_ms_per_step": {a_: round(b_[0], 3) for a_, b_ in sorted(rep.get("stages", {}).items()) if b_[1]}}
+            tg["fused_over_composed_512^3_two_thirds_rule"] = round(
+                tg["512^3_two_thirds_rule_fused"]["rk4_step_ms"] / tg["512^3_two_thirds_rule_composed"]["rk4_step_ms"], 3)
             extras["taylor_green_rk4"] = tg
         except Exception as e:      # noqa: BLE001  - the headline (slab) line must survive
             extras["taylor_green_rk4"] = {"error": "%s: %s" % (type(e).__name__, e)}
