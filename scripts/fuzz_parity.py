@@ -13,7 +13,8 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 NICE = [4, 6, 8, 10, 12, 16, 18, 20, 24, 32, 36, 40, 48, 50, 64, 72, 80, 96, 100, 128, 144, 160, 192, 200, 256]
 ODD = [14, 22, 26, 28, 30, 34, 42, 44, 52, 54, 56, 60, 66, 70, 84, 90, 98, 110, 126, 130, 150, 170, 210, 250,
-       120, 180, 240, 300]      # round 3: more of the lengths with 3 and 5 among their factors (plans.h group L)
+       120, 180, 240, 300,      # round 3: more of the lengths with 3 and 5 among their factors (plans.h group L)
+       108, 216, 288, 432]      # round 6: 27 * 2^a (plans.h group T) and 9 * 2^a meshes whose 3/2-rule images they are
 
 
 def pick(P, need_div, even_quot=False):
@@ -151,7 +152,9 @@ for case in range(ncases):
             lay = orc.SlabLayout(N, P)
             depth = int(rng.choice([0, 1, 2, 4, 8, -2, -4, -5]))   # exchange pipeline (0 default, <0 row batches)
             tag += " pipeline=%d" % depth
-            make = lambda comm: Slab_R2C(np.array(N), L, comm, prec, pipeline=depth)
+            pitch = "auto" if rng.random() < 0.4 else None      # round 6: spectrum rows a whole number of cache lines apart
+            tag += " pitch=%s" % pitch
+            make = lambda comm: Slab_R2C(np.array(N), L, comm, prec, pipeline=depth, complex_pitch=pitch)
             fwd, bwd = orc.slab_r2c_forward, orc.slab_r2c_backward
             fwdp, bwdp = orc.slab_r2c_forward_padded, orc.slab_r2c_backward_padded
             extra = ()
