@@ -456,13 +456,16 @@ static int c2r_mlds_mode() {
 // only.  profiles/r06_c2r_mlds.txt: the 12-values plans of 288 ... 3456 complex points that no shuffle serves gain 1 - 15 % on plain
 // rows and 15 - 47 % on column-limited ones (3/2-rule pair of 576^3 fp64: bwd_z 3.08 -> 1.65 ms, of 768^3: 6.60 -> 3.91); rows of more
 // than a wave's threads: real 6144 / 8192 +4 ... +15 %, real 4096 in double precision only (+10 %; single -5 %), real 3072 only
-// column-limited in single precision (+5 %; plain -2 ... -9 %).
+// column-limited in single precision (+5 %; plain -2 ... -9 %).  The 30- / 42-values plans have no such build (registers: -2.2 x).
 static bool c2r_mlds_take(int n, int prec, bool limited) {
   const int m = c2r_mlds_mode();
   if (m <= 0) return false;
   if (m == 2) return true;
   if (m == 3) return limited;
   const int c = n / 2;
+  if (c == 1000 || c == 2000) return prec == MFFT_SINGLE;      // the 20-values plans: 400 / 500 / 800 gain in both precisions
+  // (800^3 bwd_z 1.75 -> 1.50 ms, under the 2/3-rule 1.65 -> 1.32; 1000^3 3.28 -> 3.07 / 3.45 -> 2.99; 1600^3 13.7 -> 13.3 / 13.2 -> 12.2),
+  // real 2000 / 4000 in single precision only (double: -6 ... -11 %)
   if (c == 1536) return limited && prec == MFFT_SINGLE;
   if (c == 2048) return !limited && prec == MFFT_DOUBLE;
   return true;

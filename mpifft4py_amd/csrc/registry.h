@@ -524,7 +524,9 @@ template <class S, typename T> constexpr bool c2r_mlds_candidate() {
   if (S::E == 12 && (S::N == 432 || S::N == 864 || S::N == 1728 || S::N == 3456 || S::N == 288 || S::N == 576)) return true;
   // rows of more than a wave's threads (real 3072 / 6144 with 12 values per thread, real 4096 / 8192 with 16)
   if ((S::E == 12 && (S::N == 1536 || S::N == 3072)) || (S::E == 16 && (S::N == 2048 || S::N == 4096))) return true;
-  return sizeof(T) == 4 && (S::E == 20 && S::N == 1000);
+  // the 20-values plans of the 25 * 2^a and 125 * 2^a lengths (10 - 100 threads per row, no shuffle, not wave-packed)
+  if (S::E == 20 && (S::N == 400 || S::N == 500 || S::N == 800 || S::N == 1000 || S::N == 2000)) return true;
+  return false;
 }
 template <class S, typename T>
 void register_rows(const char* name) {
