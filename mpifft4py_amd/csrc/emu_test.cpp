@@ -929,7 +929,7 @@ static void test_real_zh(int m) {
 // wave-packed c2r (fft_kernels.h C2RFft WP): plain, column-limited and z-chunked, against the input of the r2c kernels
 template <class S, typename T, int WAVES, bool SPLIT>
 static void test_c2r_wave_packed() {
-  if constexpr (S::TPT < 64 && 64 % S::TPT != 0) {
+  if constexpr (S::TPT < 64 && 64 % S::TPT != 0 && S::E % 2 == 0) {      // (register pairing: even E -- registry.h wave_packable)
     constexpr int RPW = 64 / S::TPT, ROWS = WAVES * RPW;
     const int M = S::N, N = 2 * M, nrows = 2 * ROWS + 1;       // the last workgroup is ragged, its last wave too
     std::mt19937_64 rng(99 + N);
@@ -1418,6 +1418,12 @@ int main() {
 #endif
 #if EMU_HAS(14)
   MFFT_PLANS_T(MFFT_PLAN)      // round 6: 27 * 2^a, the 3/2-rule images of the 9 * 2^a meshes
+#endif
+#if EMU_HAS(15)
+  MFFT_PLANS_U(MFFT_PLAN)      // round 6: 135 * 2^a, 1350 / 2700 / 2250, 675 / 1125
+#endif
+#if EMU_HAS(16)
+  MFFT_PLANS_V(MFFT_PLAN)      // round 6: 81 * 2^a
 #endif
 #if EMU_HAS(11)
   MFFT_PLANS_P(MFFT_PLAN)

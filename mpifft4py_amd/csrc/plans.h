@@ -76,6 +76,15 @@
 #define MFFT_PLANS_T(X) X(54, 6, 3, 3) X(108, 12, 3, 3) X(216, 24, 3, 3) X(432, 24, 6, 3) X(864, 24, 12, 3) X(1728, 24, 24, 3) \
   X(3456, 24, 24, 6)
 #define MFFT_ROWPLANS_T(X) X(216, 12, 6, 3) X(432, 12, 12, 3) X(864, 12, 12, 6) X(1728, 12, 12, 12) X(3456, 12, 12, 12, 2)
+// Groups U and V (round 6): the remaining 3/2-rule images of planned meshes -- 135 * 2^a (720 -> 1080, 1440 -> 2160, 360 -> 540), 1350 / 2700 /
+// 2250 (of 900 / 1800 / 1500) and the odd halves their real axes need (675, 1125: 15 values per thread), all with the 30-values prime-factor
+// butterfly first like groups L - N; 81 * 2^a (432 -> 648, 864 -> 1296, 1728 -> 2592) with 12 values per thread.  Before, a 3/2-rule
+// transform of those meshes took the copy-based route around chirp-z transforms (as the 9 * 2^a meshes did before group T).
+#define MFFT_PLANS_U(X) X(270, 30, 3, 3) X(540, 30, 6, 3) X(1080, 30, 6, 6) X(2160, 30, 6, 6, 2) X(1350, 30, 15, 3) X(2700, 30, 30, 3) \
+  X(2250, 30, 15, 5) X(675, 15, 15, 3) X(1125, 15, 15, 5)
+#define MFFT_ROWPLANS_U(X)
+#define MFFT_PLANS_V(X) X(162, 6, 3, 3, 3) X(324, 12, 3, 3, 3) X(648, 12, 6, 3, 3) X(1296, 12, 12, 3, 3) X(2592, 12, 12, 6, 3)
+#define MFFT_ROWPLANS_V(X)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -167,7 +176,8 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
   X(768, 12, 4, 4, 4) X(1536, 12, 4, 4, 4, 2) X(3072, 12, 4, 4, 4, 4)
 // the 9 * 2^a meshes (dealias None / 2/3-rule) and their 3/2-rule images 27 * 2^a
 #define MFFT_NLZPLANS_9(X) X(144, 12, 12) X(288, 12, 12, 2) X(576, 12, 12, 4) X(1152, 12, 12, 4, 2) X(2304, 12, 12, 4, 4) \
-  X(216, 12, 6, 3) X(432, 12, 12, 3) X(864, 12, 12, 6) X(1728, 12, 12, 12) X(3456, 12, 12, 12, 2)
+  X(216, 12, 6, 3) X(432, 12, 12, 3) X(864, 12, 12, 6) X(1728, 12, 12, 12) X(3456, 12, 12, 12, 2) \
+  X(324, 12, 3, 3, 3) X(648, 12, 6, 3, 3) X(1296, 12, 12, 3, 3) X(2592, 12, 12, 6, 3)
 
 // ... and the sub-plans of its pruned 3/2-rule flavour (Nlz3Fft: X(L, radices) with L = N/2 = M/3, three sub-transforms of
 // length L per row in three thread groups)
@@ -176,4 +186,4 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
   MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X) MFFT_PLANS_N(X) \
-  MFFT_PLANS_O(X) MFFT_PLANS_P(X) MFFT_PLANS_Q(X) MFFT_PLANS_R(X) MFFT_PLANS_T(X)
+  MFFT_PLANS_O(X) MFFT_PLANS_P(X) MFFT_PLANS_Q(X) MFFT_PLANS_R(X) MFFT_PLANS_T(X) MFFT_PLANS_U(X) MFFT_PLANS_V(X)

@@ -460,7 +460,7 @@ template <class S, typename T> constexpr int row_occ_wgs(int threads) {
 #ifndef MFFT_REAL_WP
 #define MFFT_REAL_WP 1
 #endif
-template <class S> constexpr bool wave_packable() { return MFFT_REAL_WP && S::TPT < 64 && 64 % S::TPT != 0 && S::E % 15 == 0; }
+template <class S> constexpr bool wave_packable() { return MFFT_REAL_WP && S::TPT < 64 && 64 % S::TPT != 0 && S::E % 15 == 0 && S::E % 2 == 0; }   // (register pairing: even E)
 template <class S, typename T> constexpr bool r2c_wave_packed() { return wave_packable<S>(); }
 template <class S, typename T> constexpr bool c2r_wave_packed() {
   return wave_packable<S>() && (sizeof(T) == 4 || S::TPT == 10 || S::TPT == 12 || S::TPT == 20);

@@ -57,7 +57,7 @@ def _oracle_cross(a, b, N, prec, dealias, mask=None):
 @pytest.mark.parametrize("N,fused", [([32, 64, 128], True), ([64, 32, 32], True), ([8, 16, 32], True), ([16, 32, 24], None),
                                      ([128, 128, 128], True), ([20, 24, 40], None),
                                      # 9 * 2^a meshes: their 3/2-rule images are the 27 * 2^a plans (plans.h group T)
-                                     ([36, 72, 144], True), ([144, 36, 288], True)])
+                                     ([36, 72, 144], True), ([144, 36, 288], True), ([108, 216, 432], True)])
 @pytest.mark.parametrize("hermitian", [True, False])
 def test_nonlinear_cross_one_rank(N, fused, dealias, prec, hermitian):
     """One rank, slab: the fused route (x passes -> batches of y pass / fused z stage / y pass -> x passes) where every
