@@ -78,10 +78,12 @@
 #define MFFT_ROWPLANS_T(X) X(216, 12, 6, 3) X(432, 12, 12, 3) X(864, 12, 12, 6) X(1728, 12, 12, 12) X(3456, 12, 12, 12, 2)
 // Groups U and V (round 6): the remaining 3/2-rule images of planned meshes -- 135 * 2^a (720 -> 1080, 1440 -> 2160, 360 -> 540), 1350 / 2700 /
 // 2250 (of 900 / 1800 / 1500) and the odd halves their real axes need (675, 1125: 15 values per thread), all with the 30-values prime-factor
-// butterfly first like groups L - N; 81 * 2^a (432 -> 648, 864 -> 1296, 1728 -> 2592) with 12 values per thread.  Before, a 3/2-rule
+// butterfly first like groups L - N (also the odd halves 75 / 135 / 225 / 375 of the real axes of 100 / 180 / 300 / 500 and 2880 / 3600, the
+// images of 1920 / 2400); 81 * 2^a (432 -> 648, 864 -> 1296, 1728 -> 2592) with 12 values per thread.  Before, a 3/2-rule
 // transform of those meshes took the copy-based route around chirp-z transforms (as the 9 * 2^a meshes did before group T).
 #define MFFT_PLANS_U(X) X(270, 30, 3, 3) X(540, 30, 6, 3) X(1080, 30, 6, 6) X(2160, 30, 6, 6, 2) X(1350, 30, 15, 3) X(2700, 30, 30, 3) \
-  X(2250, 30, 15, 5) X(675, 15, 15, 3) X(1125, 15, 15, 5)
+  X(2250, 30, 15, 5) X(675, 15, 15, 3) X(1125, 15, 15, 5) \
+  X(75, 15, 5) X(135, 15, 3, 3) X(225, 15, 15) X(375, 15, 5, 5) X(2880, 30, 6, 2, 2, 2, 2) X(3600, 30, 30, 2, 2)
 #define MFFT_ROWPLANS_U(X)
 #define MFFT_PLANS_V(X) X(162, 6, 3, 3, 3) X(324, 12, 3, 3, 3) X(648, 12, 6, 3, 3) X(1296, 12, 12, 3, 3) X(2592, 12, 12, 6, 3)
 #define MFFT_ROWPLANS_V(X)
