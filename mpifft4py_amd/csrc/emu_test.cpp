@@ -1425,6 +1425,9 @@ int main() {
 #if EMU_HAS(16)
   MFFT_PLANS_V(MFFT_PLAN)      // round 6: 81 * 2^a
 #endif
+#if EMU_HAS(17)
+  MFFT_PLANS_W(MFFT_PLAN)      // round 6: 63 * 2^a
+#endif
 #if EMU_HAS(11)
   MFFT_PLANS_P(MFFT_PLAN)
   test_chirpz_all<Spec<8192, 32, 16, 16>>();

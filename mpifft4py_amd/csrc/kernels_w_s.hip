@@ -1,0 +1,5 @@
+// gfx950 instantiations: plan group W (63 * 2^a), single precision
+#define MFFT_TU_PLANS MFFT_PLANS_W
+#define MFFT_TU_ROWPLANS MFFT_ROWPLANS_W
+#define MFFT_TU_REAL float
+#include "kernels_tu.inc"

@@ -87,6 +87,10 @@
 #define MFFT_ROWPLANS_U(X)
 #define MFFT_PLANS_V(X) X(162, 6, 3, 3, 3) X(324, 12, 3, 3, 3) X(648, 12, 6, 3, 3) X(1296, 12, 12, 3, 3) X(2592, 12, 12, 6, 3)
 #define MFFT_ROWPLANS_V(X)
+// Group W (round 6): 63 * 2^a -- the 3/2-rule images of the 21 * 2^a meshes (168 -> 252, 336 -> 504, 672 -> 1008, 1344 -> 2016): the 42-values
+// butterfly of group R first, a radix-6 pass, radix-2 passes.  (The images of 35 * 2^a would need 210 values per thread: chirp-z.)
+#define MFFT_PLANS_W(X) X(126, 42, 3) X(252, 42, 6) X(504, 42, 6, 2) X(1008, 42, 6, 2, 2) X(2016, 42, 6, 2, 2, 2)
+#define MFFT_ROWPLANS_W(X)
 
 // Row-family overrides (RowFft / R2CFft / C2RFft of complex length N): along the contiguous
 // axis a transform's LDS exchange buffer is private, so large E (few threads per row) starves
@@ -188,4 +192,4 @@ template <typename T> constexpr bool mfft_has_col_override(int n) {
 #define MFFT_FOR_EACH_PLAN(X)                                                                                     \
   MFFT_PLANS_A(X) MFFT_PLANS_B(X) MFFT_PLANS_C(X) MFFT_PLANS_D(X) MFFT_PLANS_E(X) MFFT_PLANS_F(X) MFFT_PLANS_G(X) \
   MFFT_PLANS_H(X) MFFT_PLANS_I(X) MFFT_PLANS_J(X) MFFT_PLANS_K(X) MFFT_PLANS_L(X) MFFT_PLANS_M(X) MFFT_PLANS_N(X) \
-  MFFT_PLANS_O(X) MFFT_PLANS_P(X) MFFT_PLANS_Q(X) MFFT_PLANS_R(X) MFFT_PLANS_T(X) MFFT_PLANS_U(X) MFFT_PLANS_V(X)
+  MFFT_PLANS_O(X) MFFT_PLANS_P(X) MFFT_PLANS_Q(X) MFFT_PLANS_R(X) MFFT_PLANS_T(X) MFFT_PLANS_U(X) MFFT_PLANS_V(X) MFFT_PLANS_W(X)

@@ -92,7 +92,7 @@ def test_emulator_passes():
     csrc = os.path.join(ROOT, "mpifft4py_amd", "csrc")
     subprocess.check_call(["make", "-C", csrc, "-j", "7", "emu"])
     parts = sorted(glob.glob(os.path.join(csrc, "build", "emu_test_[0-9]")) + glob.glob(os.path.join(csrc, "build", "emu_test_[0-9][0-9]")))
-    assert len(parts) == 17, parts         # the plan list is split over seventeen binaries (Makefile: EMU_PARTS; 12 = the fused nonlinear z stage, 13 = radix 70, 14 - 16 = the 3/2-rule image plans of round 6)
+    assert len(parts) == 18, parts         # the plan list is split over eighteen binaries (Makefile: EMU_PARTS; 12 = the fused nonlinear z stage, 13 = radix 70, 14 - 17 = the 3/2-rule image plans of round 6)
     procs = [subprocess.Popen([p], stdout=subprocess.PIPE) for p in parts]
     for p, proc in zip(parts, procs):
         out = proc.communicate()[0].decode()

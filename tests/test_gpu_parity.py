@@ -263,7 +263,8 @@ def test_wide_and_narrow_tiles_over_ranks(N, P, prec):
                                [8, 288, 8],
                                # ... and the images of groups U and V: 720 -> 1080, 1440 -> 2160, 900 -> 1350, 1800 -> 2700, 432 -> 648, 864 -> 1296
                                [720, 8, 8], [8, 720, 8], [8, 8, 720], [8, 1440, 8], [8, 8, 1440], [900, 8, 8], [8, 8, 900], [8, 1800, 8], [8, 8, 1800],
-                               [432, 8, 8], [8, 8, 432], [8, 864, 8], [8, 8, 864], [8, 8, 1728], [8, 8, 500], [8, 8, 300], [1920, 8, 8], [8, 2400, 8]])
+                               [432, 8, 8], [8, 8, 432], [8, 864, 8], [8, 8, 864], [8, 8, 1728], [8, 8, 500], [8, 8, 300], [1920, 8, 8], [8, 2400, 8],
+                               [672, 8, 8], [8, 672, 8], [8, 8, 672], [8, 8, 1344], [8, 336, 8]])
 def test_padded_long_axes(N, prec):
     """3/2-rule with one LONG axis: the pad-on-load / truncate-on-store builds of the 1152- and 1536-point strided
     kernels (12 values per thread, register caps, 64-byte tiles in single precision: registry.h col_wgs) and the

@@ -27,7 +27,8 @@ LENGTHS = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096,
            # round 6: 27 * 2^a (plans.h group T: the 3/2-rule images of the 9 * 2^a meshes)
            54, 108, 216, 432, 864, 1728, 3456,
            # round 6: the other 3/2-rule images (groups U, V): 135 * 2^a, 1350 / 2700 / 2250, the odd 675 / 1125 (15 values per thread), 81 * 2^a
-           270, 540, 1080, 2160, 1350, 2700, 2250, 675, 1125, 162, 324, 648, 1296, 2592, 75, 135, 225, 375, 2880, 3600]
+           270, 540, 1080, 2160, 1350, 2700, 2250, 675, 1125, 162, 324, 648, 1296, 2592, 75, 135, 225, 375, 2880, 3600,
+           126, 252, 504, 1008, 2016]      # group W: 63 * 2^a
 
 
 @pytest.fixture(scope="module", autouse=True)
