@@ -242,7 +242,7 @@ MFFT_API int mfft_slab_unpack(const void* u_mpi, void* uc_hatT, int P, int64_t n
 MFFT_API int mfft_dealias_filter(void* fu, const uint8_t* mask_dev, size_t count, int precision);
 /* 1 if a transform of length n along an axis is supported -- every n from 1 to 2^20, as numpy.fft / FFTW, the reference's
  * backends, take every n (numpy_fft.py:25-46).  mfft_length_route tells HOW: 1 = a radix plan (one kernel, register-resident:
- * 2^a <= 8192, 3*2^a <= 6144, 5*2^a <= 5120, 7*2^a <= 7168, 9*2^a <= 4608, 21*2^a <= 2688, 25*2^a <= 1600, 27*2^a <= 3456, 81*2^a <= 2592,
+ * 2^a <= 8192, 3*2^a <= 6144, 5*2^a <= 5120, 7*2^a <= 7168, 9*2^a <= 4608, 21*2^a <= 2688, 63*2^a <= 2016, 25*2^a <= 1600, 27*2^a <= 3456, 81*2^a <= 2592,
  * 125*2^a <= 2000, 15*2^a <= 3840, 45*2^a <= 1440, 75*2^a <= 2400, 135*2^a <= 2160, 225*2^a <= 1800, 375*2^a <= 3000, 675*2^a <= 2700,
  * 1125*2^a <= 2250, in single precision also 35*2^a <= 2240; real: twice that), 2 = the one-workgroup chirp-z kernels
  * (every other length up to 4096, even real lengths up to 8192; ~0.17 of the roofline), 3 = Bluestein's convolution over a
