@@ -98,7 +98,8 @@ def median(xs):
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
 
-EXTRA = [(432, "fp64"), (864, "fp64"), (1728, "fp64"), (864, "fp32"), (1728, "fp32"), (560, "fp32"), (1120, "fp32")]
+EXTRA = [(432, "fp64"), (864, "fp64"), (1728, "fp64"), (864, "fp32"), (1728, "fp32"), (560, "fp32"), (1120, "fp32"),
+         (648, "fp64"), (1008, "fp64"), (1080, "fp64"), (1296, "fp64"), (1080, "fp32")]
 
 
 def main():
