@@ -1,7 +1,7 @@
 #!/bin/bash
 # Taylor-Green loop under the 2/3-rule: fused nonlinear operation (mask on load, every kz carried) against the composition (pruned
 # inverse passes), pitched and compact spectra
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 mkdir -p gpurun_out/r06
 O=gpurun_out/r06/dns23.txt
 : > $O

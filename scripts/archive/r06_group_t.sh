@@ -1,7 +1,7 @@
 #!/bin/bash
 # 27 * 2^a plans (plans.h group T): tests of the new lengths, then the pairs that use them -- plain 432 / 864 / 1728, the 3/2-rule
 # pairs of 288 / 576 / 1152 (which had no fused pad / truncate passes before) and the Taylor-Green loop at 576^3.
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 mkdir -p gpurun_out/r06
 O=gpurun_out/r06/group_t.txt
 : > $O

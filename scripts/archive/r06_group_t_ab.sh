@@ -1,7 +1,7 @@
 #!/bin/bash
 # Before / after of plans.h group T (27 * 2^a) and the wider c2r-through-LDS rule: _ab/prev = the library of the commit before
 # (git archive + make), the tree = this build.  Plain pairs of 432 / 864 / 1728, 3/2-rule pairs of 288 / 576 / 768 / 1152, Taylor-Green at 576^3.
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 mkdir -p gpurun_out/r06
 O=gpurun_out/r06/group_t_ab.txt
 : > $O

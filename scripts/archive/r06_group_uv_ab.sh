@@ -1,7 +1,7 @@
 #!/bin/bash
 # Before / after of plans.h groups U (135 * 2^a, 1350 / 2700 / 2250, 675 / 1125) and V (81 * 2^a): _ab/prev = the library of the commit
 # before, the tree = this build.  3/2-rule pairs of 360 / 720 / 1440 / 900 / 432 / 864, plain pairs of 1080 / 648 / 1296.
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 mkdir -p gpurun_out/r06
 O=gpurun_out/r06/group_uv_ab.txt
 : > $O

@@ -1,7 +1,7 @@
 #!/bin/bash
 # c2r mirrors through LDS on the 20-values plans (real 800 / 1000 / 1600 / 2000 / 4000): plain rows and the column-limited rows of the
 # pruned 2/3-rule, MFFT_C2R_MLDS=0 (second load) against 2 (wherever built)
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 mkdir -p gpurun_out/r06
 O=gpurun_out/r06/mlds_e20.txt
 : > $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # c2r mirrors through LDS on rows of more than a wave's threads (real 3072 / 4096 / 6144 / 8192) and fp32 1728 capped for two workgroups
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 mkdir -p gpurun_out/r06
 O=gpurun_out/r06/mlds_long.txt
 : > $O

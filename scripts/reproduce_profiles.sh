@@ -70,10 +70,10 @@ run() {
     r06_radix70.txt) bash scripts/archive/r06_gpu19.sh ;;
     r06_final_*|r06_dns_kernel_stats.csv|r06_dns_pmc_traffic.json) bash scripts/r06_final.sh prof ;;
     r06_bench_dev_run.json|r06_bench_2ranks_ipc.json|r06_bench_2ranks_mock.json) bash scripts/r06_final.sh bench ;;
-    r06_group_t.txt) echo "(before / after: git archive <commit before group T> into _ab/prev, make there, then)"; bash scripts/r06_group_t_ab.sh ;;
-    r06_group_uv.txt) echo "(before / after: git archive <commit before groups U, V> into _ab/prev, make there, then)"; bash scripts/r06_group_uv_ab.sh ;;
-    r06_c2r_mlds.txt) bash scripts/archive/r06_gpu14.sh; bash scripts/r06_mlds_t.sh; bash scripts/r06_mlds_long.sh; bash scripts/r06_mlds_e20.sh ;;
-    r06_dns_23rule.txt) bash scripts/r06_dns23.sh; echo "(before: MFFT_NO_PRUNE=1)"; python scripts/maskprof.py 1024 double pitched ;;
+    r06_group_t.txt) echo "(before / after: git archive <commit before group T> into _ab/prev, make there, then)"; bash scripts/archive/r06_group_t_ab.sh ;;
+    r06_group_uv.txt) echo "(before / after: git archive <commit before groups U, V> into _ab/prev, make there, then)"; bash scripts/archive/r06_group_uv_ab.sh ;;
+    r06_c2r_mlds.txt) bash scripts/archive/r06_gpu14.sh; bash scripts/archive/r06_mlds_t.sh; bash scripts/archive/r06_mlds_long.sh; bash scripts/archive/r06_mlds_e20.sh ;;
+    r06_dns_23rule.txt) bash scripts/archive/r06_dns23.sh; echo "(before: MFFT_NO_PRUNE=1)"; python scripts/maskprof.py 1024 double pitched ;;
     r05_col_occupancy_caps.txt|r05_row_occupancy_caps.txt) echo "(needs the library without the caps under _ab/old: see scripts/archive/r05_gpu7.sh / r05_gpu8.sh)" ;;
     r04_rank_shapes.txt) python scripts/rank_shapes.py ;;
     r04_ypass_pitch.txt) python scripts/ypass_pitch_ab.py ;;
