@@ -250,6 +250,8 @@ MFFT_API int mfft_dealias_filter(void* fu, const uint8_t* mask_dev, size_t count
  * 3/2-rule and 2/3-rule then take their copy-based routes; ~0.05 - 0.1 of the roofline), 0 = not supported (n > 2^20). */
 MFFT_API int mfft_length_supported(int64_t n, int real_transform);
 MFFT_API int mfft_length_route(int64_t n, int real_transform);
+/* ... for one precision: the 35 * 2^a lengths have radix plans in single precision only (mfft_length_route answers for double) */
+MFFT_API int mfft_length_route_precision(int64_t n, int real_transform, int precision);
 /* Which compiled kernel a strided-axis (family 0), contiguous-axis c2c (1), r2c (2) or c2r (3) transform of length n
  * runs: "<plan name> tile=<columns or rows> threads=<n> lds=<bytes>[ nt]", e.g.
  * "cols n1024(8, 8, 4, 4)double tile=8 threads=1024 lds=81792".  Device-free.  bench.py uses it to check that a

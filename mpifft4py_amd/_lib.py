@@ -95,6 +95,7 @@ _SIGNATURES = {
     "mfft_dealias_filter": ([c_void_p, c_void_p, c_size_t, c_int], c_int),
     "mfft_length_supported": ([c_int64, c_int], c_int),
     "mfft_length_route": ([c_int64, c_int], c_int),
+    "mfft_length_route_precision": ([c_int64, c_int, c_int], c_int),
     "mfft_kernel_name": ([c_int, c_int64, c_int, c_int, c_int, c_void_p, c_size_t], c_int),
     "mfft_nonlinear_cross": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int], c_int),
     "mfft_ew_cross": ([c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int], c_int),
@@ -113,7 +114,7 @@ _SIGNATURES = {
 }
 
 # functions whose int result is a count, not a status
-_COUNT_RESULT = {"mfft_version", "mfft_length_supported", "mfft_length_route", "mfft_plan_timing_get"}
+_COUNT_RESULT = {"mfft_version", "mfft_length_supported", "mfft_length_route", "mfft_length_route_precision", "mfft_plan_timing_get"}
 
 _lib = None
 

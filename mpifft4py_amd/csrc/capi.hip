@@ -164,6 +164,10 @@ int mfft_comm_destroy(mfft_comm_t c) {
 // ---- stage level ------------------------------------------------------------------
 int mfft_length_supported(int64_t n, int real_transform) { return length_supported(n, real_transform != 0) ? 1 : 0; }
 int mfft_length_route(int64_t n, int real_transform) { return length_route(n, real_transform != 0); }
+int mfft_length_route_precision(int64_t n, int real_transform, int precision) {
+  if (precision != MFFT_DOUBLE && precision != MFFT_SINGLE) return 0;
+  return length_route(n, real_transform != 0, precision);
+}
 
 int mfft_kernel_name(int family, int64_t n, int precision, int inverse, int nt, char* buf, size_t buflen) {
   if (!buf || buflen == 0 || family < FAM_COL || family > FAM_C2R) return set_error(MFFT_ERR_INVALID, "bad argument");

@@ -78,14 +78,14 @@ bool radix_plan_exists(int contiguous, int64_t n, int prec) {
   return find_kernel(contiguous ? FAM_ROW : FAM_COL, (int)n, prec, 0) != nullptr && find_kernel(contiguous ? FAM_ROW : FAM_COL, (int)n, prec, 1) != nullptr;
 }
 // 1: a radix plan, 2: the one-workgroup chirp-z kernels, 3: the scratch-buffer fallback (bigfft.hip), 0: none
-int length_route(int64_t n, bool real_transform) {
+int length_route(int64_t n, bool real_transform, int prec) {
   if (n <= 0 || n > (1 << 20)) return 0;
   if (real_transform) {
-    if (find_kernel(FAM_R2C, (int)n, MFFT_DOUBLE, 0)) return 1;
-    if (find_chirpz(FAM_R2CZ, (int)n, MFFT_DOUBLE, 0) || (n % 2 == 0 && n >= 4 && find_chirpz(FAM_R2CZH, (int)(n / 2), MFFT_DOUBLE, 0))) return 2;
+    if (find_kernel(FAM_R2C, (int)n, prec, 0)) return 1;
+    if (find_chirpz(FAM_R2CZ, (int)n, prec, 0) || (n % 2 == 0 && n >= 4 && find_chirpz(FAM_R2CZH, (int)(n / 2), prec, 0))) return 2;
   } else {
-    if (n == 1 || find_kernel(FAM_COL, (int)n, MFFT_DOUBLE, 0)) return 1;
-    if (find_chirpz(FAM_COLZ, (int)n, MFFT_DOUBLE, 0)) return 2;
+    if (n == 1 || find_kernel(FAM_COL, (int)n, prec, 0)) return 1;
+    if (find_chirpz(FAM_COLZ, (int)n, prec, 0)) return 2;
   }
   return big_length_ok(n) ? 3 : 0;
 }

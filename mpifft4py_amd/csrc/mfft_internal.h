@@ -143,7 +143,7 @@ int launch_scale(void* data, size_t count_real, double scale, int prec, hipStrea
 int launch_fill_uniform(void* data, size_t count, int prec, uint64_t seed, hipStream_t s);
 
 bool length_supported(int64_t n, bool real_transform);
-int length_route(int64_t n, bool real_transform);   // 1 radix plan, 2 one-workgroup chirp-z, 3 bigfft.hip, 0 none
+int length_route(int64_t n, bool real_transform, int prec = MFFT_DOUBLE);   // 1 radix plan, 2 one-workgroup chirp-z, 3 bigfft.hip, 0 none
 // bigfft.hip: any length up to MFFT_BIG_MAX_LENGTH through Bluestein's convolution over a four-step power-of-two transform in
 // a scratch buffer (the fallback behind the radix plans and the one-workgroup chirp-z kernels); plain transforms only
 #define MFFT_BIG_MAX_LENGTH (1 << 20)

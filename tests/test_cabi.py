@@ -72,6 +72,10 @@ def test_version_and_lengths(lib):
     assert lib.mfft_length_route(4099, 1) == 3 and lib.mfft_length_route(8194, 1) == 3
     assert lib.mfft_length_route(1024, 0) == 1 and lib.mfft_length_route(1001, 0) == 2
     assert lib.mfft_length_supported((1 << 20) + 1, 0) == 0 and lib.mfft_length_route(0, 0) == 0
+    # per precision: 35 * 2^a has radix plans in single precision only (plans.h group S); the 3/2-rule images of round 6 in both
+    assert lib.mfft_length_route_precision(1120, 0, 1) == 2 and lib.mfft_length_route_precision(1120, 0, 0) == 1
+    for n in (432, 864, 1728, 1080, 1296, 1008, 2700):
+        assert lib.mfft_length_route_precision(n, 0, 0) == 1 and lib.mfft_length_route_precision(n, 0, 1) == 1, n
 
 
 def test_fails_loudly_without_gpu(lib):
