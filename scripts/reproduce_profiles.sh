@@ -70,6 +70,7 @@ run() {
     r06_radix70.txt) bash scripts/archive/r06_gpu19.sh ;;
     r06_final_*|r06_dns_kernel_stats.csv|r06_dns_pmc_traffic.json) bash scripts/r06_final.sh prof ;;
     r06_bench_dev_run.json|r06_bench_2ranks_ipc.json|r06_bench_2ranks_mock.json) bash scripts/r06_final.sh bench ;;
+    r06_576_kernel_stats.csv|r06_576_pmc_traffic.json) bash scripts/archive/r06_prof576.sh ;;
     r06_group_t.txt) echo "(before / after: git archive <commit before group T> into _ab/prev, make there, then)"; bash scripts/archive/r06_group_t_ab.sh ;;
     r06_group_uv.txt) echo "(before / after: git archive <commit before groups U, V> into _ab/prev, make there, then)"; bash scripts/archive/r06_group_uv_ab.sh ;;
     r06_c2r_mlds.txt) bash scripts/archive/r06_gpu14.sh; bash scripts/archive/r06_mlds_t.sh; bash scripts/archive/r06_mlds_long.sh; bash scripts/archive/r06_mlds_e20.sh ;;
